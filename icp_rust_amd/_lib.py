@@ -1,0 +1,116 @@
+"""Loader + ctypes signatures of libicp_mi355x.so (the C ABI in include/icp_mi355x.h).
+
+The shared library is built in-tree by `make -C icp_rust_amd/csrc` (or
+`__graft_entry__.build()`); it is never replaced by a Python/CPU implementation: if it
+is missing, importing the compute API raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "lib", "libicp_mi355x.so")
+
+OK, NONE, EMPTY_DST, NAN_INPUT, BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, OUT_OF_MEMORY = range(8)
+NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
+
+
+class Pose(C.Structure):
+    """`icp_pose` == Transform{rot: Rotation2 (column-major), t: Vector2}, src/transform.rs:6-10."""
+
+    _fields_ = [(n, C.c_double) for n in ("r00", "r10", "r01", "r11", "tx", "ty")]
+
+    def as_tuple(self):
+        return (self.r00, self.r10, self.r01, self.r11, self.tx, self.ty)
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "icp_mi355x.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _CSRC, "-j4", "-s"])
+    return LIB_PATH
+
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+_pp = C.POINTER(Pose)
+_sz = C.c_size_t
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/icp_mi355x.h declares
+SIGNATURES = {
+    "icp_status_string": (C.c_char_p, [C.c_int]),
+    "icp_abi_version": (C.c_int, []),
+    "icp_device_count": (C.c_int, []),
+    "icp_transform_new": (None, [_dp, _pp]),
+    "icp_transform_from_rt": (None, [_dp, _dp, _pp]),
+    "icp_transform_identity": (None, [_pp]),
+    "icp_transform_apply": (None, [_pp, _dp, _dp]),
+    "icp_transform_inverse": (None, [_pp, _pp]),
+    "icp_transform_mul": (None, [_pp, _pp, _pp]),
+    "icp_se2_exp": (None, [_dp, _dp]),
+    "icp_se2_log": (None, [_dp, _dp]),
+    "icp_se2_get_rt": (None, [_dp, _dp, _dp]),
+    "icp_so2_exp": (None, [C.c_double, _dp]),
+    "icp_so2_log": (C.c_double, [_dp]),
+    "icp_norm": (C.c_double, [_dp, _sz, _sz]),
+    "icp_inverse3x3": (C.c_int, [_dp, _dp]),
+    "icp_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _sz, C.c_int]),
+    "icp_create_device": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _sz, C.c_int]),
+    "icp_destroy": (None, [_vp]),
+    "icp_set_nn_mode": (C.c_int, [_vp, C.c_int]),
+    "icp_get_nn_mode": (C.c_int, [_vp]),
+    "icp_set_stream": (C.c_int, [_vp, _vp]),
+    "icp_estimate": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
+    "icp_estimate_device": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
+    "icp_estimate_transform": (C.c_int, [_vp, _vp, _sz, _pp, _vp]),
+    "icp_weighted_gauss_newton_update": (C.c_int, [_pp, _vp, _vp, _sz, _dp]),
+    "icp_gauss_newton_update": (C.c_int, [_pp, _vp, _vp, _sz, _dp]),
+    "icp_error": (C.c_int, [_pp, _vp, _vp, _sz, _dp]),
+    "icp_huber_error": (C.c_int, [_pp, _vp, _vp, _sz, _dp]),
+    "icp_residual_stddevs": (C.c_int, [_pp, _vp, _vp, _sz, _dp]),
+    "icp_correspond_device": (C.c_int, [_vp, _vp, _sz, _pp, _vp, _vp, _vp]),
+    "icp_estimate_transform_device": (C.c_int, [_vp, _vp, _vp, _sz, _pp, _vp]),
+    "icp_nn_search_device": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "icp_synchronize": (C.c_int, [_vp]),
+    "icp_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "icp_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_uint64)]),
+    "icp_reduce_geometry": (None, [_sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C icp_rust_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class IcpError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = lib().icp_status_string(status).decode()
+        super().__init__(f"{where}: {msg} (status {status})" if where else f"{msg} (status {status})")
+
+
+def check(status, where="", allow=()):
+    if status != OK and status not in allow:
+        raise IcpError(status, where)
+    return status

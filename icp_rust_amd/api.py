@@ -1,0 +1,368 @@
+"""Host-side mirror of the reference crate's public interface (src/lib.rs:12-26) over the
+C ABI: same names, same argument meaning, same failure behaviour.
+
+    Transform, Icp2d, Icp3d, residual, error, huber_error, estimate_transform,
+    gauss_newton_update, weighted_gauss_newton_update, norm, se2, so2
+
+`Option::None` becomes Python `None`; the reference's two panics (empty `dst`, NaN
+residual) become `IcpError`.  All compute runs in libicp_mi355x.so on the GPU.
+Point sets are numpy arrays (n x 2 / n x 3 float64, C order = `&[Vector2]`/`&[Vector3]`)
+or CUDA torch tensors of the same shape, which are used in place (no copy).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import IcpError, Pose, check, lib  # noqa: F401
+
+_dp = C.POINTER(C.c_double)
+
+
+def _is_device_tensor(x):
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+def _host(a, dim):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.size == 0:
+        a = a.reshape(0, dim)
+    if a.ndim != 2 or a.shape[1] != dim:
+        raise ValueError(f"expected an (n, {dim}) float64 array, got {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data if a.size else None)
+
+
+def _vec(v, n):
+    a = np.ascontiguousarray(v, dtype=np.float64).reshape(-1)
+    if a.size != n:
+        raise ValueError(f"expected {n} values")
+    return a
+
+
+class Transform:
+    """`icp::Transform` (src/transform.rs:6-51)."""
+
+    __slots__ = ("pose",)
+
+    def __init__(self, param=None):
+        """Transform::new(&param) (src/transform.rs:13-16); no argument = identity."""
+        self.pose = Pose()
+        if param is None:
+            lib().icp_transform_identity(C.byref(self.pose))
+        else:
+            p = _vec(param, 3)
+            lib().icp_transform_new(p.ctypes.data_as(_dp), C.byref(self.pose))
+
+    @staticmethod
+    def new(param):
+        return Transform(param)
+
+    @staticmethod
+    def identity():
+        return Transform()
+
+    @staticmethod
+    def from_rt(rot, t):
+        """rot: 2x2 (row-major numpy), t: 2 (src/transform.rs:18-20)."""
+        r = np.asarray(rot, dtype=np.float64).reshape(2, 2)
+        cm = np.array([r[0, 0], r[1, 0], r[0, 1], r[1, 1]])
+        tt = _vec(t, 2)
+        o = Transform()
+        lib().icp_transform_from_rt(cm.ctypes.data_as(_dp), tt.ctypes.data_as(_dp), C.byref(o.pose))
+        return o
+
+    @staticmethod
+    def from_pose(pose):
+        o = Transform()
+        C.memmove(C.byref(o.pose), C.byref(pose), C.sizeof(Pose))
+        return o
+
+    @property
+    def rot(self):
+        p = self.pose
+        return np.array([[p.r00, p.r01], [p.r10, p.r11]])
+
+    @property
+    def t(self):
+        return np.array([self.pose.tx, self.pose.ty])
+
+    def transform(self, landmark):
+        p = _vec(landmark, 2)
+        out = np.zeros(2)
+        lib().icp_transform_apply(C.byref(self.pose), p.ctypes.data_as(_dp), out.ctypes.data_as(_dp))
+        return out
+
+    def inverse(self):
+        o = Transform()
+        lib().icp_transform_inverse(C.byref(self.pose), C.byref(o.pose))
+        return o
+
+    def __mul__(self, rhs):
+        o = Transform()
+        lib().icp_transform_mul(C.byref(self.pose), C.byref(rhs.pose), C.byref(o.pose))
+        return o
+
+    def as_array(self):
+        return np.array(self.pose.as_tuple())
+
+    def __repr__(self):
+        return f"Transform(rot={self.rot.tolist()}, t={self.t.tolist()})"
+
+
+class _Se2:
+    """`icp::se2` (src/se2.rs)."""
+
+    @staticmethod
+    def exp(param):
+        p = _vec(param, 3)
+        m = np.zeros(9)
+        lib().icp_se2_exp(p.ctypes.data_as(_dp), m.ctypes.data_as(_dp))
+        return m.reshape(3, 3)
+
+    @staticmethod
+    def log(transform):
+        m = _vec(transform, 9)
+        p = np.zeros(3)
+        lib().icp_se2_log(m.ctypes.data_as(_dp), p.ctypes.data_as(_dp))
+        return p
+
+    @staticmethod
+    def get_rt(transform):
+        m = _vec(transform, 9)
+        r = np.zeros(4)
+        t = np.zeros(2)
+        lib().icp_se2_get_rt(m.ctypes.data_as(_dp), r.ctypes.data_as(_dp), t.ctypes.data_as(_dp))
+        return r.reshape(2, 2), t
+
+    @staticmethod
+    def calc_rt(param):
+        T = Transform(param)
+        return T.rot, T.t
+
+
+class _So2:
+    """`icp::so2` (src/so2.rs)."""
+
+    @staticmethod
+    def exp(theta):
+        m = np.zeros(4)
+        lib().icp_so2_exp(float(theta), m.ctypes.data_as(_dp))
+        return np.array([[m[0], m[2]], [m[1], m[3]]])
+
+    new_rotation2 = exp
+
+    @staticmethod
+    def log(rotation):
+        r = np.asarray(rotation, dtype=np.float64).reshape(2, 2)
+        cm = np.array([r[0, 0], r[1, 0], r[0, 1], r[1, 1]])
+        return lib().icp_so2_log(cm.ctypes.data_as(_dp))
+
+
+se2 = _Se2()
+so2 = _So2()
+
+
+def norm(matrix):
+    """`icp::norm` (src/norm.rs:19-21)."""
+    m = np.asarray(matrix, dtype=np.float64)
+    m = np.asfortranarray(m.reshape(m.shape[0], -1))
+    return lib().icp_norm(m.ctypes.data_as(_dp), m.shape[0], m.shape[1])
+
+
+def residual(transform, src, dst):
+    """`icp::residual` (src/lib.rs:34-36)."""
+    return transform.transform(src) - _vec(dst, 2)
+
+
+def _pairs(src, dst):
+    a = _host(src, 2)
+    b = _host(dst, 2)
+    if a.shape != b.shape:
+        raise ValueError("src and dst differ in length")  # debug_assert_eq!, src/lib.rs:223
+    return a, b
+
+
+def error(transform, src, dst):
+    """`icp::error` (src/lib.rs:38-43)."""
+    a, b = _pairs(src, dst)
+    out = C.c_double()
+    check(lib().icp_error(C.byref(transform.pose), _ptr(a), _ptr(b), a.shape[0], C.byref(out)), "error")
+    return out.value
+
+
+def huber_error(transform, src, dst):
+    """`icp::huber_error` (src/lib.rs:45-50)."""
+    a, b = _pairs(src, dst)
+    out = C.c_double()
+    check(lib().icp_huber_error(C.byref(transform.pose), _ptr(a), _ptr(b), a.shape[0], C.byref(out)),
+          "huber_error")
+    return out.value
+
+
+def gauss_newton_update(transform, src, dst):
+    """`icp::gauss_newton_update` (src/lib.rs:191-216) -> Param or None."""
+    a, b = _pairs(src, dst)
+    d = np.zeros(3)
+    rc = check(lib().icp_gauss_newton_update(C.byref(transform.pose), _ptr(a), _ptr(b), a.shape[0],
+                                             d.ctypes.data_as(_dp)), "gauss_newton_update",
+               allow=(_lib.NONE,))
+    return None if rc == _lib.NONE else d
+
+
+def weighted_gauss_newton_update(transform, src, dst):
+    """`icp::weighted_gauss_newton_update` (src/lib.rs:218-261) -> Param or None."""
+    a, b = _pairs(src, dst)
+    d = np.zeros(3)
+    rc = check(lib().icp_weighted_gauss_newton_update(C.byref(transform.pose), _ptr(a), _ptr(b),
+                                                      a.shape[0], d.ctypes.data_as(_dp)),
+               "weighted_gauss_newton_update", allow=(_lib.NONE,))
+    return None if rc == _lib.NONE else d
+
+
+def residual_stddevs(transform, src, dst):
+    """stats::calc_stddevs over the residuals (src/stats.rs:49-60 at src/lib.rs:236)."""
+    a, b = _pairs(src, dst)
+    s = np.zeros(2)
+    rc = check(lib().icp_residual_stddevs(C.byref(transform.pose), _ptr(a), _ptr(b), a.shape[0],
+                                          s.ctypes.data_as(_dp)), "residual_stddevs", allow=(_lib.NONE,))
+    return None if rc == _lib.NONE else s
+
+
+def estimate_transform(src, dst, return_inner_iters=False):
+    """`icp::estimate_transform` (src/lib.rs:59-84)."""
+    a, b = _pairs(src, dst)
+    o = Transform()
+    inner = C.c_uint32(0)
+    check(lib().icp_estimate_transform(_ptr(a), _ptr(b), a.shape[0], C.byref(o.pose), C.byref(inner)),
+          "estimate_transform")
+    return (o, inner.value) if return_inner_iters else o
+
+
+def reduce_geometry(n):
+    b, t = C.c_int(), C.c_int()
+    lib().icp_reduce_geometry(n, C.byref(b), C.byref(t))
+    return b.value, t.value
+
+
+class _Icp:
+    DIM = 0
+
+    def __init__(self, dst, device=-1, nn_mode=_lib.NN_AUTO):
+        """Icp2d::new / Icp3d::new (src/lib.rs:97-102, 139-144)."""
+        self._h = C.c_void_p()
+        self._keep = None
+        if _is_device_tensor(dst):
+            if dst.dim() != 2 or dst.shape[1] != self.DIM or str(dst.dtype) != "torch.float64" \
+                    or not dst.is_contiguous():
+                raise ValueError(f"expected a contiguous (m, {self.DIM}) float64 CUDA tensor")
+            self._keep = dst  # borrowed for the handle's lifetime, like `&'a [Vector]`
+            self.m = dst.shape[0]
+            dev = dst.device.index if device < 0 else device
+            check(lib().icp_create_device(C.byref(self._h), self.DIM, C.c_void_p(dst.data_ptr()),
+                                          self.m, dev), "icp_create_device")
+        else:
+            d = _host(dst, self.DIM)
+            self.m = d.shape[0]
+            check(lib().icp_create(C.byref(self._h), self.DIM, _ptr(d), self.m, device), "icp_create")
+        if nn_mode != _lib.NN_AUTO:
+            check(lib().icp_set_nn_mode(self._h, nn_mode), "icp_set_nn_mode")
+
+    # -- the reference's method ------------------------------------------------------
+    def estimate(self, src, initial_transform, max_iter, return_info=False):
+        """Icp2d::estimate / Icp3d::estimate (src/lib.rs:105-130, 148-173)."""
+        o = Transform()
+        inner = np.zeros(max(max_iter, 1), dtype=np.uint32)
+        if _is_device_tensor(src):
+            import torch
+
+            n = src.shape[0]
+            idx = torch.empty(max(n, 1), dtype=torch.int32, device=src.device) if return_info else None
+            check(lib().icp_estimate_device(self._h, C.c_void_p(src.data_ptr()), n,
+                                            C.byref(initial_transform.pose), max_iter, C.byref(o.pose),
+                                            C.c_void_p(idx.data_ptr()) if return_info else None,
+                                            C.c_void_p(inner.ctypes.data)), "icp_estimate_device")
+            if return_info:
+                return o, idx[:n].cpu().numpy().view(np.uint32), inner[:max_iter]
+            return o
+        s = _host(src, self.DIM)
+        n = s.shape[0]
+        idx = np.zeros(max(n, 1), dtype=np.uint32)
+        check(lib().icp_estimate(self._h, _ptr(s), n, C.byref(initial_transform.pose), max_iter,
+                                 C.byref(o.pose), C.c_void_p(idx.ctypes.data),
+                                 C.c_void_p(inner.ctypes.data)), "icp_estimate")
+        if return_info:
+            return o, idx[:n], inner[:max_iter]
+        return o
+
+    # -- stage-level access (device tensors), used by the sharded driver and the bench --
+    def set_stream(self, stream_ptr):
+        check(lib().icp_set_stream(self._h, C.c_void_p(stream_ptr)), "icp_set_stream")
+
+    def correspond_device(self, d_src, transform, d_a, d_b, d_idx=None):
+        check(lib().icp_correspond_device(self._h, C.c_void_p(d_src.data_ptr()), d_src.shape[0],
+                                          C.byref(transform.pose), C.c_void_p(d_a.data_ptr()),
+                                          C.c_void_p(d_b.data_ptr()),
+                                          C.c_void_p(d_idx.data_ptr()) if d_idx is not None else None),
+              "icp_correspond_device")
+
+    def estimate_transform_device(self, d_a, d_b):
+        o = Transform()
+        inner = C.c_uint32(0)
+        check(lib().icp_estimate_transform_device(self._h, C.c_void_p(d_a.data_ptr()),
+                                                  C.c_void_p(d_b.data_ptr()), d_a.shape[0],
+                                                  C.byref(o.pose), C.byref(inner)),
+              "icp_estimate_transform_device")
+        return o, inner.value
+
+    def nn_search_device(self, d_q, d_idx):
+        check(lib().icp_nn_search_device(self._h, C.c_void_p(d_q.data_ptr()), d_q.shape[0],
+                                         C.c_void_p(d_idx.data_ptr())), "icp_nn_search_device")
+
+    def nn_search(self, q):
+        """exact NN indices of host points (test/observability helper)."""
+        import torch
+
+        qq = torch.from_numpy(_host(q, self.DIM)).cuda()
+        idx = torch.empty(max(qq.shape[0], 1), dtype=torch.int32, device=qq.device)
+        self.nn_search_device(qq, idx)
+        self.synchronize()
+        return idx[: qq.shape[0]].cpu().numpy().view(np.uint32)
+
+    def profile_enable(self, on=True):
+        check(lib().icp_profile_enable(self._h, int(on)), "icp_profile_enable")
+
+    def profile_read(self):
+        """(summed NN-kernel device time in ms, launches) since the last read."""
+        ms, k = C.c_double(), C.c_uint64()
+        check(lib().icp_profile_read(self._h, C.byref(ms), C.byref(k)), "icp_profile_read")
+        return ms.value, k.value
+
+    def synchronize(self):
+        check(lib().icp_synchronize(self._h), "icp_synchronize")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().icp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Icp2d(_Icp):
+    """`icp::Icp2d` (src/lib.rs:91-131)."""
+
+    DIM = 2
+
+
+class Icp3d(_Icp):
+    """`icp::Icp3d` (src/lib.rs:133-174): 3-D nearest neighbours, SE(2) pose on the xy-plane."""
+
+    DIM = 3

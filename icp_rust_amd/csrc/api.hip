@@ -1,0 +1,479 @@
+// C ABI of the MI355X ICP core (include/icp_mi355x.h): handle lifecycle, the outer ICP
+// loop (src/lib.rs:105-130, 148-173) and the inner robust Gauss-Newton loop
+// (src/lib.rs:59-84) driven from the host over the device stages in nn_brute.hip /
+// gn.hip.  Nothing here falls back to a CPU computation: without a HIP device every
+// compute entry point fails with ICP_NO_DEVICE.
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "common.hpp"
+
+using namespace icp;
+
+namespace icp {
+hipError_t launch_sel_init(icp_handle *h, size_t n);
+hipError_t launch_stddevs(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T);
+}  // namespace icp
+
+namespace {
+
+int map_hip(hipError_t e) {
+  switch (e) {
+    case hipSuccess: return ICP_OK;
+    case hipErrorOutOfMemory: return ICP_OUT_OF_MEMORY;
+    case hipErrorNoDevice:
+    case hipErrorInvalidDevice:
+    case hipErrorInsufficientDriver:
+    case hipErrorNotInitialized: return ICP_NO_DEVICE;
+    default: return ICP_HIP_ERROR;
+  }
+}
+
+#define HIP_TRY(expr)                                \
+  do {                                               \
+    hipError_t e__ = (expr);                         \
+    if (e__ != hipSuccess) return map_hip(e__);      \
+  } while (0)
+
+template <typename Tp>
+hipError_t grow(Tp *&p, size_t count) {
+  if (p) {
+    hipError_t e = hipFree(p);
+    p = nullptr;
+    if (e != hipSuccess) return e;
+  }
+  return hipMalloc(&p, (count ? count : 1) * sizeof(Tp));
+}
+
+void free_workspace(Workspace &w) {
+  (void)hipFree(w.d_src);
+  (void)hipFree(w.d_a);
+  (void)hipFree(w.d_b);
+  (void)hipFree(w.d_rx);
+  (void)hipFree(w.d_ry);
+  (void)hipFree(w.d_idx);
+  (void)hipFree(w.d_part_d);
+  (void)hipFree(w.d_part_i);
+  (void)hipFree(w.d_hist);
+  (void)hipFree(w.d_sel);
+  (void)hipFree(w.d_scal);
+  (void)hipFree(w.d_partials);
+  if (w.h_res) (void)hipHostFree(w.h_res);
+  w = Workspace();
+}
+
+}  // namespace
+
+namespace icp {
+
+hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
+  Workspace &w = h->ws;
+  hipError_t e;
+  if (!w.d_hist) {
+    if ((e = hipMalloc(&w.d_hist, kSelProblems * kSelBins * sizeof(uint32_t))) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(w.d_hist, 0, kSelProblems * kSelBins * sizeof(uint32_t), h->stream)) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_sel, kSelProblems * sizeof(SelState))) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_scal, sizeof(GnScalars))) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_partials, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipHostMalloc(&w.h_res, sizeof(GnResult), 0)) != hipSuccess) return e;
+  }
+  if (n > w.cap_n) {
+    // in-flight work may still read the old buffers
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
+    size_t cap = n + n / 8;
+    (void)hipFree(w.d_src);
+    w.d_src = nullptr;
+    if ((e = grow(w.d_a, cap * 2)) != hipSuccess) return e;
+    if ((e = grow(w.d_b, cap * 2)) != hipSuccess) return e;
+    if ((e = grow(w.d_rx, cap)) != hipSuccess) return e;
+    if ((e = grow(w.d_ry, cap)) != hipSuccess) return e;
+    if ((e = grow(w.d_idx, cap)) != hipSuccess) return e;
+    w.cap_n = cap;
+  }
+  if (need_src && !w.d_src) {
+    if ((e = hipMalloc(&w.d_src, (w.cap_n ? w.cap_n : 1) * 3 * sizeof(double))) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+}  // namespace icp
+
+// ------------------------------------------------------------------ misc ---------
+extern "C" const char *icp_status_string(int s) {
+  switch (s) {
+    case ICP_OK: return "ok";
+    case ICP_NONE: return "none (the reference returns None)";
+    case ICP_EMPTY_DST: return "empty dst (the reference panics on index.unwrap())";
+    case ICP_NAN_INPUT: return "NaN residual (the reference panics on partial_cmp().unwrap())";
+    case ICP_BAD_ARGUMENT: return "bad argument";
+    case ICP_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case ICP_HIP_ERROR: return "HIP error";
+    case ICP_OUT_OF_MEMORY: return "out of device memory";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int icp_abi_version(void) { return ICP_ABI_VERSION; }
+
+extern "C" int icp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------- host pose algebra -------
+extern "C" void icp_transform_new(const double p[3], icp_pose *out) { *out = transform_new(p); }
+extern "C" void icp_transform_from_rt(const double r[4], const double t[2], icp_pose *out) {
+  *out = icp_pose{r[0], r[1], r[2], r[3], t[0], t[1]};
+}
+extern "C" void icp_transform_identity(icp_pose *out) { *out = transform_identity(); }
+extern "C" void icp_transform_apply(const icp_pose *T, const double p[2], double out[2]) {
+  double o[2];
+  transform_apply(*T, p, o);
+  out[0] = o[0];
+  out[1] = o[1];
+}
+extern "C" void icp_transform_inverse(const icp_pose *T, icp_pose *out) { *out = transform_inverse(*T); }
+extern "C" void icp_transform_mul(const icp_pose *l, const icp_pose *r, icp_pose *out) {
+  *out = transform_mul(*l, *r);
+}
+extern "C" void icp_se2_exp(const double p[3], double m[9]) { se2_exp(p, m); }
+extern "C" void icp_se2_log(const double m[9], double p[3]) { se2_log(m, p); }
+extern "C" void icp_se2_get_rt(const double m[9], double rot[4], double t[2]) { se2_get_rt(m, rot, t); }
+extern "C" void icp_so2_exp(double theta, double m[4]) { so2_exp(theta, m); }
+extern "C" double icp_so2_log(const double m[4]) { return so2_log(m); }
+extern "C" double icp_norm(const double *m, size_t nrows, size_t ncols) { return icp::norm(m, nrows, ncols); }
+extern "C" int icp_inverse3x3(const double m[9], double out[9]) {
+  return inverse3x3(m, out) ? ICP_OK : ICP_NONE;
+}
+extern "C" void icp_reduce_geometry(size_t n, int *blocks, int *threads) { reduce_geometry(n, blocks, threads); }
+
+// ---------------------------------------------------------------- handle ---------
+static int create_common(icp_handle **out, int dim, const double *dst, size_t m, int device, bool dst_on_device) {
+  if (!out || (dim != 2 && dim != 3) || (m > 0 && !dst) || m >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ICP_NO_DEVICE;
+  if (device < 0) HIP_TRY(hipGetDevice(&device));
+  if (device >= count) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(device));
+  icp_handle *h = new (std::nothrow) icp_handle();
+  if (!h) return ICP_OUT_OF_MEMORY;
+  h->dim = dim;
+  h->m = m;
+  h->device = device;
+  int rc = ICP_OK;
+  do {
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { rc = map_hip(e); break; }
+    h->stream = h->own_stream;
+    if (dst_on_device || m == 0) {
+      h->d_dst = dst;
+      h->owns_dst = false;
+    } else {
+      double *p = nullptr;
+      if ((e = hipMalloc(&p, m * dim * sizeof(double))) != hipSuccess) { rc = map_hip(e); break; }
+      h->d_dst = p;
+      h->owns_dst = true;
+      if ((e = hipMemcpyAsync(p, dst, m * dim * sizeof(double), hipMemcpyHostToDevice, h->stream)) != hipSuccess) { rc = map_hip(e); break; }
+    }
+    if ((e = build_target_soa(h)) != hipSuccess) { rc = map_hip(e); break; }
+    if ((e = ensure_workspace(h, 0, false)) != hipSuccess) { rc = map_hip(e); break; }
+    // the host buffer may be freed by the caller as soon as we return
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) { rc = map_hip(e); break; }
+  } while (0);
+  if (rc != ICP_OK) {
+    icp_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return ICP_OK;
+}
+
+extern "C" int icp_create(icp_handle **out, int dim, const double *dst, size_t m, int device) {
+  return create_common(out, dim, dst, m, device, false);
+}
+extern "C" int icp_create_device(icp_handle **out, int dim, const double *d_dst, size_t m, int device) {
+  return create_common(out, dim, d_dst, m, device, true);
+}
+
+extern "C" void icp_destroy(icp_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  for (auto &ev : h->prof_events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  free_workspace(h->ws);
+  if (h->owns_dst) (void)hipFree(const_cast<double *>(h->d_dst));
+  (void)hipFree(h->d_dst_soa);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+extern "C" int icp_set_nn_mode(icp_handle *h, int mode) {
+  if (!h || mode < ICP_NN_AUTO || mode > ICP_NN_GRID) return ICP_BAD_ARGUMENT;
+  if (mode == ICP_NN_GRID) return ICP_BAD_ARGUMENT;  // not built yet
+  h->nn_mode = mode;
+  return ICP_OK;
+}
+extern "C" int icp_get_nn_mode(const icp_handle *h) {
+  if (!h) return ICP_BAD_ARGUMENT;
+  return ICP_NN_BRUTE;
+}
+extern "C" int icp_set_stream(icp_handle *h, void *s) {
+  if (!h) return ICP_BAD_ARGUMENT;
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return ICP_OK;
+}
+extern "C" int icp_synchronize(icp_handle *h) {
+  if (!h) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ICP_OK;
+}
+
+extern "C" int icp_profile_enable(icp_handle *h, int enable) {
+  if (!h) return ICP_BAD_ARGUMENT;
+  h->profile = enable != 0;
+  return ICP_OK;
+}
+extern "C" int icp_profile_read(icp_handle *h, double *ms, uint64_t *launches) {
+  if (!h) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double total = 0.;
+  for (auto &ev : h->prof_events) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) total += t;
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (ms) *ms = total;
+  if (launches) *launches = h->prof_events.size();
+  h->prof_events.clear();
+  return ICP_OK;
+}
+
+// ------------------------------------------------------------ stage calls --------
+extern "C" int icp_correspond_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T,
+                                     double *d_a, double *d_b, uint32_t *d_idx) {
+  if (!h || !T || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  if (n == 0) return ICP_OK;
+  if (h->m == 0) return ICP_EMPTY_DST;  // index.unwrap() on an empty tree, src/lib.rs:122,165
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(launch_nn_brute(h, d_src, n, T, d_a, d_b, d_idx));
+  return ICP_OK;
+}
+
+extern "C" int icp_nn_search_device(icp_handle *h, const double *d_q, size_t n, uint32_t *d_idx) {
+  if (!h || (n > 0 && (!d_q || !d_idx)) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  if (n == 0) return ICP_OK;
+  if (h->m == 0) return ICP_EMPTY_DST;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(launch_nn_brute(h, d_q, n, nullptr, nullptr, nullptr, d_idx));
+  return ICP_OK;
+}
+
+// check_input_size, src/lib.rs:186-189
+static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
+
+// weighted_gauss_newton_update on device pairs (src/lib.rs:218-261); also yields the
+// Huber error of the same T (src/lib.rs:75), which shares the pass.
+static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
+                    double delta[3], double *huber_err) {
+  HIP_TRY(launch_weighted_gn(h, d_a, d_b, n, T));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const GnResult &r = *h->ws.h_res;
+  if (r.nan_flag) return ICP_NAN_INPUT;
+  if (huber_err) *huber_err = r.acc[12];
+  return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
+}
+
+extern "C" int icp_estimate_transform_device(icp_handle *h, const double *d_a, const double *d_b, size_t n,
+                                             icp_pose *out, uint32_t *inner_iters) {
+  if (!h || !out || (n > 0 && (!d_a || !d_b)) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  Pose T = transform_identity();
+  uint32_t applied = 0;
+  if (input_size_ok(n)) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(ensure_workspace(h, n, false));
+    HIP_TRY(launch_sel_init(h, n));
+    double prev_error = DBL_MAX;  // f64::MAX, src/lib.rs:63
+    for (int it = 0; it < ICP_INNER_MAX_ITER; ++it) {
+      double delta[3], err = 0.;
+      const int rc = wgn_step(h, d_a, d_b, n, T, delta, &err);
+      if (rc == ICP_NONE) break;           // src/lib.rs:67-69
+      if (rc != ICP_OK) return rc;
+      if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD)
+        break;                             // src/lib.rs:71-73
+      if (err > prev_error) break;         // src/lib.rs:75-78
+      prev_error = err;
+      T = transform_mul(transform_new(delta), T);  // src/lib.rs:81
+      ++applied;
+    }
+  }
+  *out = T;
+  if (inner_iters) *inner_iters = applied;
+  return ICP_OK;
+}
+
+extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *init,
+                                   size_t max_iter, icp_pose *out, uint32_t *d_last_idx,
+                                   uint32_t *inner_iters) {
+  if (!h || !init || !out || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(ensure_workspace(h, n, false));
+  Pose T = *init;
+  for (size_t it = 0; it < max_iter; ++it) {
+    uint32_t *idx_out = (it + 1 == max_iter) ? d_last_idx : nullptr;
+    int rc = icp_correspond_device(h, d_src, n, &T, h->ws.d_a, h->ws.d_b, idx_out);
+    if (rc != ICP_OK) return rc;
+    Pose dT;
+    uint32_t inner = 0;
+    rc = icp_estimate_transform_device(h, h->ws.d_a, h->ws.d_b, n, &dT, &inner);
+    if (rc != ICP_OK) return rc;
+    if (inner_iters) inner_iters[it] = inner;
+    T = transform_mul(dT, T);  // src/lib.rs:127, 170
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *out = T;
+  return ICP_OK;
+}
+
+extern "C" int icp_estimate(icp_handle *h, const double *src, size_t n, const icp_pose *init, size_t max_iter,
+                            icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters) {
+  if (!h || !init || !out || (n > 0 && !src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(ensure_workspace(h, n, true));
+  if (n > 0)
+    HIP_TRY(hipMemcpyAsync(h->ws.d_src, src, n * h->dim * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const int rc = icp_estimate_device(h, h->ws.d_src, n, init, max_iter, out,
+                                     last_idx ? h->ws.d_idx : nullptr, inner_iters);
+  if (rc != ICP_OK) return rc;
+  if (last_idx && n > 0 && max_iter > 0) {
+    HIP_TRY(hipMemcpyAsync(last_idx, h->ws.d_idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return ICP_OK;
+}
+
+// ------------------------------------------- free functions on host buffers ------
+namespace {
+
+std::mutex g_scratch_mu;
+icp_handle *g_scratch = nullptr;  // dim 2, no targets; lives for the process
+
+int scratch_handle(icp_handle **out) {
+  if (!g_scratch) {
+    const int rc = icp_create(&g_scratch, 2, nullptr, 0, -1);
+    if (rc != ICP_OK) return rc;
+  }
+  *out = g_scratch;
+  return ICP_OK;
+}
+
+// stage host pairs into the scratch handle's a/b buffers
+int stage_pairs(icp_handle *h, const double *a, const double *b, size_t n) {
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(ensure_workspace(h, n, false));
+  if (n > 0) {
+    HIP_TRY(hipMemcpyAsync(h->ws.d_a, a, n * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->ws.d_b, b, n * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  return ICP_OK;
+}
+
+}  // namespace
+
+extern "C" int icp_estimate_transform(const double *a, const double *b, size_t n, icp_pose *out,
+                                      uint32_t *inner_iters) {
+  if (!out || (n > 0 && (!a || !b))) return ICP_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  icp_handle *h;
+  int rc = scratch_handle(&h);
+  if (rc != ICP_OK) return rc;
+  if ((rc = stage_pairs(h, a, b, n)) != ICP_OK) return rc;
+  return icp_estimate_transform_device(h, h->ws.d_a, h->ws.d_b, n, out, inner_iters);
+}
+
+extern "C" int icp_weighted_gauss_newton_update(const icp_pose *T, const double *a, const double *b, size_t n,
+                                                double delta[3]) {
+  if (!T || !delta || (n > 0 && (!a || !b))) return ICP_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  icp_handle *h;
+  int rc = scratch_handle(&h);  // a missing device is reported before any result
+  if (rc != ICP_OK) return rc;
+  if (!input_size_ok(n)) return ICP_NONE;  // src/lib.rs:225-228
+  if ((rc = stage_pairs(h, a, b, n)) != ICP_OK) return rc;
+  HIP_TRY(launch_sel_init(h, n));
+  return wgn_step(h, h->ws.d_a, h->ws.d_b, n, *T, delta, nullptr);
+}
+
+static int plain_pass(const icp_pose *T, const double *a, const double *b, size_t n, GnResult *res) {
+  icp_handle *h;
+  int rc = scratch_handle(&h);
+  if (rc != ICP_OK) return rc;
+  if ((rc = stage_pairs(h, a, b, n)) != ICP_OK) return rc;
+  HIP_TRY(launch_plain_gn(h, h->ws.d_a, h->ws.d_b, n, *T));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *res = *h->ws.h_res;
+  return ICP_OK;
+}
+
+extern "C" int icp_gauss_newton_update(const icp_pose *T, const double *a, const double *b, size_t n,
+                                       double delta[3]) {
+  if (!T || !delta || (n > 0 && (!a || !b))) return ICP_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  icp_handle *h;
+  int rc = scratch_handle(&h);
+  if (rc != ICP_OK) return rc;
+  if (!input_size_ok(n)) return ICP_NONE;  // src/lib.rs:196-199
+  GnResult r;
+  if ((rc = plain_pass(T, a, b, n, &r)) != ICP_OK) return rc;
+  return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
+}
+
+extern "C" int icp_error(const icp_pose *T, const double *a, const double *b, size_t n, double *out) {
+  if (!T || !out || (n > 0 && (!a || !b))) return ICP_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  GnResult r;
+  const int rc = plain_pass(T, a, b, n, &r);
+  if (rc != ICP_OK) return rc;
+  *out = r.acc[13];
+  return ICP_OK;
+}
+
+extern "C" int icp_huber_error(const icp_pose *T, const double *a, const double *b, size_t n, double *out) {
+  if (!T || !out || (n > 0 && (!a || !b))) return ICP_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  GnResult r;
+  const int rc = plain_pass(T, a, b, n, &r);
+  if (rc != ICP_OK) return rc;
+  *out = r.acc[12];
+  return ICP_OK;
+}
+
+extern "C" int icp_residual_stddevs(const icp_pose *T, const double *a, const double *b, size_t n,
+                                    double sigma[2]) {
+  if (!T || !sigma || (n > 0 && (!a || !b))) return ICP_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  icp_handle *h;
+  int rc = scratch_handle(&h);
+  if (rc != ICP_OK) return rc;
+  if (n == 0) return ICP_NONE;  // mutable_median of an empty input, src/stats.rs:15-17
+  if ((rc = stage_pairs(h, a, b, n)) != ICP_OK) return rc;
+  HIP_TRY(launch_sel_init(h, n));
+  HIP_TRY(launch_stddevs(h, h->ws.d_a, h->ws.d_b, n, *T));
+  GnScalars s;
+  HIP_TRY(hipMemcpyAsync(&s, h->ws.d_scal, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (s.nan_flag) return ICP_NAN_INPUT;
+  sigma[0] = s.sigma[0];
+  sigma[1] = s.sigma[1];
+  return ICP_OK;
+}

@@ -1,0 +1,110 @@
+// Shared declarations of the device side: handle layout, workspace, kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "pose.hpp"
+
+namespace icp {
+
+constexpr int kReduceThreads = 256;   // threads per block of the GN reduction tree
+constexpr int kReduceMaxBlocks = 1024;
+constexpr int kNAcc = 13;             // jtj[9], jtr[3], huber error
+constexpr int kSelProblems = 4;       // {x, y} x {lower, upper middle order statistic}
+constexpr int kSelBins = 4096;        // 12-bit radix digits
+constexpr int kSelPasses = 6;         // 12+12+12+12+12+4 bits
+
+inline void reduce_geometry(size_t n, int *blocks, int *threads) {
+  size_t b = (n + kReduceThreads - 1) / kReduceThreads;
+  if (b < 1) b = 1;
+  if (b > (size_t)kReduceMaxBlocks) b = kReduceMaxBlocks;
+  *blocks = (int)b;
+  *threads = kReduceThreads;
+}
+
+// One exact order-statistic search (radix select state), device resident.
+struct SelState {
+  unsigned long long prefix;  // key bits fixed so far (high bits)
+  unsigned long long rank;    // rank of the wanted element inside the prefix group
+  int alias;                  // >= 0: shares the histogram of that problem (same prefix)
+  int pad;
+};
+
+// Device-resident scalars of one inner iteration.
+struct GnScalars {
+  double median[2];
+  double sigma[2];
+  int nan_flag;
+  int pad;
+};
+
+// What the last kernel of an inner iteration hands to the host (pinned, mapped).
+struct GnResult {
+  double acc[kNAcc + 1];  // jtj[9], jtr[3], huber error, (plain) error
+  double sigma[2];
+  int nan_flag;
+  int pad;
+};
+
+struct Workspace {
+  size_t cap_n = 0;        // points the per-point buffers hold
+  double *d_src = nullptr; // staged source cloud (host API), cap_n x dim
+  double *d_a = nullptr;   // transformed source xy, cap_n x 2
+  double *d_b = nullptr;   // matched target xy, cap_n x 2
+  double *d_rx = nullptr;  // residual x, cap_n
+  double *d_ry = nullptr;  // residual y, cap_n
+  uint32_t *d_idx = nullptr;
+  // brute-force NN partial minima when the target range is split over blockIdx.y
+  size_t cap_part = 0;
+  double *d_part_d = nullptr;
+  uint32_t *d_part_i = nullptr;
+  // selection + reduction scratch (fixed size)
+  uint32_t *d_hist = nullptr;   // kSelProblems x kSelBins
+  SelState *d_sel = nullptr;    // kSelProblems
+  GnScalars *d_scal = nullptr;
+  double *d_partials = nullptr; // kReduceMaxBlocks x (kNAcc+1)
+  GnResult *h_res = nullptr;    // pinned host, device-visible
+};
+
+}  // namespace icp
+
+struct icp_handle {
+  int dim = 0;
+  size_t m = 0;
+  int device = 0;
+  int nn_mode = ICP_NN_AUTO;
+  bool owns_dst = false;
+  const double *d_dst = nullptr; // AoS m x dim (owned or borrowed)
+  double *d_dst_soa = nullptr;   // x[m_pad] | y[m_pad] | z[m_pad], padded with +inf
+  size_t m_pad = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  icp::Workspace ws;
+  // live kernel timing (icp_profile_*): event pairs around the NN search kernel
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+};
+
+namespace icp {
+
+// ---- launchers (each enqueues on h->stream and returns the HIP error) ---------------
+hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src);
+hipError_t build_target_soa(icp_handle *h);
+
+// transform (optional) + brute-force exact NN + gather of the matched xy pairs
+hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n, const Pose *T,
+                           double *d_a, double *d_b, uint32_t *d_idx);
+
+// one inner Gauss-Newton iteration's device work; results land in h->ws.h_res after the
+// stream is synchronised
+hipError_t launch_weighted_gn(icp_handle *h, const double *d_a, const double *d_b, size_t n,
+                              const Pose &T);
+// unweighted accumulation (gauss_newton_update / error / huber_error)
+hipError_t launch_plain_gn(icp_handle *h, const double *d_a, const double *d_b, size_t n,
+                           const Pose &T);
+
+}  // namespace icp

@@ -1,0 +1,269 @@
+// Exact brute-force nearest neighbour for gfx950, fused with the pose transform.
+//
+// Replaces, for one outer ICP iteration, the reference's
+//   src.map(transform / transform_xy)            src/lib.rs:113-116, 156-159 (-> :52-57)
+//   .map(|sp| dst[kdtree.search(&sp).0.unwrap()]) src/lib.rs:118-124, 161-167
+//   get_xy(..)                                    src/lib.rs:86-89
+// The kd-tree (un-vendored crate `nearest_neighbor`) is replaced by an exhaustive scan:
+// exact NN is exact NN.  Contract: d^2 = ((dx*dx + dy*dy) + dz*dz) in f64
+// without FMA contraction, ties -> lowest target index (targets are scanned in ascending
+// index order with a strict `<`).
+//
+// Mapping to the hardware: the path is FP64-VALU bound (8 f64 flops + compare/select per
+// pair, N*M pairs; 52 MB of compulsory HBM traffic at 1M x 1M), so the kernel is built
+// to keep the vector ALUs busy and everything else off the critical path:
+//   * every lane owns R query points in registers (R x {x,y,z,best,idx});
+//   * targets stream through LDS as SoA tiles, filled with coalesced 8-B loads and read
+//     back with wave-uniform addresses (LDS broadcast: one ds_read feeds 64 x R pairs);
+//   * the target array is padded with +inf to a whole number of tiles, so the inner loop
+//     has no bounds test;
+//   * small source clouds split the target range over blockIdx.y so that the grid still
+//     covers the 1024 SIMDs; the per-chunk minima are merged in index order.
+#include "common.hpp"
+
+namespace icp {
+
+constexpr int kNnThreads = 256;
+constexpr int kNnTile = 1024;  // targets per LDS tile
+
+template <int DIM, int R, bool XFORM>
+__global__ __launch_bounds__(kNnThreads) void k_nn_brute(
+    const double *__restrict__ src, unsigned n, const double *__restrict__ tx,
+    const double *__restrict__ ty, const double *__restrict__ tz, unsigned m_pad, unsigned chunk,
+    Pose T, double *__restrict__ part_d, uint32_t *__restrict__ part_i) {
+  __shared__ double sx[kNnTile];
+  __shared__ double sy[kNnTile];
+  __shared__ double sz[DIM == 3 ? kNnTile : 1];
+
+  const unsigned q0 = blockIdx.x * (kNnThreads * R) + threadIdx.x;
+  double qx[R], qy[R], qz[R], best[R];
+  unsigned bi[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const unsigned q = q0 + r * kNnThreads;
+    double x = 0., y = 0., z = 0.;
+    if (q < n) {
+      x = src[(size_t)q * DIM + 0];
+      y = src[(size_t)q * DIM + 1];
+      if (DIM == 3) z = src[(size_t)q * DIM + 2];
+    }
+    if (XFORM) {  // Transform::transform, src/transform.rs:22-24 (z untouched, lib.rs:52-57)
+      const double nx = (T.r00 * x + T.r01 * y) + T.tx;
+      const double ny = (T.r10 * x + T.r11 * y) + T.ty;
+      x = nx;
+      y = ny;
+    }
+    qx[r] = x;
+    qy[r] = y;
+    qz[r] = z;
+    best[r] = __builtin_huge_val();
+    bi[r] = 0xffffffffu;
+  }
+
+  const unsigned t_begin = blockIdx.y * chunk;
+  const unsigned t_end = min(m_pad, t_begin + chunk);
+  for (unsigned t0 = t_begin; t0 < t_end; t0 += kNnTile) {
+    __syncthreads();
+    for (unsigned k = threadIdx.x; k < kNnTile; k += kNnThreads) {
+      sx[k] = tx[t0 + k];
+      sy[k] = ty[t0 + k];
+      if (DIM == 3) sz[k] = tz[t0 + k];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (unsigned k = 0; k < kNnTile; ++k) {
+      const double px = sx[k], py = sy[k];
+      const double pz = (DIM == 3) ? sz[k] : 0.;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double dx = qx[r] - px;
+        const double dy = qy[r] - py;
+        double d = dx * dx + dy * dy;
+        if (DIM == 3) {
+          const double dz = qz[r] - pz;
+          d = d + dz * dz;
+        }
+        if (d < best[r]) {
+          best[r] = d;
+          bi[r] = t0 + k;
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const unsigned q = q0 + r * kNnThreads;
+    if (q < n) {
+      part_i[(size_t)blockIdx.y * n + q] = bi[r];
+      if (gridDim.y > 1) part_d[(size_t)blockIdx.y * n + q] = best[r];
+    }
+  }
+}
+
+// Merge the per-chunk minima (ascending chunk order + strict `<` keeps the lowest
+// index on ties), then emit idx and the matched xy pairs a = xy(T.src), b = xy(dst[idx]).
+template <int DIM, bool XFORM>
+__global__ __launch_bounds__(256) void k_nn_finalize(
+    const double *__restrict__ src, unsigned n, Pose T, const double *__restrict__ part_d,
+    const uint32_t *__restrict__ part_i, unsigned chunks, const double *__restrict__ tx,
+    const double *__restrict__ ty, uint32_t *__restrict__ idx, double2 *__restrict__ a,
+    double2 *__restrict__ b) {
+  const unsigned q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= n) return;
+  unsigned bi = part_i[q];
+  if (chunks > 1) {
+    double best = part_d[q];
+    for (unsigned c = 1; c < chunks; ++c) {
+      const double d = part_d[(size_t)c * n + q];
+      if (d < best) {
+        best = d;
+        bi = part_i[(size_t)c * n + q];
+      }
+    }
+  }
+  if (bi == 0xffffffffu) bi = 0;  // no finite distance at all: index 0, as a scan from 0 would
+  if (idx) idx[q] = bi;
+  if (a) {
+    double x = src[(size_t)q * DIM + 0];
+    double y = src[(size_t)q * DIM + 1];
+    if (XFORM) {
+      const double nx = (T.r00 * x + T.r01 * y) + T.tx;
+      const double ny = (T.r10 * x + T.r11 * y) + T.ty;
+      x = nx;
+      y = ny;
+    }
+    a[q] = make_double2(x, y);
+  }
+  if (b) b[q] = make_double2(tx[bi], ty[bi]);
+}
+
+// AoS (as handed over by the host) -> padded SoA x|y|z used by the scan
+__global__ void k_build_soa(const double *__restrict__ dst, unsigned m, unsigned m_pad, int dim,
+                            double *__restrict__ soa) {
+  const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m_pad) return;
+  const double inf = __builtin_huge_val();
+  for (int d = 0; d < 3; ++d) {
+    double v = inf;
+    if (j < m) v = (d < dim) ? dst[(size_t)j * dim + d] : 0.;
+    soa[(size_t)d * m_pad + j] = v;
+  }
+}
+
+hipError_t build_target_soa(icp_handle *h) {
+  const size_t m_pad = ((h->m + kNnTile - 1) / kNnTile) * kNnTile;
+  h->m_pad = m_pad;
+  if (m_pad == 0) return hipSuccess;
+  hipError_t e = hipMalloc(&h->d_dst_soa, 3 * m_pad * sizeof(double));
+  if (e != hipSuccess) return e;
+  const unsigned blocks = (unsigned)((m_pad + 255) / 256);
+  hipLaunchKernelGGL(k_build_soa, dim3(blocks), dim3(256), 0, h->stream, h->d_dst, (unsigned)h->m,
+                     (unsigned)m_pad, h->dim, h->d_dst_soa);
+  return hipGetLastError();
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+template <int DIM, int R, bool XFORM>
+static void launch_one(icp_handle *h, const double *d_src, unsigned n, const Pose &T, unsigned qblocks,
+                       unsigned chunks, unsigned chunk) {
+  const double *tx = h->d_dst_soa, *ty = tx + h->m_pad, *tz = ty + h->m_pad;
+  hipLaunchKernelGGL((k_nn_brute<DIM, R, XFORM>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
+                     d_src, n, tx, ty, tz, (unsigned)h->m_pad, chunk, T, h->ws.d_part_d, h->ws.d_part_i);
+}
+
+template <int DIM, bool XFORM>
+static void launch_r(icp_handle *h, int R, const double *d_src, unsigned n, const Pose &T, unsigned qblocks,
+                     unsigned chunks, unsigned chunk) {
+  switch (R) {
+    case 1: launch_one<DIM, 1, XFORM>(h, d_src, n, T, qblocks, chunks, chunk); break;
+    case 2: launch_one<DIM, 2, XFORM>(h, d_src, n, T, qblocks, chunks, chunk); break;
+    case 4: launch_one<DIM, 4, XFORM>(h, d_src, n, T, qblocks, chunks, chunk); break;
+    default: launch_one<DIM, 8, XFORM>(h, d_src, n, T, qblocks, chunks, chunk); break;
+  }
+}
+
+hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n_, const Pose *Tp, double *d_a,
+                           double *d_b, uint32_t *d_idx) {
+  if (n_ == 0) return hipSuccess;
+  const unsigned n = (unsigned)n_;
+  const bool xform = Tp != nullptr;
+  const Pose T = xform ? *Tp : transform_identity();
+
+  // queries per lane: enough waves to cover 1024 SIMDs several times over, then as
+  // many registers-resident queries as that allows (fewer LDS reads per pair)
+  static const int forced_r = env_int("ICP_NN_R", 0);
+  int R = 1;
+  if (n >= 4u * 256u * 1024u) R = 8;
+  else if (n >= 2u * 256u * 1024u) R = 4;
+  else if (n >= 256u * 1024u) R = 2;
+  if (forced_r == 1 || forced_r == 2 || forced_r == 4 || forced_r == 8) R = forced_r;
+  const unsigned qblocks = (n + kNnThreads * R - 1) / (kNnThreads * R);
+  const unsigned tiles = (unsigned)(h->m_pad / kNnTile);
+  // split the targets when the query blocks alone cannot fill the chip
+  static const int forced_chunks = env_int("ICP_NN_CHUNKS", 0);
+  unsigned chunks = 1;
+  const unsigned want_blocks = 2048;
+  if (qblocks < want_blocks) chunks = (want_blocks + qblocks - 1) / qblocks;
+  if (forced_chunks > 0) chunks = (unsigned)forced_chunks;
+  if (chunks > tiles) chunks = tiles;
+  if (chunks > 64) chunks = 64;
+  if (chunks < 1) chunks = 1;
+  const unsigned tiles_per_chunk = (tiles + chunks - 1) / chunks;
+  chunks = (tiles + tiles_per_chunk - 1) / tiles_per_chunk;
+  const unsigned chunk = tiles_per_chunk * kNnTile;
+
+  // partial buffers
+  const size_t need = (size_t)chunks * n;
+  if (need > h->ws.cap_part) {
+    if (h->ws.d_part_d) (void)hipFree(h->ws.d_part_d);
+    if (h->ws.d_part_i) (void)hipFree(h->ws.d_part_i);
+    h->ws.d_part_d = nullptr;
+    h->ws.d_part_i = nullptr;
+    h->ws.cap_part = 0;
+    hipError_t e = hipMalloc(&h->ws.d_part_d, need * sizeof(double));
+    if (e != hipSuccess) return e;
+    e = hipMalloc(&h->ws.d_part_i, need * sizeof(uint32_t));
+    if (e != hipSuccess) return e;
+    h->ws.cap_part = need;
+  }
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (h->profile) {
+    if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
+      (void)hipEventRecord(ev0, h->stream);
+  }
+  if (h->dim == 3) {
+    if (xform) launch_r<3, true>(h, R, d_src, n, T, qblocks, chunks, chunk);
+    else       launch_r<3, false>(h, R, d_src, n, T, qblocks, chunks, chunk);
+  } else {
+    if (xform) launch_r<2, true>(h, R, d_src, n, T, qblocks, chunks, chunk);
+    else       launch_r<2, false>(h, R, d_src, n, T, qblocks, chunks, chunk);
+  }
+  hipError_t e = hipGetLastError();
+  if (ev0 && ev1) {
+    (void)hipEventRecord(ev1, h->stream);
+    h->prof_events.emplace_back(ev0, ev1);
+  }
+  if (e != hipSuccess) return e;
+
+  const double *tx = h->d_dst_soa, *ty = tx + h->m_pad;
+  const unsigned fblocks = (n + 255) / 256;
+#define FIN(DIM, XF)                                                                             \
+  hipLaunchKernelGGL((k_nn_finalize<DIM, XF>), dim3(fblocks), dim3(256), 0, h->stream, d_src, n, T, \
+                     h->ws.d_part_d, h->ws.d_part_i, chunks, tx, ty, d_idx, (double2 *)d_a,       \
+                     (double2 *)d_b)
+  if (h->dim == 3) {
+    if (xform) FIN(3, true); else FIN(3, false);
+  } else {
+    if (xform) FIN(2, true); else FIN(2, false);
+  }
+#undef FIN
+  return hipGetLastError();
+}
+
+}  // namespace icp

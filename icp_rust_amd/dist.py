@@ -1,0 +1,99 @@
+"""Multi-GPU driver: the source cloud shards across ranks, the target cloud is replicated.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  Per outer ICP
+iteration (src/lib.rs:155-171):
+
+  1. every rank transforms + nearest-neighbour-matches ITS contiguous range of the source
+     cloud (no communication: source points are independent);
+  2. one all-gather of the matched xy pairs (32 B/point) gives every rank all N pairs in
+     the global point order;
+  3. every rank runs the identical, deterministic inner Gauss-Newton loop on all N pairs
+     (exact medians are not all-reducible sums; replicating the loop costs < 1 % of step 1
+     and needs no further collective), so all ranks hold bit-identical poses and the
+     N-GPU result equals the 1-GPU result bit for bit.
+
+The compute is delegated to a `stages` object so that the orchestration (ranges, gather,
+replication) is testable on CPU with the gloo backend; production uses HipStages.
+"""
+import numpy as np
+
+from .api import Transform
+
+
+def shard_range(n, rank, world):
+    """contiguous range [lo, hi) of rank `rank`: sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class HipStages:
+    """The two device stages of the C ABI on torch CUDA tensors (include/icp_mi355x.h, section 4)."""
+
+    def __init__(self, icp):
+        import torch
+
+        self.icp = icp
+        self.torch = torch
+        icp.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def correspond(self, src_shard, T, a_out, b_out):
+        self.icp.correspond_device(src_shard, T, a_out, b_out)
+
+    def estimate_transform(self, a_full, b_full):
+        return self.icp.estimate_transform_device(a_full, b_full)
+
+
+class ShardedIcp:
+    def __init__(self, stages, n_total, rank=0, world=1, group=None, mul=None):
+        self.stages = stages
+        self.n = n_total
+        self.rank, self.world, self.group = rank, world, group
+        self.lo, self.hi = shard_range(n_total, rank, world)
+        self.max_shard = shard_range(n_total, 0, world)[1]
+        self._mul = mul or (lambda a, b: a * b)
+        self._bufs = None
+
+    def _buffers(self, like):
+        import torch
+
+        if self._bufs is None:
+            kw = dict(dtype=torch.float64, device=like.device)
+            W, ms = self.world, self.max_shard
+            even = self.n % W == 0
+            gathered = torch.empty((2, W * ms, 2), **kw)  # [a|b] x rank-major padded shards
+            local = torch.empty((2, ms, 2), **kw)
+            full = gathered if even else torch.empty((2, self.n, 2), **kw)
+            self._bufs = (local, gathered, full, even)
+        return self._bufs
+
+    def step(self, src_shard, T):
+        """one outer iteration; returns (dT * T, inner_iters)."""
+        import torch
+        import torch.distributed as dist
+
+        local, gathered, full, even = self._buffers(src_shard)
+        ns = self.hi - self.lo
+        self.stages.correspond(src_shard, T, local[0, :ns], local[1, :ns])
+        if self.world > 1:
+            # a and b travel in one collective each so that the receive layout is rank-major
+            dist.all_gather_into_tensor(gathered[0], local[0], group=self.group)
+            dist.all_gather_into_tensor(gathered[1], local[1], group=self.group)
+            if not even:
+                ms = self.max_shard
+                for r in range(self.world):
+                    lo, hi = shard_range(self.n, r, self.world)
+                    full[:, lo:hi] = gathered[:, r * ms: r * ms + (hi - lo)]
+        else:
+            full = local
+        dT, inner = self.stages.estimate_transform(full[0, : self.n], full[1, : self.n])
+        return self._mul(dT, T), inner
+
+    def estimate(self, src_shard, initial_transform, max_iter):
+        """Icp{2,3}d::estimate over the sharded source (src/lib.rs:105-130, 148-173)."""
+        T = initial_transform
+        inner = []
+        for _ in range(max_iter):
+            T, k = self.step(src_shard, T)
+            inner.append(k)
+        return T, np.array(inner, dtype=np.uint32)

@@ -1,0 +1,176 @@
+/*
+ * icp_mi355x.h -- C ABI of the MI355X (gfx950) ICP registration core.
+ *
+ * Drop-in boundary for the hot path of tier4/icp_rust: the reference has no FFI of its
+ * own; its boundary is the crate's public Rust API (src/lib.rs:12-26).  Each entry
+ * point below names the Rust item (file:line under /root/reference) it stands in for.
+ * INTEGRATION.md shows the `extern "C"` block + safe wrappers a maintainer adds to the
+ * crate so that `Icp2d`, `Icp3d`, `Transform`, `estimate_transform`, ... keep their
+ * signatures.  Plain pointers and sizes only; no C++ or torch types cross this line.
+ *
+ * Conventions
+ *  - points are dense AoS doubles exactly as `&[Vector2]` / `&[Vector3]` lie in memory
+ *    (nalgebra ArrayStorage<f64, D, 1>: stride 16 B / 24 B), src/types.rs:4-12;
+ *  - `icp_pose` is `Transform { rot: Rotation2, t: Vector2 }` (src/transform.rs:6-10),
+ *    rotation column-major as nalgebra stores it;
+ *  - every function returns an icp_status; the reference's `None` is ICP_NONE, its two
+ *    panics (empty dst: src/lib.rs:122,165; NaN residual: src/stats.rs:12) are
+ *    ICP_EMPTY_DST / ICP_NAN_INPUT;
+ *  - one in-flight call per handle (it owns scratch + a HIP stream); handles are
+ *    independent.  All compute runs on the GPU: without a usable HIP device every
+ *    compute entry point returns ICP_NO_DEVICE -- there is no CPU fallback.
+ */
+#ifndef ICP_MI355X_H
+#define ICP_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICP_ABI_VERSION 1
+
+typedef enum icp_status {
+  ICP_OK = 0,
+  ICP_NONE = 1,        /* Option::None (src/lib.rs:67-69, 186-189, 257-260)           */
+  ICP_EMPTY_DST = 2,   /* reference panics: index.unwrap(), src/lib.rs:122,165        */
+  ICP_NAN_INPUT = 3,   /* reference panics: partial_cmp().unwrap(), src/stats.rs:12   */
+  ICP_BAD_ARGUMENT = 4,
+  ICP_NO_DEVICE = 5,   /* HIP runtime/device unavailable -- no CPU fallback exists    */
+  ICP_HIP_ERROR = 6,
+  ICP_OUT_OF_MEMORY = 7
+} icp_status;
+
+/* Transform (src/transform.rs:6-10) */
+typedef struct icp_pose {
+  double r00, r10, r01, r11; /* Rotation2, column-major */
+  double tx, ty;             /* Vector2                 */
+} icp_pose;
+
+/* constants of the path (read-only; src/lib.rs:32,60,61, src/stats.rs:42) */
+#define ICP_HUBER_K 1.345
+#define ICP_DELTA_NORM_THRESHOLD 1e-6
+#define ICP_INNER_MAX_ITER 200
+#define ICP_PPF34 1.482602218505602
+
+/* nearest-neighbour engines: identical results (exact NN, d^2 = ((dx^2+dy^2)+dz^2)
+ * without FMA, ties -> lowest index), different cost. */
+typedef enum icp_nn_mode {
+  ICP_NN_AUTO = 0,
+  ICP_NN_BRUTE = 1, /* LDS-tiled brute force, O(N*M) f64                              */
+  ICP_NN_GRID = 2   /* exact uniform-grid search built on device at icp_create        */
+} icp_nn_mode;
+
+const char *icp_status_string(int status);
+int icp_abi_version(void);
+/* number of usable HIP devices (0 on a CPU-only host; never initialises a context) */
+int icp_device_count(void);
+
+/* ================================================================================
+ * 1. Host-side pose algebra: Transform / se2 / so2 (tiny, runs on the host exactly as
+ *    in the reference; exported so the host mirror and the tests share one definition)
+ * ============================================================================== */
+void icp_transform_new(const double param[3], icp_pose *out);      /* Transform::new, transform.rs:13-16 -> se2::calc_rt se2.rs:21-41 */
+void icp_transform_from_rt(const double rot_colmajor[4], const double t[2], icp_pose *out); /* transform.rs:18-20 */
+void icp_transform_identity(icp_pose *out);                        /* transform.rs:34-39 */
+void icp_transform_apply(const icp_pose *T, const double p[2], double out[2]);   /* Transform::transform, transform.rs:22-24 */
+void icp_transform_inverse(const icp_pose *T, icp_pose *out);      /* transform.rs:26-32 */
+void icp_transform_mul(const icp_pose *lhs, const icp_pose *rhs, icp_pose *out); /* impl Mul, transform.rs:42-51 */
+void icp_se2_exp(const double param[3], double m3_rowmajor[9]);    /* se2::exp, se2.rs:43-52 */
+void icp_se2_log(const double m3_rowmajor[9], double param[3]);    /* se2::log, se2.rs:54-77 */
+void icp_se2_get_rt(const double m3_rowmajor[9], double rot_rowmajor[4], double t[2]); /* se2::get_rt, se2.rs:11-19 */
+void icp_so2_exp(double theta, double m2_colmajor[4]);             /* so2::exp / new_rotation2, so2.rs:8-31 */
+double icp_so2_log(const double m2_colmajor[4]);                   /* so2::log, so2.rs:19-21 */
+double icp_norm(const double *m_colmajor, size_t nrows, size_t ncols); /* icp::norm, norm.rs:19-21 */
+int icp_inverse3x3(const double m_rowmajor[9], double out_rowmajor[9]); /* linalg::inverse3x3, linalg.rs:3-29 (ICP_NONE iff det == 0) */
+
+/* ================================================================================
+ * 2. The registration handle: Icp2d / Icp3d
+ * ============================================================================== */
+typedef struct icp_handle icp_handle;
+
+/* Icp2d::new (src/lib.rs:97-102) / Icp3d::new (src/lib.rs:139-144).  dim = 2 | 3.
+ * Copies `dst` (m points, AoS) to the device and builds the search structure there, so
+ * `dst` may be freed afterwards (stricter than the reference's borrow `'a`, never
+ * weaker).  device < 0 selects the current HIP device. */
+int icp_create(icp_handle **out, int dim, const double *dst, size_t m, int device);
+/* same, but `d_dst` already lives in device memory (m x dim doubles, AoS); it is
+ * borrowed for the lifetime of the handle, like the reference's `&'a [Vector]`. */
+int icp_create_device(icp_handle **out, int dim, const double *d_dst, size_t m, int device);
+void icp_destroy(icp_handle *h);
+
+int icp_set_nn_mode(icp_handle *h, int mode);   /* icp_nn_mode; default ICP_NN_AUTO */
+int icp_get_nn_mode(const icp_handle *h);       /* the engine AUTO resolved to      */
+/* run the handle's kernels on a caller-owned HIP stream (hipStream_t) instead of the
+ * handle's own; pass NULL to go back.  Used by hosts that interleave their own device
+ * work (e.g. RCCL collectives) with the stage-level calls of section 4. */
+int icp_set_stream(icp_handle *h, void *hip_stream);
+
+/* Icp2d::estimate (src/lib.rs:105-130) / Icp3d::estimate (src/lib.rs:148-173):
+ * exactly `max_iter` outer iterations of transform -> exact NN -> estimate_transform
+ * -> compose.  src: n points AoS (host).  Optional outputs (NULL to skip):
+ *   last_idx[n]          correspondence indices of the last outer iteration,
+ *   inner_iters[max_iter] inner Gauss-Newton updates applied per outer iteration. */
+int icp_estimate(icp_handle *h, const double *src, size_t n, const icp_pose *init,
+                 size_t max_iter, icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters);
+/* same with `d_src` (and optional d_last_idx) resident in device memory */
+int icp_estimate_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *init,
+                        size_t max_iter, icp_pose *out, uint32_t *d_last_idx,
+                        uint32_t *inner_iters);
+
+/* ================================================================================
+ * 3. The robust pose estimator as free functions (host buffers; a, b are n x 2 AoS)
+ * ============================================================================== */
+/* icp::estimate_transform, src/lib.rs:59-84.  inner_iters (nullable) = updates applied */
+int icp_estimate_transform(const double *a_xy, const double *b_xy, size_t n, icp_pose *out,
+                           uint32_t *inner_iters);
+/* icp::weighted_gauss_newton_update, src/lib.rs:218-261 (ICP_NONE where it returns None) */
+int icp_weighted_gauss_newton_update(const icp_pose *T, const double *a_xy, const double *b_xy,
+                                     size_t n, double delta[3]);
+/* icp::gauss_newton_update, src/lib.rs:191-216 */
+int icp_gauss_newton_update(const icp_pose *T, const double *a_xy, const double *b_xy, size_t n,
+                            double delta[3]);
+/* icp::error, src/lib.rs:38-43 and icp::huber_error, src/lib.rs:45-50 */
+int icp_error(const icp_pose *T, const double *a_xy, const double *b_xy, size_t n, double *out);
+int icp_huber_error(const icp_pose *T, const double *a_xy, const double *b_xy, size_t n, double *out);
+/* stats::calc_stddevs over the residuals T*a - b (src/stats.rs:49-60, called at
+ * src/lib.rs:236): sigma[2] = 1.4826 * MAD per dimension.  Exposed for parity tests. */
+int icp_residual_stddevs(const icp_pose *T, const double *a_xy, const double *b_xy, size_t n,
+                         double sigma[2]);
+
+/* ================================================================================
+ * 4. Stage-level calls on device memory (what a multi-GPU host composes: shard the
+ *    source cloud over ranks, all-gather the matched pairs, replicate the tiny solve)
+ * ============================================================================== */
+/* stage (i) of one outer iteration, src/lib.rs:113-124 / 156-167 (+ get_xy :86-89):
+ * s' = T (.) src; idx = NN(s'); a = xy(s'); b = xy(dst[idx]).  d_src: n x dim AoS;
+ * d_a, d_b: n x 2 AoS out; d_idx: n out (nullable).  Asynchronous on the handle's
+ * stream. */
+int icp_correspond_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T,
+                          double *d_a_xy, double *d_b_xy, uint32_t *d_idx);
+/* stage (ii)+(iii): the whole inner loop of src/lib.rs:59-84 on device-resident pairs;
+ * synchronises the stream (the 3x3 solve and the break tests run on the host). */
+int icp_estimate_transform_device(icp_handle *h, const double *d_a_xy, const double *d_b_xy,
+                                  size_t n, icp_pose *out, uint32_t *inner_iters);
+/* brute-force / grid NN alone (parity tests): d_q n x dim AoS -> d_idx[n] */
+int icp_nn_search_device(icp_handle *h, const double *d_q, size_t n, uint32_t *d_idx);
+int icp_synchronize(icp_handle *h);
+
+/* Live kernel timing for the benchmark: while enabled, HIP events bracket every launch
+ * of the nearest-neighbour search kernel on the handle's stream.  icp_profile_read
+ * synchronises the stream, returns the summed device time (ms) and launch count since
+ * the last read, and clears them. */
+int icp_profile_enable(icp_handle *h, int enable);
+int icp_profile_read(icp_handle *h, double *nn_kernel_ms, uint64_t *nn_kernel_launches);
+
+/* The N-term sums (jtj, jtr, Huber error) are added in a fixed, run-to-run
+ * deterministic tree; this reports its geometry for n points so a checker can
+ * reproduce the exact association order (DESIGN.md "GN reduction order"). */
+void icp_reduce_geometry(size_t n, int *blocks, int *threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICP_MI355X_H */

@@ -1,0 +1,107 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header
+declares, the host-only pose algebra agrees with the oracle bit for bit, and the compute
+entry points fail loudly (no CPU fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import icp_rust_amd as I
+import oracle_ffi as O
+from icp_rust_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    I.build()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "icp_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(icp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/icp_mi355x.h but not exported"
+    # and the Python binding covers exactly the header
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_abi_version_and_status_strings():
+    assert I.lib().icp_abi_version() == 1
+    for s in range(8):
+        assert I.lib().icp_status_string(s)
+
+
+def test_pose_algebra_matches_oracle_bit_for_bit():
+    rng = np.random.default_rng(11)
+    for _ in range(200):
+        p, q = rng.normal(size=3) * [10, 10, 2], rng.normal(size=3)
+        if rng.random() < 0.1:
+            p[2] = 0.0
+        T, U = I.Transform(p), I.Transform(q)
+        oT, oU = O.transform_new(p), O.transform_new(q)
+        assert np.array_equal(T.as_array(), oT.as_array())
+        assert np.array_equal((T * U).as_array(), O.transform_mul(oT, oU).as_array())
+        assert np.array_equal(T.inverse().as_array(), O.transform_inverse(oT).as_array())
+        x = rng.normal(size=2) * 50
+        assert np.array_equal(T.transform(x), O.transform_apply(oT, x))
+        m = I.se2.exp(p)
+        assert np.array_equal(I.se2.log(m), np.array(_orc_se2_log(m)))
+
+
+def _orc_se2_log(m):
+    out = np.zeros(3)
+    mm = np.ascontiguousarray(m, dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    O.lib().orc_se2_log(mm.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    return out
+
+
+def test_inverse3x3_none_cases():  # linalg.rs:52-60
+    out = np.zeros(9)
+    dp = C.POINTER(C.c_double)
+    z = np.zeros(9)
+    assert I.lib().icp_inverse3x3(z.ctypes.data_as(dp), out.ctypes.data_as(dp)) == _lib.NONE
+    m = np.array([3.0, 1.0, 2.0, 6.0, 2.0, 4.0, 9.0, 9.0, 7.0])
+    assert I.lib().icp_inverse3x3(m.ctypes.data_as(dp), out.ctypes.data_as(dp)) == _lib.NONE
+
+
+def test_reduce_geometry():
+    assert I.reduce_geometry(1) == (1, 256)
+    assert I.reduce_geometry(257) == (2, 256)
+    assert I.reduce_geometry(10**6) == (1024, 256)
+
+
+@pytest.mark.skipif(I.lib().icp_device_count() > 0, reason="a GPU is present")
+def test_compute_fails_loudly_without_a_gpu():
+    pts = np.random.default_rng(0).normal(size=(10, 2))
+    with pytest.raises(I.IcpError) as e:
+        I.Icp2d(pts)
+    assert e.value.status == _lib.NO_DEVICE
+    T = I.Transform()
+    for fn in (I.error, I.huber_error, I.gauss_newton_update, I.weighted_gauss_newton_update):
+        with pytest.raises(I.IcpError) as e:
+            fn(T, pts, pts)
+        assert e.value.status == _lib.NO_DEVICE
+    with pytest.raises(I.IcpError):
+        I.estimate_transform(pts, pts)
+
+
+def test_product_never_touches_the_oracle():
+    """No file of the product package or the C/HIP sources mentions oracle/."""
+    pkg = os.path.join(ROOT, "icp_rust_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
+                text = open(os.path.join(d, f)).read()
+                assert "oracle_ffi" not in text and "icp_oracle" not in text and "orc_" not in text, f
