@@ -94,6 +94,14 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `make -C icp_rust_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and this
+        # library links the same SONAME from /opt/rocm.  Whichever is loaded first serves both,
+        # and torch does not work on the system copy, so when torch is installed let it load
+        # its runtime first (device pointers and streams are shared with torch anyway).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)

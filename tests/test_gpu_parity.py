@@ -159,13 +159,8 @@ def test_estimate_transform_matches_oracle(n):
     assert inner == want_inner
     # same summation order => same bits
     blocks, threads = I.reduce_geometry(n)
-    opts = O.IcpOpts(0, 1, blocks, threads)
-    import ctypes as C
-
-    ot = O.Pose()
     aa, bb = np.ascontiguousarray(a), np.ascontiguousarray(b)
-    # the tree-order estimator is reachable through orc_icp_estimate on identity NN; simpler:
-    # replay the loop here with the oracle's tree update
+    # replay src/lib.rs:59-84 with the oracle's tree-order update
     T = O.transform_identity()
     prev = np.finfo(np.float64).max
     applied = 0
@@ -260,7 +255,11 @@ def test_icp_recovers_known_pose_roundtrip():
     dst[:, 1] = (p.r10 * src[:, 0] + p.r11 * src[:, 1]) + p.ty
     icp = I.Icp3d(dst)
     got = icp.estimate(src, I.Transform(), 20)
-    assert np.allclose(got.as_array(), Tt.as_array(), atol=1e-6)
+    # the inner loop never applies an update with |delta|^2 < 1e-6 (src/lib.rs:71-73), so the
+    # fixed point sits within ~1e-3 of the truth, not on it
+    assert np.allclose(got.as_array(), Tt.as_array(), atol=2e-3)
+    again = icp.estimate(src, got, 5)
+    assert np.allclose(again.as_array(), got.as_array(), atol=2e-3)
 
 
 def test_device_resident_inputs_equal_host_inputs():
