@@ -181,6 +181,7 @@ static int create_common(icp_handle **out, int dim, const double *dst, size_t m,
       if ((e = hipMemcpyAsync(p, dst, m * dim * sizeof(double), hipMemcpyHostToDevice, h->stream)) != hipSuccess) { rc = map_hip(e); break; }
     }
     if ((e = build_target_soa(h)) != hipSuccess) { rc = map_hip(e); break; }
+    if ((e = build_grid(h)) != hipSuccess) { rc = map_hip(e); break; }
     if ((e = ensure_workspace(h, 0, false)) != hipSuccess) { rc = map_hip(e); break; }
     // the host buffer may be freed by the caller as soon as we return
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) { rc = map_hip(e); break; }
@@ -211,19 +212,37 @@ extern "C" void icp_destroy(icp_handle *h) {
   free_workspace(h->ws);
   if (h->owns_dst) (void)hipFree(const_cast<double *>(h->d_dst));
   (void)hipFree(h->d_dst_soa);
+  (void)hipFree(h->grid.d_start);
+  (void)hipFree(h->grid.d_pts);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
 
 extern "C" int icp_set_nn_mode(icp_handle *h, int mode) {
   if (!h || mode < ICP_NN_AUTO || mode > ICP_NN_GRID) return ICP_BAD_ARGUMENT;
-  if (mode == ICP_NN_GRID) return ICP_BAD_ARGUMENT;  // not built yet
+  if (mode == ICP_NN_GRID && !h->grid.built && h->m > 0) return ICP_BAD_ARGUMENT;  // non-finite targets
   h->nn_mode = mode;
   return ICP_OK;
 }
+
+// AUTO: the grid pays off once the target cloud is large enough to amortise the
+// scattered cell reads; tiny clouds (2-D LiDAR scans, ~650 points) stay on the sweep.
+static int resolved_nn_mode(const icp_handle *h) {
+  static const long grid_min_m = getenv("ICP_NN_GRID_MIN_M") ? atol(getenv("ICP_NN_GRID_MIN_M")) : 8192;
+  if (h->nn_mode == ICP_NN_BRUTE || !h->grid.built) return ICP_NN_BRUTE;
+  if (h->nn_mode == ICP_NN_GRID) return ICP_NN_GRID;
+  return (long)h->m >= grid_min_m ? ICP_NN_GRID : ICP_NN_BRUTE;
+}
+
+static hipError_t launch_nn(icp_handle *h, const double *d_src, size_t n, const Pose *T, double *d_a,
+                            double *d_b, uint32_t *d_idx) {
+  if (resolved_nn_mode(h) == ICP_NN_GRID) return launch_nn_grid(h, d_src, n, T, d_a, d_b, d_idx);
+  return launch_nn_brute(h, d_src, n, T, d_a, d_b, d_idx);
+}
+
 extern "C" int icp_get_nn_mode(const icp_handle *h) {
   if (!h) return ICP_BAD_ARGUMENT;
-  return ICP_NN_BRUTE;
+  return resolved_nn_mode(h);
 }
 extern "C" int icp_set_stream(icp_handle *h, void *s) {
   if (!h) return ICP_BAD_ARGUMENT;
@@ -266,7 +285,7 @@ extern "C" int icp_correspond_device(icp_handle *h, const double *d_src, size_t 
   if (n == 0) return ICP_OK;
   if (h->m == 0) return ICP_EMPTY_DST;  // index.unwrap() on an empty tree, src/lib.rs:122,165
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(launch_nn_brute(h, d_src, n, T, d_a, d_b, d_idx));
+  HIP_TRY(launch_nn(h, d_src, n, T, d_a, d_b, d_idx));
   return ICP_OK;
 }
 
@@ -275,7 +294,7 @@ extern "C" int icp_nn_search_device(icp_handle *h, const double *d_q, size_t n, 
   if (n == 0) return ICP_OK;
   if (h->m == 0) return ICP_EMPTY_DST;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(launch_nn_brute(h, d_q, n, nullptr, nullptr, nullptr, d_idx));
+  HIP_TRY(launch_nn(h, d_q, n, nullptr, nullptr, nullptr, d_idx));
   return ICP_OK;
 }
 

@@ -70,6 +70,29 @@ struct Workspace {
   GnResult *h_res = nullptr;    // pinned host, device-visible
 };
 
+// ---- uniform grid over the target cloud (nn_grid.hip) ------------------------------
+struct GridParams {
+  double lo[3];
+  double hi[3];
+  double h, inv_h;
+  int n[3];
+  double scale;  // coordinate magnitude used for the rounding margin of the pruning bounds
+};
+
+struct GridPoint {  // one target, cell-sorted; 32 B so a candidate is two 16-B loads
+  double x, y, z;
+  uint32_t idx;  // original index in dst
+  uint32_t pad;
+};
+
+struct Grid {
+  bool built = false;
+  GridParams p;
+  uint32_t ncell = 0;
+  uint32_t *d_start = nullptr;  // ncell + 1 cell offsets into d_pts
+  GridPoint *d_pts = nullptr;   // m targets sorted by cell
+};
+
 }  // namespace icp
 
 struct icp_handle {
@@ -84,6 +107,7 @@ struct icp_handle {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   icp::Workspace ws;
+  icp::Grid grid;
   // live kernel timing (icp_profile_*): event pairs around the NN search kernel
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -98,6 +122,11 @@ hipError_t build_target_soa(icp_handle *h);
 // transform (optional) + brute-force exact NN + gather of the matched xy pairs
 hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n, const Pose *T,
                            double *d_a, double *d_b, uint32_t *d_idx);
+
+// exact uniform-grid NN: same outputs, same results as launch_nn_brute
+hipError_t build_grid(icp_handle *h);
+hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n, const Pose *T, double *d_a,
+                          double *d_b, uint32_t *d_idx);
 
 // one inner Gauss-Newton iteration's device work; results land in h->ws.h_res after the
 // stream is synchronised

@@ -1,0 +1,377 @@
+// Exact nearest neighbour through a uniform grid built on the device.
+//
+// Same contract as the brute-force sweep (nn_brute.hip) and therefore the same results,
+// bit for bit: d^2 = ((dx*dx + dy*dy) + dz*dz) in f64 without FMA contraction, ties ->
+// lowest target index.  It replaces the reference's kd-tree (nearest_neighbor::KdTree,
+// src/lib.rs:99,121,141,164) the MI355X way: instead of a pointer-chasing tree, targets
+// are counting-sorted into cells (32-B records: x, y, z, original index), a query walks
+// Chebyshev shells of cells around its own cell and stops as soon as no unvisited cell
+// can hold a closer-or-equal point.  Exactness does not depend on the cell size or on
+// floating-point rounding of the cell assignment: every pruning bound is relaxed by a
+// margin that is orders of magnitude above the rounding of the cell arithmetic, so a
+// bound can only cause extra visits, never a missed candidate; candidates are compared
+// by (d^2, original index), so the visiting order cannot change the winner.
+#include "common.hpp"
+
+namespace icp {
+
+__device__ __forceinline__ int cell_coord(double v, double lo, double inv_h, int n) {
+  double t = floor((v - lo) * inv_h);
+  t = fmin(fmax(t, 0.), (double)(n - 1));  // NaN -> 0
+  return (int)t;
+}
+
+// ---------------------------------------------------------------- build ----------
+__global__ void k_grid_bbox(const double *__restrict__ dst, unsigned m, int dim, double *__restrict__ part) {
+  __shared__ double smn[3][256], smx[3][256];
+  double mn[3], mx[3];
+  for (int d = 0; d < 3; ++d) {
+    mn[d] = __builtin_huge_val();
+    mx[d] = -__builtin_huge_val();
+  }
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256)
+    for (int d = 0; d < dim; ++d) {
+      const double v = dst[(size_t)i * dim + d];
+      mn[d] = fmin(mn[d], v);
+      mx[d] = fmax(mx[d], v);
+    }
+  for (int d = 0; d < 3; ++d) {
+    smn[d][threadIdx.x] = mn[d];
+    smx[d][threadIdx.x] = mx[d];
+  }
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int d = 0; d < 3; ++d) {
+        smn[d][threadIdx.x] = fmin(smn[d][threadIdx.x], smn[d][threadIdx.x + s]);
+        smx[d][threadIdx.x] = fmax(smx[d][threadIdx.x], smx[d][threadIdx.x + s]);
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int d = 0; d < 3; ++d) {
+      part[blockIdx.x * 6 + d] = smn[d][0];
+      part[blockIdx.x * 6 + 3 + d] = smx[d][0];
+    }
+}
+
+__global__ void k_grid_count(const double *__restrict__ dst, unsigned m, int dim, GridParams g,
+                             uint32_t *__restrict__ cell_of, uint32_t *__restrict__ cnt) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  int c[3] = {0, 0, 0};
+  for (int d = 0; d < dim; ++d) c[d] = cell_coord(dst[(size_t)i * dim + d], g.lo[d], g.inv_h, g.n[d]);
+  const uint32_t cell = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0] + c[0];
+  cell_of[i] = cell;
+  atomicAdd(&cnt[cell], 1u);
+}
+
+// exclusive scan, three phases; 2048 items per block
+constexpr int kScanItems = 2048;
+__global__ __launch_bounds__(256) void k_scan_local(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                    unsigned n, uint32_t *__restrict__ block_tot) {
+  __shared__ uint32_t wsum[4];
+  const unsigned base = blockIdx.x * kScanItems + threadIdx.x * 8;
+  uint32_t v[8], tot = 0;
+  for (int j = 0; j < 8; ++j) {
+    v[j] = (base + j < n) ? in[base + j] : 0u;
+    tot += v[j];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = tot;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t wb = 0;
+  for (int w = 0; w < wave; ++w) wb += wsum[w];
+  uint32_t run = wb + inc - tot;
+  for (int j = 0; j < 8; ++j) {
+    if (base + j < n) out[base + j] = run;
+    run += v[j];
+  }
+  if (threadIdx.x == 255) block_tot[blockIdx.x] = run;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_totals(uint32_t *__restrict__ block_tot, unsigned nb,
+                                                      uint32_t *__restrict__ grand_total) {
+  // one block; nb <= 1024 * 16
+  __shared__ uint32_t wsum[16];
+  const int per = (nb + 1023) / 1024;
+  uint32_t v[16], tot = 0;
+  for (int j = 0; j < per; ++j) {
+    const unsigned k = threadIdx.x * per + j;
+    v[j] = k < nb ? block_tot[k] : 0u;
+    tot += v[j];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = tot;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t wb = 0;
+  for (int w = 0; w < wave; ++w) wb += wsum[w];
+  uint32_t run = wb + inc - tot;
+  for (int j = 0; j < per; ++j) {
+    const unsigned k = threadIdx.x * per + j;
+    if (k < nb) block_tot[k] = run;
+    run += v[j];
+  }
+  if (threadIdx.x == 1023) *grand_total = run;
+}
+
+__global__ void k_scan_add(uint32_t *__restrict__ out, unsigned n, const uint32_t *__restrict__ block_tot) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += block_tot[i / kScanItems];
+}
+
+__global__ void k_grid_scatter(const double *__restrict__ dst, unsigned m, int dim,
+                               const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ start,
+                               uint32_t *__restrict__ cursor, GridPoint *__restrict__ pts) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t cell = cell_of[i];
+  const uint32_t pos = start[cell] + atomicAdd(&cursor[cell], 1u);
+  GridPoint p;
+  p.x = dst[(size_t)i * dim + 0];
+  p.y = dst[(size_t)i * dim + 1];
+  p.z = dim == 3 ? dst[(size_t)i * dim + 2] : 0.;
+  p.idx = i;
+  p.pad = 0;
+  pts[pos] = p;
+}
+
+hipError_t build_grid(icp_handle *h) {
+  Grid &G = h->grid;
+  G.built = false;
+  const unsigned m = (unsigned)h->m;
+  if (m == 0) return hipSuccess;
+  hipError_t e;
+  hipStream_t s = h->stream;
+  // 1. bounding box
+  const int bb = 256;
+  double *d_part = nullptr;
+  if ((e = hipMalloc(&d_part, bb * 6 * sizeof(double))) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_grid_bbox, dim3(bb), dim3(256), 0, s, h->d_dst, m, h->dim, d_part);
+  double part[bb * 6];
+  e = hipMemcpyAsync(part, d_part, sizeof(part), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d_part);
+  if (e != hipSuccess) return e;
+  GridParams g;
+  for (int d = 0; d < 3; ++d) {
+    g.lo[d] = __builtin_huge_val();
+    g.hi[d] = -__builtin_huge_val();
+  }
+  for (int b = 0; b < bb; ++b)
+    for (int d = 0; d < 3; ++d) {
+      g.lo[d] = fmin(g.lo[d], part[b * 6 + d]);
+      g.hi[d] = fmax(g.hi[d], part[b * 6 + 3 + d]);
+    }
+  double ext[3], emax = 0., scale = 0.;
+  for (int d = 0; d < 3; ++d) {
+    if (d >= h->dim) g.lo[d] = g.hi[d] = 0.;
+    if (!std::isfinite(g.lo[d]) || !std::isfinite(g.hi[d])) return hipSuccess;  // no grid: brute force serves
+    ext[d] = g.hi[d] - g.lo[d];
+    emax = fmax(emax, ext[d]);
+    scale = fmax(scale, fmax(fabs(g.lo[d]), fabs(g.hi[d])));
+  }
+  if (!std::isfinite(emax)) return hipSuccess;
+  // 2. cell size: ~1 target per cell over the non-degenerate extents, <= 2^24 cells
+  int k = 0;
+  double vol = 1.;
+  for (int d = 0; d < h->dim; ++d)
+    if (ext[d] > 1e-9 * emax) {
+      vol *= ext[d];
+      ++k;
+    }
+  double hh = k > 0 ? pow(vol / (double)m, 1. / k) : 1.;
+  if (!(hh > 0.) || !std::isfinite(hh)) hh = 1.;
+  for (;;) {
+    double cells = 1.;
+    for (int d = 0; d < 3; ++d) {
+      const double nd = (d < h->dim && ext[d] > 1e-9 * emax) ? floor(ext[d] / hh) + 1. : 1.;
+      g.n[d] = (int)fmin(nd, 4096.);
+      cells *= g.n[d];
+    }
+    if (cells <= 16777216.) break;
+    hh *= 1.26;
+  }
+  g.h = hh;
+  g.inv_h = 1. / hh;
+  g.scale = scale + hh;
+  G.p = g;
+  G.ncell = (uint32_t)g.n[0] * g.n[1] * g.n[2];
+  // 3. counting sort of the targets by cell
+  uint32_t *cell_of = nullptr, *cnt = nullptr, *btot = nullptr;
+  const unsigned nscan = G.ncell + 1;
+  const unsigned nb = (nscan + kScanItems - 1) / kScanItems;
+  do {
+    if ((e = hipMalloc(&cell_of, (size_t)m * 4)) != hipSuccess) break;
+    if ((e = hipMalloc(&cnt, (size_t)nscan * 4)) != hipSuccess) break;
+    if ((e = hipMalloc(&btot, ((size_t)nb + 1) * 4)) != hipSuccess) break;
+    if ((e = hipMalloc(&G.d_start, (size_t)nscan * 4)) != hipSuccess) break;
+    if ((e = hipMalloc(&G.d_pts, (size_t)m * sizeof(GridPoint))) != hipSuccess) break;
+    if ((e = hipMemsetAsync(cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) break;
+    hipLaunchKernelGGL(k_grid_count, dim3((m + 255) / 256), dim3(256), 0, s, h->d_dst, m, h->dim, g, cell_of, cnt);
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, s, cnt, G.d_start, nscan, btot);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, btot, nb, btot + nb);
+    hipLaunchKernelGGL(k_scan_add, dim3((nscan + 255) / 256), dim3(256), 0, s, G.d_start, nscan, btot);
+    if ((e = hipMemsetAsync(cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) break;
+    hipLaunchKernelGGL(k_grid_scatter, dim3((m + 255) / 256), dim3(256), 0, s, h->d_dst, m, h->dim, cell_of,
+                       G.d_start, cnt, G.d_pts);
+    if ((e = hipGetLastError()) != hipSuccess) break;
+    e = hipStreamSynchronize(s);
+  } while (0);
+  (void)hipFree(cell_of);
+  (void)hipFree(cnt);
+  (void)hipFree(btot);
+  if (e != hipSuccess) return e;
+  G.built = true;
+  return hipSuccess;
+}
+
+// ---------------------------------------------------------------- query ----------
+template <int DIM, bool XFORM>
+__global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src, unsigned n, Pose T,
+                                                 GridParams g, const uint32_t *__restrict__ start,
+                                                 const GridPoint *__restrict__ pts,
+                                                 uint32_t *__restrict__ idx, double2 *__restrict__ a,
+                                                 double2 *__restrict__ b) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double q[3];
+  q[0] = src[(size_t)i * DIM + 0];
+  q[1] = src[(size_t)i * DIM + 1];
+  q[2] = DIM == 3 ? src[(size_t)i * DIM + 2] : 0.;
+  if (XFORM) {  // Transform::transform, src/transform.rs:22-24
+    const double nx = (T.r00 * q[0] + T.r01 * q[1]) + T.tx;
+    const double ny = (T.r10 * q[0] + T.r11 * q[1]) + T.ty;
+    q[0] = nx;
+    q[1] = ny;
+  }
+  int c[3];
+  double mg[3];  // rounding margin per axis: >> ulp(cell arithmetic), << cell size
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    c[d] = (d < DIM) ? cell_coord(q[d], g.lo[d], g.inv_h, g.n[d]) : 0;
+    mg[d] = 1e-9 * (fabs(q[d]) + g.scale);
+  }
+  double best = __builtin_huge_val();
+  uint32_t bi = 0xffffffffu;
+  double bx = 0., by = 0.;
+
+  // distance from q to the slab of cells [i0, i1] on axis d (0 inside); outermost cells
+  // extend to infinity (targets are clamped into them)
+  auto slab = [&](int d, int i0, int i1) -> double {
+    const double lo_b = (i0 <= 0) ? -__builtin_huge_val() : (g.lo[d] + i0 * g.h) - mg[d];
+    const double hi_b = (i1 >= g.n[d] - 1) ? __builtin_huge_val() : (g.lo[d] + (i1 + 1) * g.h) + mg[d];
+    const double v = fmax(lo_b - q[d], q[d] - hi_b);
+    return v > 0. ? v : 0.;
+  };
+
+  const int rmax = max(max(g.n[0], g.n[1]), g.n[2]);
+  for (int r = 0; r <= rmax; ++r) {
+    const int z0 = DIM == 3 ? max(c[2] - r, 0) : 0, z1 = DIM == 3 ? min(c[2] + r, g.n[2] - 1) : 0;
+    const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
+    for (int iz = z0; iz <= z1; ++iz) {
+      const bool ze = DIM == 3 && (iz == c[2] - r || iz == c[2] + r);
+      const double dz = DIM == 3 ? slab(2, iz, iz) : 0.;
+      for (int iy = y0; iy <= y1; ++iy) {
+        const bool edge = ze || iy == c[1] - r || iy == c[1] + r;
+        const double dy = slab(1, iy, iy);
+        const double dyz = dy * dy + dz * dz;
+        if (dyz > best) continue;
+        // cells of this row that belong to shell r: the whole run on an edge row, else
+        // only the two end cells
+        const int nruns = (edge || r == 0) ? 1 : 2;
+        for (int run = 0; run < nruns; ++run) {
+          int x0, x1;
+          if (edge || r == 0) {
+            x0 = c[0] - r;
+            x1 = c[0] + r;
+          } else {
+            x0 = x1 = (run == 0) ? c[0] - r : c[0] + r;
+          }
+          if (x1 < 0 || x0 > g.n[0] - 1) continue;
+          x0 = max(x0, 0);
+          x1 = min(x1, g.n[0] - 1);
+          const double dx = slab(0, x0, x1);
+          if (dx * dx + dyz > best) continue;  // strictly farther: cannot win or tie
+          const uint32_t row = ((uint32_t)iz * g.n[1] + iy) * g.n[0];
+          const uint32_t s = start[row + x0], e = start[row + x1 + 1];
+          for (uint32_t p = s; p < e; ++p) {
+            const GridPoint t = pts[p];
+            const double ddx = q[0] - t.x;
+            const double ddy = q[1] - t.y;
+            double dd = ddx * ddx + ddy * ddy;
+            if (DIM == 3) {
+              const double ddz = q[2] - t.z;
+              dd = dd + ddz * ddz;
+            }
+            if (dd < best || (dd == best && t.idx < bi)) {
+              best = dd;
+              bi = t.idx;
+              bx = t.x;
+              by = t.y;
+            }
+          }
+        }
+      }
+    }
+    // can anything outside the visited block [c-r, c+r] still win or tie?
+    double L = __builtin_huge_val();
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      if (c[d] - r > 0) L = fmin(L, (q[d] - (g.lo[d] + (c[d] - r) * g.h)) - mg[d]);
+      if (c[d] + r < g.n[d] - 1) L = fmin(L, ((g.lo[d] + (c[d] + r + 1) * g.h) - q[d]) - mg[d]);
+    }
+    if (L == __builtin_huge_val()) break;       // the whole grid has been visited
+    if (L > 0. && best < L * L) break;          // every unvisited target is strictly farther
+  }
+  if (bi == 0xffffffffu) {  // no finite distance (NaN query): index 0, as a scan from 0 would
+    bi = 0;
+    // its coordinates live wherever target 0 was sorted to; the caller gathers them
+    bx = by = __builtin_nan("");
+  }
+  if (idx) idx[i] = bi;
+  if (a) a[i] = make_double2(q[0], q[1]);
+  if (b) b[i] = make_double2(bx, by);
+}
+
+hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const Pose *Tp, double *d_a,
+                          double *d_b, uint32_t *d_idx) {
+  if (n_ == 0) return hipSuccess;
+  const unsigned n = (unsigned)n_;
+  const bool xform = Tp != nullptr;
+  const Pose T = xform ? *Tp : transform_identity();
+  const Grid &G = h->grid;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (h->profile) {
+    if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
+      (void)hipEventRecord(ev0, h->stream);
+  }
+  const unsigned blocks = (n + 255) / 256;
+#define GRID(DIM, XF)                                                                                   \
+  hipLaunchKernelGGL((k_nn_grid<DIM, XF>), dim3(blocks), dim3(256), 0, h->stream, d_src, n, T, G.p,      \
+                     G.d_start, G.d_pts, d_idx, (double2 *)d_a, (double2 *)d_b)
+  if (h->dim == 3) {
+    if (xform) GRID(3, true); else GRID(3, false);
+  } else {
+    if (xform) GRID(2, true); else GRID(2, false);
+  }
+#undef GRID
+  hipError_t e = hipGetLastError();
+  if (ev0 && ev1) {
+    (void)hipEventRecord(ev1, h->stream);
+    h->prof_events.emplace_back(ev0, ev1);
+  }
+  return e;
+}
+
+}  // namespace icp

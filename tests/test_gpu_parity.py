@@ -302,3 +302,77 @@ def test_zero_max_iter_returns_initial_transform():
     T0 = I.Transform([0.1, 0.2, 0.3])
     T = I.Icp3d(dst).estimate(src, T0, 0)
     assert np.array_equal(T.as_array(), T0.as_array())
+
+
+# ------------------------------------------------- exact grid NN == brute force == oracle --
+
+
+def _nn(dst, q, mode):
+    dim = dst.shape[1]
+    icp = (I.Icp3d if dim == 3 else I.Icp2d)(dst, nn_mode=mode)
+    assert I.lib().icp_get_nn_mode(icp._h) == mode
+    return icp.nn_search(q)
+
+
+def _grid_cases():
+    rng = np.random.default_rng(2024)
+    cases = {}
+    for dim in (2, 3):
+        cases[f"normal{dim}"] = (rng.normal(size=(20_000, dim)) * 10, rng.normal(size=(15_000, dim)) * 10)
+        # queries far outside the target bounding box, on every side
+        far = rng.normal(size=(4000, dim)) * 300
+        cases[f"far{dim}"] = (rng.normal(size=(9000, dim)), far)
+        # integer lattice: exact ties and duplicates everywhere
+        cases[f"lattice{dim}"] = (rng.integers(-8, 8, size=(12_000, dim)).astype(np.float64),
+                                  rng.integers(-20, 20, size=(6000, dim)).astype(np.float64) * 0.5)
+        # strongly non-uniform density (two tight clusters + sparse background)
+        cl = np.concatenate([rng.normal(size=(8000, dim)) * 0.01, rng.normal(size=(8000, dim)) * 0.01 + 50,
+                             rng.uniform(-100, 100, size=(2000, dim))])
+        cases[f"clusters{dim}"] = (cl, np.concatenate([rng.uniform(-120, 120, size=(5000, dim)),
+                                                       rng.normal(size=(3000, dim)) * 0.02]))
+        # all targets identical / a single target
+        cases[f"same{dim}"] = (np.ones((300, dim)) * 3.25, rng.normal(size=(500, dim)))
+        cases[f"single{dim}"] = (np.array([[1.0, 2.0, 3.0][:dim]]), rng.normal(size=(100, dim)))
+    # 3-D data that is flat in z, and on a line
+    flat = rng.normal(size=(10_000, 3)) * 5
+    flat[:, 2] = 1.5
+    cases["flat3"] = (flat, rng.normal(size=(4000, 3)) * 5)
+    line = np.zeros((5000, 3))
+    line[:, 0] = rng.uniform(-10, 10, size=5000)
+    cases["line3"] = (line, rng.normal(size=(3000, 3)) * 4)
+    return cases
+
+
+@pytest.mark.parametrize("name", sorted(_grid_cases()))
+def test_grid_nn_equals_brute_force_and_oracle(name):
+    dst, q = _grid_cases()[name]
+    g = _nn(dst, q, I.NN_GRID)
+    b = _nn(dst, q, I.NN_BRUTE)
+    assert np.array_equal(g, b)
+    rc, want = O.KdTree(dst).search(q)
+    assert rc == O.OK
+    assert np.array_equal(g, want)
+
+
+def test_grid_nn_full_size_vs_kdtree():
+    """BASELINE's 1M x 1M synthetic pair: every correspondence index equals the oracle's."""
+    src, dst = synth.synthetic_pair(1_000_000, 1_000_000)
+    got = _nn(dst, src, I.NN_GRID)
+    rc, want = O.KdTree(dst).search(src)
+    assert rc == O.OK
+    assert np.array_equal(got, want)
+
+
+def test_icp_grid_mode_is_bit_identical_to_brute_mode():
+    src, dst = synth.synthetic_pair(60_000, 50_000)
+    a = I.Icp3d(dst, nn_mode=I.NN_GRID).estimate(src, I.Transform(), 4, return_info=True)
+    b = I.Icp3d(dst, nn_mode=I.NN_BRUTE).estimate(src, I.Transform(), 4, return_info=True)
+    assert np.array_equal(a[0].as_array(), b[0].as_array())
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_auto_mode_picks_grid_for_large_targets_and_brute_for_small():
+    big = I.Icp3d(synth.synthetic_pair(1, 20_000)[1])
+    small = I.Icp2d(load_scan2d(os.path.join(GOLDEN, "scans2d", "002.txt")))
+    assert I.lib().icp_get_nn_mode(big._h) == I.NN_GRID
+    assert I.lib().icp_get_nn_mode(small._h) == I.NN_BRUTE
