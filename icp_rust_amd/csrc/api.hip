@@ -58,6 +58,8 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_part_d);
   (void)hipFree(w.d_part_i);
   (void)hipFree(w.d_hist);
+  (void)hipFree(w.d_cand);
+  (void)hipFree(w.d_ctl);
   (void)hipFree(w.d_sel);
   (void)hipFree(w.d_scal);
   (void)hipFree(w.d_partials);
@@ -73,8 +75,12 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
   Workspace &w = h->ws;
   hipError_t e;
   if (!w.d_hist) {
-    if ((e = hipMalloc(&w.d_hist, kSelProblems * kSelBins * sizeof(uint32_t))) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(w.d_hist, 0, kSelProblems * kSelBins * sizeof(uint32_t), h->stream)) != hipSuccess) return e;
+    const size_t hist_bytes = (size_t)kSelRoles * kSelProblems * kSelBins * sizeof(uint32_t);
+    if ((e = hipMalloc(&w.d_hist, hist_bytes)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(w.d_hist, 0, hist_bytes, h->stream)) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_cand, (size_t)kSelProblems * kSelCap * sizeof(unsigned long long))) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_ctl, sizeof(SelCtl))) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(w.d_ctl, 0, sizeof(SelCtl), h->stream)) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_sel, kSelProblems * sizeof(SelState))) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_scal, sizeof(GnScalars))) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_partials, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double))) != hipSuccess) return e;
@@ -305,8 +311,18 @@ static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
 // Huber error of the same T (src/lib.rs:75), which shares the pass.
 static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
                     double delta[3], double *huber_err) {
-  HIP_TRY(launch_weighted_gn(h, d_a, d_b, n, T));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  static const bool force_radix = getenv("ICP_GN_RADIX") != nullptr;
+  bool done = false;
+  if (!force_radix) {
+    HIP_TRY(launch_weighted_gn_fast(h, d_a, d_b, n, T));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    done = !h->ws.h_res->overflow;
+  }
+  if (!done) {  // heavy duplicates around a median: the general 6-pass radix select
+    HIP_TRY(launch_sel_init(h, n));
+    HIP_TRY(launch_weighted_gn(h, d_a, d_b, n, T));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
   const GnResult &r = *h->ws.h_res;
   if (r.nan_flag) return ICP_NAN_INPUT;
   if (huber_err) *huber_err = r.acc[12];

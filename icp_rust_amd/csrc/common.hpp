@@ -17,6 +17,8 @@ constexpr int kNAcc = 13;             // jtj[9], jtr[3], huber error
 constexpr int kSelProblems = 4;       // {x, y} x {lower, upper middle order statistic}
 constexpr int kSelBins = 4096;        // 12-bit radix digits
 constexpr int kSelPasses = 6;         // 12+12+12+12+12+4 bits
+constexpr int kSelRoles = 4;          // fast path: histogram buffers {median, MAD} x {pass 0, pass 1}
+constexpr int kSelCap = 1024;         // fast path: candidates kept per problem after two passes
 
 inline void reduce_geometry(size_t n, int *blocks, int *threads) {
   size_t b = (n + kReduceThreads - 1) / kReduceThreads;
@@ -39,7 +41,13 @@ struct GnScalars {
   double median[2];
   double sigma[2];
   int nan_flag;
-  int pad;
+  int overflow;  // fast selection path gave up (too many candidates): redo with the radix path
+};
+
+// Arrival tickets and candidate counters of the fast selection path (zero between launches).
+struct SelCtl {
+  unsigned ticket[4];
+  unsigned cand_cnt[kSelProblems];
 };
 
 // What the last kernel of an inner iteration hands to the host (pinned, mapped).
@@ -47,7 +55,7 @@ struct GnResult {
   double acc[kNAcc + 1];  // jtj[9], jtr[3], huber error, (plain) error
   double sigma[2];
   int nan_flag;
-  int pad;
+  int overflow;
 };
 
 struct Workspace {
@@ -63,7 +71,9 @@ struct Workspace {
   double *d_part_d = nullptr;
   uint32_t *d_part_i = nullptr;
   // selection + reduction scratch (fixed size)
-  uint32_t *d_hist = nullptr;   // kSelProblems x kSelBins
+  uint32_t *d_hist = nullptr;   // kSelRoles x kSelProblems x kSelBins (role 0 also serves the radix path)
+  unsigned long long *d_cand = nullptr;  // kSelProblems x kSelCap candidate keys
+  SelCtl *d_ctl = nullptr;
   SelState *d_sel = nullptr;    // kSelProblems
   GnScalars *d_scal = nullptr;
   double *d_partials = nullptr; // kReduceMaxBlocks x (kNAcc+1)
@@ -132,6 +142,10 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n, const Po
 // stream is synchronised
 hipError_t launch_weighted_gn(icp_handle *h, const double *d_a, const double *d_b, size_t n,
                               const Pose &T);
+// the same through the short pipeline (7 launches, or 3 when n <= kSelCap); sets
+// h_res->overflow when the caller has to redo the evaluation with launch_weighted_gn
+hipError_t launch_weighted_gn_fast(icp_handle *h, const double *d_a, const double *d_b, size_t n,
+                                   const Pose &T);
 // unweighted accumulation (gauss_newton_update / error / huber_error)
 hipError_t launch_plain_gn(icp_handle *h, const double *d_a, const double *d_b, size_t n,
                            const Pose &T);

@@ -11,38 +11,15 @@
 // prefix).  Sums use a fixed tree (DESIGN.md "GN reduction order"): no float atomics,
 // run-to-run bit-identical.
 #include "common.hpp"
+#include "gn_device.hpp"
 
 namespace icp {
 
-// ------------------------------------------------------------------ keys ---------
-__device__ __forceinline__ unsigned long long f2k(double v) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double k2f(unsigned long long k) {
-  const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-  return __longlong_as_double((long long)u);
-}
-
-__device__ __forceinline__ int pass_shift(int pass) { return pass < 5 ? 52 - 12 * pass : 0; }
-__device__ __forceinline__ int pass_bits(int pass) { return pass < 5 ? 12 : 4; }
-
-// huber::rho / huber::drho on the squared error (src/huber.rs:6-26), k = HUBER_K
-__device__ __forceinline__ double huber_rho(double e) {
-  const double k = ICP_HUBER_K;
-  const double k2 = k * k;
-  return (e <= k2) ? e : (2. * k * __dsqrt_rn(e) - k2);
-}
-__device__ __forceinline__ double huber_drho(double e) {
-  const double k = ICP_HUBER_K;
-  const double k2 = k * k;
-  return (e <= k2) ? 1. : (k / __dsqrt_rn(e));
-}
-
 // ------------------------------------------------------------- selection ---------
-__global__ void k_sel_init(SelState *sel, GnScalars *scal, uint32_t *hist, unsigned n) {
+__global__ void k_sel_init(SelState *sel, GnScalars *scal, uint32_t *hist, SelCtl *ctl, unsigned n) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-  for (unsigned i = t; i < kSelProblems * kSelBins; i += gridDim.x * blockDim.x) hist[i] = 0;
+  for (unsigned i = t; i < kSelRoles * kSelProblems * kSelBins; i += gridDim.x * blockDim.x) hist[i] = 0;
+  if (t < sizeof(SelCtl) / sizeof(unsigned)) reinterpret_cast<unsigned *>(ctl)[t] = 0;
   if (t < kSelProblems) {
     const bool hi = t & 1;
     sel[t].prefix = 0;
@@ -52,6 +29,7 @@ __global__ void k_sel_init(SelState *sel, GnScalars *scal, uint32_t *hist, unsig
   }
   if (t == 0) {
     scal->nan_flag = 0;
+    scal->overflow = 0;
     scal->median[0] = scal->median[1] = 0.;
     scal->sigma[0] = scal->sigma[1] = 0.;
   }
@@ -208,29 +186,6 @@ __global__ __launch_bounds__(256) void k_sel_scan(uint32_t *__restrict__ hist, S
   for (int i = tid; i < kSelProblems * kSelBins; i += 256) hist[i] = 0;
 }
 
-// ------------------------------------------------------------- reductions --------
-// Fixed association order (mirrored by the oracle's *_tree variant): a wave folds with
-// v[l] += v[l+off], off = 32..1; thread 0 left-folds the wave sums from wave 0.
-template <int N>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[N], double *__restrict__ out) {
-  __shared__ double sm[4][N];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    double v = acc[k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_down(v, off);
-    if (lane == 0) sm[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < N) {
-    const int k = threadIdx.x;
-    double s = sm[0][k];
-    for (int w = 1; w < 4; ++w) s = s + sm[w][k];
-    out[k] = s;
-  }
-}
-
 // src/lib.rs:238-255 (+ :45-50 fused: same T, same residuals)
 __global__ __launch_bounds__(256) void k_wgn_accumulate(const double2 *__restrict__ a,
                                                         const double *__restrict__ rx,
@@ -316,6 +271,7 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
     res->sigma[0] = scal->sigma[0];
     res->sigma[1] = scal->sigma[1];
     res->nan_flag = scal->nan_flag;
+    res->overflow = 0;
   }
 }
 
@@ -329,7 +285,7 @@ static unsigned hist_blocks(unsigned n) {
 
 hipError_t launch_sel_init(icp_handle *h, size_t n) {
   Workspace &w = h->ws;
-  hipLaunchKernelGGL(k_sel_init, dim3(16), dim3(256), 0, h->stream, w.d_sel, w.d_scal, w.d_hist,
+  hipLaunchKernelGGL(k_sel_init, dim3(64), dim3(256), 0, h->stream, w.d_sel, w.d_scal, w.d_hist, w.d_ctl,
                      (unsigned)n);
   return hipGetLastError();
 }

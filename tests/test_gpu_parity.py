@@ -376,3 +376,36 @@ def test_auto_mode_picks_grid_for_large_targets_and_brute_for_small():
     small = I.Icp2d(load_scan2d(os.path.join(GOLDEN, "scans2d", "002.txt")))
     assert I.lib().icp_get_nn_mode(big._h) == I.NN_GRID
     assert I.lib().icp_get_nn_mode(small._h) == I.NN_BRUTE
+
+
+# ------------------------------------- fast selection pipeline: overflow -> radix fallback --
+
+
+@pytest.mark.parametrize("n", [900, 10_000, 200_001])
+def test_weighted_gn_with_a_run_of_duplicates_at_the_median(n):
+    """30 % of the x residuals are one exact value sitting on the median: more equal-prefix
+    keys than the candidate buffer holds, so the short pipeline must hand over to the general
+    radix select -- same bits either way."""
+    rng = np.random.default_rng(n)
+    a = rng.normal(size=(n, 2)) * 10
+    r = rng.normal(size=(n, 2)) * 0.2
+    k = int(0.3 * n)
+    r[:k, 0] = 0.0
+    r[k:k + (n - k) // 2, 0] = -np.abs(r[k:k + (n - k) // 2, 0]) - 1e-3
+    r[k + (n - k) // 2:, 0] = np.abs(r[k + (n - k) // 2:, 0]) + 1e-3
+    b = a - r  # identity pose: residual = a - b = r exactly? (a - (a - r)) may round; fine, oracle sees the same
+    T = I.Transform()
+    got = I.weighted_gauss_newton_update(T, a, b)
+    blocks, threads = I.reduce_geometry(n)
+    rc, want, _ = O.weighted_gauss_newton_update_tree(opose(T), a, b, blocks, threads)
+    assert rc == O.OK and got is not None
+    assert np.array_equal(got, want)
+
+
+def test_estimate_transform_small_inputs_use_the_single_launch_stages():
+    for n in (2, 3, 5, 64, 1024, 1025):
+        a, b = make_pairs(n, 11 * n)
+        got, inner = I.estimate_transform(a, b, return_inner_iters=True)
+        want, want_inner = O.estimate_transform(a, b)
+        assert inner == want_inner
+        assert_pose_close(got, want)
