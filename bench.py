@@ -102,6 +102,7 @@ def main():
         torch.cuda.synchronize()
 
     T = I.Transform()
+    driver.stages.prepare(d_src, T)
     for _ in range(args.warmup):
         T, _ = driver.step(d_src, T)
     icp.profile_enable(True)
@@ -109,6 +110,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     inner = []
+    # per-estimate setup (cell-sorted snapshot of the source cloud) is inside the timed region:
+    # the K timed steps are one Icp3d::estimate(src, T, K) call
+    driver.stages.prepare(d_src, T)
     for _ in range(args.steps):
         T, k = driver.step(d_src, T)
         inner.append(int(k))

@@ -309,6 +309,10 @@ class _Icp:
                                           C.c_void_p(d_idx.data_ptr()) if d_idx is not None else None),
               "icp_correspond_device")
 
+    def prepare_source_device(self, d_src, transform):
+        check(lib().icp_prepare_source_device(self._h, C.c_void_p(d_src.data_ptr()), d_src.shape[0],
+                                              C.byref(transform.pose)), "icp_prepare_source_device")
+
     def estimate_transform_device(self, d_a, d_b):
         o = Transform()
         inner = C.c_uint32(0)

@@ -220,6 +220,12 @@ extern "C" void icp_destroy(icp_handle *h) {
   (void)hipFree(h->d_dst_soa);
   (void)hipFree(h->grid.d_start);
   (void)hipFree(h->grid.d_pts);
+  (void)hipFree(h->qsort.d_cnt);
+  (void)hipFree(h->qsort.d_start);
+  (void)hipFree(h->qsort.d_btot);
+  (void)hipFree(h->qsort.d_cell_of);
+  (void)hipFree(h->qsort.d_perm);
+  (void)hipFree(h->qsort.d_sorted);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -295,6 +301,16 @@ extern "C" int icp_correspond_device(icp_handle *h, const double *d_src, size_t 
   return ICP_OK;
 }
 
+extern "C" int icp_prepare_source_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T) {
+  if (!h || !T || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  h->qsort.valid = false;
+  static const long min_n = getenv("ICP_QSORT_MIN_N") ? atol(getenv("ICP_QSORT_MIN_N")) : 16384;
+  if (resolved_nn_mode(h) != ICP_NN_GRID || (long)n < min_n) return ICP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(prepare_queries(h, d_src, n, *T));
+  return ICP_OK;
+}
+
 extern "C" int icp_nn_search_device(icp_handle *h, const double *d_q, size_t n, uint32_t *d_idx) {
   if (!h || (n > 0 && (!d_q || !d_idx)) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
   if (n == 0) return ICP_OK;
@@ -364,6 +380,10 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(ensure_workspace(h, n, false));
   Pose T = *init;
+  if (max_iter > 0) {
+    const int prc = icp_prepare_source_device(h, d_src, n, init);
+    if (prc != ICP_OK) return prc;
+  }
   for (size_t it = 0; it < max_iter; ++it) {
     uint32_t *idx_out = (it + 1 == max_iter) ? d_last_idx : nullptr;
     int rc = icp_correspond_device(h, d_src, n, &T, h->ws.d_a, h->ws.d_b, idx_out);
@@ -376,6 +396,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     T = transform_mul(dT, T);  // src/lib.rs:127, 170
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->qsort.valid = false;  // the caller may reuse or rewrite the source buffer
   *out = T;
   return ICP_OK;
 }

@@ -44,10 +44,19 @@ struct GnScalars {
   int overflow;  // fast selection path gave up (too many candidates): redo with the radix path
 };
 
-// Arrival tickets and candidate counters of the fast selection path (zero between launches).
+// Arrival tickets of one kernel role: 16 shard counters + one top counter, each on a
+// 128-B line of its own (a single word saturates at ~88 returning atomics per us; ~500
+// workgroups finishing together would queue for ~6 us on it).
+struct TicketSet {
+  unsigned shard[16][32];
+  unsigned top[32];
+};
+
+// Tickets and candidate counters of the fast selection path (all zero between launches).
 struct SelCtl {
-  unsigned ticket[4];
+  TicketSet t[3];
   unsigned cand_cnt[kSelProblems];
+  unsigned pad[28];
 };
 
 // What the last kernel of an inner iteration hands to the host (pinned, mapped).
@@ -103,6 +112,16 @@ struct Grid {
   GridPoint *d_pts = nullptr;   // m targets sorted by cell
 };
 
+// cell-sorted copy of a source cloud (prepare_queries): locality for the grid search
+struct QuerySort {
+  bool valid = false;
+  const double *src = nullptr;  // the device buffer this snapshot was taken from
+  size_t n = 0, cap = 0;
+  uint32_t *d_cnt = nullptr, *d_start = nullptr, *d_btot = nullptr;
+  uint32_t *d_cell_of = nullptr, *d_perm = nullptr;
+  double *d_sorted = nullptr;
+};
+
 }  // namespace icp
 
 struct icp_handle {
@@ -118,6 +137,7 @@ struct icp_handle {
   hipStream_t stream = nullptr;
   icp::Workspace ws;
   icp::Grid grid;
+  icp::QuerySort qsort;
   // live kernel timing (icp_profile_*): event pairs around the NN search kernel
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -135,6 +155,7 @@ hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n, const P
 
 // exact uniform-grid NN: same outputs, same results as launch_nn_brute
 hipError_t build_grid(icp_handle *h);
+hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n, const Pose &T);
 hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n, const Pose *T, double *d_a,
                           double *d_b, uint32_t *d_idx);
 

@@ -32,9 +32,9 @@ __device__ __forceinline__ double huber_drho(double e) {
 // ------------------------------------------------------------- reductions --------
 // Fixed association order (mirrored by the oracle's *_tree variant): a wave folds with
 // v[l] += v[l+off], off = 32..1; thread 0 left-folds the wave sums from wave 0.
-template <int N>
+template <int N, bool SC1 = false>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double *__restrict__ out) {
-  __shared__ double sm[4][N];
+  __shared__ double sm[16][N];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -47,30 +47,37 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double *__r
   if (threadIdx.x < N) {
     const int k = threadIdx.x;
     double s = sm[0][k];
-    for (int w = 1; w < 4; ++w) s = s + sm[w][k];
-    out[k] = s;
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s = s + sm[w][k];
+    if (SC1) __hip_atomic_store(out + k, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else out[k] = s;
   }
 }
 
 
-// The last workgroup to arrive gets `true` (CDNA4: per-CU L1s are never refreshed and the
-// per-XCD L2s are not coherent, so the hand-off follows the agent-scope release/acquire
-// recipe: every wave drains its stores/atomics, workgroup barrier, one lane releases and
-// takes a ticket, the last arriver acquires before anyone in it loads).  The ticket word is
+// The last workgroup to arrive gets `true`.  CDNA4 hand-off rules (per-CU L1s are never
+// refreshed, per-XCD L2s are not coherent): every byte handed to the last workgroup is
+// written by a device-scope atomic or an `sc1` (write-through) store and read back with
+// `sc1` loads (__hip_atomic_load/_store, relaxed, agent scope), so no L2 write-back or
+// invalidate is needed -- a release fence here costs 10-20 us per launch because the L2 is
+// full of freshly written residuals.  What IS needed: every wave drains its own stores and
+// atomics (s_waitcnt vmcnt(0)) before the workgroup barrier behind which one lane takes the
+// ticket; the last arriver's other waves load only after the second barrier.  The ticket is
 // reset by the last arriver, so it is zero again for the next launch.
-__device__ __forceinline__ bool last_block_arrives(unsigned *ticket) {
+__device__ __forceinline__ bool last_block_arrives(TicketSet *t) {
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == gridDim.x - 1);
-    if (last) {
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned nb = gridDim.x, sh = blockIdx.x & 15u;
+    const unsigned in_shard = (nb - sh + 15u) >> 4;  // workgroups with this shard id
+    int last = 0;
+    if (__hip_atomic_fetch_add(&t->shard[sh][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+      __hip_atomic_store(&t->shard[sh][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned nshards = nb < 16u ? nb : 16u;
+      if (__hip_atomic_fetch_add(&t->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1) {
+        __hip_atomic_store(&t->top[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
     }
     s_last = last;
   }

@@ -10,12 +10,15 @@
 //   A          Huber-weighted normal equations + Huber error, fixed reduction tree; the last
 //              block folds the block sums and hands 13 doubles to the host
 //
-// "Last block" = the workgroup whose arrival ticket is the final one; it sees the other
-// workgroups' atomics/stores through the agent-scope release/acquire of
-// last_block_arrives() (gn_device.hpp).  Integer histograms and rank counting are exact
-// and independent of arrival order; the sums use the same tree as gn.hip.  If a median
-// sits in a run of more than kSelCap equal-prefix keys (heavy duplicates), the pipeline
-// raises `overflow` and the host repeats the evaluation with the general radix path.
+// These kernels move 16-48 MB that sits in L2/MALL; they are latency-bound, not
+// bandwidth-bound, so each lane issues a batch of independent loads before it touches
+// any of them, the serial tail of a launch is spread over waves (one problem per wave), and
+// the arrival tickets are sharded (gn_device.hpp).  "Last block" = the workgroup whose ticket
+// is the final one; everything handed to it is written by device-scope atomics or sc1
+// stores and read with sc1 loads.  Integer histograms and rank counting are exact and
+// independent of arrival order; the sums use the same tree as gn.hip.  If a median sits in
+// a run of more than kSelCap equal-prefix keys (heavy duplicates), the pipeline raises
+// `overflow` and the host repeats the evaluation with the general radix path.
 #include "common.hpp"
 #include "gn_device.hpp"
 
@@ -23,72 +26,103 @@ namespace icp {
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-template <int MODE>
-__device__ __forceinline__ void load_values(unsigned i, const double2 *__restrict__ a,
-                                            const double2 *__restrict__ b, const Pose &T,
-                                            double *__restrict__ rx, double *__restrict__ ry, double med0,
-                                            double med1, double &v0, double &v1, bool &saw_nan) {
-  if (MODE == 0) {  // residual(), src/lib.rs:34-36, stored for the later passes
-    const double2 s = a[i], d = b[i];
-    v0 = ((T.r00 * s.x + T.r01 * s.y) + T.tx) - d.x;
-    v1 = ((T.r10 * s.x + T.r11 * s.y) + T.ty) - d.y;
-    rx[i] = v0;
-    ry[i] = v1;
-    saw_nan |= (v0 != v0) | (v1 != v1);
-  } else {
-    v0 = rx[i];
-    v1 = ry[i];
-    if (MODE == 2) {  // src/stats.rs:35
-      v0 = fabs(v0 - med0);
-      v1 = fabs(v1 - med1);
+constexpr int kFastThreads = 1024; // 16 waves, one workgroup (64 KB of LDS histograms) per CU
+constexpr int kFastBatch = 4;      // independent elements in flight per lane
+constexpr int kScanPad = kSelBins + kSelBins / 64;  // +1 word per 64 bins: conflict-free column reads
+
+// MODE 0: r = T*a - b computed here (residual(), src/lib.rs:34-36) and stored as rx|ry
+// MODE 1: keys of the stored residuals; MODE 2: keys of |r - median| (src/stats.rs:35)
+template <int MODE, typename F>
+__device__ __forceinline__ void for_each_value(const double2 *__restrict__ a, const double2 *__restrict__ b,
+                                               const Pose &T, double *__restrict__ rx,
+                                               double *__restrict__ ry, unsigned n, double med0, double med1,
+                                               bool &saw_nan, F &&f) {
+  const unsigned G = gridDim.x * blockDim.x;
+  for (unsigned base = blockIdx.x * blockDim.x + threadIdx.x; base < n; base += G * kFastBatch) {
+    double v0[kFastBatch], v1[kFastBatch];
+    double2 s[kFastBatch], d[kFastBatch];
+#pragma unroll
+    for (int u = 0; u < kFastBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i < n) {
+        if (MODE == 0) {
+          s[u] = a[i];
+          d[u] = b[i];
+        } else {
+          v0[u] = rx[i];
+          v1[u] = ry[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kFastBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i < n) {
+        if (MODE == 0) {
+          v0[u] = ((T.r00 * s[u].x + T.r01 * s[u].y) + T.tx) - d[u].x;
+          v1[u] = ((T.r10 * s[u].x + T.r11 * s[u].y) + T.ty) - d[u].y;
+          rx[i] = v0[u];
+          ry[i] = v1[u];
+          saw_nan |= (v0[u] != v0[u]) | (v1[u] != v1[u]);
+        } else if (MODE == 2) {
+          v0[u] = fabs(v0[u] - med0);
+          v1[u] = fabs(v1[u] - med1);
+        }
+        f(f2k(v0[u]), f2k(v1[u]));
+      }
     }
   }
 }
 
-// Executed by the last block (256 threads): for every problem find the digit bin that
-// holds its rank and descend into it.
-__device__ void scan_descend(const uint32_t *hist, SelState *sel, GnScalars *scal, int pass, bool check_cap) {
-  constexpr int PER = kSelBins / 256;
-  __shared__ unsigned wave_sum[4];
+// Tail of a histogram launch, run by the last block: wave p finds the digit bin that holds
+// problem p's rank.  The block's LDS histogram area is dead by now and is reused as a
+// padded staging buffer (bin + bin/64), so that lane l can walk bins [64 l, 64 l + 64).
+__device__ __forceinline__ void scan_descend(uint32_t *lds, const uint32_t *hist, SelState *sel,
+                                             GnScalars *scal, int pass, bool check_cap) {
   __shared__ unsigned found_bin[kSelProblems], found_below[kSelProblems], found_cnt[kSelProblems];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int p = 0; p < kSelProblems; ++p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < kSelProblems) {
+    const int p = wave;
     const int src = sel[p].alias >= 0 ? sel[p].alias : p;
-    const unsigned long long rank = sel[p].rank;
     const uint32_t *hp = hist + src * kSelBins;
-    unsigned loc[PER], tot = 0;
+    uint32_t *stage = lds + p * kScanPad;
+    unsigned v[64];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      loc[j] = __hip_atomic_load(hp + tid * PER + j, RLX_AGENT);
-      tot += loc[j];
-    }
+    for (int j = 0; j < 64; ++j) v[j] = __hip_atomic_load(hp + j * 64 + lane, RLX_AGENT);
+#pragma unroll
+    for (int j = 0; j < 64; ++j) stage[j * 65 + lane] = v[j];  // bin j*64+lane -> bin + bin/64
+  }
+  __syncthreads();
+  if (wave < kSelProblems) {
+    const int p = wave;
+    const unsigned long long rank = sel[p].rank;
+    const uint32_t *stage = lds + p * kScanPad + lane * 65;  // bins [64 lane, 64 lane + 64)
+    unsigned tot = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) tot += stage[j];
     unsigned inc = tot;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      const unsigned v = __shfl_up(inc, off);
-      if (lane >= off) inc += v;
+      const unsigned t = __shfl_up(inc, off);
+      if (lane >= off) inc += t;
     }
-    if (lane == 63) wave_sum[wave] = inc;
-    __syncthreads();
-    unsigned base = 0;
-    for (int w = 0; w < wave; ++w) base += wave_sum[w];
-    const unsigned excl = base + inc - tot;
+    const unsigned excl = inc - tot;
     if ((unsigned long long)excl <= rank && rank < (unsigned long long)excl + tot) {
       unsigned below = excl;
-#pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        if (rank < (unsigned long long)below + loc[j]) {
-          found_bin[p] = tid * PER + j;
+      for (int j = 0; j < 64; ++j) {
+        const unsigned c = stage[j];
+        if (rank < (unsigned long long)below + c) {
+          found_bin[p] = lane * 64 + j;
           found_below[p] = below;
-          found_cnt[p] = loc[j];
+          found_cnt[p] = c;
           break;
         }
-        below += loc[j];
+        below += c;
       }
     }
-    __syncthreads();
   }
-  if (tid == 0) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
     const int shift = pass_shift(pass);
     bool over = false;
     for (int p = 0; p < kSelProblems; ++p) {
@@ -103,11 +137,12 @@ __device__ void scan_descend(const uint32_t *hist, SelState *sel, GnScalars *sca
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_fast_hist(const double2 *__restrict__ a, const double2 *__restrict__ b,
-                                                   Pose T, double *__restrict__ rx, double *__restrict__ ry,
-                                                   unsigned n, int pass, SelState *sel, GnScalars *scal,
-                                                   uint32_t *hist, SelCtl *ctl) {
-  __shared__ uint32_t lh[kSelProblems][kSelBins];
+__global__ __launch_bounds__(kFastThreads) void k_fast_hist(const double2 *__restrict__ a,
+                                                            const double2 *__restrict__ b, Pose T,
+                                                            double *__restrict__ rx, double *__restrict__ ry,
+                                                            unsigned n, int pass, SelState *sel,
+                                                            GnScalars *scal, uint32_t *hist, SelCtl *ctl) {
+  __shared__ uint32_t lh[kSelProblems * kScanPad];  // histograms at p*kSelBins; padded staging later
   unsigned long long prefix[kSelProblems];
   bool active[kSelProblems];
 #pragma unroll
@@ -118,54 +153,69 @@ __global__ __launch_bounds__(256) void k_fast_hist(const double2 *__restrict__ a
 #pragma unroll
   for (int p = 0; p < kSelProblems; ++p)
     if (active[p])
-      for (unsigned i = threadIdx.x; i < kSelBins; i += 256) lh[p][i] = 0;
+      for (unsigned i = threadIdx.x; i < kSelBins; i += kFastThreads) lh[p * kSelBins + i] = 0;
   __syncthreads();
 
   const int shift = pass_shift(pass);
   const unsigned mask = (1u << pass_bits(pass)) - 1u;
-  const int hs = shift + pass_bits(pass);
+  const int hs = shift + pass_bits(pass);  // bits above the current digit (64 at pass 0)
   double med0 = 0., med1 = 0.;
   if (MODE == 2) {
     med0 = scal->median[0];
     med1 = scal->median[1];
   }
   bool saw_nan = false;
-  const unsigned G = gridDim.x * 256;
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += G) {
-    double v0, v1;
-    load_values<MODE>(i, a, b, T, rx, ry, med0, med1, v0, v1, saw_nan);
-    const unsigned long long k0 = f2k(v0), k1 = f2k(v1);
+  for_each_value<MODE>(a, b, T, rx, ry, n, med0, med1, saw_nan, [&](unsigned long long k0, unsigned long long k1) {
 #pragma unroll
     for (int p = 0; p < kSelProblems; ++p) {
       if (!active[p]) continue;
       const unsigned long long key = (p < 2) ? k0 : k1;
       const bool match = (hs >= 64) || ((key >> hs) == (prefix[p] >> hs));
-      if (match) atomicAdd(&lh[p][(unsigned)(key >> shift) & mask], 1u);
+      const unsigned digit = (unsigned)(key >> shift) & mask;
+      if (pass == 0) {
+        // top digit = sign + exponent: a wave's 64 keys fall into a handful of bins, and 64
+        // LDS atomics on one address serialise.  Aggregate equal digits first (a few rounds),
+        // then let whatever is left go one by one.
+        unsigned long long todo = __ballot(match);
+        for (int round = 0; round < 4 && todo; ++round) {
+          const int leader = __ffsll((long long)todo) - 1;  // wave-uniform
+          const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)digit, leader);
+          const unsigned long long same = __ballot(digit == d0) & todo;
+          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[p * kSelBins + d0], (unsigned)__popcll(same));
+          todo &= ~same;
+        }
+        if ((todo >> (threadIdx.x & 63)) & 1) atomicAdd(&lh[p * kSelBins + digit], 1u);
+      } else if (match) {
+        atomicAdd(&lh[p * kSelBins + digit], 1u);
+      }
     }
-  }
+  });
   if (MODE == 0 && saw_nan) atomicOr(&scal->nan_flag, 1);
   __syncthreads();
 #pragma unroll
   for (int p = 0; p < kSelProblems; ++p)
     if (active[p])
-      for (unsigned i = threadIdx.x; i < kSelBins; i += 256) {
-        const uint32_t c = lh[p][i];
+      for (unsigned i = threadIdx.x; i < kSelBins; i += kFastThreads) {
+        const uint32_t c = lh[p * kSelBins + i];
         if (c) atomicAdd(&hist[p * kSelBins + i], c);
       }
-  if (last_block_arrives(&ctl->ticket[0])) scan_descend(hist, sel, scal, pass, /*check_cap=*/pass == 1);
+  if (last_block_arrives(&ctl->t[0])) scan_descend(lh, hist, sel, scal, pass, /*check_cap=*/pass == 1);
 }
 
 // Append the keys that share the first `prefix_bits` bits with a problem's prefix to its
-// candidate list; the last block then ranks each list and produces median (stage 0) or
-// sigma (stage 1), and re-arms the search state for the next stage.
+// candidate list; in the last block wave p ranks problem p's list and the block produces
+// median (stage 0) or sigma (stage 1) and re-arms the search state for the next stage.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_fast_compact(const double2 *__restrict__ a,
-                                                      const double2 *__restrict__ b, Pose T,
-                                                      double *__restrict__ rx, double *__restrict__ ry,
-                                                      unsigned n, int prefix_bits, int stage, SelState *sel,
-                                                      GnScalars *scal, unsigned long long *cand, SelCtl *ctl) {
-  __shared__ unsigned long long keys[kSelCap];
+__global__ __launch_bounds__(kFastThreads) void k_fast_compact(const double2 *__restrict__ a,
+                                                               const double2 *__restrict__ b, Pose T,
+                                                               double *__restrict__ rx,
+                                                               double *__restrict__ ry, unsigned n,
+                                                               int prefix_bits, int stage, SelState *sel,
+                                                               GnScalars *scal, unsigned long long *cand,
+                                                               SelCtl *ctl) {
+  __shared__ unsigned long long keys[kSelProblems][kSelCap];
   __shared__ unsigned long long result[kSelProblems];
+  __shared__ int s_over;
   unsigned long long prefix[kSelProblems];
   bool active[kSelProblems];
 #pragma unroll
@@ -180,11 +230,7 @@ __global__ __launch_bounds__(256) void k_fast_compact(const double2 *__restrict_
   }
   const int hs = 64 - prefix_bits;
   bool saw_nan = false;
-  const unsigned G = gridDim.x * 256;
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += G) {
-    double v0, v1;
-    load_values<MODE>(i, a, b, T, rx, ry, med0, med1, v0, v1, saw_nan);
-    const unsigned long long k0 = f2k(v0), k1 = f2k(v1);
+  for_each_value<MODE>(a, b, T, rx, ry, n, med0, med1, saw_nan, [&](unsigned long long k0, unsigned long long k1) {
 #pragma unroll
     for (int p = 0; p < kSelProblems; ++p) {
       if (!active[p]) continue;
@@ -192,32 +238,35 @@ __global__ __launch_bounds__(256) void k_fast_compact(const double2 *__restrict_
       const bool match = (hs >= 64) || ((key >> hs) == (prefix[p] >> hs));
       if (match) {
         const unsigned pos = atomicAdd(&ctl->cand_cnt[p], 1u);
-        if (pos < (unsigned)kSelCap) cand[p * kSelCap + pos] = key;
+        if (pos < (unsigned)kSelCap) __hip_atomic_store(&cand[p * kSelCap + pos], key, RLX_AGENT);
       }
     }
-  }
+  });
   if (MODE == 0 && saw_nan) atomicOr(&scal->nan_flag, 1);
 
-  if (!last_block_arrives(&ctl->ticket[1])) return;
-  const int tid = threadIdx.x;
-  bool over = false;
-  for (int p = 0; p < kSelProblems; ++p) {
+  if (!last_block_arrives(&ctl->t[1])) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_over = 0;
+  __syncthreads();
+  if (wave < kSelProblems) {
+    const int p = wave;
     const int src = sel[p].alias >= 0 ? sel[p].alias : p;
     unsigned c = __hip_atomic_load(&ctl->cand_cnt[src], RLX_AGENT);
     if (c > (unsigned)kSelCap) {
-      over = true;
+      if (lane == 0) s_over = 1;
       c = kSelCap;
     }
     const unsigned long long rank = sel[p].rank;
-    __syncthreads();
-    for (unsigned i = tid; i < c; i += 256) keys[i] = cand[src * kSelCap + i];
-    if (tid == 0) result[p] = 0;
-    __syncthreads();
-    for (unsigned i = tid; i < c; i += 256) {
-      const unsigned long long ki = keys[i];
+    for (unsigned i = lane; i < c; i += 64) keys[p][i] = __hip_atomic_load(&cand[src * kSelCap + i], RLX_AGENT);
+    if (lane == 0) result[p] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (unsigned i = lane; i < c; i += 64) {
+      const unsigned long long ki = keys[p][i];
       unsigned less = 0, eq = 0;
       for (unsigned j = 0; j < c; ++j) {
-        const unsigned long long kj = keys[j];
+        const unsigned long long kj = keys[p][j];
         less += kj < ki;
         eq += kj == ki;
       }
@@ -225,7 +274,7 @@ __global__ __launch_bounds__(256) void k_fast_compact(const double2 *__restrict_
     }
   }
   __syncthreads();
-  if (tid == 0) {
+  if (threadIdx.x == 0) {
     for (int j = 0; j < 2; ++j) {
       const double lo = k2f(result[2 * j]), hi = k2f(result[2 * j + 1]);
       const double med = (n & 1) ? lo : (lo + hi) / 2.;  // src/stats.rs:18-27
@@ -239,60 +288,84 @@ __global__ __launch_bounds__(256) void k_fast_compact(const double2 *__restrict_
       sel[p].alias = hi ? p - 1 : -1;
       __hip_atomic_store(&ctl->cand_cnt[p], 0u, RLX_AGENT);
     }
-    if (over) scal->overflow = 1;
+    if (s_over) scal->overflow = 1;
   }
 }
 
 // src/lib.rs:238-255 (+ :45-50), block sums, and -- in the last block -- the second stage of
 // the fixed reduction tree (identical to k_final_reduce in gn.hip).  Every block also clears
 // its slice of the histograms for the next evaluation.
-__global__ __launch_bounds__(256) void k_fast_accumulate(const double2 *__restrict__ a,
-                                                         const double *__restrict__ rx,
-                                                         const double *__restrict__ ry, unsigned n, Pose T,
-                                                         GnScalars *scal, double *partials, uint32_t *hist,
-                                                         SelCtl *ctl, GnResult *res) {
+__global__ __launch_bounds__(kReduceThreads) void k_fast_accumulate(const double2 *__restrict__ a,
+                                                                    const double *__restrict__ rx,
+                                                                    const double *__restrict__ ry,
+                                                                    unsigned n, Pose T, GnScalars *scal,
+                                                                    double *partials, uint32_t *hist,
+                                                                    SelCtl *ctl, GnResult *res) {
   const double sig[2] = {scal->sigma[0], scal->sigma[1]};
   double g[2];
   g[0] = 1. / sig[0];
   g[1] = 1. / sig[1];
+  const double k2 = ICP_HUBER_K * ICP_HUBER_K;
   double acc[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; ++k) acc[k] = 0.;
-  const unsigned G = gridDim.x * 256;
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += G) {
-    const double2 s = a[i];
-    const double r[2] = {rx[i], ry[i]};
-    const double a0 = -s.y, a1 = s.x;  // jacobian(), src/lib.rs:176-184
-    const double b0 = T.r00 * a0 + T.r01 * a1;
-    const double b1 = T.r10 * a0 + T.r11 * a1;
-    const double J[2][3] = {{T.r00, T.r01, b0}, {T.r10, T.r11, b1}};
+  const unsigned G = gridDim.x * kReduceThreads;
+  for (unsigned base = blockIdx.x * kReduceThreads + threadIdx.x; base < n; base += G * kFastBatch) {
+    double2 s[kFastBatch];
+    double r0[kFastBatch], r1[kFastBatch];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (sig[j] == 0.) continue;  // src/lib.rs:243-245
-      const double r_ij = r[j];
-      const double w_ij = huber_drho(r_ij * r_ij);
-      const double wg = w_ij * g[j];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) acc[9 + k] = acc[9 + k] + (wg * J[j][k]) * r_ij;
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) acc[3 * p + q] = acc[3 * p + q] + (wg * J[j][p]) * J[j][q];
+    for (int u = 0; u < kFastBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i < n) {
+        s[u] = a[i];
+        r0[u] = rx[i];
+        r1[u] = ry[i];
+      }
     }
-    acc[12] = acc[12] + huber_rho(r[0] * r[0] + r[1] * r[1]);
+#pragma unroll
+    for (int u = 0; u < kFastBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i >= n) continue;
+      const double r[2] = {r0[u], r1[u]};
+      const double a0 = -s[u].y, a1 = s[u].x;  // jacobian(), src/lib.rs:176-184
+      const double b0 = T.r00 * a0 + T.r01 * a1;
+      const double b1 = T.r10 * a0 + T.r11 * a1;
+      const double J[2][3] = {{T.r00, T.r01, b0}, {T.r10, T.r11, b1}};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (sig[j] == 0.) continue;  // src/lib.rs:243-245
+        const double r_ij = r[j];
+        const double e = r_ij * r_ij;
+        double w_ij = 1.;  // huber::drho, src/huber.rs:17-26; sqrt+divide only where a lane needs it
+        if (__ballot(e > k2)) w_ij = huber_drho(e);
+        const double wg = w_ij * g[j];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[9 + k] = acc[9 + k] + (wg * J[j][k]) * r_ij;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc[3 * p + q] = acc[3 * p + q] + (wg * J[j][p]) * J[j][q];
+      }
+      const double e2 = r[0] * r[0] + r[1] * r[1];
+      double rho = e2;  // huber::rho, src/huber.rs:6-15
+      if (__ballot(e2 > k2)) rho = huber_rho(e2);
+      acc[12] = acc[12] + rho;
+    }
   }
-  block_reduce_store<kNAcc>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)(kSelRoles * kSelProblems * kSelBins); i += G)
+  block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
+  for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x;
+       i < (unsigned)(kSelRoles * kSelProblems * kSelBins); i += G)
     hist[i] = 0;
 
-  if (!last_block_arrives(&ctl->ticket[2])) return;
+  if (!last_block_arrives(&ctl->t[2])) return;
   double tot[kNAcc + 1];
 #pragma unroll
   for (int k = 0; k < kNAcc + 1; ++k) tot[k] = 0.;
   const int blocks = gridDim.x;
-  for (int i = threadIdx.x; i < blocks; i += 256)
+  for (int i = threadIdx.x; i < blocks; i += kReduceThreads)
 #pragma unroll
-    for (int k = 0; k < kNAcc; ++k) tot[k] = tot[k] + partials[(size_t)i * (kNAcc + 1) + k];
+    for (int k = 0; k < kNAcc; ++k)
+      tot[k] = tot[k] + __hip_atomic_load(&partials[(size_t)i * (kNAcc + 1) + k], RLX_AGENT);
   block_reduce_store<kNAcc + 1>(tot, res->acc);
   if (threadIdx.x == 0) {
     res->sigma[0] = sig[0];
@@ -304,9 +377,10 @@ __global__ __launch_bounds__(256) void k_fast_accumulate(const double2 *__restri
 }
 
 static unsigned fast_blocks(unsigned n) {
-  unsigned b = (n + 256 * 8 - 1) / (256 * 8);
+  const unsigned per = kFastThreads * kFastBatch;
+  unsigned b = (n + per - 1) / per;
   if (b < 1) b = 1;
-  if (b > 512) b = 512;
+  if (b > 256) b = 256;  // one per CU: every extra workgroup costs a histogram flush of global atomics
   return b;
 }
 
@@ -317,12 +391,12 @@ hipError_t launch_weighted_gn_fast(icp_handle *h, const double *d_a, const doubl
   const double2 *a = (const double2 *)d_a, *b = (const double2 *)d_b;
   hipStream_t s = h->stream;
   const size_t role = (size_t)kSelProblems * kSelBins;
-#define HIST(MODE, PASS, ROLE)                                                                          \
-  hipLaunchKernelGGL(k_fast_hist<MODE>, dim3(hb), dim3(256), 0, s, a, b, T, w.d_rx, w.d_ry, n, PASS,    \
-                     w.d_sel, w.d_scal, w.d_hist + (ROLE) * role, w.d_ctl)
-#define COMPACT(MODE, BITS, STAGE)                                                                      \
-  hipLaunchKernelGGL(k_fast_compact<MODE>, dim3(hb), dim3(256), 0, s, a, b, T, w.d_rx, w.d_ry, n, BITS,  \
-                     STAGE, w.d_sel, w.d_scal, w.d_cand, w.d_ctl)
+#define HIST(MODE, PASS, ROLE)                                                                            \
+  hipLaunchKernelGGL(k_fast_hist<MODE>, dim3(hb), dim3(kFastThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n,    \
+                     PASS, w.d_sel, w.d_scal, w.d_hist + (ROLE) * role, w.d_ctl)
+#define COMPACT(MODE, BITS, STAGE)                                                                        \
+  hipLaunchKernelGGL(k_fast_compact<MODE>, dim3(hb), dim3(kFastThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, \
+                     BITS, STAGE, w.d_sel, w.d_scal, w.d_cand, w.d_ctl)
   if (n > (unsigned)kSelCap) {
     HIST(0, 0, 0);
     HIST(1, 1, 1);

@@ -238,17 +238,21 @@ hipError_t build_grid(icp_handle *h) {
 
 // ---------------------------------------------------------------- query ----------
 template <int DIM, bool XFORM>
-__global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src, unsigned n, Pose T,
+__global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
+                                                 const uint32_t *__restrict__ perm, unsigned n, Pose T,
                                                  GridParams g, const uint32_t *__restrict__ start,
                                                  const GridPoint *__restrict__ pts,
                                                  uint32_t *__restrict__ idx, double2 *__restrict__ a,
                                                  double2 *__restrict__ b) {
-  const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  const unsigned k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  // perm != null: src is the cell-sorted copy made by prepare_queries (neighbouring lanes
+  // search neighbouring cells); results go back to the original positions
+  const unsigned i = perm ? perm[k] : k;
   double q[3];
-  q[0] = src[(size_t)i * DIM + 0];
-  q[1] = src[(size_t)i * DIM + 1];
-  q[2] = DIM == 3 ? src[(size_t)i * DIM + 2] : 0.;
+  q[0] = src[(size_t)k * DIM + 0];
+  q[1] = src[(size_t)k * DIM + 1];
+  q[2] = DIM == 3 ? src[(size_t)k * DIM + 2] : 0.;
   if (XFORM) {  // Transform::transform, src/transform.rs:22-24
     const double nx = (T.r00 * q[0] + T.r01 * q[1]) + T.tx;
     const double ny = (T.r10 * q[0] + T.r11 * q[1]) + T.ty;
@@ -275,51 +279,100 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
     return v > 0. ? v : 0.;
   };
 
-  const int rmax = max(max(g.n[0], g.n[1]), g.n[2]);
-  for (int r = 0; r <= rmax; ++r) {
-    const int z0 = DIM == 3 ? max(c[2] - r, 0) : 0, z1 = DIM == 3 ? min(c[2] + r, g.n[2] - 1) : 0;
-    const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
-    for (int iz = z0; iz <= z1; ++iz) {
-      const bool ze = DIM == 3 && (iz == c[2] - r || iz == c[2] + r);
-      const double dz = DIM == 3 ? slab(2, iz, iz) : 0.;
-      for (int iy = y0; iy <= y1; ++iy) {
-        const bool edge = ze || iy == c[1] - r || iy == c[1] + r;
+  auto consider = [&](const GridPoint &t) {
+    const double ddx = q[0] - t.x;
+    const double ddy = q[1] - t.y;
+    double dd = ddx * ddx + ddy * ddy;
+    if (DIM == 3) {
+      const double ddz = q[2] - t.z;
+      dd = dd + ddz * ddz;
+    }
+    if (dd < best || (dd == best && t.idx < bi)) {
+      best = dd;
+      bi = t.idx;
+      bx = t.x;
+      by = t.y;
+    }
+  };
+  // a contiguous run of cell-sorted targets, four records in flight per lane (the tail
+  // re-reads the last record: evaluating a target twice cannot change the winner)
+  auto scan_run = [&](uint32_t s, uint32_t e) {
+    for (uint32_t p = s; p < e; p += 4) {
+      const uint32_t last = e - 1;
+      const GridPoint t0 = pts[p];
+      const GridPoint t1 = pts[min(p + 1, last)];
+      const GridPoint t2 = pts[min(p + 2, last)];
+      const GridPoint t3 = pts[min(p + 3, last)];
+      consider(t0);
+      consider(t1);
+      consider(t2);
+      consider(t3);
+    }
+  };
+
+  // Rings 0 and 1 in one go: the block [c-1, c+1]^DIM is 3 (2-D) or 9 (3-D) rows, each one
+  // contiguous run of up to three cells.  All row bounds are fetched before any target is
+  // (18 independent loads), the centre row goes first so that `best` is tight early, and the
+  // other rows are skipped when their box cannot hold a closer-or-equal target.
+  {
+    constexpr int NROWS = DIM == 3 ? 9 : 3;
+    constexpr int DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+    constexpr int DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+    const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, g.n[0] - 1);
+    const double dx = slab(0, x0, x1);
+    uint32_t rs[NROWS], re[NROWS];
+    double rb[NROWS];
+#pragma unroll
+    for (int t = 0; t < NROWS; ++t) {
+      const int iy = c[1] + DY[t], iz = DIM == 3 ? c[2] + DZ[t] : 0;
+      const bool valid = iy >= 0 && iy < g.n[1] && iz >= 0 && iz < g.n[2];
+      rs[t] = re[t] = 0;
+      rb[t] = __builtin_huge_val();
+      if (valid) {
+        const uint32_t row = ((uint32_t)iz * g.n[1] + iy) * g.n[0];
+        rs[t] = start[row + x0];
+        re[t] = start[row + x1 + 1];
         const double dy = slab(1, iy, iy);
-        const double dyz = dy * dy + dz * dz;
-        if (dyz > best) continue;
-        // cells of this row that belong to shell r: the whole run on an edge row, else
-        // only the two end cells
-        const int nruns = (edge || r == 0) ? 1 : 2;
-        for (int run = 0; run < nruns; ++run) {
-          int x0, x1;
-          if (edge || r == 0) {
-            x0 = c[0] - r;
-            x1 = c[0] + r;
-          } else {
-            x0 = x1 = (run == 0) ? c[0] - r : c[0] + r;
-          }
-          if (x1 < 0 || x0 > g.n[0] - 1) continue;
-          x0 = max(x0, 0);
-          x1 = min(x1, g.n[0] - 1);
-          const double dx = slab(0, x0, x1);
-          if (dx * dx + dyz > best) continue;  // strictly farther: cannot win or tie
-          const uint32_t row = ((uint32_t)iz * g.n[1] + iy) * g.n[0];
-          const uint32_t s = start[row + x0], e = start[row + x1 + 1];
-          for (uint32_t p = s; p < e; ++p) {
-            const GridPoint t = pts[p];
-            const double ddx = q[0] - t.x;
-            const double ddy = q[1] - t.y;
-            double dd = ddx * ddx + ddy * ddy;
-            if (DIM == 3) {
-              const double ddz = q[2] - t.z;
-              dd = dd + ddz * ddz;
+        const double dz = DIM == 3 ? slab(2, iz, iz) : 0.;
+        rb[t] = dx * dx + (dy * dy + dz * dz);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NROWS; ++t)
+      if (!(rb[t] > best)) scan_run(rs[t], re[t]);  // strictly farther boxes cannot win or tie
+  }
+
+  const int rmax = max(max(g.n[0], g.n[1]), g.n[2]);
+  for (int r = 1; r <= rmax; ++r) {
+    if (r >= 2) {  // shell r of the general walk (rings 0 and 1 were handled above)
+      const int z0 = DIM == 3 ? max(c[2] - r, 0) : 0, z1 = DIM == 3 ? min(c[2] + r, g.n[2] - 1) : 0;
+      const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
+      for (int iz = z0; iz <= z1; ++iz) {
+        const bool ze = DIM == 3 && (iz == c[2] - r || iz == c[2] + r);
+        const double dz = DIM == 3 ? slab(2, iz, iz) : 0.;
+        for (int iy = y0; iy <= y1; ++iy) {
+          const bool edge = ze || iy == c[1] - r || iy == c[1] + r;
+          const double dy = slab(1, iy, iy);
+          const double dyz = dy * dy + dz * dz;
+          if (dyz > best) continue;
+          // cells of this row that belong to shell r: the whole run on an edge row, else
+          // only the two end cells
+          const int nruns = edge ? 1 : 2;
+          for (int run = 0; run < nruns; ++run) {
+            int x0, x1;
+            if (edge) {
+              x0 = c[0] - r;
+              x1 = c[0] + r;
+            } else {
+              x0 = x1 = (run == 0) ? c[0] - r : c[0] + r;
             }
-            if (dd < best || (dd == best && t.idx < bi)) {
-              best = dd;
-              bi = t.idx;
-              bx = t.x;
-              by = t.y;
-            }
+            if (x1 < 0 || x0 > g.n[0] - 1) continue;
+            x0 = max(x0, 0);
+            x1 = min(x1, g.n[0] - 1);
+            const double dx = slab(0, x0, x1);
+            if (dx * dx + dyz > best) continue;  // strictly farther: cannot win or tie
+            const uint32_t row = ((uint32_t)iz * g.n[1] + iy) * g.n[0];
+            scan_run(start[row + x0], start[row + x1 + 1]);
           }
         }
       }
@@ -344,6 +397,84 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   if (b) b[i] = make_double2(bx, by);
 }
 
+// ------------------------------------------------ query locality (optional) -------
+// Counting-sort the source cloud by the target-grid cell of T*src.  The sorted copy keeps
+// the ORIGINAL coordinates (the search kernel applies the current pose with the same
+// arithmetic as always) plus the permutation, so outputs land at the original indices and
+// nothing downstream can tell the difference -- except the memory system: a wave's 64
+// queries now walk the same few cells.
+__global__ void k_query_count(const double *__restrict__ src, unsigned n, int dim, Pose T, GridParams g,
+                              uint32_t *__restrict__ cell_of, uint32_t *__restrict__ cnt) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double q[3] = {src[(size_t)i * dim], src[(size_t)i * dim + 1], dim == 3 ? src[(size_t)i * dim + 2] : 0.};
+  const double nx = (T.r00 * q[0] + T.r01 * q[1]) + T.tx;
+  const double ny = (T.r10 * q[0] + T.r11 * q[1]) + T.ty;
+  q[0] = nx;
+  q[1] = ny;
+  int c[3] = {0, 0, 0};
+  for (int d = 0; d < dim; ++d) c[d] = cell_coord(q[d], g.lo[d], g.inv_h, g.n[d]);
+  const uint32_t cell = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0] + c[0];
+  cell_of[i] = cell;
+  atomicAdd(&cnt[cell], 1u);
+}
+
+__global__ void k_query_scatter(const double *__restrict__ src, unsigned n, int dim,
+                                const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ start,
+                                uint32_t *__restrict__ cursor, double *__restrict__ sorted,
+                                uint32_t *__restrict__ perm) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t cell = cell_of[i];
+  const uint32_t pos = start[cell] + atomicAdd(&cursor[cell], 1u);
+  perm[pos] = i;
+  for (int d = 0; d < dim; ++d) sorted[(size_t)pos * dim + d] = src[(size_t)i * dim + d];
+}
+
+hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const Pose &T) {
+  Grid &G = h->grid;
+  QuerySort &Q = h->qsort;
+  Q.valid = false;
+  if (!G.built || n_ == 0) return hipSuccess;
+  const unsigned n = (unsigned)n_;
+  hipError_t e;
+  hipStream_t s = h->stream;
+  const unsigned nscan = G.ncell + 1;
+  const unsigned nb = (nscan + kScanItems - 1) / kScanItems;
+  if (!Q.d_cnt) {
+    if ((e = hipMalloc(&Q.d_cnt, (size_t)nscan * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&Q.d_start, (size_t)nscan * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&Q.d_btot, ((size_t)nb + 1) * 4)) != hipSuccess) return e;
+  }
+  if (n_ > Q.cap) {
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    (void)hipFree(Q.d_cell_of);
+    (void)hipFree(Q.d_perm);
+    (void)hipFree(Q.d_sorted);
+    Q.d_cell_of = Q.d_perm = nullptr;
+    Q.d_sorted = nullptr;
+    Q.cap = 0;
+    if ((e = hipMalloc(&Q.d_cell_of, n_ * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&Q.d_perm, n_ * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&Q.d_sorted, n_ * h->dim * sizeof(double))) != hipSuccess) return e;
+    Q.cap = n_;
+  }
+  if ((e = hipMemsetAsync(Q.d_cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_query_count, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, T, G.p,
+                     Q.d_cell_of, Q.d_cnt);
+  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, s, Q.d_cnt, Q.d_start, nscan, Q.d_btot);
+  hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, Q.d_btot, nb, Q.d_btot + nb);
+  hipLaunchKernelGGL(k_scan_add, dim3((nscan + 255) / 256), dim3(256), 0, s, Q.d_start, nscan, Q.d_btot);
+  if ((e = hipMemsetAsync(Q.d_cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, Q.d_cell_of,
+                     Q.d_start, Q.d_cnt, Q.d_sorted, Q.d_perm);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  Q.src = d_src;
+  Q.n = n_;
+  Q.valid = true;
+  return hipSuccess;
+}
+
 hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const Pose *Tp, double *d_a,
                           double *d_b, uint32_t *d_idx) {
   if (n_ == 0) return hipSuccess;
@@ -351,6 +482,10 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   const bool xform = Tp != nullptr;
   const Pose T = xform ? *Tp : transform_identity();
   const Grid &G = h->grid;
+  const QuerySort &Q = h->qsort;
+  const bool sorted = xform && Q.valid && Q.src == d_src && Q.n == n_;
+  const double *q_src = sorted ? Q.d_sorted : d_src;
+  const uint32_t *q_perm = sorted ? Q.d_perm : nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (h->profile) {
     if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
@@ -358,8 +493,8 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   }
   const unsigned blocks = (n + 255) / 256;
 #define GRID(DIM, XF)                                                                                   \
-  hipLaunchKernelGGL((k_nn_grid<DIM, XF>), dim3(blocks), dim3(256), 0, h->stream, d_src, n, T, G.p,      \
-                     G.d_start, G.d_pts, d_idx, (double2 *)d_a, (double2 *)d_b)
+  hipLaunchKernelGGL((k_nn_grid<DIM, XF>), dim3(blocks), dim3(256), 0, h->stream, q_src, q_perm, n, T,   \
+                     G.p, G.d_start, G.d_pts, d_idx, (double2 *)d_a, (double2 *)d_b)
   if (h->dim == 3) {
     if (xform) GRID(3, true); else GRID(3, false);
   } else {

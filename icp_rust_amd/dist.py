@@ -37,6 +37,9 @@ class HipStages:
         self.torch = torch
         icp.set_stream(torch.cuda.current_stream().cuda_stream)
 
+    def prepare(self, src_shard, T):
+        self.icp.prepare_source_device(src_shard, T)
+
     def correspond(self, src_shard, T, a_out, b_out):
         self.icp.correspond_device(src_shard, T, a_out, b_out)
 
@@ -93,6 +96,8 @@ class ShardedIcp:
         """Icp{2,3}d::estimate over the sharded source (src/lib.rs:105-130, 148-173)."""
         T = initial_transform
         inner = []
+        if max_iter > 0 and hasattr(self.stages, "prepare"):
+            self.stages.prepare(src_shard, T)  # once per estimate call, like Icp::estimate itself
         for _ in range(max_iter):
             T, k = self.step(src_shard, T)
             inner.append(k)

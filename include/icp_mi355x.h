@@ -150,6 +150,12 @@ int icp_residual_stddevs(const icp_pose *T, const double *a_xy, const double *b_
  * stream. */
 int icp_correspond_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T,
                           double *d_a_xy, double *d_b_xy, uint32_t *d_idx);
+/* Optional, before a run of icp_correspond_device calls on the same source buffer: takes a
+ * cell-sorted snapshot of (d_src, n) under pose T so that neighbouring GPU lanes search
+ * neighbouring cells (results are unchanged, bit for bit; only memory locality changes).
+ * The snapshot is used by later icp_correspond_device calls with the same (d_src, n) and
+ * must be retaken if the buffer's contents change.  icp_estimate* do this themselves. */
+int icp_prepare_source_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T);
 /* stage (ii)+(iii): the whole inner loop of src/lib.rs:59-84 on device-resident pairs;
  * synchronises the stream (the 3x3 solve and the break tests run on the host). */
 int icp_estimate_transform_device(icp_handle *h, const double *d_a_xy, const double *d_b_xy,
