@@ -24,6 +24,7 @@ import numpy as np  # noqa: E402
 
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (public spec)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+MAX_ITER = 20                  # outer iterations per estimate() call (both reference examples pass 20)
 
 
 def cpu_baseline(src, dst, iters):
@@ -60,11 +61,15 @@ def cpu_baseline(src, dst, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n-src", type=int, default=1_000_000)
     ap.add_argument("--n-dst", type=int, default=1_000_000)
-    ap.add_argument("--nn", choices=["auto", "brute", "grid"], default="brute")
+    ap.add_argument("--nn", choices=["auto", "brute", "grid"], default="auto",
+                    help="NN engine of the headline value (auto = the library default: exact grid search "
+                         "at this size); all engines return bit-identical correspondences")
+    ap.add_argument("--brute-steps", type=int, default=3,
+                    help="outer iterations of the brute-force sweep measured alongside (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=3, help="outer iterations of the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -93,49 +98,78 @@ def main():
     d_dst = torch.from_numpy(dst_np).cuda()
     d_src = torch.from_numpy(src_np).cuda()
     nn_mode = {"auto": I.NN_AUTO, "brute": I.NN_BRUTE, "grid": I.NN_GRID}[args.nn]
-    icp = I.Icp3d(d_dst, device=local_rank, nn_mode=nn_mode)
-    driver = ShardedIcp(HipStages(icp), n, rank, world)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    T = I.Transform()
-    driver.stages.prepare(d_src, T)
-    for _ in range(args.warmup):
-        T, _ = driver.step(d_src, T)
-    icp.profile_enable(True)
-    icp.profile_read()
-    barrier()
-    t0 = time.perf_counter()
-    inner = []
-    # per-estimate setup (cell-sorted snapshot of the source cloud) is inside the timed region:
-    # the K timed steps are one Icp3d::estimate(src, T, K) call
-    driver.stages.prepare(d_src, T)
-    for _ in range(args.steps):
-        T, k = driver.step(d_src, T)
-        inner.append(int(k))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    nn_ms, nn_launches = icp.profile_read()
-    icp.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure(mode, steps, warmup):
+        """K timed outer iterations = one Icp3d::estimate(src, T, K) call on resident data."""
+        icp = I.Icp3d(d_dst, device=local_rank, nn_mode=mode)
+        driver = ShardedIcp(HipStages(icp), n, rank, world)
+        T = I.Transform()
+        driver.stages.prepare(d_src, T)
+        for _ in range(warmup):
+            T, _ = driver.step(d_src, T)
+        icp.profile_enable(True)
+        icp.profile_read()
+        barrier()
+        t0 = time.perf_counter()
+        inner = []
+        for k_step in range(steps):
+            if k_step % MAX_ITER == 0:
+                # a new Icp3d::estimate(src, identity, 20) call, as examples/scan3d.rs:131 issues per
+                # frame: its per-call setup (cell-sorted snapshot of the source cloud) is timed too
+                T = I.Transform()
+                driver.stages.prepare(d_src, T)
+            T, k = driver.step(d_src, T)
+            inner.append(int(k))
+        barrier()
+        elapsed = time.perf_counter() - t0
+        nn_ms, nn_launches = icp.profile_read()
+        icp.profile_enable(False)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        engine = {I.NN_BRUTE: "brute", I.NN_GRID: "grid"}[I.lib().icp_get_nn_mode(icp._h)]
+        icp.close()
+        return dict(elapsed=elapsed, steps=steps, inner=inner, nn_ms=nn_ms, nn_launches=nn_launches, T=T,
+                    engine=engine)
+
+    def nn_roofline(r, n_shard):
+        """Roofline of the dominant kernel (the NN search) from the live HIP-event timing."""
+        avg_s = 1e-3 * r["nn_ms"] / max(r["nn_launches"], 1)
+        # SURVEY.md 8(d): compulsory bytes 24 B/source in + 4 B idx out + 24 B/target in (once)
+        nn_bytes = 28.0 * n_shard + 24.0 * m
+        gbs = nn_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        if r["engine"] == "brute":
+            flops = 8.0 * n_shard * m  # 3 sub, 3 mul, 2 add per (source, target) pair, f64
+            tf = flops / avg_s / 1e12 if avg_s > 0 else 0.0
+            return {"kernel": "k_nn_brute", "bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_ms": 1e3 * avg_s, "launches": int(r["nn_launches"]),
+                    "algorithmic_flops_per_launch": flops,
+                    "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "algorithmic_bytes_per_launch": nn_bytes}}
+        return {"kernel": "k_nn_grid", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": 1e3 * avg_s,
+                "launches": int(r["nn_launches"]), "algorithmic_bytes_per_launch": nn_bytes}
+
+    res = measure(nn_mode, args.steps, args.warmup)
+    brute = None
+    if args.brute_steps > 0 and res["engine"] != "brute":
+        brute = measure(I.NN_BRUTE, args.brute_steps, 1)
+    elapsed, inner, T = res["elapsed"], res["inner"], res["T"]
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         n_shard = hi - lo
-        # dominant kernel: the brute-force NN sweep.  Algorithmic work per launch:
-        # 8 f64 flop per (source, target) pair; compulsory bytes 24 B/source + 24 B/target + 4 B idx.
-        avg_nn_s = 1e-3 * nn_ms / max(nn_launches, 1)
-        flops = 8.0 * n_shard * m
-        nn_bytes = 24.0 * n_shard + 24.0 * m + 4.0 * n_shard
-        ach_tflops = flops / avg_nn_s / 1e12 if avg_nn_s > 0 else 0.0
-        ach_gbs = nn_bytes / avg_nn_s / 1e9 if avg_nn_s > 0 else 0.0
         truth = I.Transform(synth.TRUTH_PARAM).as_array()
+        evals = [k + 1 for k in inner]  # GN evaluations per step: the applied updates + the terminating one
+        # whole-step algorithmic HBM bytes (SURVEY.md 8(d)): 28 N + 24 M + k * 96 N
+        step_bytes = 28.0 * n + 24.0 * m + float(np.mean(evals)) * 96.0 * n
         out = {
             "metric": "ICP iterations/sec on 1M-pt 3D pair",
             "value": args.steps / elapsed,
@@ -150,34 +184,28 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "synthetic 3D 1M-vs-1M point clouds, brute-force NN + Huber, "
-                            "point-to-point SE(2)-on-xy ICP (BASELINE.json configs[2]; sharded = configs[3])",
-                "n_src": n, "n_dst": m, "nn": args.nn,
+                "workload": "synthetic 3D 1M-vs-1M point clouds, exact NN + Huber/MAD Gauss-Newton, "
+                            "point-to-point SE(2)-on-xy ICP (BASELINE.json configs[2]; sharded = configs[3]); "
+                            "NN engine = " + res["engine"] + " (bit-identical correspondences to the "
+                            "brute-force sweep, which is timed alongside under `brute_force`)",
+                "n_src": n, "n_dst": m, "nn": res["engine"], "outer_iterations_per_estimate_call": MAX_ITER,
                 "parallelism": f"source cloud sharded x{world}, target replicated, inner loop replicated",
                 "seed": hex(synth.SEED),
             },
-            "roofline": {
-                # The NN sweep is FP64-vector-ALU bound, not HBM bound: 8 flop per
-                # pair against 52 MB of compulsory traffic.  The binding roof is reported; the HBM
-                # fraction is reported beside it and is << 1 % by construction.
-                "kernel": "k_nn_brute",
-                "bound": "fp64_valu",
-                "achieved": ach_tflops,
-                "peak": FP64_VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": ach_tflops / FP64_VALU_PEAK_TFLOPS,
-                "traffic": None,
-                "avg_launch_ms": 1e3 * avg_nn_s,
-                "launches": int(nn_launches),
-                "algorithmic_flops_per_launch": flops,
-                "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nn_bytes},
-            },
+            "roofline": nn_roofline(res, n_shard),
+            "step_hbm": {"algorithmic_bytes_per_step": step_bytes,
+                         "achieved_GBs": step_bytes / (elapsed / args.steps) / 1e9,
+                         "frac_of_8TBs": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             "inner_iterations_per_step": inner,
-            "nn_share_of_step": (nn_ms / max(nn_launches, 1)) / ms_per_step if ms_per_step > 0 else None,
+            "nn_share_of_step": (res["nn_ms"] / max(res["nn_launches"], 1)) / ms_per_step,
             "pose": T.as_array().tolist(),
             "pose_abs_err_vs_truth": float(np.max(np.abs(T.as_array() - truth))),
         }
+        if brute is not None:
+            out["brute_force"] = {
+                "value": brute["steps"] / brute["elapsed"], "unit": "iterations/s", "steps": brute["steps"],
+                "ms_per_step": 1e3 * brute["elapsed"] / brute["steps"], "roofline": nn_roofline(brute, n_shard),
+            }
         if world == 1 and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(src_np, dst_np, args.cpu_iters)
         else:
