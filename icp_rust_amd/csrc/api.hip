@@ -226,6 +226,7 @@ extern "C" void icp_destroy(icp_handle *h) {
   (void)hipFree(h->qsort.d_cell_of);
   (void)hipFree(h->qsort.d_perm);
   (void)hipFree(h->qsort.d_sorted);
+  (void)hipFree(h->qsort.d_prev);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }

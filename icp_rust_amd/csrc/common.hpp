@@ -98,10 +98,9 @@ struct GridParams {
   double scale;  // coordinate magnitude used for the rounding margin of the pruning bounds
 };
 
-struct GridPoint {  // one target, cell-sorted; 32 B so a candidate is two 16-B loads
-  double x, y, z;
-  uint32_t idx;  // original index in dst
-  uint32_t pad;
+struct GridPoint {  // one target, cell-sorted: a 16-B pre-filter record = one load per candidate
+  float x, y, z;   // fl32(coordinate - grid lo); exact f64 coordinates are read from dst by idx
+  uint32_t idx;    // original index in dst
 };
 
 struct Grid {
@@ -119,6 +118,7 @@ struct QuerySort {
   size_t n = 0, cap = 0;
   uint32_t *d_cnt = nullptr, *d_start = nullptr, *d_btot = nullptr;
   uint32_t *d_cell_of = nullptr, *d_perm = nullptr;
+  uint32_t *d_prev = nullptr;  // per sorted slot: target index of the last match, ~0u = none
   double *d_sorted = nullptr;
 };
 

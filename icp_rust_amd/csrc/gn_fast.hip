@@ -172,22 +172,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_hist(const double2 *__res
       const unsigned long long key = (p < 2) ? k0 : k1;
       const bool match = (hs >= 64) || ((key >> hs) == (prefix[p] >> hs));
       const unsigned digit = (unsigned)(key >> shift) & mask;
-      if (pass == 0) {
-        // top digit = sign + exponent: a wave's 64 keys fall into a handful of bins, and 64
-        // LDS atomics on one address serialise.  Aggregate equal digits first (a few rounds),
-        // then let whatever is left go one by one.
-        unsigned long long todo = __ballot(match);
-        for (int round = 0; round < 4 && todo; ++round) {
-          const int leader = __ffsll((long long)todo) - 1;  // wave-uniform
-          const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)digit, leader);
-          const unsigned long long same = __ballot(digit == d0) & todo;
-          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[p * kSelBins + d0], (unsigned)__popcll(same));
-          todo &= ~same;
-        }
-        if ((todo >> (threadIdx.x & 63)) & 1) atomicAdd(&lh[p * kSelBins + digit], 1u);
-      } else if (match) {
-        atomicAdd(&lh[p * kSelBins + digit], 1u);
-      }
+      if (match) atomicAdd(&lh[p * kSelBins + digit], 1u);
     }
   });
   if (MODE == 0 && saw_nan) atomicOr(&scal->nan_flag, 1);

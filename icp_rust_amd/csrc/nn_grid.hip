@@ -132,17 +132,16 @@ __global__ void k_scan_add(uint32_t *__restrict__ out, unsigned n, const uint32_
 
 __global__ void k_grid_scatter(const double *__restrict__ dst, unsigned m, int dim,
                                const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ start,
-                               uint32_t *__restrict__ cursor, GridPoint *__restrict__ pts) {
+                               uint32_t *__restrict__ cursor, GridParams g, GridPoint *__restrict__ pts) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const uint32_t cell = cell_of[i];
   const uint32_t pos = start[cell] + atomicAdd(&cursor[cell], 1u);
   GridPoint p;
-  p.x = dst[(size_t)i * dim + 0];
-  p.y = dst[(size_t)i * dim + 1];
-  p.z = dim == 3 ? dst[(size_t)i * dim + 2] : 0.;
+  p.x = (float)(dst[(size_t)i * dim + 0] - g.lo[0]);
+  p.y = (float)(dst[(size_t)i * dim + 1] - g.lo[1]);
+  p.z = dim == 3 ? (float)(dst[(size_t)i * dim + 2] - g.lo[2]) : 0.f;
   p.idx = i;
-  p.pad = 0;
   pts[pos] = p;
 }
 
@@ -224,7 +223,7 @@ hipError_t build_grid(icp_handle *h) {
     hipLaunchKernelGGL(k_scan_add, dim3((nscan + 255) / 256), dim3(256), 0, s, G.d_start, nscan, btot);
     if ((e = hipMemsetAsync(cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) break;
     hipLaunchKernelGGL(k_grid_scatter, dim3((m + 255) / 256), dim3(256), 0, s, h->d_dst, m, h->dim, cell_of,
-                       G.d_start, cnt, G.d_pts);
+                       G.d_start, cnt, g, G.d_pts);
     if ((e = hipGetLastError()) != hipSuccess) break;
     e = hipStreamSynchronize(s);
   } while (0);
@@ -242,8 +241,9 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
                                                  const uint32_t *__restrict__ perm, unsigned n, Pose T,
                                                  GridParams g, const uint32_t *__restrict__ start,
                                                  const GridPoint *__restrict__ pts,
-                                                 uint32_t *__restrict__ idx, double2 *__restrict__ a,
-                                                 double2 *__restrict__ b) {
+                                                 const double *__restrict__ dst, uint32_t *__restrict__ idx,
+                                                 double2 *__restrict__ a, double2 *__restrict__ b,
+                                                 uint32_t *__restrict__ prev) {
   const unsigned k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n) return;
   // perm != null: src is the cell-sorted copy made by prepare_queries (neighbouring lanes
@@ -259,17 +259,73 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
     q[0] = nx;
     q[1] = ny;
   }
-  int c[3];
   double mg[3];  // rounding margin per axis: >> ulp(cell arithmetic), << cell size
 #pragma unroll
+  for (int d = 0; d < 3; ++d) mg[d] = 1e-9 * (fabs(q[d]) + g.scale);
+
+  // Candidates are screened in f32 (one 16-B record each) and only the survivors are
+  // evaluated exactly.  A record holds fl32(p - lo); with qf = fl32(q - lo) every component of
+  // df = qf - pf differs from the true q - p by at most ec = 2^-23 (E + |q - lo|) (three f32
+  // roundings of magnitudes <= E resp. |q - lo|), so the true distance is >= |df| - sqrt(3) ec,
+  // and |df|^2 is >= s32 (1 - 1e-6) for the f32-evaluated sum s32.  A candidate may be skipped
+  // iff that lower bound is > sqrt(best); equivalently s32 > thr32 with thr32 rounded up.
+  // Anything that could win OR TIE is therefore evaluated exactly, in f64, with the contract's
+  // formula -- the screen changes which candidates are looked at, never the result.
+  float qf[3];
+  double ec = 0.;
+#pragma unroll
   for (int d = 0; d < 3; ++d) {
-    c[d] = (d < DIM) ? cell_coord(q[d], g.lo[d], g.inv_h, g.n[d]) : 0;
-    mg[d] = 1e-9 * (fabs(q[d]) + g.scale);
+    const double off = (d < DIM) ? q[d] - g.lo[d] : 0.;
+    qf[d] = (float)off;
+    ec = fmax(ec, fabs(off));
   }
+  // extent E <= 2 * g.scale; 1.2e-7 > 2^-23; the factor sqrt(3) turns the per-component bound
+  // into a bound on the norm of the error vector
+  ec = (ec + 2. * g.scale) * 1.2e-7 * 1.7320508075688774;
+
+  // The running winner is (best, bi) only -- its coordinates are fetched once at the end.
   double best = __builtin_huge_val();
   uint32_t bi = 0xffffffffu;
-  double bx = 0., by = 0.;
-
+  float thr32 = __builtin_huge_valf();
+  auto consider = [&](uint32_t ti) {  // exact: d^2 = ((dx*dx + dy*dy) + dz*dz), ties -> lowest index
+    const double ddx = q[0] - dst[(size_t)ti * DIM + 0];
+    const double ddy = q[1] - dst[(size_t)ti * DIM + 1];
+    double dd = ddx * ddx + ddy * ddy;
+    if (DIM == 3) {
+      const double ddz = q[2] - dst[(size_t)ti * DIM + 2];
+      dd = dd + ddz * ddz;
+    }
+    if (dd < best || (dd == best && ti < bi)) {
+      best = dd;
+      bi = ti;
+      const double r = sqrt(dd) + ec;
+      thr32 = (float)(r * r * 1.000004) ;
+      thr32 = thr32 * 1.000001f + 1e-37f;  // round up past the f64->f32 conversion
+    }
+  };
+  auto screen = [&](const GridPoint &t) -> float {
+    const float fx = qf[0] - t.x, fy = qf[1] - t.y;
+    float s = fx * fx + fy * fy;
+    if (DIM == 3) {
+      const float fz = qf[2] - t.z;
+      s = s + fz * fz;
+    }
+    return s;
+  };
+  // four records of a contiguous run in flight per lane (the tail re-reads the last record:
+  // evaluating a target twice cannot change the winner)
+  auto batch = [&](uint32_t p, uint32_t e) {
+    const uint32_t last = e - 1;
+    const GridPoint t0 = pts[p];
+    const GridPoint t1 = pts[min(p + 1, last)];
+    const GridPoint t2 = pts[min(p + 2, last)];
+    const GridPoint t3 = pts[min(p + 3, last)];
+    const float s0 = screen(t0), s1 = screen(t1), s2 = screen(t2), s3 = screen(t3);
+    if (!(s0 > thr32)) consider(t0.idx);
+    if (!(s1 > thr32)) consider(t1.idx);
+    if (!(s2 > thr32)) consider(t2.idx);
+    if (!(s3 > thr32)) consider(t3.idx);
+  };
   // distance from q to the slab of cells [i0, i1] on axis d (0 inside); outermost cells
   // extend to infinity (targets are clamped into them)
   auto slab = [&](int d, int i0, int i1) -> double {
@@ -279,122 +335,147 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
     return v > 0. ? v : 0.;
   };
 
-  auto consider = [&](const GridPoint &t) {
-    const double ddx = q[0] - t.x;
-    const double ddy = q[1] - t.y;
-    double dd = ddx * ddx + ddy * ddy;
+  // Walk the rows (iy, iz) of the cell box [lo, hi] as ONE flat loop per lane: a lane refills
+  // from its next unpruned row when its current run is exhausted, so a wave's trip count is the
+  // largest per-lane total, not the sum of per-row maxima.  Rows whose box is strictly farther
+  // than the current best cannot win or tie and are skipped.
+  auto walk_box = [&](const int lo[3], const int hi[3]) {
+    const double dx = slab(0, lo[0], hi[0]);
+    const double dx2 = dx * dx;
+    int iz = lo[2], iy = lo[1];
+    double dz2 = 0.;
     if (DIM == 3) {
-      const double ddz = q[2] - t.z;
-      dd = dd + ddz * ddz;
+      const double dz = slab(2, iz, iz);
+      dz2 = dz * dz;
     }
-    if (dd < best || (dd == best && t.idx < bi)) {
-      best = dd;
-      bi = t.idx;
-      bx = t.x;
-      by = t.y;
-    }
-  };
-  // a contiguous run of cell-sorted targets, four records in flight per lane (the tail
-  // re-reads the last record: evaluating a target twice cannot change the winner)
-  auto scan_run = [&](uint32_t s, uint32_t e) {
-    for (uint32_t p = s; p < e; p += 4) {
-      const uint32_t last = e - 1;
-      const GridPoint t0 = pts[p];
-      const GridPoint t1 = pts[min(p + 1, last)];
-      const GridPoint t2 = pts[min(p + 2, last)];
-      const GridPoint t3 = pts[min(p + 3, last)];
-      consider(t0);
-      consider(t1);
-      consider(t2);
-      consider(t3);
+    uint32_t p = 0, e = 0;
+    for (;;) {
+      if (p >= e) {
+        bool found = false;
+        while (iz <= hi[2]) {
+          if (iy > hi[1]) {
+            iy = lo[1];
+            ++iz;
+            if (DIM == 3 && iz <= hi[2]) {
+              const double dz = slab(2, iz, iz);
+              dz2 = dz * dz;
+            }
+            continue;
+          }
+          const int cy = iy++;
+          const double dy = slab(1, cy, cy);
+          if (dx2 + (dy * dy + dz2) > best) continue;
+          const uint32_t row = ((uint32_t)iz * g.n[1] + cy) * g.n[0];
+          p = start[row + lo[0]];
+          e = start[row + hi[0] + 1];
+          if (p < e) {
+            found = true;
+            break;
+          }
+        }
+        if (!found) break;
+      }
+      batch(p, e);
+      p += 4;
     }
   };
 
-  // Rings 0 and 1 in one go: the block [c-1, c+1]^DIM is 3 (2-D) or 9 (3-D) rows, each one
-  // contiguous run of up to three cells.  All row bounds are fetched before any target is
-  // (18 independent loads), the centre row goes first so that `best` is tight early, and the
-  // other rows are skipped when their box cannot hold a closer-or-equal target.
-  {
-    constexpr int NROWS = DIM == 3 ? 9 : 3;
-    constexpr int DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
-    constexpr int DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
-    const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, g.n[0] - 1);
-    const double dx = slab(0, x0, x1);
-    uint32_t rs[NROWS], re[NROWS];
-    double rb[NROWS];
+  // Warm start (second and later outer iterations of one estimate call): the pose moved a
+  // little, so the previous match is almost always still (nearly) the nearest target.  Its
+  // distance bounds the search: every target within sqrt(best) of q lies in a cell of the box
+  // [cell(q - r), cell(q + r)] (cell_coord is monotone), typically 1-2 cells per axis instead
+  // of the 3^DIM block.  The previous match is a real target and every cell that can hold a
+  // closer-or-equal one is visited, so the result is the same exact minimum by (d^2, index).
+  bool done = false;
+  if (prev) {
+    const uint32_t pi = prev[k];
+    if (pi != 0xffffffffu) {
+      consider(pi);
+      if (best < __builtin_huge_val()) {
+        const double rad = sqrt(best) * (1. + 1e-9);
+        int lo_c[3] = {0, 0, 0}, hi_c[3] = {0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < NROWS; ++t) {
-      const int iy = c[1] + DY[t], iz = DIM == 3 ? c[2] + DZ[t] : 0;
-      const bool valid = iy >= 0 && iy < g.n[1] && iz >= 0 && iz < g.n[2];
-      rs[t] = re[t] = 0;
-      rb[t] = __builtin_huge_val();
-      if (valid) {
-        const uint32_t row = ((uint32_t)iz * g.n[1] + iy) * g.n[0];
-        rs[t] = start[row + x0];
-        re[t] = start[row + x1 + 1];
-        const double dy = slab(1, iy, iy);
-        const double dz = DIM == 3 ? slab(2, iz, iz) : 0.;
-        rb[t] = dx * dx + (dy * dy + dz * dz);
+        for (int d = 0; d < DIM; ++d) {
+          lo_c[d] = cell_coord(q[d] - rad - mg[d], g.lo[d], g.inv_h, g.n[d]);
+          hi_c[d] = cell_coord(q[d] + rad + mg[d], g.lo[d], g.inv_h, g.n[d]);
+        }
+        walk_box(lo_c, hi_c);
+        done = true;
       }
     }
-#pragma unroll
-    for (int t = 0; t < NROWS; ++t)
-      if (!(rb[t] > best)) scan_run(rs[t], re[t]);  // strictly farther boxes cannot win or tie
   }
 
-  const int rmax = max(max(g.n[0], g.n[1]), g.n[2]);
-  for (int r = 1; r <= rmax; ++r) {
-    if (r >= 2) {  // shell r of the general walk (rings 0 and 1 were handled above)
-      const int z0 = DIM == 3 ? max(c[2] - r, 0) : 0, z1 = DIM == 3 ? min(c[2] + r, g.n[2] - 1) : 0;
-      const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
-      for (int iz = z0; iz <= z1; ++iz) {
-        const bool ze = DIM == 3 && (iz == c[2] - r || iz == c[2] + r);
-        const double dz = DIM == 3 ? slab(2, iz, iz) : 0.;
-        for (int iy = y0; iy <= y1; ++iy) {
-          const bool edge = ze || iy == c[1] - r || iy == c[1] + r;
-          const double dy = slab(1, iy, iy);
-          const double dyz = dy * dy + dz * dz;
-          if (dyz > best) continue;
-          // cells of this row that belong to shell r: the whole run on an edge row, else
-          // only the two end cells
-          const int nruns = edge ? 1 : 2;
-          for (int run = 0; run < nruns; ++run) {
-            int x0, x1;
-            if (edge) {
-              x0 = c[0] - r;
-              x1 = c[0] + r;
-            } else {
-              x0 = x1 = (run == 0) ? c[0] - r : c[0] + r;
+  if (!done) {
+    int c[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) c[d] = (d < DIM) ? cell_coord(q[d], g.lo[d], g.inv_h, g.n[d]) : 0;
+    // Rings 0 and 1 in one go: the block [c-1, c+1]^DIM, centre row first so that `best` is
+    // tight early.
+    {
+      const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, g.n[0] - 1);
+      const uint32_t row = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0];
+      const uint32_t s = start[row + x0], e = start[row + x1 + 1];
+      for (uint32_t p = s; p < e; p += 4) batch(p, e);
+      int lo_c[3], hi_c[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        lo_c[d] = max(c[d] - 1, 0);
+        hi_c[d] = min(c[d] + 1, g.n[d] - 1);
+      }
+      walk_box(lo_c, hi_c);  // re-reads the centre row (cached); the other rows are pruned by `best`
+    }
+    const int rmax = max(max(g.n[0], g.n[1]), g.n[2]);
+    for (int r = 1; r <= rmax; ++r) {
+      if (r >= 2) {  // shell r of the general walk (rings 0 and 1 were handled above)
+        const int z0 = DIM == 3 ? max(c[2] - r, 0) : 0, z1 = DIM == 3 ? min(c[2] + r, g.n[2] - 1) : 0;
+        const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
+        for (int iz = z0; iz <= z1; ++iz) {
+          const bool ze = DIM == 3 && (iz == c[2] - r || iz == c[2] + r);
+          const double dz = DIM == 3 ? slab(2, iz, iz) : 0.;
+          for (int iy = y0; iy <= y1; ++iy) {
+            const bool edge = ze || iy == c[1] - r || iy == c[1] + r;
+            const double dy = slab(1, iy, iy);
+            const double dyz = dy * dy + dz * dz;
+            if (dyz > best) continue;
+            // cells of this row that belong to shell r: the whole run on an edge row, else
+            // only the two end cells
+            const int nruns = edge ? 1 : 2;
+            for (int run = 0; run < nruns; ++run) {
+              int x0, x1;
+              if (edge) {
+                x0 = c[0] - r;
+                x1 = c[0] + r;
+              } else {
+                x0 = x1 = (run == 0) ? c[0] - r : c[0] + r;
+              }
+              if (x1 < 0 || x0 > g.n[0] - 1) continue;
+              x0 = max(x0, 0);
+              x1 = min(x1, g.n[0] - 1);
+              const double dx = slab(0, x0, x1);
+              if (dx * dx + dyz > best) continue;  // strictly farther: cannot win or tie
+              const uint32_t row = ((uint32_t)iz * g.n[1] + iy) * g.n[0];
+              const uint32_t s = start[row + x0], e = start[row + x1 + 1];
+              for (uint32_t p = s; p < e; p += 4) batch(p, e);
             }
-            if (x1 < 0 || x0 > g.n[0] - 1) continue;
-            x0 = max(x0, 0);
-            x1 = min(x1, g.n[0] - 1);
-            const double dx = slab(0, x0, x1);
-            if (dx * dx + dyz > best) continue;  // strictly farther: cannot win or tie
-            const uint32_t row = ((uint32_t)iz * g.n[1] + iy) * g.n[0];
-            scan_run(start[row + x0], start[row + x1 + 1]);
           }
         }
       }
-    }
-    // can anything outside the visited block [c-r, c+r] still win or tie?
-    double L = __builtin_huge_val();
+      // can anything outside the visited block [c-r, c+r] still win or tie?
+      double L = __builtin_huge_val();
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) {
-      if (c[d] - r > 0) L = fmin(L, (q[d] - (g.lo[d] + (c[d] - r) * g.h)) - mg[d]);
-      if (c[d] + r < g.n[d] - 1) L = fmin(L, ((g.lo[d] + (c[d] + r + 1) * g.h) - q[d]) - mg[d]);
+      for (int d = 0; d < DIM; ++d) {
+        if (c[d] - r > 0) L = fmin(L, (q[d] - (g.lo[d] + (c[d] - r) * g.h)) - mg[d]);
+        if (c[d] + r < g.n[d] - 1) L = fmin(L, ((g.lo[d] + (c[d] + r + 1) * g.h) - q[d]) - mg[d]);
+      }
+      if (L == __builtin_huge_val()) break;  // the whole grid has been visited
+      if (L > 0. && best < L * L) break;     // every unvisited target is strictly farther
     }
-    if (L == __builtin_huge_val()) break;       // the whole grid has been visited
-    if (L > 0. && best < L * L) break;          // every unvisited target is strictly farther
   }
-  if (bi == 0xffffffffu) {  // no finite distance (NaN query): index 0, as a scan from 0 would
-    bi = 0;
-    // its coordinates live wherever target 0 was sorted to; the caller gathers them
-    bx = by = __builtin_nan("");
-  }
+  if (prev) prev[k] = bi;
+  if (bi == 0xffffffffu) bi = 0;  // no finite distance at all (NaN query): index 0, as a scan from 0 would
   if (idx) idx[i] = bi;
   if (a) a[i] = make_double2(q[0], q[1]);
-  if (b) b[i] = make_double2(bx, by);
+  if (b) b[i] = make_double2(dst[(size_t)bi * DIM + 0], dst[(size_t)bi * DIM + 1]);
 }
 
 // ------------------------------------------------ query locality (optional) -------
@@ -451,12 +532,15 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     (void)hipFree(Q.d_cell_of);
     (void)hipFree(Q.d_perm);
     (void)hipFree(Q.d_sorted);
+    (void)hipFree(Q.d_prev);
+    Q.d_prev = nullptr;
     Q.d_cell_of = Q.d_perm = nullptr;
     Q.d_sorted = nullptr;
     Q.cap = 0;
     if ((e = hipMalloc(&Q.d_cell_of, n_ * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_perm, n_ * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_sorted, n_ * h->dim * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipMalloc(&Q.d_prev, n_ * 4)) != hipSuccess) return e;
     Q.cap = n_;
   }
   if ((e = hipMemsetAsync(Q.d_cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) return e;
@@ -468,6 +552,7 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   if ((e = hipMemsetAsync(Q.d_cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, Q.d_cell_of,
                      Q.d_start, Q.d_cnt, Q.d_sorted, Q.d_perm);
+  if ((e = hipMemsetAsync(Q.d_prev, 0xff, n_ * 4, s)) != hipSuccess) return e;  // no previous match yet
   if ((e = hipGetLastError()) != hipSuccess) return e;
   Q.src = d_src;
   Q.n = n_;
@@ -486,6 +571,7 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   const bool sorted = xform && Q.valid && Q.src == d_src && Q.n == n_;
   const double *q_src = sorted ? Q.d_sorted : d_src;
   const uint32_t *q_perm = sorted ? Q.d_perm : nullptr;
+  uint32_t *q_prev = sorted ? Q.d_prev : nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (h->profile) {
     if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
@@ -494,7 +580,7 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   const unsigned blocks = (n + 255) / 256;
 #define GRID(DIM, XF)                                                                                   \
   hipLaunchKernelGGL((k_nn_grid<DIM, XF>), dim3(blocks), dim3(256), 0, h->stream, q_src, q_perm, n, T,   \
-                     G.p, G.d_start, G.d_pts, d_idx, (double2 *)d_a, (double2 *)d_b)
+                     G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, q_prev)
   if (h->dim == 3) {
     if (xform) GRID(3, true); else GRID(3, false);
   } else {
