@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_sel_scan(uint32_t *__restrict__ hist, S
 }
 
 // src/lib.rs:238-255 (+ :45-50 fused: same T, same residuals)
-__global__ __launch_bounds__(256) void k_wgn_accumulate(const double2 *__restrict__ a,
+__global__ __launch_bounds__(kReduceThreads) void k_wgn_accumulate(const double2 *__restrict__ a,
                                                         const double *__restrict__ rx,
                                                         const double *__restrict__ ry, unsigned n,
                                                         Pose T, const GnScalars *__restrict__ scal,
@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) void k_wgn_accumulate(const double2 *__restric
   double acc[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; ++k) acc[k] = 0.;
-  const unsigned G = gridDim.x * 256;
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += G) {
+  const unsigned G = gridDim.x * kReduceThreads;
+  for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x; i < n; i += G) {
     const double2 s = a[i];
     const double r[2] = {rx[i], ry[i]};
     // jacobian(), src/lib.rs:176-184
@@ -227,14 +227,14 @@ __global__ __launch_bounds__(256) void k_wgn_accumulate(const double2 *__restric
 }
 
 // gauss_newton_update (src/lib.rs:191-216), error (:38-43), huber_error (:45-50)
-__global__ __launch_bounds__(256) void k_plain_accumulate(const double2 *__restrict__ a,
+__global__ __launch_bounds__(kReduceThreads) void k_plain_accumulate(const double2 *__restrict__ a,
                                                           const double2 *__restrict__ b, unsigned n,
                                                           Pose T, double *__restrict__ partials) {
   double acc[kNAcc + 1];
 #pragma unroll
   for (int k = 0; k < kNAcc + 1; ++k) acc[k] = 0.;
-  const unsigned G = gridDim.x * 256;
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += G) {
+  const unsigned G = gridDim.x * kReduceThreads;
+  for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x; i < n; i += G) {
     const double2 s = a[i], d = b[i];
     const double r0 = ((T.r00 * s.x + T.r01 * s.y) + T.tx) - d.x;
     const double r1 = ((T.r10 * s.x + T.r11 * s.y) + T.ty) - d.y;
@@ -256,13 +256,13 @@ __global__ __launch_bounds__(256) void k_plain_accumulate(const double2 *__restr
 }
 
 // second stage: one block over the block sums; hands the result to the host
-__global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__ partials, int blocks,
+__global__ __launch_bounds__(kReduceThreads) void k_final_reduce(const double *__restrict__ partials, int blocks,
                                                       int nacc, const GnScalars *__restrict__ scal,
                                                       GnResult *__restrict__ res) {
   double acc[kNAcc + 1];
 #pragma unroll
   for (int k = 0; k < kNAcc + 1; ++k) acc[k] = 0.;
-  for (int i = threadIdx.x; i < blocks; i += 256)
+  for (int i = threadIdx.x; i < blocks; i += kReduceThreads)
 #pragma unroll
     for (int k = 0; k < kNAcc + 1; ++k)
       if (k < nacc) acc[k] = acc[k] + partials[(size_t)i * (kNAcc + 1) + k];
@@ -322,7 +322,7 @@ hipError_t launch_weighted_gn(icp_handle *h, const double *d_a, const double *d_
   reduce_geometry(n_, &blocks, &threads);
   hipLaunchKernelGGL(k_wgn_accumulate, dim3(blocks), dim3(threads), 0, h->stream, (const double2 *)d_a,
                      w.d_rx, w.d_ry, n, T, w.d_scal, w.d_partials);
-  hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(256), 0, h->stream, w.d_partials, blocks, kNAcc, w.d_scal,
+  hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(kReduceThreads), 0, h->stream, w.d_partials, blocks, kNAcc, w.d_scal,
                      w.h_res);
   return hipGetLastError();
 }
@@ -334,7 +334,7 @@ hipError_t launch_plain_gn(icp_handle *h, const double *d_a, const double *d_b, 
   reduce_geometry(n_, &blocks, &threads);
   hipLaunchKernelGGL(k_plain_accumulate, dim3(blocks), dim3(threads), 0, h->stream, (const double2 *)d_a,
                      (const double2 *)d_b, n, T, w.d_partials);
-  hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(256), 0, h->stream, w.d_partials, blocks, kNAcc + 1,
+  hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(kReduceThreads), 0, h->stream, w.d_partials, blocks, kNAcc + 1,
                      w.d_scal, w.h_res);
   return hipGetLastError();
 }

@@ -77,9 +77,11 @@ def test_inverse3x3_none_cases():  # linalg.rs:52-60
 
 
 def test_reduce_geometry():
-    assert I.reduce_geometry(1) == (1, 256)
-    assert I.reduce_geometry(257) == (2, 256)
-    assert I.reduce_geometry(10**6) == (1024, 256)
+    b1, t = I.reduce_geometry(1)
+    assert b1 == 1 and t % 64 == 0
+    assert I.reduce_geometry(t + 1) == (2, t)
+    bmax, _ = I.reduce_geometry(10**9)
+    assert I.reduce_geometry(10**6)[0] == min((10**6 + t - 1) // t, bmax)
 
 
 @pytest.mark.skipif(I.lib().icp_device_count() > 0, reason="a GPU is present")
