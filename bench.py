@@ -153,8 +153,17 @@ def main():
                     "algorithmic_flops_per_launch": flops,
                     "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                             "algorithmic_bytes_per_launch": nn_bytes}}
+        # `traffic`: fabric-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected in
+        # separate passes and committed under profiles/ (a PMC pass cannot run inside this process); only
+        # valid for the full-size single-GPU workload it was measured on
+        traffic = None
+        tf_path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+        if os.path.exists(tf_path) and world == 1 and n == 1_000_000 and m == 1_000_000:
+            traffic = json.load(open(tf_path))["k_nn_grid"]["traffic_bytes_per_launch"]
         return {"kernel": "k_nn_grid", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": 1e3 * avg_s,
+                "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/r01_traffic_pmc.json (separate rocprofv3 --pmc passes)",
+                "avg_launch_ms": 1e3 * avg_s,
                 "launches": int(r["nn_launches"]), "algorithmic_bytes_per_launch": nn_bytes}
 
     res = measure(nn_mode, args.steps, args.warmup)

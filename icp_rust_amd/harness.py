@@ -1,0 +1,69 @@
+"""Headless frame loops of the reference's two examples: same file
+handling, same warm start, same per-frame `Icp::new` + `estimate(src, transform, 20)`, the
+trajectory instead of a window.
+
+`icp_factory(dst) -> object with .estimate(src, Transform, max_iter) -> Transform` defaults to
+the GPU classes; tests inject an oracle-backed factory to check the loop semantics on CPU.
+"""
+import os
+
+import numpy as np
+
+from .api import Icp2d, Icp3d, Transform
+from .scans import load_scan2d
+from .synth import PACKETS_PER_FRAME, remove_invalid_values
+
+
+def run_scan2d(scan_dir, max_iter=20, icp_factory=None, max_frames=None):
+    """examples/scan2d.rs:62-115.  `index` starts at 0 and is incremented BEFORE use, so
+    000.txt is never read and 001.txt is the fixed source (:63,69-77); every later frame k
+    loads dst = k.txt, builds Icp2d::new(&dst) and estimates warm-started from the previous
+    frame (:85-88); the plotted pose is transform.inverse() (:90) and its translation is
+    appended to the path (:105).  The loop ends at the first missing file (:72).
+    Returns (transforms, inverse_transforms, path_xy)."""
+    icp_factory = icp_factory or Icp2d
+    index = 0
+    src = None
+    transform = Transform.identity()
+    transforms, inverses, path = [], [], []
+    while max_frames is None or len(transforms) < max_frames:
+        index += 1
+        filename = os.path.join(scan_dir, f"{index:03d}.txt")
+        if not os.path.exists(filename):
+            break
+        if index == 1:
+            src = load_scan2d(filename)
+            continue
+        dst = load_scan2d(filename)
+        icp = icp_factory(dst)
+        transform = icp.estimate(src, transform, max_iter)
+        inv = transform.inverse()
+        transforms.append(transform)
+        inverses.append(inv)
+        path.append(inv.t.copy())
+    return transforms, inverses, np.array(path).reshape(-1, 2)
+
+
+def run_scan3d(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=None):
+    """examples/scan3d.rs:104-158 on an in-memory packet array (n_packets, 384, 3): the source
+    is packets [0, step) with invalid returns removed (:104-107, 63-69); every frame takes
+    dst = packets [index, index+step), filtered, THEN advances index (:113-121) -- so the first
+    frame registers the source against itself; Icp3d::new(&dst); estimate warm-started
+    (:130-131); path of transform.inverse().t (:133,144).
+    Returns (transforms, inverse_transforms, path_xy)."""
+    icp_factory = icp_factory or Icp3d
+    packets = np.asarray(packets, dtype=np.float64)
+    src = remove_invalid_values(packets[0:step])
+    transform = Transform.identity()
+    transforms, inverses, path = [], [], []
+    index = 0
+    while index + step <= packets.shape[0]:
+        dst = remove_invalid_values(packets[index:index + step])
+        index += step
+        icp = icp_factory(dst)
+        transform = icp.estimate(src, transform, max_iter)
+        inv = transform.inverse()
+        transforms.append(transform)
+        inverses.append(inv)
+        path.append(inv.t.copy())
+    return transforms, inverses, np.array(path).reshape(-1, 2)
