@@ -84,7 +84,8 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     if ((e = hipMalloc(&w.d_sel, kSelProblems * sizeof(SelState))) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_scal, sizeof(GnScalars))) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_partials, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double))) != hipSuccess) return e;
-    if ((e = hipHostMalloc(&w.h_res, sizeof(GnResult), 0)) != hipSuccess) return e;
+    if ((e = hipHostMalloc(&w.h_res, sizeof(GnResult), hipHostMallocCoherent)) != hipSuccess) return e;
+    memset(w.h_res, 0, sizeof(GnResult));
   }
   if (n > w.cap_n) {
     // in-flight work may still read the old buffers
@@ -321,6 +322,22 @@ extern "C" int icp_nn_search_device(icp_handle *h, const double *d_q, size_t n, 
   return ICP_OK;
 }
 
+// Wait for the fast pipeline's result: poll the sequence number its last workgroup releases
+// into pinned memory (a few us earlier than the stream's completion signal, three times per
+// outer iteration); after ~2 ms of polling fall back to a blocking stream wait.
+static hipError_t wait_result(icp_handle *h) {
+  static const bool no_poll = getenv("ICP_NO_POLL") != nullptr;
+  const unsigned want = h->ws.seq;
+  volatile unsigned *seq = &h->ws.h_res->seq;
+  if (!no_poll) {
+    for (unsigned spins = 0; spins < 2000000u; ++spins) {
+      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) return hipSuccess;
+      __builtin_ia32_pause();
+    }
+  }
+  return hipStreamSynchronize(h->stream);
+}
+
 // check_input_size, src/lib.rs:186-189
 static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
 
@@ -332,7 +349,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   bool done = false;
   if (!force_radix) {
     HIP_TRY(launch_weighted_gn_fast(h, d_a, d_b, n, T));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(wait_result(h));
     done = !h->ws.h_res->overflow;
   }
   if (!done) {  // heavy duplicates around a median: the general 6-pass radix select

@@ -65,6 +65,8 @@ struct GnResult {
   double sigma[2];
   int nan_flag;
   int overflow;
+  unsigned seq;  // written last, system scope: the host polls it instead of waiting for the stream
+  unsigned pad;
 };
 
 struct Workspace {
@@ -86,7 +88,8 @@ struct Workspace {
   SelState *d_sel = nullptr;    // kSelProblems
   GnScalars *d_scal = nullptr;
   double *d_partials = nullptr; // kReduceMaxBlocks x (kNAcc+1)
-  GnResult *h_res = nullptr;    // pinned host, device-visible
+  GnResult *h_res = nullptr;    // pinned coherent host memory, written by the last workgroup
+  unsigned seq = 0;             // sequence number of the last fast evaluation launched
 };
 
 // ---- uniform grid over the target cloud (nn_grid.hip) ------------------------------

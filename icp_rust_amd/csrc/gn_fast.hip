@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_fast_accumulate(const double
                                                                     const double *__restrict__ ry,
                                                                     unsigned n, Pose T, GnScalars *scal,
                                                                     double *partials, uint32_t *hist,
-                                                                    SelCtl *ctl, GnResult *res) {
+                                                                    SelCtl *ctl, GnResult *res, unsigned seq) {
   const double sig[2] = {scal->sigma[0], scal->sigma[1]};
   double g[2];
   g[0] = 1. / sig[0];
@@ -352,12 +352,19 @@ __global__ __launch_bounds__(kReduceThreads) void k_fast_accumulate(const double
     for (int k = 0; k < kNAcc; ++k)
       tot[k] = tot[k] + __hip_atomic_load(&partials[(size_t)i * (kNAcc + 1) + k], RLX_AGENT);
   block_reduce_store<kNAcc + 1>(tot, res->acc);
+  // Publish to the host: the result lives in coherent pinned memory; every writing lane makes
+  // its stores visible at system scope before lane 0 releases the sequence number the host
+  // is polling (saves the kernel-completion -> stream-sync wake-up on every inner iteration).
+  __threadfence_system();
+  __syncthreads();
   if (threadIdx.x == 0) {
     res->sigma[0] = sig[0];
     res->sigma[1] = sig[1];
     res->nan_flag = scal->nan_flag;
     res->overflow = scal->overflow;
     scal->overflow = 0;
+    __threadfence_system();
+    __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -398,7 +405,7 @@ hipError_t launch_weighted_gn_fast(icp_handle *h, const double *d_a, const doubl
   int blocks, threads;
   reduce_geometry(n_, &blocks, &threads);
   hipLaunchKernelGGL(k_fast_accumulate, dim3(blocks), dim3(threads), 0, s, a, w.d_rx, w.d_ry, n, T, w.d_scal,
-                     w.d_partials, w.d_hist, w.d_ctl, w.h_res);
+                     w.d_partials, w.d_hist, w.d_ctl, w.h_res, ++w.seq);
   return hipGetLastError();
 }
 
