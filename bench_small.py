@@ -1,0 +1,39 @@
+"""Timing of the reference-sized workloads (BASELINE configs[0] scale: a 2-D scan pair; configs[1]: a
+28.8k-point 3-D window): GPU estimate(20 iterations) next to the single-thread CPU oracle.
+Not the headline benchmark (bench.py); a tool to keep the small-problem latency honest."""
+import sys, time, os
+ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np, torch
+import icp_rust_amd as I
+import oracle_ffi as O
+from icp_rust_amd import synth, harness
+from icp_rust_amd.scans import load_scan2d
+G = os.path.join(ROOT, 'tests', 'golden', 'scans2d')
+src = load_scan2d(f'{G}/001.txt'); dst = load_scan2d(f'{G}/002.txt')
+icp = I.Icp2d(dst)
+T = icp.estimate(src, I.Transform(), 20)
+t0 = time.perf_counter()
+for _ in range(20): T, idx, inner = icp.estimate(src, I.Transform(), 20, return_info=True)
+t = (time.perf_counter() - t0) / 20
+print(f"2D scan ({len(src)}x{len(dst)}): GPU estimate(20 it) {t*1e3:.3f} ms, inner {inner.tolist()}")
+t0 = time.perf_counter()
+for _ in range(20): I.Icp2d(dst)
+print(f"   Icp2d::new {1e3*(time.perf_counter()-t0)/20:.3f} ms")
+tree = O.KdTree(dst)
+t0 = time.perf_counter()
+for _ in range(20): rc, oT, _, oin = tree.estimate(src, O.transform_identity(), 20)
+print(f"   CPU oracle estimate(20 it) {1e3*(time.perf_counter()-t0)/20:.3f} ms, inner {oin.tolist()}")
+pk = synth.synthetic_scan3d_packets(150)
+s3 = synth.remove_invalid_values(pk[:75]); d3 = synth.remove_invalid_values(pk[75:150])
+icp3 = I.Icp3d(d3)
+icp3.estimate(s3, I.Transform(), 20)
+t0 = time.perf_counter()
+for _ in range(10): T3, idx, inner = icp3.estimate(s3, I.Transform(), 20, return_info=True)
+print(f"3D scan ({len(s3)}x{len(d3)}): GPU estimate(20 it) {1e3*(time.perf_counter()-t0)/10:.3f} ms, inner {inner.tolist()}")
+t0 = time.perf_counter()
+for _ in range(10): I.Icp3d(d3)
+print(f"   Icp3d::new {1e3*(time.perf_counter()-t0)/10:.3f} ms")
+t0=time.perf_counter(); tree3 = O.KdTree(d3); tb=time.perf_counter()-t0
+t0 = time.perf_counter()
+for _ in range(3): rc, oT, _, oin = tree3.estimate(s3, O.transform_identity(), 20)
+print(f"   CPU oracle estimate(20 it) {1e3*(time.perf_counter()-t0)/3:.3f} ms (+ kd build {tb*1e3:.2f} ms), inner {oin.tolist()}")
