@@ -10,7 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "lib", "libicp_mi355x.so")
+# ICP_MI355X_LIB: load another build of the same library (e.g. the diagnostic one with counters)
+LIB_PATH = os.environ.get("ICP_MI355X_LIB") or os.path.join(_HERE, "lib", "libicp_mi355x.so")
 
 OK, NONE, EMPTY_DST, NAN_INPUT, BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, OUT_OF_MEMORY = range(8)
 NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2

@@ -114,6 +114,11 @@ struct Grid {
   GridPoint *d_pts = nullptr;   // m targets sorted by cell
 };
 
+struct PrevMatch {  // a query's previous nearest neighbour, stored per sorted slot (coalesced)
+  double x, y, z;
+  uint32_t idx, pad;
+};
+
 // cell-sorted copy of a source cloud (prepare_queries): locality for the grid search
 struct QuerySort {
   bool valid = false;
@@ -121,7 +126,7 @@ struct QuerySort {
   size_t n = 0, cap = 0;
   uint32_t *d_cnt = nullptr, *d_start = nullptr, *d_btot = nullptr;
   uint32_t *d_cell_of = nullptr, *d_perm = nullptr;
-  uint32_t *d_prev = nullptr;  // per sorted slot: target index of the last match, ~0u = none
+  PrevMatch *d_prev = nullptr; // per sorted slot: the last match (idx = ~0u: none)
   double *d_sorted = nullptr;
 };
 

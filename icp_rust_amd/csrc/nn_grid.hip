@@ -236,6 +236,17 @@ hipError_t build_grid(icp_handle *h) {
 }
 
 // ---------------------------------------------------------------- query ----------
+#ifdef ICP_NN_STATS
+// Diagnostic build only (make STATS=1 -> libicp_mi355x_stats.so, never the product library):
+// per-launch totals of what the search actually does.  [0] queries, [1] row-bound fetches,
+// [2] record batches, [3] exact evaluations, [4] sum over waves of wave-level loop steps,
+// [5] sum over waves of lifetime in shader cycles, [6] waves, [7] warm queries.
+__device__ unsigned long long g_nn_stats[8];
+#define NN_STAT(i, v) (st[i] += (v))
+#else
+#define NN_STAT(i, v) ((void)0)
+#endif
+
 template <int DIM, bool XFORM>
 __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
                                                  const uint32_t *__restrict__ perm, unsigned n, Pose T,
@@ -243,7 +254,11 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
                                                  const GridPoint *__restrict__ pts,
                                                  const double *__restrict__ dst, uint32_t *__restrict__ idx,
                                                  double2 *__restrict__ a, double2 *__restrict__ b,
-                                                 uint32_t *__restrict__ prev) {
+                                                 PrevMatch *__restrict__ prev) {
+#ifdef ICP_NN_STATS
+  unsigned st[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
   const unsigned k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n) return;
   // perm != null: src is the cell-sorted copy made by prepare_queries (neighbouring lanes
@@ -287,21 +302,32 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   double best = __builtin_huge_val();
   uint32_t bi = 0xffffffffu;
   float thr32 = __builtin_huge_valf();
-  auto consider = [&](uint32_t ti) {  // exact: d^2 = ((dx*dx + dy*dy) + dz*dz), ties -> lowest index
-    const double ddx = q[0] - dst[(size_t)ti * DIM + 0];
-    const double ddy = q[1] - dst[(size_t)ti * DIM + 1];
+  double bx = 0., by = 0., bz = 0.;  // the winner's exact coordinates (outputs + next warm start)
+  auto eval = [&](uint32_t ti, double tx, double ty, double tz) {
+    NN_STAT(3, 1);
+    const double ddx = q[0] - tx;
+    const double ddy = q[1] - ty;
     double dd = ddx * ddx + ddy * ddy;
     if (DIM == 3) {
-      const double ddz = q[2] - dst[(size_t)ti * DIM + 2];
+      const double ddz = q[2] - tz;
       dd = dd + ddz * ddz;
     }
     if (dd < best || (dd == best && ti < bi)) {
       best = dd;
       bi = ti;
+      bx = tx;
+      by = ty;
+      bz = tz;
       const double r = sqrt(dd) + ec;
-      thr32 = (float)(r * r * 1.000004) ;
+      thr32 = (float)(r * r * 1.000004);
       thr32 = thr32 * 1.000001f + 1e-37f;  // round up past the f64->f32 conversion
     }
+  };
+  // exact: d^2 = ((dx*dx + dy*dy) + dz*dz), ties -> lowest index.  The current winner is not
+  // re-evaluated when the scan meets it again (it always passes its own screen).
+  auto consider = [&](uint32_t ti) {
+    if (ti == bi) return;
+    eval(ti, dst[(size_t)ti * DIM + 0], dst[(size_t)ti * DIM + 1], DIM == 3 ? dst[(size_t)ti * DIM + 2] : 0.);
   };
   auto screen = [&](const GridPoint &t) -> float {
     const float fx = qf[0] - t.x, fy = qf[1] - t.y;
@@ -315,6 +341,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   // four records of a contiguous run in flight per lane (the tail re-reads the last record:
   // evaluating a target twice cannot change the winner)
   auto batch = [&](uint32_t p, uint32_t e) {
+    NN_STAT(2, 1);
     const uint32_t last = e - 1;
     const GridPoint t0 = pts[p];
     const GridPoint t1 = pts[min(p + 1, last)];
@@ -350,6 +377,9 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
     }
     uint32_t p = 0, e = 0;
     for (;;) {
+#ifdef ICP_NN_STATS
+      if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) st[4] += 1;
+#endif
       if (p >= e) {
         bool found = false;
         while (iz <= hi[2]) {
@@ -366,6 +396,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
           const double dy = slab(1, cy, cy);
           if (dx2 + (dy * dy + dz2) > best) continue;
           const uint32_t row = ((uint32_t)iz * g.n[1] + cy) * g.n[0];
+          NN_STAT(1, 1);
           p = start[row + lo[0]];
           e = start[row + hi[0] + 1];
           if (p < e) {
@@ -388,9 +419,10 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   // closer-or-equal one is visited, so the result is the same exact minimum by (d^2, index).
   bool done = false;
   if (prev) {
-    const uint32_t pi = prev[k];
-    if (pi != 0xffffffffu) {
-      consider(pi);
+    const PrevMatch pm = prev[k];  // coalesced per-slot record (index + exact coordinates), not a gather
+    if (pm.idx != 0xffffffffu) {
+      NN_STAT(7, 1);
+      eval(pm.idx, pm.x, pm.y, pm.z);
       if (best < __builtin_huge_val()) {
         const double rad = sqrt(best) * (1. + 1e-9);
         int lo_c[3] = {0, 0, 0}, hi_c[3] = {0, 0, 0};
@@ -471,11 +503,36 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
       if (L > 0. && best < L * L) break;     // every unvisited target is strictly farther
     }
   }
-  if (prev) prev[k] = bi;
-  if (bi == 0xffffffffu) bi = 0;  // no finite distance at all (NaN query): index 0, as a scan from 0 would
+#ifdef ICP_NN_STATS
+  {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    for (int j = 0; j < 5; ++j)
+      if (j != 4) atomicAdd(&g_nn_stats[j], (unsigned long long)st[j]);
+    atomicAdd(&g_nn_stats[4], (unsigned long long)st[4]);
+    atomicAdd(&g_nn_stats[7], (unsigned long long)st[7]);
+    if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) {
+      atomicAdd(&g_nn_stats[5], t_end - t_begin);
+      atomicAdd(&g_nn_stats[6], 1ull);
+    }
+  }
+#endif
+  if (prev) {
+    PrevMatch pm;
+    pm.x = bx;
+    pm.y = by;
+    pm.z = bz;
+    pm.idx = bi;
+    pm.pad = 0;
+    prev[k] = pm;
+  }
+  if (bi == 0xffffffffu) {  // no finite distance at all (NaN query): index 0, as a scan from 0 would
+    bi = 0;
+    bx = dst[0];
+    by = dst[1];
+  }
   if (idx) idx[i] = bi;
   if (a) a[i] = make_double2(q[0], q[1]);
-  if (b) b[i] = make_double2(dst[(size_t)bi * DIM + 0], dst[(size_t)bi * DIM + 1]);
+  if (b) b[i] = make_double2(bx, by);
 }
 
 // ------------------------------------------------ query locality (optional) -------
@@ -540,7 +597,7 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     if ((e = hipMalloc(&Q.d_cell_of, n_ * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_perm, n_ * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_sorted, n_ * h->dim * sizeof(double))) != hipSuccess) return e;
-    if ((e = hipMalloc(&Q.d_prev, n_ * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&Q.d_prev, n_ * sizeof(PrevMatch))) != hipSuccess) return e;
     Q.cap = n_;
   }
   if ((e = hipMemsetAsync(Q.d_cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) return e;
@@ -552,7 +609,7 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   if ((e = hipMemsetAsync(Q.d_cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, Q.d_cell_of,
                      Q.d_start, Q.d_cnt, Q.d_sorted, Q.d_perm);
-  if ((e = hipMemsetAsync(Q.d_prev, 0xff, n_ * 4, s)) != hipSuccess) return e;  // no previous match yet
+  if ((e = hipMemsetAsync(Q.d_prev, 0xff, n_ * sizeof(PrevMatch), s)) != hipSuccess) return e;  // idx = ~0u: none yet
   if ((e = hipGetLastError()) != hipSuccess) return e;
   Q.src = d_src;
   Q.n = n_;
@@ -571,7 +628,7 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   const bool sorted = xform && Q.valid && Q.src == d_src && Q.n == n_;
   const double *q_src = sorted ? Q.d_sorted : d_src;
   const uint32_t *q_perm = sorted ? Q.d_perm : nullptr;
-  uint32_t *q_prev = sorted ? Q.d_prev : nullptr;
+  PrevMatch *q_prev = sorted ? Q.d_prev : nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (h->profile) {
     if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
@@ -594,5 +651,16 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   }
   return e;
 }
+
+#ifdef ICP_NN_STATS
+extern "C" int icp_debug_nn_stats(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    const unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 
 }  // namespace icp

@@ -1,0 +1,24 @@
+"""Diagnostic: what the grid NN search does per launch (needs `make -C icp_rust_amd/csrc stats`).
+Run as:  ICP_MI355X_LIB=icp_rust_amd/lib/libicp_mi355x_stats.so python profiles/nn_stats.py"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+import icp_rust_amd as I
+from icp_rust_amd import synth
+from icp_rust_amd.dist import HipStages, ShardedIcp
+n = m = 1_000_000
+src, dst = synth.synthetic_pair(n, m)
+d_src, d_dst = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+icp = I.Icp3d(d_dst)
+drv = ShardedIcp(HipStages(icp), n)
+L = I.lib(); L.icp_debug_nn_stats.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+out = (C.c_uint64 * 8)()
+T = I.Transform(); drv.stages.prepare(d_src, T)
+names = ["queries", "row_bound_fetches", "record_batches", "exact_evals", "wave_loop_steps", "wave_cycles", "waves", "warm_queries"]
+for it in range(4):
+    L.icp_debug_nn_stats(out, 1)
+    T, k = drv.step(d_src, T); torch.cuda.synchronize()
+    L.icp_debug_nn_stats(out, 0)
+    v = list(out); q = max(v[0], 1); w = max(v[6], 1)
+    print(f"iter {it}:", {nm: x for nm, x in zip(names, v)})
+    print(f"   per query: rows {v[1]/q:.2f} batches {v[2]/q:.2f} exact {v[3]/q:.2f} | per wave: loop steps {v[4]/w:.1f} lifetime {v[5]/w:.0f} cycles")
