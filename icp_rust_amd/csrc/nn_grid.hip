@@ -340,18 +340,22 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   };
   // four records of a contiguous run in flight per lane (the tail re-reads the last record:
   // evaluating a target twice cannot change the winner)
+  // kBatch records of a contiguous run in flight per lane (the tail re-reads the last record:
+  // evaluating a target twice cannot change the winner, and a repeated address costs next to
+  // nothing -- divergent control flow is what is expensive here)
+  constexpr uint32_t kBatch = 8;
   auto batch = [&](uint32_t p, uint32_t e) {
     NN_STAT(2, 1);
     const uint32_t last = e - 1;
-    const GridPoint t0 = pts[p];
-    const GridPoint t1 = pts[min(p + 1, last)];
-    const GridPoint t2 = pts[min(p + 2, last)];
-    const GridPoint t3 = pts[min(p + 3, last)];
-    const float s0 = screen(t0), s1 = screen(t1), s2 = screen(t2), s3 = screen(t3);
-    if (!(s0 > thr32)) consider(t0.idx);
-    if (!(s1 > thr32)) consider(t1.idx);
-    if (!(s2 > thr32)) consider(t2.idx);
-    if (!(s3 > thr32)) consider(t3.idx);
+    GridPoint t[kBatch];
+#pragma unroll
+    for (uint32_t u = 0; u < kBatch; ++u) t[u] = pts[min(p + u, last)];
+    float sc[kBatch];
+#pragma unroll
+    for (uint32_t u = 0; u < kBatch; ++u) sc[u] = screen(t[u]);
+#pragma unroll
+    for (uint32_t u = 0; u < kBatch; ++u)
+      if (!(sc[u] > thr32)) consider(t[u].idx);
   };
   // distance from q to the slab of cells [i0, i1] on axis d (0 inside); outermost cells
   // extend to infinity (targets are clamped into them)
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
         if (!found) break;
       }
       batch(p, e);
-      p += 4;
+      p += kBatch;
     }
   };
 
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
       const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, g.n[0] - 1);
       const uint32_t row = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0];
       const uint32_t s = start[row + x0], e = start[row + x1 + 1];
-      for (uint32_t p = s; p < e; p += 4) batch(p, e);
+      for (uint32_t p = s; p < e; p += kBatch) batch(p, e);
       int lo_c[3], hi_c[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
               if (dx * dx + dyz > best) continue;  // strictly farther: cannot win or tie
               const uint32_t row = ((uint32_t)iz * g.n[1] + iy) * g.n[0];
               const uint32_t s = start[row + x0], e = start[row + x1 + 1];
-              for (uint32_t p = s; p < e; p += 4) batch(p, e);
+              for (uint32_t p = s; p < e; p += kBatch) batch(p, e);
             }
           }
         }
