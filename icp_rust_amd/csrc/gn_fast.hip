@@ -74,32 +74,51 @@ __device__ __forceinline__ void for_each_value(const double2 *__restrict__ a, co
   }
 }
 
-// Tail of a histogram launch, run by the last block: wave p finds the digit bin that holds
-// problem p's rank.  The block's LDS histogram area is dead by now and is reused as a
-// padded staging buffer (bin + bin/64), so that lane l can walk bins [64 l, 64 l + 64).
+// Tail of a histogram launch, run by the last block (1024 threads).  Measured with in-kernel
+// stamps, a one-wave-per-problem tail (64 dependent-ish sc1 loads per lane, then a serial
+// 64-bin walk) took 6-16 us -- more than streaming the data.  So: (1) ALL threads fetch the
+// live histograms together, 16 coalesced sc1 loads per lane, into a padded LDS image
+// (bin + bin/64, so that lane l can sum bins [64 l, 64 l + 64) without bank conflicts);
+// (2) wave p locates problem p's rank: column sums -> wave scan -> the owning lane, then the
+// 64 lanes look at that lane's 64 bins in parallel (second wave scan) instead of walking them.
 __device__ __forceinline__ void scan_descend(uint32_t *lds, const uint32_t *hist, SelState *sel,
                                              GnScalars *scal, int pass, bool check_cap) {
   __shared__ unsigned found_bin[kSelProblems], found_below[kSelProblems], found_cnt[kSelProblems];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave < kSelProblems) {
-    const int p = wave;
-    const int src = sel[p].alias >= 0 ? sel[p].alias : p;
-    const uint32_t *hp = hist + src * kSelBins;
-    uint32_t *stage = lds + p * kScanPad;
-    unsigned v[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the search state is read ONCE into registers (every later use of `sel` would be a dependent
+  // global load of a line this kernel is about to rewrite: ~1-2 us each, serially, on one lane)
+  SelState st[kSelProblems];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) v[j] = __hip_atomic_load(hp + j * 64 + lane, RLX_AGENT);
+  for (int p = 0; p < kSelProblems; ++p) st[p] = sel[p];
+  bool live[kSelProblems];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) stage[j * 65 + lane] = v[j];  // bin j*64+lane -> bin + bin/64
+  for (int p = 0; p < kSelProblems; ++p) live[p] = st[p].alias < 0;
+  unsigned v[(kSelProblems * kSelBins) / kFastThreads];
+#pragma unroll
+  for (int u = 0; u < (kSelProblems * kSelBins) / kFastThreads; ++u) {
+    const int j = tid + kFastThreads * u, p = j / kSelBins;
+    v[u] = live[p] ? __hip_atomic_load(hist + j, RLX_AGENT) : 0u;
+  }
+#pragma unroll
+  for (int u = 0; u < (kSelProblems * kSelBins) / kFastThreads; ++u) {
+    const int j = tid + kFastThreads * u, p = j / kSelBins, bin = j % kSelBins;
+    lds[p * kScanPad + bin + (bin >> 6)] = v[u];
   }
   __syncthreads();
   if (wave < kSelProblems) {
     const int p = wave;
-    const unsigned long long rank = sel[p].rank;
-    const uint32_t *stage = lds + p * kScanPad + lane * 65;  // bins [64 lane, 64 lane + 64)
+    int src = p;
+    unsigned rank = 0;
+#pragma unroll
+    for (int pp = 0; pp < kSelProblems; ++pp)
+      if (pp == p) {
+        src = st[pp].alias >= 0 ? st[pp].alias : pp;
+        rank = (unsigned)st[pp].rank;
+      }
+    const uint32_t *img = lds + src * kScanPad;
     unsigned tot = 0;
-#pragma unroll 8
-    for (int j = 0; j < 64; ++j) tot += stage[j];
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) tot += img[lane * 65 + j];
     unsigned inc = tot;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -107,17 +126,22 @@ __device__ __forceinline__ void scan_descend(uint32_t *lds, const uint32_t *hist
       if (lane >= off) inc += t;
     }
     const unsigned excl = inc - tot;
-    if ((unsigned long long)excl <= rank && rank < (unsigned long long)excl + tot) {
-      unsigned below = excl;
-      for (int j = 0; j < 64; ++j) {
-        const unsigned c = stage[j];
-        if (rank < (unsigned long long)below + c) {
-          found_bin[p] = lane * 64 + j;
-          found_below[p] = below;
-          found_cnt[p] = c;
-          break;
-        }
-        below += c;
+    const unsigned long long owners = __ballot(excl <= rank && rank < excl + tot);
+    if (owners) {
+      const int L = __ffsll((long long)owners) - 1;
+      const unsigned base = __shfl(excl, L);
+      const unsigned c = img[L * 65 + lane];  // bin 64 L + lane
+      unsigned inc2 = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(inc2, off);
+        if (lane >= off) inc2 += t;
+      }
+      const unsigned below = base + inc2 - c;
+      if (c > 0 && below <= rank && rank < below + c) {
+        found_bin[p] = L * 64 + lane;
+        found_below[p] = below;
+        found_cnt[p] = c;
       }
     }
   }
@@ -125,16 +149,32 @@ __device__ __forceinline__ void scan_descend(uint32_t *lds, const uint32_t *hist
   if (threadIdx.x == 0) {
     const int shift = pass_shift(pass);
     bool over = false;
+#pragma unroll
     for (int p = 0; p < kSelProblems; ++p) {
-      sel[p].prefix |= (unsigned long long)found_bin[p] << shift;
-      sel[p].rank -= found_below[p];
+      st[p].prefix |= (unsigned long long)found_bin[p] << shift;
+      st[p].rank -= found_below[p];
       over |= check_cap && found_cnt[p] > (unsigned)kSelCap;
     }
-    for (int p = 0; p < kSelProblems; ++p)
-      if (sel[p].alias >= 0 && sel[p].prefix != sel[sel[p].alias].prefix) sel[p].alias = -1;
+    // an "upper middle" problem keeps sharing its partner's histogram only while both sit in
+    // the same bin (aliases are always p -> p - 1)
+#pragma unroll
+    for (int p = 1; p < kSelProblems; p += 2)
+      if (st[p].alias >= 0 && st[p].prefix != st[p - 1].prefix) st[p].alias = -1;
+#pragma unroll
+    for (int p = 0; p < kSelProblems; ++p) sel[p] = st[p];
     if (over) scal->overflow = 1;
   }
 }
+
+#ifdef ICP_NN_STATS
+// diagnostic build only: per (MODE, pass) sums of phase times (shader cycles, thread 0 of each
+// workgroup): [0] zero LDS, [1] stream + LDS atomics, [2] flush, [3] ticket, [4] tail (last
+// workgroup only), [5] workgroups, [6] tails
+__device__ unsigned long long g_hist_stamps[6][8];
+#define HSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define HSTAMP(var) ((void)0)
+#endif
 
 template <int MODE>
 __global__ __launch_bounds__(kFastThreads) void k_fast_hist(const double2 *__restrict__ a,
@@ -143,6 +183,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_hist(const double2 *__res
                                                             unsigned n, int pass, SelState *sel,
                                                             GnScalars *scal, uint32_t *hist, SelCtl *ctl) {
   __shared__ uint32_t lh[kSelProblems * kScanPad];  // histograms at p*kSelBins; padded staging later
+  HSTAMP(ts0);
   unsigned long long prefix[kSelProblems];
   bool active[kSelProblems];
 #pragma unroll
@@ -155,6 +196,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_hist(const double2 *__res
     if (active[p])
       for (unsigned i = threadIdx.x; i < kSelBins; i += kFastThreads) lh[p * kSelBins + i] = 0;
   __syncthreads();
+  HSTAMP(ts1);
 
   const int shift = pass_shift(pass);
   const unsigned mask = (1u << pass_bits(pass)) - 1u;
@@ -177,6 +219,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_hist(const double2 *__res
   });
   if (MODE == 0 && saw_nan) atomicOr(&scal->nan_flag, 1);
   __syncthreads();
+  HSTAMP(ts2);
 #pragma unroll
   for (int p = 0; p < kSelProblems; ++p)
     if (active[p])
@@ -184,7 +227,28 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_hist(const double2 *__res
         const uint32_t c = lh[p * kSelBins + i];
         if (c) atomicAdd(&hist[p * kSelBins + i], c);
       }
-  if (last_block_arrives(&ctl->t[0])) scan_descend(lh, hist, sel, scal, pass, /*check_cap=*/pass == 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  HSTAMP(ts3);
+  const bool last = last_block_arrives(&ctl->t[0]);
+  HSTAMP(ts4);
+  if (last) scan_descend(lh, hist, sel, scal, pass, /*check_cap=*/pass == 1);
+#ifdef ICP_NN_STATS
+  if (last) __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long ts5 = __builtin_amdgcn_s_memtime();
+    unsigned long long *g = g_hist_stamps[(MODE == 0 ? 0 : (MODE == 1 ? 1 : 2 + (pass != 0)))];
+    atomicAdd(&g[0], ts1 - ts0);
+    atomicAdd(&g[1], ts2 - ts1);
+    atomicAdd(&g[2], ts3 - ts2);
+    atomicAdd(&g[3], ts4 - ts3);
+    atomicAdd(&g[5], 1ull);
+    if (last) {
+      atomicAdd(&g[4], ts5 - ts4);
+      atomicAdd(&g[6], 1ull);
+    }
+  }
+#endif
 }
 
 // Append the keys that share the first `prefix_bits` bits with a problem's prefix to its
@@ -238,9 +302,13 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_compact(const double2 *__
   const int tid = threadIdx.x;
   if (tid == 0) s_over = 0;
   if (tid < kSelProblems) result[tid] = 0;
+  SelState st[kSelProblems];  // read once (see scan_descend)
+#pragma unroll
+  for (int p = 0; p < kSelProblems; ++p) st[p] = sel[p];
   __syncthreads();
+#pragma unroll
   for (int l = 0; l < kSelProblems; ++l) {
-    if (sel[l].alias >= 0) continue;  // reads another problem's list
+    if (st[l].alias >= 0) continue;  // reads another problem's list
     unsigned c = __hip_atomic_load(&ctl->cand_cnt[l], RLX_AGENT);
     if (c > (unsigned)kSelCap) {
       if (tid == 0) s_over = 1;
@@ -256,9 +324,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_compact(const double2 *__
         less += kj < ki;
         eq += kj == ki;
       }
+#pragma unroll
       for (int p = l; p < kSelProblems; ++p) {
-        if (p != l && sel[p].alias != l) continue;
-        const unsigned long long rank = sel[p].rank;
+        if (p != l && st[p].alias != l) continue;
+        const unsigned long long rank = st[p].rank;
         if ((unsigned long long)less <= rank && rank < (unsigned long long)less + eq) result[p] = ki;
       }
     }
@@ -575,3 +644,14 @@ hipError_t launch_weighted_gn_fast(icp_handle *h, const double *d_a, const doubl
 }
 
 }  // namespace icp
+
+#ifdef ICP_NN_STATS
+extern "C" int icp_debug_hist_stamps(unsigned long long out[48], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(icp::g_hist_stamps), 48 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    const unsigned long long z[48] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(icp::g_hist_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
