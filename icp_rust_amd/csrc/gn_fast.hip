@@ -361,6 +361,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_fast_accumulate(const double
                                                                     unsigned n, Pose T, GnScalars *scal,
                                                                     double *partials, uint32_t *hist,
                                                                     SelCtl *ctl, GnResult *res, unsigned seq) {
+  HSTAMP(ta0);
   const double sig[2] = {scal->sigma[0], scal->sigma[1]};
   double g[2];
   g[0] = 1. / sig[0];
@@ -412,20 +413,39 @@ __global__ __launch_bounds__(kReduceThreads) void k_fast_accumulate(const double
       acc[12] = acc[12] + rho;
     }
   }
+  HSTAMP(ta1);
   block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
+  HSTAMP(ta2);
   for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x;
        i < (unsigned)(kSelRoles * kSelProblems * kSelBins); i += G)
     hist[i] = 0;
 
-  if (!last_block_arrives(&ctl->t[2])) return;
+  const bool last_blk = last_block_arrives(&ctl->t[2]);
+#ifdef ICP_NN_STATS
+  if (threadIdx.x == 0) {
+    const unsigned long long ta3 = __builtin_amdgcn_s_memtime();
+    unsigned long long *gs = g_hist_stamps[4];
+    atomicAdd(&gs[0], ta1 - ta0);
+    atomicAdd(&gs[1], ta2 - ta1);
+    atomicAdd(&gs[2], ta3 - ta2);
+    atomicAdd(&gs[5], 1ull);
+  }
+  const unsigned long long ta4 = __builtin_amdgcn_s_memtime();
+#endif
+  if (!last_blk) return;
+  const int nan_flag = scal->nan_flag, overflow = scal->overflow;  // issued now, used at the very end
   double tot[kNAcc + 1];
 #pragma unroll
   for (int k = 0; k < kNAcc + 1; ++k) tot[k] = 0.;
   const int blocks = gridDim.x;
-  for (int i = threadIdx.x; i < blocks; i += kReduceThreads)
+  for (int i = threadIdx.x; i < blocks; i += kReduceThreads) {
+    double v[kNAcc];  // all 13 loads in flight before the first add (a load-add-load-add chain
+                      // would pay the sc1 latency 13 times over)
 #pragma unroll
-    for (int k = 0; k < kNAcc; ++k)
-      tot[k] = tot[k] + __hip_atomic_load(&partials[(size_t)i * (kNAcc + 1) + k], RLX_AGENT);
+    for (int k = 0; k < kNAcc; ++k) v[k] = __hip_atomic_load(&partials[(size_t)i * (kNAcc + 1) + k], RLX_AGENT);
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k) tot[k] = tot[k] + v[k];
+  }
   block_reduce_store<kNAcc + 1>(tot, res->acc);
   // Publish to the host: the result lives in coherent pinned memory; every writing lane makes
   // its stores visible at system scope before lane 0 releases the sequence number the host
@@ -435,8 +455,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_fast_accumulate(const double
   if (threadIdx.x == 0) {
     res->sigma[0] = sig[0];
     res->sigma[1] = sig[1];
-    res->nan_flag = scal->nan_flag;
-    res->overflow = scal->overflow;
+    res->nan_flag = nan_flag;
+    res->overflow = overflow;
     scal->overflow = 0;
     __threadfence_system();
     __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -479,11 +499,16 @@ template <int N>
 __device__ __forceinline__ void group_reduce(double (&acc)[N], double (*sm)[N], int wave) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    double v = acc[k];
+  for (int off = 32; off >= 1; off >>= 1) {  // step-major: see block_reduce_store
+    double t[N];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_down(v, off);
-    if (lane == 0) sm[wave][k] = v;
+    for (int k = 0; k < N; ++k) t[k] = __shfl_down(acc[k], off);
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = acc[k] + t[k];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) sm[wave][k] = acc[k];
   }
 }
 

@@ -36,3 +36,6 @@ for row, nm in enumerate(["H0 (MODE0 p0)", "H1 (MODE1 p1)", "H0' (MODE2 p0)", "H
     r = v[row * 8: row * 8 + 8]
     wg, tails = max(r[5], 1), max(r[6], 1)
     print(f"{nm}: per workgroup cycles: zero {r[0]/wg:.0f} stream {r[1]/wg:.0f} flush {r[2]/wg:.0f} ticket {r[3]/wg:.0f} | tail {r[4]/tails:.0f} (launches {r[6]})")
+r = v[4 * 8: 4 * 8 + 8]
+wg, tails = max(r[5], 1), max(r[6], 1)
+print(f"A (accumulate): per workgroup cycles: stream+math {r[0]/wg:.0f} block reduce {r[1]/wg:.0f} zero+ticket {r[2]/wg:.0f} | tail {r[4]/tails:.0f} (launches {r[6]})")
