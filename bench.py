@@ -87,9 +87,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # ICP_BENCH_SHARE_GPU=1 (debugging on a 1-GPU box only): all ranks use cuda:0 and talk gloo,
+    # to exercise the sharded path end to end; never set for a measurement
+    share_gpu = os.environ.get("ICP_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     I.build()
     n, m = args.n_src, args.n_dst

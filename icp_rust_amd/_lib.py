@@ -67,6 +67,7 @@ SIGNATURES = {
     "icp_set_nn_mode": (C.c_int, [_vp, C.c_int]),
     "icp_get_nn_mode": (C.c_int, [_vp]),
     "icp_set_stream": (C.c_int, [_vp, _vp]),
+    "icp_use_own_stream": (C.c_int, [_vp]),
     "icp_estimate": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
     "icp_estimate_device": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
     "icp_estimate_transform": (C.c_int, [_vp, _vp, _sz, _pp, _vp]),

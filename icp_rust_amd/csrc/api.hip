@@ -212,6 +212,7 @@ extern "C" void icp_destroy(icp_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  if (h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);  // work enqueued on a caller's stream
   for (auto &ev : h->prof_events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -260,7 +261,12 @@ extern "C" int icp_get_nn_mode(const icp_handle *h) {
 }
 extern "C" int icp_set_stream(icp_handle *h, void *s) {
   if (!h) return ICP_BAD_ARGUMENT;
-  h->stream = s ? (hipStream_t)s : h->own_stream;
+  h->stream = (hipStream_t)s;  // NULL = the HIP default stream, a legitimate choice
+  return ICP_OK;
+}
+extern "C" int icp_use_own_stream(icp_handle *h) {
+  if (!h) return ICP_BAD_ARGUMENT;
+  h->stream = h->own_stream;
   return ICP_OK;
 }
 extern "C" int icp_synchronize(icp_handle *h) {

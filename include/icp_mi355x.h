@@ -103,10 +103,13 @@ void icp_destroy(icp_handle *h);
 
 int icp_set_nn_mode(icp_handle *h, int mode);   /* icp_nn_mode; default ICP_NN_AUTO */
 int icp_get_nn_mode(const icp_handle *h);       /* the engine AUTO resolved to      */
-/* run the handle's kernels on a caller-owned HIP stream (hipStream_t) instead of the
- * handle's own; pass NULL to go back.  Used by hosts that interleave their own device
- * work (e.g. RCCL collectives) with the stage-level calls of section 4. */
+/* run the handle's kernels on a caller-chosen HIP stream (hipStream_t) instead of the handle's
+ * own non-blocking stream.  NULL is the HIP default (null) stream -- what torch.cuda's default
+ * stream is -- not "reset".  Used by hosts that interleave their own device work (e.g. RCCL
+ * collectives, torch ops) with the stage-level calls of section 4: everything is then ordered
+ * on that one stream.  icp_use_own_stream goes back to the private stream. */
 int icp_set_stream(icp_handle *h, void *hip_stream);
+int icp_use_own_stream(icp_handle *h);
 
 /* Icp2d::estimate (src/lib.rs:105-130) / Icp3d::estimate (src/lib.rs:148-173):
  * exactly `max_iter` outer iterations of transform -> exact NN -> estimate_transform

@@ -409,3 +409,39 @@ def test_estimate_transform_small_inputs_use_the_single_launch_stages():
         want, want_inner = O.estimate_transform(a, b)
         assert inner == want_inner
         assert_pose_close(got, want)
+
+
+def test_stage_calls_on_the_default_stream_are_ordered_and_shards_equal_the_whole():
+    """Two handles each matching half of the source cloud into one pair buffer, then the
+    replicated inner loop -- all on torch's default (NULL) stream with no explicit
+    synchronisation, as the multi-GPU driver does around its all-gather.  Must equal the
+    unsharded estimate bit for bit (regression: NULL used to mean "own stream")."""
+    import torch
+
+    from icp_rust_amd.dist import HipStages, ShardedIcp, shard_range
+
+    n = m = 150_000
+    src, dst = synth.synthetic_pair(n, m)
+    d_src, d_dst = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+    whole = I.Icp3d(d_dst)
+    T1, inner1 = ShardedIcp(HipStages(whole), n).estimate(d_src, I.Transform(), 4)
+    shards = [shard_range(n, r, 2) for r in range(2)]
+    srcs = [d_src[lo:hi].contiguous() for lo, hi in shards]
+    parts = [I.Icp3d(d_dst) for _ in shards]
+    a = torch.empty((n, 2), dtype=torch.float64, device="cuda")
+    b = torch.empty_like(a)
+    T = I.Transform()
+    for ic, s in zip(parts, srcs):
+        ic.set_stream(torch.cuda.current_stream().cuda_stream)
+        ic.prepare_source_device(s, T)
+    inner2 = []
+    for _ in range(4):
+        for ic, s, (lo, hi) in zip(parts, srcs, shards):
+            ic.correspond_device(s, T, a[lo:hi], b[lo:hi])
+        dT, k = whole.estimate_transform_device(a, b)
+        T = dT * T
+        inner2.append(k)
+    assert np.array_equal(T1.as_array(), T.as_array())
+    assert inner1.tolist() == inner2
+    ref = I.Icp3d(d_dst).estimate(d_src, I.Transform(), 4)
+    assert np.array_equal(ref.as_array(), T.as_array())
