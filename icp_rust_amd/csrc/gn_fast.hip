@@ -641,9 +641,14 @@ hipError_t launch_weighted_gn_fast(icp_handle *h, const double *d_a, const doubl
       return hipGetLastError();
     }
   }
+  // second-digit passes flush dense histograms (8192 global atomics per workgroup): half the
+  // workgroups, twice the elements per lane
+  static const unsigned hb1_div = getenv("ICP_HB1_DIV") ? (unsigned)atoi(getenv("ICP_HB1_DIV")) : 2u;
+  const unsigned hb1 = hb / hb1_div > 0 ? hb / hb1_div : 1;
   const size_t role = (size_t)kSelProblems * kSelBins;
 #define HIST(MODE, PASS, ROLE)                                                                            \
-  hipLaunchKernelGGL(k_fast_hist<MODE>, dim3(hb), dim3(kFastThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n,    \
+  hipLaunchKernelGGL(k_fast_hist<MODE>, dim3((PASS) == 1 ? hb1 : hb), dim3(kFastThreads), 0, s, a, b, T,  \
+                     w.d_rx, w.d_ry, n,                                                                    \
                      PASS, w.d_sel, w.d_scal, w.d_hist + (ROLE) * role, w.d_ctl)
 #define COMPACT(MODE, BITS, STAGE)                                                                        \
   hipLaunchKernelGGL(k_fast_compact<MODE>, dim3(hb), dim3(kFastThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, \
