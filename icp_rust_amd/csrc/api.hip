@@ -189,6 +189,7 @@ static int create_common(icp_handle **out, int dim, const double *dst, size_t m,
     }
     if ((e = build_target_soa(h)) != hipSuccess) { rc = map_hip(e); break; }
     if ((e = build_grid(h)) != hipSuccess) { rc = map_hip(e); break; }
+    if ((e = build_target_screen(h)) != hipSuccess) { rc = map_hip(e); break; }
     if ((e = ensure_workspace(h, 0, false)) != hipSuccess) { rc = map_hip(e); break; }
     // the host buffer may be freed by the caller as soon as we return
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) { rc = map_hip(e); break; }
@@ -220,6 +221,7 @@ extern "C" void icp_destroy(icp_handle *h) {
   free_workspace(h->ws);
   if (h->owns_dst) (void)hipFree(const_cast<double *>(h->d_dst));
   (void)hipFree(h->d_dst_soa);
+  (void)hipFree(h->d_dst_f32);
   (void)hipFree(h->grid.d_start);
   (void)hipFree(h->grid.d_pts);
   (void)hipFree(h->qsort.d_cnt);

@@ -140,6 +140,7 @@ struct icp_handle {
   bool owns_dst = false;
   const double *d_dst = nullptr; // AoS m x dim (owned or borrowed)
   double *d_dst_soa = nullptr;   // x[m_pad] | y[m_pad] | z[m_pad], padded with +inf
+  float *d_dst_f32 = nullptr;    // fl32(p - bbox lo), same layout: the sweep's f32 screen
   size_t m_pad = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -156,6 +157,7 @@ namespace icp {
 // ---- launchers (each enqueues on h->stream and returns the HIP error) ---------------
 hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src);
 hipError_t build_target_soa(icp_handle *h);
+hipError_t build_target_screen(icp_handle *h);  // after build_grid
 
 // transform (optional) + brute-force exact NN + gather of the matched xy pairs
 hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n, const Pose *T,

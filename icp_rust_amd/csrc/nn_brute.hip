@@ -101,6 +101,127 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute(
   }
 }
 
+// The same sweep with an f32 screen in front of the exact f64 test.  Targets are also kept as
+// fl32(p - org) (org = lower corner of the target bounding box); with qf = fl32(q - org) every
+// component of df = qf - pf is within 2^-23 (E + |q - org|) of the true q - p, so the true
+// distance is >= |df| - ec (ec = sqrt(3) times that bound) and |df|^2 >= s32 (1 - 1e-6) for the
+// f32-evaluated sum.  A pair is skipped iff that lower bound exceeds sqrt(best) -- it can
+// neither win nor tie -- and every other pair is evaluated exactly with the contract's f64
+// formula, in the same ascending target order with the same strict `<`.  Same indices, bit
+// for bit; ~8 f32 instead of ~12 f64-rate instructions for all but ~ln(M) pairs per query.
+template <int DIM, int R, bool XFORM>
+__global__ __launch_bounds__(kNnThreads) void k_nn_brute_scr(
+    const double *__restrict__ src, unsigned n, const double *__restrict__ tx,
+    const double *__restrict__ ty, const double *__restrict__ tz, const float *__restrict__ fx,
+    const float *__restrict__ fy, const float *__restrict__ fz, unsigned m_pad, unsigned chunk, Pose T,
+    double ox, double oy, double oz, double scale, double *__restrict__ part_d,
+    uint32_t *__restrict__ part_i) {
+  __shared__ double sx[kNnTile];
+  __shared__ double sy[kNnTile];
+  __shared__ double sz[DIM == 3 ? kNnTile : 1];
+  __shared__ float gx[kNnTile];
+  __shared__ float gy[kNnTile];
+  __shared__ float gz[DIM == 3 ? kNnTile : 1];
+
+  const unsigned q0 = blockIdx.x * (kNnThreads * R) + threadIdx.x;
+  double qx[R], qy[R], qz[R], best[R], ec[R];
+  float hx[R], hy[R], hz[R], thr[R];
+  unsigned bi[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const unsigned q = q0 + r * kNnThreads;
+    double x = 0., y = 0., z = 0.;
+    if (q < n) {
+      x = src[(size_t)q * DIM + 0];
+      y = src[(size_t)q * DIM + 1];
+      if (DIM == 3) z = src[(size_t)q * DIM + 2];
+    }
+    if (XFORM) {  // Transform::transform, src/transform.rs:22-24 (z untouched, lib.rs:52-57)
+      const double nx = (T.r00 * x + T.r01 * y) + T.tx;
+      const double ny = (T.r10 * x + T.r11 * y) + T.ty;
+      x = nx;
+      y = ny;
+    }
+    qx[r] = x;
+    qy[r] = y;
+    qz[r] = z;
+    const double ax = x - ox, ay = y - oy, az = DIM == 3 ? z - oz : 0.;
+    hx[r] = (float)ax;
+    hy[r] = (float)ay;
+    hz[r] = (float)az;
+    ec[r] = (fmax(fmax(fabs(ax), fabs(ay)), fabs(az)) + 2. * scale) * 1.2e-7 * 1.7320508075688774;
+    best[r] = __builtin_huge_val();
+    thr[r] = __builtin_huge_valf();
+    bi[r] = 0xffffffffu;
+  }
+
+  const unsigned t_begin = blockIdx.y * chunk;
+  const unsigned t_end = min(m_pad, t_begin + chunk);
+  for (unsigned t0 = t_begin; t0 < t_end; t0 += kNnTile) {
+    __syncthreads();
+    for (unsigned k = threadIdx.x; k < kNnTile; k += kNnThreads) {
+      sx[k] = tx[t0 + k];
+      sy[k] = ty[t0 + k];
+      gx[k] = fx[t0 + k];
+      gy[k] = fy[t0 + k];
+      if (DIM == 3) {
+        sz[k] = tz[t0 + k];
+        gz[k] = fz[t0 + k];
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (unsigned k = 0; k < kNnTile; ++k) {
+      const float px = gx[k], py = gy[k];
+      const float pz = (DIM == 3) ? gz[k] : 0.f;
+      float s[R];
+      unsigned long long any = 0;  // per-r compares go straight to scalar masks, OR-ed on the SALU
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float dx = hx[r] - px;
+        const float dy = hy[r] - py;
+        float v = dx * dx + dy * dy;
+        if (DIM == 3) {
+          const float dz = hz[r] - pz;
+          v = v + dz * dz;
+        }
+        s[r] = v;
+        any |= __ballot(!(v > thr[r]));
+      }
+      if (any) {  // wave-uniform: some lane has a pair that could win or tie
+        const double ex = sx[k], ey = sy[k];
+        const double ez = (DIM == 3) ? sz[k] : 0.;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (s[r] > thr[r]) continue;
+          const double dx = qx[r] - ex;
+          const double dy = qy[r] - ey;
+          double d = dx * dx + dy * dy;
+          if (DIM == 3) {
+            const double dz = qz[r] - ez;
+            d = d + dz * dz;
+          }
+          if (d < best[r]) {
+            best[r] = d;
+            bi[r] = t0 + k;
+            const double rr = sqrt(d) + ec[r];
+            thr[r] = (float)(rr * rr * 1.000004) * 1.000001f + 1e-37f;  // rounded up
+          }
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const unsigned q = q0 + r * kNnThreads;
+    if (q < n) {
+      part_i[(size_t)blockIdx.y * n + q] = bi[r];
+      if (gridDim.y > 1) part_d[(size_t)blockIdx.y * n + q] = best[r];
+    }
+  }
+}
+
 // Merge the per-chunk minima (ascending chunk order + strict `<` keeps the lowest
 // index on ties), then emit idx and the matched xy pairs a = xy(T.src), b = xy(dst[idx]).
 template <int DIM, bool XFORM>
@@ -151,6 +272,30 @@ __global__ void k_build_soa(const double *__restrict__ dst, unsigned m, unsigned
   }
 }
 
+// fl32(p - org) per axis, padded with +inf like the f64 tiles
+__global__ void k_build_soa_f32(const double *__restrict__ dst, unsigned m, unsigned m_pad, int dim, double ox,
+                                double oy, double oz, float *__restrict__ soa) {
+  const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m_pad) return;
+  const double org[3] = {ox, oy, oz};
+  for (int d = 0; d < 3; ++d) {
+    float v = __builtin_huge_valf();
+    if (j < m) v = (d < dim) ? (float)(dst[(size_t)j * dim + d] - org[d]) : 0.f;
+    soa[(size_t)d * m_pad + j] = v;
+  }
+}
+
+// needs the target bounding box (build_grid); without one the plain f64 sweep serves
+hipError_t build_target_screen(icp_handle *h) {
+  if (!h->grid.built || h->m_pad == 0) return hipSuccess;
+  hipError_t e = hipMalloc(&h->d_dst_f32, 3 * h->m_pad * sizeof(float));
+  if (e != hipSuccess) return e;
+  const GridParams &g = h->grid.p;
+  hipLaunchKernelGGL(k_build_soa_f32, dim3((unsigned)((h->m_pad + 255) / 256)), dim3(256), 0, h->stream, h->d_dst,
+                     (unsigned)h->m, (unsigned)h->m_pad, h->dim, g.lo[0], g.lo[1], g.lo[2], h->d_dst_f32);
+  return hipGetLastError();
+}
+
 hipError_t build_target_soa(icp_handle *h) {
   const size_t m_pad = ((h->m + kNnTile - 1) / kNnTile) * kNnTile;
   h->m_pad = m_pad;
@@ -172,6 +317,15 @@ template <int DIM, int R, bool XFORM>
 static void launch_one(icp_handle *h, const double *d_src, unsigned n, const Pose &T, unsigned qblocks,
                        unsigned chunks, unsigned chunk) {
   const double *tx = h->d_dst_soa, *ty = tx + h->m_pad, *tz = ty + h->m_pad;
+  static const bool no_screen = getenv("ICP_NN_NO_SCREEN") != nullptr;
+  if (h->d_dst_f32 && !no_screen) {
+    const float *fx = h->d_dst_f32, *fy = fx + h->m_pad, *fz = fy + h->m_pad;
+    const GridParams &g = h->grid.p;
+    hipLaunchKernelGGL((k_nn_brute_scr<DIM, R, XFORM>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
+                       d_src, n, tx, ty, tz, fx, fy, fz, (unsigned)h->m_pad, chunk, T, g.lo[0], g.lo[1], g.lo[2],
+                       g.scale, h->ws.d_part_d, h->ws.d_part_i);
+    return;
+  }
   hipLaunchKernelGGL((k_nn_brute<DIM, R, XFORM>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
                      d_src, n, tx, ty, tz, (unsigned)h->m_pad, chunk, T, h->ws.d_part_d, h->ws.d_part_i);
 }
