@@ -78,10 +78,10 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     const size_t hist_bytes = (size_t)kSelRoles * kSelProblems * kSelBins * sizeof(uint32_t);
     if ((e = hipMalloc(&w.d_hist, hist_bytes)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(w.d_hist, 0, hist_bytes, h->stream)) != hipSuccess) return e;
-    if ((e = hipMalloc(&w.d_cand, (size_t)kSelProblems * kSelCap * sizeof(unsigned long long))) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_cand, (size_t)2 * kSelProblems * kSelCap * sizeof(unsigned long long))) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_ctl, sizeof(SelCtl))) != hipSuccess) return e;
     if ((e = hipMemsetAsync(w.d_ctl, 0, sizeof(SelCtl), h->stream)) != hipSuccess) return e;
-    if ((e = hipMalloc(&w.d_sel, kSelProblems * sizeof(SelState))) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_sel, 2 * kSelProblems * sizeof(SelState))) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_scal, sizeof(GnScalars))) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_partials, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double))) != hipSuccess) return e;
     if ((e = hipHostMalloc(&w.h_res, sizeof(GnResult), hipHostMallocCoherent)) != hipSuccess) return e;

@@ -56,7 +56,8 @@ struct TicketSet {
 struct SelCtl {
   TicketSet t[3];
   unsigned cand_cnt[kSelProblems];
-  unsigned pad[28];
+  unsigned cand_cnt_pull[2][kSelProblems];  // gn_pull.hip: candidates per stage (median, MAD)
+  unsigned pad[20];
 };
 
 // What the last kernel of an inner iteration hands to the host (pinned, mapped).
@@ -83,9 +84,9 @@ struct Workspace {
   uint32_t *d_part_i = nullptr;
   // selection + reduction scratch (fixed size)
   uint32_t *d_hist = nullptr;   // kSelRoles x kSelProblems x kSelBins (role 0 also serves the radix path)
-  unsigned long long *d_cand = nullptr;  // kSelProblems x kSelCap candidate keys
+  unsigned long long *d_cand = nullptr;  // 2 stages x kSelProblems x kSelCap candidate keys
   SelCtl *d_ctl = nullptr;
-  SelState *d_sel = nullptr;    // kSelProblems
+  SelState *d_sel = nullptr;    // 2 x kSelProblems (gn_pull.hip ping-pongs between the halves)
   GnScalars *d_scal = nullptr;
   double *d_partials = nullptr; // kReduceMaxBlocks x (kNAcc+1)
   GnResult *h_res = nullptr;    // pinned coherent host memory, written by the last workgroup
@@ -176,6 +177,8 @@ hipError_t launch_weighted_gn(icp_handle *h, const double *d_a, const double *d_
 // the same through the short pipeline (7 launches, or 3 when n <= kSelCap); sets
 // h_res->overflow when the caller has to redo the evaluation with launch_weighted_gn
 hipError_t launch_weighted_gn_fast(icp_handle *h, const double *d_a, const double *d_b, size_t n,
+                                   const Pose &T);
+hipError_t launch_weighted_gn_pull(icp_handle *h, const double *d_a, const double *d_b, size_t n,
                                    const Pose &T);
 // unweighted accumulation (gauss_newton_update / error / huber_error)
 hipError_t launch_plain_gn(icp_handle *h, const double *d_a, const double *d_b, size_t n,

@@ -641,6 +641,8 @@ hipError_t launch_weighted_gn_fast(icp_handle *h, const double *d_a, const doubl
       return hipGetLastError();
     }
   }
+  static const bool push = getenv("ICP_GN_PUSH") != nullptr;
+  if (!push) return launch_weighted_gn_pull(h, d_a, d_b, n_, T);  // same launches, no serial tails
   // second-digit passes flush dense histograms (8192 global atomics per workgroup): half the
   // workgroups, twice the elements per lane
   static const unsigned hb1_div = getenv("ICP_HB1_DIV") ? (unsigned)atoi(getenv("ICP_HB1_DIV")) : 2u;

@@ -1,0 +1,475 @@
+// "Pull" variant of the short pipeline for one inner Gauss-Newton evaluation
+// (src/lib.rs:218-261 + :45-50): the same seven launches as gn_fast.hip,
+//     H(median, digit 0)  H(median, digit 1)  C(median)  H(MAD, digit 0)  H(MAD, digit 1)  C(MAD)  A
+// but nobody waits for a last workgroup any more.  In gn_fast.hip every selection launch ends
+// with a serial tail (arrival ticket -> one workgroup scans the histograms / ranks the
+// candidates: 3.5-8 us per launch by in-kernel stamps).  Here the NEXT launch resolves the
+// previous launch's output in its prologue, redundantly in every workgroup (a 2 x 4096-bin
+// histogram or a <= 1024-key candidate list is a few us of L2-resident reads, all workgroups
+// in parallel): the kernel boundary is the only synchronisation, and workgroup 0 records the
+// resolved state for the launch after next.  Only A, which must produce ONE sum, keeps a
+// last-workgroup tail.  Results are bit-identical to gn_fast.hip / gn.hip: integer
+// histograms, exact rank counting, the same reduction tree.
+#include "common.hpp"
+#include "gn_device.hpp"
+
+namespace icp {
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+constexpr int kPullThreads = 1024;
+constexpr int kPullBatch = 4;
+constexpr int kPullPad = kSelBins + kSelBins / 64;  // bin + bin/64: conflict-free column sums
+
+__device__ __forceinline__ void init_state(SelState (&st)[kSelProblems], unsigned n) {
+#pragma unroll
+  for (int p = 0; p < kSelProblems; ++p) {
+    const bool hi = p & 1;
+    st[p].prefix = 0;
+    st[p].rank = hi ? (n / 2) : ((n - 1) / 2);  // src/stats.rs:18-27
+    st[p].alias = hi ? p - 1 : -1;
+    st[p].pad = 0;
+  }
+}
+
+// Descend one radix digit for all problems from the histograms another launch produced.
+// Executed by every workgroup (1024 threads); `lds` holds kSelProblems * kPullPad words.
+__device__ __forceinline__ void resolve_hist(uint32_t *lds, const uint32_t *__restrict__ hist,
+                                             SelState (&st)[kSelProblems], int pass, bool check_cap,
+                                             bool &over) {
+  __shared__ unsigned found_bin[kSelProblems], found_below[kSelProblems], found_cnt[kSelProblems];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bool live[kSelProblems];
+#pragma unroll
+  for (int p = 0; p < kSelProblems; ++p) live[p] = st[p].alias < 0;
+  constexpr int PER = (kSelProblems * kSelBins) / kPullThreads;
+  unsigned v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int j = tid + kPullThreads * u, p = j / kSelBins;
+    v[u] = live[p] ? hist[j] : 0u;
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int j = tid + kPullThreads * u, p = j / kSelBins, bin = j % kSelBins;
+    lds[p * kPullPad + bin + (bin >> 6)] = v[u];
+  }
+  __syncthreads();
+  if (wave < kSelProblems) {
+    const int p = wave;
+    int src = p;
+    unsigned rank = 0;
+#pragma unroll
+    for (int pp = 0; pp < kSelProblems; ++pp)
+      if (pp == p) {
+        src = st[pp].alias >= 0 ? st[pp].alias : pp;
+        rank = (unsigned)st[pp].rank;
+      }
+    const uint32_t *img = lds + src * kPullPad;
+    unsigned tot = 0;
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) tot += img[lane * 65 + j];
+    unsigned inc = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned t = __shfl_up(inc, off);
+      if (lane >= off) inc += t;
+    }
+    const unsigned excl = inc - tot;
+    const unsigned long long owners = __ballot(excl <= rank && rank < excl + tot);
+    if (owners) {
+      const int L = __ffsll((long long)owners) - 1;
+      const unsigned base = __shfl(excl, L);
+      const unsigned c = img[L * 65 + lane];
+      unsigned inc2 = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(inc2, off);
+        if (lane >= off) inc2 += t;
+      }
+      const unsigned below = base + inc2 - c;
+      if (c > 0 && below <= rank && rank < below + c) {
+        found_bin[p] = L * 64 + lane;
+        found_below[p] = below;
+        found_cnt[p] = c;
+      }
+    }
+  }
+  __syncthreads();
+  const int shift = pass_shift(pass);
+#pragma unroll
+  for (int p = 0; p < kSelProblems; ++p) {
+    st[p].prefix |= (unsigned long long)found_bin[p] << shift;
+    st[p].rank -= found_below[p];
+    over |= check_cap && found_cnt[p] > (unsigned)kSelCap;
+  }
+#pragma unroll
+  for (int p = 1; p < kSelProblems; p += 2)
+    if (st[p].alias >= 0 && st[p].prefix != st[p - 1].prefix) st[p].alias = -1;
+  __syncthreads();  // the caller reuses `lds`
+}
+
+// The order statistics themselves, from the candidate lists another launch appended.
+// Executed by every workgroup (any blockDim); out[p] = key of problem p.
+__device__ __forceinline__ void resolve_cand(unsigned long long *keys, const unsigned long long *__restrict__ cand,
+                                             const unsigned *__restrict__ cand_cnt,
+                                             const SelState (&st)[kSelProblems],
+                                             unsigned long long (&out)[kSelProblems], bool &over) {
+  __shared__ unsigned long long result[kSelProblems];
+  const unsigned tid = threadIdx.x, nt = blockDim.x;
+  if (tid < kSelProblems) result[tid] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < kSelProblems; ++l) {
+    if (st[l].alias >= 0) continue;  // reads its partner's list
+    unsigned c = cand_cnt[l];
+    if (c > (unsigned)kSelCap) {
+      over = true;
+      c = kSelCap;
+    }
+    for (unsigned i = tid; i < c; i += nt) keys[i] = cand[l * kSelCap + i];
+    __syncthreads();
+    for (unsigned i = tid; i < c; i += nt) {
+      const unsigned long long ki = keys[i];
+      unsigned less = 0, eq = 0;
+      for (unsigned j = 0; j < c; ++j) {
+        const unsigned long long kj = keys[j];
+        less += kj < ki;
+        eq += kj == ki;
+      }
+#pragma unroll
+      for (int p = l; p < kSelProblems; ++p) {
+        if (p != l && st[p].alias != l) continue;
+        const unsigned long long rank = st[p].rank;
+        if ((unsigned long long)less <= rank && rank < (unsigned long long)less + eq) result[p] = ki;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int p = 0; p < kSelProblems; ++p) out[p] = result[p];
+  __syncthreads();
+}
+
+__device__ __forceinline__ double middle(unsigned n, unsigned long long klo, unsigned long long khi) {
+  const double lo = k2f(klo), hi = k2f(khi);
+  return (n & 1) ? lo : (lo + hi) / 2.;  // src/stats.rs:18-27
+}
+
+// the element stream shared by H and C: MODE 0 computes and stores the residuals
+// (residual(), src/lib.rs:34-36), MODE 1 re-reads them, MODE 2 keys |r - median| (stats.rs:35)
+template <int MODE, typename F>
+__device__ __forceinline__ void stream_keys(const double2 *__restrict__ a, const double2 *__restrict__ b,
+                                            const Pose &T, double *__restrict__ rx, double *__restrict__ ry,
+                                            unsigned n, double med0, double med1, bool &saw_nan, F &&f) {
+  const unsigned G = gridDim.x * blockDim.x;
+  for (unsigned base = blockIdx.x * blockDim.x + threadIdx.x; base < n; base += G * kPullBatch) {
+    double v0[kPullBatch], v1[kPullBatch];
+    double2 s[kPullBatch], d[kPullBatch];
+#pragma unroll
+    for (int u = 0; u < kPullBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i < n) {
+        if (MODE == 0) {
+          s[u] = a[i];
+          d[u] = b[i];
+        } else {
+          v0[u] = rx[i];
+          v1[u] = ry[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kPullBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i < n) {
+        if (MODE == 0) {
+          v0[u] = ((T.r00 * s[u].x + T.r01 * s[u].y) + T.tx) - d[u].x;
+          v1[u] = ((T.r10 * s[u].x + T.r11 * s[u].y) + T.ty) - d[u].y;
+          rx[i] = v0[u];
+          ry[i] = v1[u];
+          saw_nan |= (v0[u] != v0[u]) | (v1[u] != v1[u]);
+        } else if (MODE == 2) {
+          v0[u] = fabs(v0[u] - med0);
+          v1[u] = fabs(v1[u] - med1);
+        }
+        f(f2k(v0[u]), f2k(v1[u]));
+      }
+    }
+  }
+}
+
+// H: histogram of digit `pass` of the keys that match the prefix resolved so far.
+//   MODE 0: median stage, digit 0.   MODE 1: median stage, digit 1 (resolves digit 0 first).
+//   MODE 2: MAD stage; pass 0 first turns the median candidates into the median, pass 1
+//           resolves digit 0 of the MAD search.
+template <int MODE>
+__global__ __launch_bounds__(kPullThreads) void k_pull_hist(const double2 *__restrict__ a,
+                                                            const double2 *__restrict__ b, Pose T,
+                                                            double *__restrict__ rx, double *__restrict__ ry,
+                                                            unsigned n, int pass, const SelState *sel_in,
+                                                            SelState *sel_out, GnScalars *scal,
+                                                            const uint32_t *__restrict__ hist_prev,
+                                                            uint32_t *hist_out,
+                                                            const unsigned long long *__restrict__ cand_prev,
+                                                            SelCtl *ctl) {
+  __shared__ uint32_t lh[kSelProblems * kPullPad];
+  SelState st[kSelProblems];
+  bool over = false;
+  double med0 = 0., med1 = 0.;
+  if (MODE == 2 && pass == 0) {
+    // the median: rank the candidates the previous launch collected (state of the median search in `sel`)
+#pragma unroll
+    for (int p = 0; p < kSelProblems; ++p) st[p] = sel_in[p];
+    unsigned long long key[kSelProblems];
+    resolve_cand(reinterpret_cast<unsigned long long *>(lh), cand_prev, ctl->cand_cnt_pull[0], st, key, over);
+    med0 = middle(n, key[0], key[1]);
+    med1 = middle(n, key[2], key[3]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      scal->median[0] = med0;
+      scal->median[1] = med1;
+    }
+    init_state(st, n);
+  } else {
+    if (MODE == 2) {
+      med0 = scal->median[0];
+      med1 = scal->median[1];
+    }
+    init_state(st, n);
+    if (pass == 1) {
+      resolve_hist(lh, hist_prev, st, 0, false, over);
+      if (blockIdx.x == 0 && threadIdx.x == 0)
+#pragma unroll
+        for (int p = 0; p < kSelProblems; ++p) sel_out[p] = st[p];
+    } else if (blockIdx.x == 0 && threadIdx.x < kSelProblems) {
+      ctl->cand_cnt_pull[1][threadIdx.x] = 0;  // MAD candidates of the previous evaluation: A has read them
+    }
+  }
+  if (over && blockIdx.x == 0 && threadIdx.x == 0) scal->overflow = 1;
+
+  bool active[kSelProblems];
+  unsigned long long prefix[kSelProblems];
+#pragma unroll
+  for (int p = 0; p < kSelProblems; ++p) {
+    active[p] = st[p].alias < 0;
+    prefix[p] = st[p].prefix;
+  }
+#pragma unroll
+  for (int p = 0; p < kSelProblems; ++p)
+    if (active[p])
+      for (unsigned i = threadIdx.x; i < kSelBins; i += kPullThreads) lh[p * kSelBins + i] = 0;
+  __syncthreads();
+
+  const int shift = pass_shift(pass);
+  const unsigned mask = (1u << pass_bits(pass)) - 1u;
+  const int hs = shift + pass_bits(pass);  // bits above the current digit (64 at pass 0)
+  bool saw_nan = false;
+  stream_keys<MODE>(a, b, T, rx, ry, n, med0, med1, saw_nan, [&](unsigned long long k0, unsigned long long k1) {
+#pragma unroll
+    for (int p = 0; p < kSelProblems; ++p) {
+      if (!active[p]) continue;
+      const unsigned long long key = (p < 2) ? k0 : k1;
+      const bool match = (hs >= 64) || ((key >> hs) == (prefix[p] >> hs));
+      if (match) atomicAdd(&lh[p * kSelBins + ((unsigned)(key >> shift) & mask)], 1u);
+    }
+  });
+  if (MODE == 0 && saw_nan) atomicOr(&scal->nan_flag, 1);
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < kSelProblems; ++p)
+    if (active[p])
+      for (unsigned i = threadIdx.x; i < kSelBins; i += kPullThreads) {
+        const uint32_t c = lh[p * kSelBins + i];
+        if (c) atomicAdd(&hist_out[p * kSelBins + i], c);
+      }
+}
+
+// C: resolve digit 1, then append the keys sharing the 24-bit prefix to the candidate lists
+template <int MODE>
+__global__ __launch_bounds__(kPullThreads) void k_pull_compact(const double2 *__restrict__ a,
+                                                               const double2 *__restrict__ b, Pose T,
+                                                               double *__restrict__ rx, double *__restrict__ ry,
+                                                               unsigned n, int stage, const SelState *sel_in,
+                                                               SelState *sel_out, GnScalars *scal,
+                                                               const uint32_t *__restrict__ hist_prev,
+                                                               unsigned long long *cand, SelCtl *ctl) {
+  __shared__ uint32_t lh[kSelProblems * kPullPad];
+  SelState st[kSelProblems];
+  bool over = false;
+  double med0 = 0., med1 = 0.;
+  if (MODE == 2) {
+    med0 = scal->median[0];
+    med1 = scal->median[1];
+  }
+#pragma unroll
+  for (int p = 0; p < kSelProblems; ++p) st[p] = sel_in[p];
+  resolve_hist(lh, hist_prev, st, 1, true, over);
+  // the resolved state goes to the OTHER half of the state buffer: workgroups of this launch
+  // that start later must still read the input state
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int p = 0; p < kSelProblems; ++p) sel_out[p] = st[p];
+    if (over) scal->overflow = 1;
+  }
+  bool active[kSelProblems];
+  unsigned long long prefix[kSelProblems];
+#pragma unroll
+  for (int p = 0; p < kSelProblems; ++p) {
+    active[p] = st[p].alias < 0;
+    prefix[p] = st[p].prefix;
+  }
+  bool saw_nan = false;
+  unsigned *cnt = ctl->cand_cnt_pull[stage];
+  stream_keys<MODE>(a, b, T, rx, ry, n, med0, med1, saw_nan, [&](unsigned long long k0, unsigned long long k1) {
+#pragma unroll
+    for (int p = 0; p < kSelProblems; ++p) {
+      if (!active[p]) continue;
+      const unsigned long long key = (p < 2) ? k0 : k1;
+      if ((key >> 40) == (prefix[p] >> 40)) {
+        const unsigned pos = atomicAdd(&cnt[p], 1u);
+        if (pos < (unsigned)kSelCap) cand[p * kSelCap + pos] = key;
+      }
+    }
+  });
+}
+
+// A: sigma from the MAD candidates, then src/lib.rs:238-255 (+ :45-50) in the fixed tree; the
+// last workgroup folds the block sums and publishes to the host (as in gn_fast.hip).
+__global__ __launch_bounds__(kReduceThreads) void k_pull_accumulate(const double2 *__restrict__ a,
+                                                                    const double *__restrict__ rx,
+                                                                    const double *__restrict__ ry,
+                                                                    unsigned n, Pose T, const SelState *sel,
+                                                                    GnScalars *scal,
+                                                                    const unsigned long long *__restrict__ cand,
+                                                                    double *partials, uint32_t *hist,
+                                                                    SelCtl *ctl, GnResult *res, unsigned seq) {
+  __shared__ unsigned long long keys[kSelCap];
+  SelState st[kSelProblems];
+#pragma unroll
+  for (int p = 0; p < kSelProblems; ++p) st[p] = sel[p];
+  bool over = false;
+  unsigned long long key[kSelProblems];
+  resolve_cand(keys, cand, ctl->cand_cnt_pull[1], st, key, over);
+  const double sig[2] = {ICP_PPF34 * middle(n, key[0], key[1]),  // src/stats.rs:42-46
+                         ICP_PPF34 * middle(n, key[2], key[3])};
+  double g[2];
+  g[0] = 1. / sig[0];
+  g[1] = 1. / sig[1];
+  const double k2 = ICP_HUBER_K * ICP_HUBER_K;
+  double acc[kNAcc];
+#pragma unroll
+  for (int k = 0; k < kNAcc; ++k) acc[k] = 0.;
+  const unsigned G = gridDim.x * kReduceThreads;
+  for (unsigned base = blockIdx.x * kReduceThreads + threadIdx.x; base < n; base += G * kPullBatch) {
+    double2 s[kPullBatch];
+    double r0[kPullBatch], r1[kPullBatch];
+#pragma unroll
+    for (int u = 0; u < kPullBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i < n) {
+        s[u] = a[i];
+        r0[u] = rx[i];
+        r1[u] = ry[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kPullBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i >= n) continue;
+      const double r[2] = {r0[u], r1[u]};
+      const double a0 = -s[u].y, a1 = s[u].x;  // jacobian(), src/lib.rs:176-184
+      const double b0 = T.r00 * a0 + T.r01 * a1;
+      const double b1 = T.r10 * a0 + T.r11 * a1;
+      const double J[2][3] = {{T.r00, T.r01, b0}, {T.r10, T.r11, b1}};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (sig[j] == 0.) continue;  // src/lib.rs:243-245
+        const double r_ij = r[j];
+        const double e = r_ij * r_ij;
+        double w_ij = 1.;  // huber::drho, src/huber.rs:17-26; sqrt+divide only where a lane needs it
+        if (__ballot(e > k2)) w_ij = huber_drho(e);
+        const double wg = w_ij * g[j];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[9 + k] = acc[9 + k] + (wg * J[j][k]) * r_ij;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc[3 * p + q] = acc[3 * p + q] + (wg * J[j][p]) * J[j][q];
+      }
+      const double e2 = r[0] * r[0] + r[1] * r[1];
+      double rho = e2;  // huber::rho, src/huber.rs:6-15
+      if (__ballot(e2 > k2)) rho = huber_rho(e2);
+      acc[12] = acc[12] + rho;
+    }
+  }
+  block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
+  // clear what the next evaluation accumulates into (nobody reads these in this launch)
+  for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x;
+       i < (unsigned)(kSelRoles * kSelProblems * kSelBins); i += G)
+    hist[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < kSelProblems) ctl->cand_cnt_pull[0][threadIdx.x] = 0;
+
+  if (!last_block_arrives(&ctl->t[2])) return;
+  const int nan_flag = scal->nan_flag, overflow = scal->overflow | (over ? 1 : 0);
+  double tot[kNAcc + 1];
+#pragma unroll
+  for (int k = 0; k < kNAcc + 1; ++k) tot[k] = 0.;
+  const int blocks = gridDim.x;
+  for (int i = threadIdx.x; i < blocks; i += kReduceThreads) {
+    double v[kNAcc];
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k) v[k] = __hip_atomic_load(&partials[(size_t)i * (kNAcc + 1) + k], RLX_AGENT);
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k) tot[k] = tot[k] + v[k];
+  }
+  block_reduce_store<kNAcc + 1>(tot, res->acc);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    res->sigma[0] = sig[0];
+    res->sigma[1] = sig[1];
+    res->nan_flag = nan_flag;
+    res->overflow = overflow;
+    scal->overflow = 0;
+    __threadfence_system();
+    __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+hipError_t launch_weighted_gn_pull(icp_handle *h, const double *d_a, const double *d_b, size_t n_, const Pose &T) {
+  Workspace &w = h->ws;
+  const unsigned n = (unsigned)n_;
+  const unsigned per = kPullThreads * kPullBatch;
+  unsigned hb = (n + per - 1) / per;
+  if (hb > 256) hb = 256;  // one workgroup per CU
+  const unsigned hb1 = hb / 2 > 0 ? hb / 2 : 1;  // digit-1 passes flush dense histograms: fewer, fatter workgroups
+  const double2 *a = (const double2 *)d_a, *b = (const double2 *)d_b;
+  hipStream_t s = h->stream;
+  const size_t role = (size_t)kSelProblems * kSelBins;
+  uint32_t *H = w.d_hist;
+  unsigned long long *C0 = w.d_cand, *C1 = w.d_cand + (size_t)kSelProblems * kSelCap;
+  const dim3 bt(kPullThreads);
+  SelState *SA = w.d_sel, *SB = w.d_sel + kSelProblems;  // ping-pong: a launch never rewrites what it reads
+  hipLaunchKernelGGL(k_pull_hist<0>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 0, (const SelState *)SB, SA,
+                     w.d_scal, (const uint32_t *)nullptr, H + 0 * role, (const unsigned long long *)nullptr,
+                     w.d_ctl);
+  hipLaunchKernelGGL(k_pull_hist<1>, dim3(hb1), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 1, (const SelState *)SB, SA,
+                     w.d_scal, (const uint32_t *)(H + 0 * role), H + 1 * role,
+                     (const unsigned long long *)nullptr, w.d_ctl);
+  hipLaunchKernelGGL(k_pull_compact<1>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 0, (const SelState *)SA,
+                     SB, w.d_scal, (const uint32_t *)(H + 1 * role), C0, w.d_ctl);
+  hipLaunchKernelGGL(k_pull_hist<2>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 0, (const SelState *)SB, SA,
+                     w.d_scal, (const uint32_t *)nullptr, H + 2 * role, (const unsigned long long *)C0, w.d_ctl);
+  hipLaunchKernelGGL(k_pull_hist<2>, dim3(hb1), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 1, (const SelState *)SB, SA,
+                     w.d_scal, (const uint32_t *)(H + 2 * role), H + 3 * role,
+                     (const unsigned long long *)nullptr, w.d_ctl);
+  hipLaunchKernelGGL(k_pull_compact<2>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 1, (const SelState *)SA,
+                     SB, w.d_scal, (const uint32_t *)(H + 3 * role), C1, w.d_ctl);
+  int blocks, threads;
+  reduce_geometry(n_, &blocks, &threads);
+  hipLaunchKernelGGL(k_pull_accumulate, dim3(blocks), dim3(threads), 0, s, a, w.d_rx, w.d_ry, n, T,
+                     (const SelState *)SB, w.d_scal, (const unsigned long long *)C1, w.d_partials, w.d_hist, w.d_ctl, w.h_res, ++w.seq);
+  return hipGetLastError();
+}
+
+}  // namespace icp
