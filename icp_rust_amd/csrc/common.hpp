@@ -12,7 +12,7 @@
 namespace icp {
 
 constexpr int kReduceThreads = 512;   // threads per block of the GN reduction tree
-constexpr int kReduceMaxBlocks = 512;
+constexpr int kReduceMaxBlocks = 256;
 constexpr int kNAcc = 13;             // jtj[9], jtr[3], huber error
 constexpr int kSelProblems = 4;       // {x, y} x {lower, upper middle order statistic}
 constexpr int kSelBins = 4096;        // 12-bit radix digits

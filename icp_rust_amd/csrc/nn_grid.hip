@@ -181,7 +181,7 @@ hipError_t build_grid(icp_handle *h) {
     scale = fmax(scale, fmax(fabs(g.lo[d]), fabs(g.hi[d])));
   }
   if (!std::isfinite(emax)) return hipSuccess;
-  // 2. cell size: ~1 target per cell over the non-degenerate extents, <= 2^24 cells
+  // 2. cell size: ~2 targets per cell over the non-degenerate extents (measured sweet spot 2-4), <= 2^24 cells
   int k = 0;
   double vol = 1.;
   for (int d = 0; d < h->dim; ++d)
@@ -189,7 +189,9 @@ hipError_t build_grid(icp_handle *h) {
       vol *= ext[d];
       ++k;
     }
-  double hh = k > 0 ? pow(vol / (double)m, 1. / k) : 1.;
+  // ICP_GRID_OCC: targets per cell the cell size aims at (tuning knob; any value is exact)
+  static const double occ = getenv("ICP_GRID_OCC") ? atof(getenv("ICP_GRID_OCC")) : 2.;
+  double hh = k > 0 ? pow(occ * vol / (double)m, 1. / k) : 1.;
   if (!(hh > 0.) || !std::isfinite(hh)) hh = 1.;
   for (;;) {
     double cells = 1.;
