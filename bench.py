@@ -106,6 +106,11 @@ def main():
     src_np, dst_np = synth.synthetic_pair(n, m, src_first=lo, src_count=hi - lo)
     d_dst = torch.from_numpy(dst_np).cuda()
     d_src = torch.from_numpy(src_np).cuda()
+    d_src_full = None
+    if world > 1:
+        # the source cloud is replicated (24 MB) so that ranks exchange 4-byte indices, not 32-byte pairs
+        full_np, _ = synth.synthetic_pair(n, 1)
+        d_src_full = torch.from_numpy(full_np).cuda()
     nn_mode = {"auto": I.NN_AUTO, "brute": I.NN_BRUTE, "grid": I.NN_GRID}[args.nn]
 
     def barrier():
@@ -116,7 +121,7 @@ def main():
     def measure(mode, steps, warmup):
         """K timed outer iterations = one Icp3d::estimate(src, T, K) call on resident data."""
         icp = I.Icp3d(d_dst, device=local_rank, nn_mode=mode)
-        driver = ShardedIcp(HipStages(icp), n, rank, world)
+        driver = ShardedIcp(HipStages(icp), n, rank, world, src_full=d_src_full)
         T = I.Transform()
         driver.stages.prepare(d_src, T)
         for _ in range(warmup):
@@ -211,7 +216,8 @@ def main():
                             "NN engine = " + res["engine"] + " (bit-identical correspondences to the "
                             "brute-force sweep, which is timed alongside under `brute_force`)",
                 "n_src": n, "n_dst": m, "nn": res["engine"], "outer_iterations_per_estimate_call": MAX_ITER,
-                "parallelism": f"source cloud sharded x{world}, target replicated, inner loop replicated",
+                "parallelism": f"NN over the source cloud sharded x{world} (index all-gather), target replicated, "
+                               "inner loop replicated",
                 "seed": hex(synth.SEED),
             },
             "roofline": nn_roofline(res, n_shard),

@@ -77,6 +77,7 @@ SIGNATURES = {
     "icp_huber_error": (C.c_int, [_pp, _vp, _vp, _sz, _dp]),
     "icp_residual_stddevs": (C.c_int, [_pp, _vp, _vp, _sz, _dp]),
     "icp_correspond_device": (C.c_int, [_vp, _vp, _sz, _pp, _vp, _vp, _vp]),
+    "icp_materialize_pairs_device": (C.c_int, [_vp, _vp, _sz, _pp, _vp, _vp, _vp]),
     "icp_prepare_source_device": (C.c_int, [_vp, _vp, _sz, _pp]),
     "icp_estimate_transform_device": (C.c_int, [_vp, _vp, _vp, _sz, _pp, _vp]),
     "icp_nn_search_device": (C.c_int, [_vp, _vp, _sz, _vp]),

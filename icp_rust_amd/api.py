@@ -304,10 +304,17 @@ class _Icp:
 
     def correspond_device(self, d_src, transform, d_a, d_b, d_idx=None):
         check(lib().icp_correspond_device(self._h, C.c_void_p(d_src.data_ptr()), d_src.shape[0],
-                                          C.byref(transform.pose), C.c_void_p(d_a.data_ptr()),
-                                          C.c_void_p(d_b.data_ptr()),
+                                          C.byref(transform.pose),
+                                          C.c_void_p(d_a.data_ptr()) if d_a is not None else None,
+                                          C.c_void_p(d_b.data_ptr()) if d_b is not None else None,
                                           C.c_void_p(d_idx.data_ptr()) if d_idx is not None else None),
               "icp_correspond_device")
+
+    def materialize_pairs_device(self, d_src, transform, d_idx, d_a, d_b):
+        check(lib().icp_materialize_pairs_device(self._h, C.c_void_p(d_src.data_ptr()), d_src.shape[0],
+                                                 C.byref(transform.pose), C.c_void_p(d_idx.data_ptr()),
+                                                 C.c_void_p(d_a.data_ptr()), C.c_void_p(d_b.data_ptr())),
+              "icp_materialize_pairs_device")
 
     def prepare_source_device(self, d_src, transform):
         check(lib().icp_prepare_source_device(self._h, C.c_void_p(d_src.data_ptr()), d_src.shape[0],

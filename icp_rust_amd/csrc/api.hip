@@ -311,6 +311,16 @@ extern "C" int icp_correspond_device(icp_handle *h, const double *d_src, size_t 
   return ICP_OK;
 }
 
+extern "C" int icp_materialize_pairs_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T,
+                                            const uint32_t *d_idx, double *d_a, double *d_b) {
+  if (!h || !T || (n > 0 && (!d_src || !d_idx || !d_a || !d_b)) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  if (n == 0) return ICP_OK;
+  if (h->m == 0) return ICP_EMPTY_DST;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(launch_materialize(h, d_src, n, *T, d_idx, d_a, d_b));
+  return ICP_OK;
+}
+
 extern "C" int icp_prepare_source_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T) {
   if (!h || !T || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
   h->qsort.valid = false;

@@ -164,6 +164,8 @@ hipError_t build_target_screen(icp_handle *h);  // after build_grid
 hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n, const Pose *T,
                            double *d_a, double *d_b, uint32_t *d_idx);
 
+hipError_t launch_materialize(icp_handle *h, const double *d_src, size_t n, const Pose &T, const uint32_t *d_idx,
+                              double *d_a, double *d_b);
 // exact uniform-grid NN: same outputs, same results as launch_nn_brute
 hipError_t build_grid(icp_handle *h);
 hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n, const Pose &T);

@@ -259,6 +259,34 @@ __global__ __launch_bounds__(256) void k_nn_finalize(
   if (b) b[q] = make_double2(tx[bi], ty[bi]);
 }
 
+// pairs from given indices: a = xy(T.src) (Transform::transform, src/transform.rs:22-24),
+// b = xy(dst[idx]) (get_xy, src/lib.rs:86-89)
+template <int DIM>
+__global__ __launch_bounds__(256) void k_materialize(const double *__restrict__ src, unsigned n, Pose T,
+                                                     const uint32_t *__restrict__ idx,
+                                                     const double *__restrict__ dst, double2 *__restrict__ a,
+                                                     double2 *__restrict__ b) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double x = src[(size_t)i * DIM + 0], y = src[(size_t)i * DIM + 1];
+  const uint32_t j = idx[i];
+  a[i] = make_double2((T.r00 * x + T.r01 * y) + T.tx, (T.r10 * x + T.r11 * y) + T.ty);
+  b[i] = make_double2(dst[(size_t)j * DIM + 0], dst[(size_t)j * DIM + 1]);
+}
+
+hipError_t launch_materialize(icp_handle *h, const double *d_src, size_t n, const Pose &T, const uint32_t *d_idx,
+                              double *d_a, double *d_b) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (h->dim == 3)
+    hipLaunchKernelGGL(k_materialize<3>, dim3(blocks), dim3(256), 0, h->stream, d_src, (unsigned)n, T, d_idx,
+                       h->d_dst, (double2 *)d_a, (double2 *)d_b);
+  else
+    hipLaunchKernelGGL(k_materialize<2>, dim3(blocks), dim3(256), 0, h->stream, d_src, (unsigned)n, T, d_idx,
+                       h->d_dst, (double2 *)d_a, (double2 *)d_b);
+  return hipGetLastError();
+}
+
 // AoS (as handed over by the host) -> padded SoA x|y|z used by the scan
 __global__ void k_build_soa(const double *__restrict__ dst, unsigned m, unsigned m_pad, int dim,
                             double *__restrict__ soa) {

@@ -153,6 +153,12 @@ int icp_residual_stddevs(const icp_pose *T, const double *a_xy, const double *b_
  * stream. */
 int icp_correspond_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T,
                           double *d_a_xy, double *d_b_xy, uint32_t *d_idx);
+/* a = xy(T (.) src), b = xy(dst[idx]) for n points from given correspondence indices -- the
+ * second half of icp_correspond_device on its own.  A multi-GPU host that replicates the source
+ * cloud all-gathers only the 4-byte indices of each rank's shard (instead of 32 bytes of pairs
+ * per point) and rebuilds the pairs locally with this call; same arithmetic, same bits. */
+int icp_materialize_pairs_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T,
+                                 const uint32_t *d_idx, double *d_a_xy, double *d_b_xy);
 /* Optional, before a run of icp_correspond_device calls on the same source buffer: takes a
  * cell-sorted snapshot of (d_src, n) under pose T so that neighbouring GPU lanes search
  * neighbouring cells (results are unchanged, bit for bit; only memory locality changes).

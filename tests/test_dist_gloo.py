@@ -39,8 +39,22 @@ class OracleStages:
         st[:, 1] = (p.r10 * s[:, 0] + p.r11 * s[:, 1]) + p.ty
         rc, idx = self.tree.search(st)
         assert rc == O.OK
+        self._last_idx = idx
         a_out.copy_(torch.from_numpy(np.ascontiguousarray(st[:, :2])))
         b_out.copy_(torch.from_numpy(np.ascontiguousarray(self.dst[idx][:, :2])))
+
+    def correspond_idx(self, src_shard, T, idx_out):
+        a = torch.empty((src_shard.shape[0], 2), dtype=torch.float64)
+        b = torch.empty_like(a)
+        self.correspond(src_shard, T, a, b)
+        idx_out.copy_(torch.from_numpy(self._last_idx.astype(np.int32)))
+
+    def materialize(self, src_full, T, idx_full, a_out, b_out):
+        p = T.pose
+        s = src_full.numpy()
+        a_out[:, 0] = torch.from_numpy((p.r00 * s[:, 0] + p.r01 * s[:, 1]) + p.tx)
+        a_out[:, 1] = torch.from_numpy((p.r10 * s[:, 0] + p.r11 * s[:, 1]) + p.ty)
+        b_out.copy_(torch.from_numpy(np.ascontiguousarray(self.dst[idx_full.numpy()][:, :2])))
 
     def estimate_transform(self, a_full, b_full):
         T, applied = O.estimate_transform(a_full.numpy(), b_full.numpy())
@@ -53,7 +67,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, m, max_iter, out):
+def _worker(rank, world, port, n, m, max_iter, out, idx_gather=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -61,7 +75,8 @@ def _worker(rank, world, port, n, m, max_iter, out):
         lo, hi = shard_range(n, rank, world)
         src_shard, dst = synth.synthetic_pair(n, m, src_first=lo, src_count=hi - lo)
         stages = OracleStages(dst)
-        drv = ShardedIcp(stages, n, rank, world)
+        full = torch.from_numpy(synth.synthetic_pair(n, 1)[0]) if idx_gather else None
+        drv = ShardedIcp(stages, n, rank, world, src_full=full)
         T, inner = drv.estimate(torch.from_numpy(src_shard), I.Transform(), max_iter)
         assert stages.prepared == 1
         # every rank must hold the same pose, bit for bit
@@ -76,11 +91,12 @@ def _worker(rank, world, port, n, m, max_iter, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 4000), (2, 4001), (3, 3001)])
-def test_sharded_driver_equals_single_process(tmp_path, world, n):
+@pytest.mark.parametrize("world,n,idx_gather", [(2, 4000, False), (2, 4001, False), (3, 3001, False),
+                                                (2, 4000, True), (3, 3001, True)])
+def test_sharded_driver_equals_single_process(tmp_path, world, n, idx_gather):
     m, max_iter = 3000, 4
     out = str(tmp_path / "pose.npy")
-    mp.spawn(_worker, args=(world, _free_port(), n, m, max_iter, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, m, max_iter, out, idx_gather), nprocs=world, join=True)
     got = np.load(out)
     src, dst = synth.synthetic_pair(n, m)
     rc, T, _, inner = O.icp_estimate(3, dst, src, O.transform_identity(), max_iter, use_kdtree=True)
