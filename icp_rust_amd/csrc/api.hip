@@ -63,6 +63,10 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_sel);
   (void)hipFree(w.d_scal);
   (void)hipFree(w.d_partials);
+  (void)hipFree(w.d_whist);
+  (void)hipFree(w.d_wstate);
+  (void)hipFree(w.d_wmed);
+  (void)hipFree(w.d_wring);
   if (w.h_res) (void)hipHostFree(w.h_res);
   w = Workspace();
 }
@@ -84,6 +88,13 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     if ((e = hipMalloc(&w.d_sel, 2 * kSelProblems * sizeof(SelState))) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_scal, sizeof(GnScalars))) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_partials, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double))) != hipSuccess) return e;
+    const size_t whist_bytes = (size_t)2 * kWinBins * sizeof(uint32_t);
+    if ((e = hipMalloc(&w.d_whist, whist_bytes)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(w.d_whist, 0, whist_bytes, h->stream)) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_wstate, sizeof(WinState))) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(w.d_wstate, 0, sizeof(WinState), h->stream)) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_wmed, (size_t)2 * kWinCapMed * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_wring, (size_t)2 * kWinCapRing * sizeof(double))) != hipSuccess) return e;
     if ((e = hipHostMalloc(&w.h_res, sizeof(GnResult), hipHostMallocCoherent)) != hipSuccess) return e;
     memset(w.h_res, 0, sizeof(GnResult));
   }
@@ -218,6 +229,8 @@ extern "C" void icp_destroy(icp_handle *h) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
   }
+  if (getenv("ICP_DBG_WIN") && h->ws.win_tried)
+    fprintf(stderr, "[icp] window evaluations: %llu tried, %llu missed\n", h->ws.win_tried, h->ws.win_missed);
   free_workspace(h->ws);
   if (h->owns_dst) (void)hipFree(const_cast<double *>(h->d_dst));
   (void)hipFree(h->d_dst_soa);
@@ -364,18 +377,46 @@ static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
 static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
                     double delta[3], double *huber_err) {
   static const bool force_radix = getenv("ICP_GN_RADIX") != nullptr;
-  bool done = false;
+  Workspace &w = h->ws;
+  bool done = false, has_median = false;
   if (!force_radix) {
-    HIP_TRY(launch_weighted_gn_fast(h, d_a, d_b, n, T));
-    HIP_TRY(wait_result(h));
-    done = !h->ws.h_res->overflow;
+    WinParams P;
+    if (window_usable(h, n, &P)) {  // three launches around the previous evaluation's median and sigma
+      ++w.win_tried;
+      HIP_TRY(launch_weighted_gn_win(h, d_a, d_b, n, T, P));
+      HIP_TRY(wait_result(h));
+      done = has_median = !w.h_res->overflow;
+      if (!done) {
+        ++w.win_missed;
+        w.win_wide = true;
+      } else if (w.win_wide) {  // back to narrow windows once the statistics have settled
+        double shift = 0.;
+        for (int d = 0; d < 2; ++d)
+          shift = fmax(shift, (fabs(w.h_res->median[d] - w.win_med[d]) + fabs(w.h_res->sigma[d] - w.win_sigma[d])) /
+                                  w.win_sigma[d]);
+        if (shift < 0.01) w.win_wide = false;
+      }
+    }
+    if (!done) {
+      HIP_TRY(launch_weighted_gn_fast(h, d_a, d_b, n, T));
+      HIP_TRY(wait_result(h));
+      done = !w.h_res->overflow;
+      static const bool push = getenv("ICP_GN_PUSH") != nullptr;
+      has_median = done && n > 1024 && !push;  // only gn_pull.hip reports the median
+    }
   }
   if (!done) {  // heavy duplicates around a median: the general 6-pass radix select
     HIP_TRY(launch_sel_init(h, n));
     HIP_TRY(launch_weighted_gn(h, d_a, d_b, n, T));
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
-  const GnResult &r = *h->ws.h_res;
+  const GnResult &r = *w.h_res;
+  w.win_valid = has_median;
+  if (has_median)
+    for (int d = 0; d < 2; ++d) {
+      w.win_med[d] = r.median[d];
+      w.win_sigma[d] = r.sigma[d];
+    }
   if (r.nan_flag) return ICP_NAN_INPUT;
   if (huber_err) *huber_err = r.acc[12];
   return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;

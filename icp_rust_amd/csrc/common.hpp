@@ -19,6 +19,15 @@ constexpr int kSelBins = 4096;        // 12-bit radix digits
 constexpr int kSelPasses = 6;         // 12+12+12+12+12+4 bits
 constexpr int kSelRoles = 4;          // fast path: histogram buffers {median, MAD} x {pass 0, pass 1}
 constexpr int kSelCap = 1024;         // fast path: candidates kept per problem after two passes
+// window path (gn_win.hip): one piecewise-linear histogram per dimension instead of radix digits
+constexpr int kWinFine = 512;         // bins of each of the three fine windows (median, median -+ MAD)
+constexpr int kWinCoarse = 255;       // bins of each of the two stretches between them
+constexpr int kWinBins = 2 + 3 * kWinFine + 2 * kWinCoarse;  // + everything below / above
+constexpr int kWinCapMed = 1024;      // candidates around the median, per dimension
+constexpr int kWinCapRing = 4096;     // candidates around median -+ MAD, per dimension
+constexpr int kWinBlocks = 256;       // workgroups of the streaming launches (one per CU)
+constexpr int kWinBlkMed = 32;        // candidates one workgroup can stage, per dimension
+constexpr int kWinBlkRing = 96;
 
 inline void reduce_geometry(size_t n, int *blocks, int *threads) {
   size_t b = (n + kReduceThreads - 1) / kReduceThreads;
@@ -60,12 +69,36 @@ struct SelCtl {
   unsigned pad[20];
 };
 
+// The bins of one dimension: (-inf, x[0]) | fine | coarse | fine | coarse | fine | [x[5], inf),
+// the fine windows centred on the predicted median - MAD, median, median + MAD.
+struct WinDim {
+  double x[6];
+  double sf, sc;  // bins per unit inside the fine windows / the coarse stretches
+};
+struct WinParams {
+  WinDim d[2];
+};
+
+// What k_win_compact resolves from the histograms for k_win_accumulate (per dimension).
+struct WinState {
+  unsigned fail;           // the window missed an order statistic: evaluate again with gn_pull.hip
+  unsigned pad0;
+  unsigned med_base[2];    // points in bins below the median bins
+  unsigned med_cnt[2];     // points in the median bins (= candidates the compaction delivers)
+  unsigned ring_inner[2];  // points surely closer to the median than the MAD
+  unsigned ring_cnt[2];    // points that may be at MAD distance (= candidates)
+  double med_lo[2], med_hi[2];    // value range of the median candidates
+  double ring_lo[2], ring_hi[2];  // distance range that holds the MAD
+  unsigned list_cnt[4][32];       // appended so far {med x, med y, ring x, ring y}, a 128-B line each
+};
+
 // What the last kernel of an inner iteration hands to the host (pinned, mapped).
 struct GnResult {
   double acc[kNAcc + 1];  // jtj[9], jtr[3], huber error, (plain) error
   double sigma[2];
+  double median[2];       // gn_pull.hip / gn_win.hip only: centre of the next evaluation's window
   int nan_flag;
-  int overflow;
+  int overflow;  // 1: too many candidates (radix path needed), 2: the window missed (gn_pull.hip needed)
   unsigned seq;  // written last, system scope: the host polls it instead of waiting for the stream
   unsigned pad;
 };
@@ -91,6 +124,15 @@ struct Workspace {
   double *d_partials = nullptr; // kReduceMaxBlocks x (kNAcc+1)
   GnResult *h_res = nullptr;    // pinned coherent host memory, written by the last workgroup
   unsigned seq = 0;             // sequence number of the last fast evaluation launched
+  // window path (gn_win.hip)
+  uint32_t *d_whist = nullptr;  // 2 x kWinBins, zero between evaluations
+  WinState *d_wstate = nullptr;
+  double *d_wmed = nullptr;     // 2 x kWinCapMed residuals
+  double *d_wring = nullptr;    // 2 x kWinCapRing residuals
+  bool win_valid = false;       // median/sigma of the previous evaluation are known
+  bool win_wide = false;        // the last window missed: use wider fine windows until it settles
+  double win_med[2] = {0., 0.}, win_sigma[2] = {0., 0.};
+  unsigned long long win_tried = 0, win_missed = 0;
 };
 
 // ---- uniform grid over the target cloud (nn_grid.hip) ------------------------------
@@ -182,6 +224,10 @@ hipError_t launch_weighted_gn_fast(icp_handle *h, const double *d_a, const doubl
                                    const Pose &T);
 hipError_t launch_weighted_gn_pull(icp_handle *h, const double *d_a, const double *d_b, size_t n,
                                    const Pose &T);
+// three launches around a predicted window (gn_win.hip); h_res->overflow == 2 when it missed
+bool window_usable(const icp_handle *h, size_t n, WinParams *P);
+hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double *d_b, size_t n,
+                                  const Pose &T, const WinParams &P);
 // unweighted accumulation (gauss_newton_update / error / huber_error)
 hipError_t launch_plain_gn(icp_handle *h, const double *d_a, const double *d_b, size_t n,
                            const Pose &T);

@@ -93,4 +93,91 @@ __device__ __forceinline__ bool last_block_arrives(TicketSet *t) {
   return s_last != 0;
 }
 
+// src/lib.rs:238-255 (+ :45-50) over this thread's points g, g + G, ... in index order (the
+// first level of the fixed reduction tree); residuals come from the arrays the first launch wrote
+constexpr int kAccBatch = 4;
+__device__ __forceinline__ void accumulate_points(const double2 *__restrict__ a, const double *__restrict__ rx,
+                                                  const double *__restrict__ ry, unsigned n, const Pose &T,
+                                                  const double (&sig)[2], double (&acc)[kNAcc]) {
+  double g[2];
+  g[0] = 1. / sig[0];
+  g[1] = 1. / sig[1];
+  const double k2 = ICP_HUBER_K * ICP_HUBER_K;
+  const unsigned G = gridDim.x * kReduceThreads;
+  for (unsigned base = blockIdx.x * kReduceThreads + threadIdx.x; base < n; base += G * kAccBatch) {
+    double2 s[kAccBatch];
+    double r0[kAccBatch], r1[kAccBatch];
+#pragma unroll
+    for (int u = 0; u < kAccBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i < n) {
+        s[u] = a[i];
+        r0[u] = rx[i];
+        r1[u] = ry[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kAccBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i >= n) continue;
+      const double r[2] = {r0[u], r1[u]};
+      const double a0 = -s[u].y, a1 = s[u].x;  // jacobian(), src/lib.rs:176-184
+      const double b0 = T.r00 * a0 + T.r01 * a1;
+      const double b1 = T.r10 * a0 + T.r11 * a1;
+      const double J[2][3] = {{T.r00, T.r01, b0}, {T.r10, T.r11, b1}};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (sig[j] == 0.) continue;  // src/lib.rs:243-245
+        const double r_ij = r[j];
+        const double e = r_ij * r_ij;
+        double w_ij = 1.;  // huber::drho, src/huber.rs:17-26; sqrt+divide only where a lane needs it
+        if (__ballot(e > k2)) w_ij = huber_drho(e);
+        const double wg = w_ij * g[j];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[9 + k] = acc[9 + k] + (wg * J[j][k]) * r_ij;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc[3 * p + q] = acc[3 * p + q] + (wg * J[j][p]) * J[j][q];
+      }
+      const double e2 = r[0] * r[0] + r[1] * r[1];
+      double rho = e2;  // huber::rho, src/huber.rs:6-15
+      if (__ballot(e2 > k2)) rho = huber_rho(e2);
+      acc[12] = acc[12] + rho;
+    }
+  }
+}
+
+// Executed by the last workgroup: fold the block sums (block order, same tree) and release the
+// result to the host, which polls `seq` in pinned memory.
+__device__ __forceinline__ void publish_result(const double *partials, GnResult *res, unsigned seq,
+                                               const double (&sig)[2], const double (&med)[2], int nan_flag,
+                                               int overflow) {
+  double tot[kNAcc + 1];
+#pragma unroll
+  for (int k = 0; k < kNAcc + 1; ++k) tot[k] = 0.;
+  const int blocks = gridDim.x;
+  for (int i = threadIdx.x; i < blocks; i += kReduceThreads) {
+    double v[kNAcc];
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k)
+      v[k] = __hip_atomic_load(&partials[(size_t)i * (kNAcc + 1) + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k) tot[k] = tot[k] + v[k];
+  }
+  block_reduce_store<kNAcc + 1>(tot, res->acc);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    res->sigma[0] = sig[0];
+    res->sigma[1] = sig[1];
+    res->median[0] = med[0];
+    res->median[1] = med[1];
+    res->nan_flag = nan_flag;
+    res->overflow = overflow;
+    __threadfence_system();
+    __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 }  // namespace icp

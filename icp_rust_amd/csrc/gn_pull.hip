@@ -352,58 +352,13 @@ __global__ __launch_bounds__(kReduceThreads) void k_pull_accumulate(const double
   resolve_cand(keys, cand, ctl->cand_cnt_pull[1], st, key, over);
   const double sig[2] = {ICP_PPF34 * middle(n, key[0], key[1]),  // src/stats.rs:42-46
                          ICP_PPF34 * middle(n, key[2], key[3])};
-  double g[2];
-  g[0] = 1. / sig[0];
-  g[1] = 1. / sig[1];
-  const double k2 = ICP_HUBER_K * ICP_HUBER_K;
   double acc[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; ++k) acc[k] = 0.;
-  const unsigned G = gridDim.x * kReduceThreads;
-  for (unsigned base = blockIdx.x * kReduceThreads + threadIdx.x; base < n; base += G * kPullBatch) {
-    double2 s[kPullBatch];
-    double r0[kPullBatch], r1[kPullBatch];
-#pragma unroll
-    for (int u = 0; u < kPullBatch; ++u) {
-      const unsigned i = base + u * G;
-      if (i < n) {
-        s[u] = a[i];
-        r0[u] = rx[i];
-        r1[u] = ry[i];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kPullBatch; ++u) {
-      const unsigned i = base + u * G;
-      if (i >= n) continue;
-      const double r[2] = {r0[u], r1[u]};
-      const double a0 = -s[u].y, a1 = s[u].x;  // jacobian(), src/lib.rs:176-184
-      const double b0 = T.r00 * a0 + T.r01 * a1;
-      const double b1 = T.r10 * a0 + T.r11 * a1;
-      const double J[2][3] = {{T.r00, T.r01, b0}, {T.r10, T.r11, b1}};
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (sig[j] == 0.) continue;  // src/lib.rs:243-245
-        const double r_ij = r[j];
-        const double e = r_ij * r_ij;
-        double w_ij = 1.;  // huber::drho, src/huber.rs:17-26; sqrt+divide only where a lane needs it
-        if (__ballot(e > k2)) w_ij = huber_drho(e);
-        const double wg = w_ij * g[j];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) acc[9 + k] = acc[9 + k] + (wg * J[j][k]) * r_ij;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int q = 0; q < 3; ++q) acc[3 * p + q] = acc[3 * p + q] + (wg * J[j][p]) * J[j][q];
-      }
-      const double e2 = r[0] * r[0] + r[1] * r[1];
-      double rho = e2;  // huber::rho, src/huber.rs:6-15
-      if (__ballot(e2 > k2)) rho = huber_rho(e2);
-      acc[12] = acc[12] + rho;
-    }
-  }
+  accumulate_points(a, rx, ry, n, T, sig, acc);
   block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
   // clear what the next evaluation accumulates into (nobody reads these in this launch)
+  const unsigned G = gridDim.x * kReduceThreads;
   for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x;
        i < (unsigned)(kSelRoles * kSelProblems * kSelBins); i += G)
     hist[i] = 0;
@@ -411,29 +366,9 @@ __global__ __launch_bounds__(kReduceThreads) void k_pull_accumulate(const double
 
   if (!last_block_arrives(&ctl->t[2])) return;
   const int nan_flag = scal->nan_flag, overflow = scal->overflow | (over ? 1 : 0);
-  double tot[kNAcc + 1];
-#pragma unroll
-  for (int k = 0; k < kNAcc + 1; ++k) tot[k] = 0.;
-  const int blocks = gridDim.x;
-  for (int i = threadIdx.x; i < blocks; i += kReduceThreads) {
-    double v[kNAcc];
-#pragma unroll
-    for (int k = 0; k < kNAcc; ++k) v[k] = __hip_atomic_load(&partials[(size_t)i * (kNAcc + 1) + k], RLX_AGENT);
-#pragma unroll
-    for (int k = 0; k < kNAcc; ++k) tot[k] = tot[k] + v[k];
-  }
-  block_reduce_store<kNAcc + 1>(tot, res->acc);
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    res->sigma[0] = sig[0];
-    res->sigma[1] = sig[1];
-    res->nan_flag = nan_flag;
-    res->overflow = overflow;
-    scal->overflow = 0;
-    __threadfence_system();
-    __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  const double med[2] = {scal->median[0], scal->median[1]};
+  if (threadIdx.x == 0) scal->overflow = 0;
+  publish_result(partials, res, seq, sig, med, nan_flag, overflow);
 }
 
 hipError_t launch_weighted_gn_pull(icp_handle *h, const double *d_a, const double *d_b, size_t n_, const Pose &T) {

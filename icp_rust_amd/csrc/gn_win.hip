@@ -1,0 +1,630 @@
+// "Window" variant of one inner Gauss-Newton evaluation (src/lib.rs:218-261 + :45-50): three
+// launches instead of the seven of gn_pull.hip,
+//     W (residuals + histograms)   C (compaction of the candidates)   A (accumulate)
+//
+// The radix pipelines spend two histogram passes and a compaction on the median
+// (src/stats.rs:11-28) and the same again on the MAD (:30-37), because the MAD keys
+// |r - median| do not exist before the median does.  Here the host predicts where the order
+// statistics of this evaluation lie from the previous evaluation's median and sigma (they move
+// by ~1e-2 sigma between evaluations of a converging registration) and W counts the residuals
+// of each dimension into ONE histogram whose bins are fine in three windows -- around the
+// predicted median and around median -+ MAD -- and coarse in between.  Any monotone bin
+// function keeps order statistics exact; from the counts alone C derives
+//   * the bins [jlo, jhi] holding the two middle order statistics -> median candidates;
+//   * knowing only that the median lies in those bins: a set I of bins whose points are surely
+//     closer to the median than the MAD, and a ring of bins around I that surely contains every
+//     point at MAD distance (the bracket is derived at resolve_window below);
+// and appends both candidate sets while re-reading the residuals once.  A ranks the median
+// candidates, turns the ring into distances to that exact median, ranks those behind |I|, and
+// accumulates.  Every order statistic is the exact one, so the results are bit-identical to
+// gn_pull.hip / gn_fast.hip / gn.hip and to the oracle's tree variant.  When the prediction
+// is off (an order statistic outside its fine window, too many candidates) the evaluation
+// reports `overflow = 2` and the host repeats it with gn_pull.hip, which also re-centres the
+// windows.  (A single fine histogram over the whole range needs ~2 scattered global atomics per
+// point: 92 us at 1M points, measured -- scattered atomics run at ~20 G/s on this chip.  The
+// piecewise bins keep the histogram at 2 x 2048 words, small enough for LDS privatisation and a
+// dense flush.)
+#include "common.hpp"
+#include "gn_device.hpp"
+
+namespace icp {
+
+constexpr int kWinThreads = 1024;
+constexpr int kWinBatch = 4;
+constexpr int kSubBins = 1024;   // select_pair: linear sub-bins over the candidates
+constexpr int kSmallCap = 256;   // select_pair: keys ranked by counting, per dimension
+constexpr size_t kWinMinN = 1u << 15;
+constexpr size_t kWinMaxN = 1u << 22;
+
+// first bin of each region
+constexpr int kF0 = 1, kC0 = kF0 + kWinFine, kF1 = kC0 + kWinCoarse, kC1 = kF1 + kWinFine, kF2 = kC1 + kWinCoarse;
+static_assert(kF2 + kWinFine == kWinBins - 1, "bin layout");
+
+__device__ __forceinline__ unsigned region_bin(double off, double scale, int first, int count) {
+  const unsigned k = (unsigned)(off * scale);  // off >= 0
+  return (unsigned)first + (k < (unsigned)count ? k : (unsigned)(count - 1));
+}
+
+// Monotone non-decreasing in r: the regions are ordered, and inside a region it is two
+// correctly rounded monotone operations, a floor and a clamp.
+__device__ __forceinline__ unsigned wbin(double r, const WinDim &w) {
+  if (!(r >= w.x[0])) return 0u;  // below (NaN residuals are reported through nan_flag)
+  if (r >= w.x[5]) return (unsigned)(kWinBins - 1);
+  if (r < w.x[1]) return region_bin(r - w.x[0], w.sf, kF0, kWinFine);
+  if (r < w.x[2]) return region_bin(r - w.x[1], w.sc, kC0, kWinCoarse);
+  if (r < w.x[3]) return region_bin(r - w.x[2], w.sf, kF1, kWinFine);
+  if (r < w.x[4]) return region_bin(r - w.x[3], w.sc, kC1, kWinCoarse);
+  return region_bin(r - w.x[4], w.sf, kF2, kWinFine);
+}
+
+// lower edge of regular bin j (1 <= j <= kWinBins-1; the upper edge of j is the lower edge of j+1)
+__device__ __forceinline__ double wedge(int j, const WinDim &w) {
+  if (j >= kWinBins - 1) return w.x[5];
+  if (j >= kF2) return w.x[4] + (double)(j - kF2) / w.sf;
+  if (j >= kC1) return w.x[3] + (double)(j - kC1) / w.sc;
+  if (j >= kF1) return w.x[2] + (double)(j - kF1) / w.sf;
+  if (j >= kC0) return w.x[1] + (double)(j - kC0) / w.sc;
+  return w.x[0] + (double)(j - kF0) / w.sf;
+}
+
+// ---- W ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWinThreads) void k_win_hist(const double2 *__restrict__ a,
+                                                          const double2 *__restrict__ b, Pose T,
+                                                          double *__restrict__ rx, double *__restrict__ ry,
+                                                          unsigned n, WinParams P, uint32_t *whist, WinState *st,
+                                                          GnScalars *scal) {
+  __shared__ uint32_t lh[2 * kWinBins];
+  for (unsigned i = threadIdx.x; i < 2u * kWinBins; i += kWinThreads) lh[i] = 0;
+  __syncthreads();
+  unsigned edge[4] = {0u, 0u, 0u, 0u};  // {below, above} x {x, y}: one word each, kept out of the LDS atomics
+  bool saw_nan = false;
+  const unsigned G = gridDim.x * kWinThreads;
+  for (unsigned base = blockIdx.x * kWinThreads + threadIdx.x; base < n; base += G * kWinBatch) {
+    double2 s[kWinBatch], d[kWinBatch];
+#pragma unroll
+    for (int u = 0; u < kWinBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i < n) {
+        s[u] = a[i];
+        d[u] = b[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kWinBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i >= n) continue;
+      // residual(), src/lib.rs:34-36
+      const double v0 = ((T.r00 * s[u].x + T.r01 * s[u].y) + T.tx) - d[u].x;
+      const double v1 = ((T.r10 * s[u].x + T.r11 * s[u].y) + T.ty) - d[u].y;
+      rx[i] = v0;
+      ry[i] = v1;
+      saw_nan |= (v0 != v0) | (v1 != v1);
+      const unsigned j0 = wbin(v0, P.d[0]), j1 = wbin(v1, P.d[1]);
+      if (j0 == 0u) ++edge[0];
+      else if (j0 == (unsigned)(kWinBins - 1)) ++edge[1];
+      else atomicAdd(&lh[j0], 1u);
+      if (j1 == 0u) ++edge[2];
+      else if (j1 == (unsigned)(kWinBins - 1)) ++edge[3];
+      else atomicAdd(&lh[kWinBins + j1], 1u);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned v = edge[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
+  }
+  if (saw_nan) atomicOr(&scal->nan_flag, 1);
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < 2u * kWinBins; i += kWinThreads) {  // dense flush: contiguous words
+    const uint32_t c = lh[i];
+    if (c) atomicAdd(&whist[i], c);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4) st->list_cnt[threadIdx.x][0] = 0;  // the previous evaluation has read them
+}
+
+// ---- C ------------------------------------------------------------------------------
+// largest t in [lo, hi] with pred(t), for a predicate that holds on a prefix of the range
+// (lo - 1 if nowhere); the 64 lanes of a wave probe 64 positions per round
+template <typename F>
+__device__ __forceinline__ int wave_last_true(int lo, int hi, F &&pred) {
+  const int lane = threadIdx.x & 63;
+  int best = lo - 1;
+  while (lo <= hi) {
+    const int step = (hi - lo + 64) >> 6;
+    const int t = lo + lane * step;
+    const bool ok = t <= hi && pred(t);
+    const int cnt = __popcll(__ballot(ok));
+    if (cnt == 0) break;
+    best = lo + (cnt - 1) * step;
+    const int nhi = best + step - 1 < hi ? best + step - 1 : hi;
+    lo = best + 1;
+    hi = nhi;
+  }
+  return best;
+}
+
+struct WinRanges {  // bins, per dimension
+  int mlo, mhi;     // median candidates: [mlo, mhi]
+  int a0, b1;       // ring: [a0, b1] without [i0, i1]
+  int i0, i1;
+};
+
+// The bracket.  The median m lies in the bins [jlo, jhi] of the two middle ranks, i.e. in
+// [mL, mU] = [lower edge of jlo, upper edge of jhi].  For a radius d
+//   inside(d)   = bins entirely within [mU - d, mL + d]: every point has |r - m| <= d;
+//   possible(d) = bins meeting [mL - d, mU + d]:        every OTHER point has |r - m| > d.
+// With k the wanted ranks of the distances (0-based) and d_t = t fine bins,
+// t1 = max{t: #possible(d_t) <= klo} and t2 = min{t: #inside(d_t) > khi}: at most klo distances
+// are <= d_t1, so both order statistics are > d_t1, and more than khi distances are <= d_t2, so
+// they are <= d_t2.  With a margin q of a quarter fine bin, I = inside(d_t1 - 2q) holds only
+// points closer than the order statistics by more than q, and every point outside
+// possible(d_t2 + 2q) is farther by more than q; ranking the ring possible(d_t2 + 2q) \ I by
+// exact distance behind |I| therefore yields the exact order statistics (fl(|r - m|) is
+// monotone in the true distance, and q is ~2^38 times the rounding error of the bin function
+// and of the edges -- the host refuses windows whose fine bins are narrower than 1e-10 of the
+// coordinates -- so neither rounding nor the evaluation of edges can create ties or misplace
+// a bin; the bins probed are additionally shrunk / widened by q).
+__device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, const WinDim &w, WinRanges &R,
+                                               unsigned &med_base, unsigned &med_cnt, unsigned &inner,
+                                               unsigned &ring_cnt, double (&range)[4]) {
+  auto C = [&](int j) -> unsigned { return j >= kWinBins ? n : c[j]; };  // points in bins < j
+  const unsigned klo = (n - 1) / 2, khi = n / 2;                          // src/stats.rs:18-27
+  const int jlo = wave_last_true(0, kWinBins - 1, [&](int j) { return c[j] <= klo; });
+  const int jhi = wave_last_true(0, kWinBins - 1, [&](int j) { return c[j] <= khi; });
+  if (jlo < 1 || jhi > kWinBins - 2) return false;  // a middle rank outside the windows
+  const double mL = wedge(jlo, w), mU = wedge(jhi + 1, w);
+  const double fine = 1. / w.sf, q = 0.25 * fine;
+  auto inside_bins = [&](double d, int &s, int &e) {  // [s, e): regular bins only
+    s = (int)wbin(mU - d + q, w) + 1;
+    e = (int)wbin(mL + d - q, w);
+  };
+  auto possible_bins = [&](double d, int &s, int &e) {  // [s, e): may include the catch-all bins
+    s = (int)wbin(mL - d - q, w);
+    e = (int)wbin(mU + d + q, w) + 1;
+  };
+  auto n_possible = [&](int t) -> unsigned {
+    int s, e;
+    possible_bins((double)t * fine, s, e);
+    return C(e) - C(s);
+  };
+  auto n_inside = [&](int t) -> unsigned {
+    int s, e;
+    inside_bins((double)t * fine, s, e);
+    return s < e ? C(e) - C(s) : 0u;
+  };
+  const int tmax = (int)((w.x[5] - w.x[0]) * w.sf) + 2;
+  const int t1 = wave_last_true(0, tmax, [&](int t) { return n_possible(t) <= klo; });
+  const int t2 = wave_last_true(0, tmax, [&](int t) { return n_inside(t) <= khi; }) + 1;
+  if (t1 < 0 || t2 > tmax) return false;
+  int is, ie, ps, pe;
+  inside_bins((double)t1 * fine - 2. * q, is, ie);
+  possible_bins((double)t2 * fine + 2. * q, ps, pe);
+  if (ps < 1 || pe > kWinBins - 1) return false;  // the ring reaches a catch-all bin
+  R.mlo = jlo;
+  R.mhi = jhi;
+  R.a0 = ps;
+  R.b1 = pe - 1;
+  if (is < ie) {
+    R.i0 = is;
+    R.i1 = ie - 1;
+    inner = C(ie) - C(is);
+  } else {  // nothing is surely inside
+    R.i0 = 1;
+    R.i1 = 0;
+    inner = 0u;
+  }
+  med_base = c[jlo];
+  med_cnt = C(jhi + 1) - c[jlo];
+  ring_cnt = (C(pe) - C(ps)) - inner;
+  range[0] = mL;  // every median candidate lies in [mL, mU]
+  range[1] = mU;
+  range[2] = t1 > 0 ? (double)(t1 - 1) * fine : 0.;  // the MAD lies in (t1, t2] fine bins
+  range[3] = (double)(t2 + 1) * fine;
+  return med_cnt <= (unsigned)kWinCapMed && ring_cnt <= (unsigned)kWinCapRing;
+}
+
+__global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__restrict__ rx,
+                                                             const double *__restrict__ ry, unsigned n,
+                                                             WinParams P, const uint32_t *__restrict__ whist,
+                                                             WinState *st, double *wmed, double *wring) {
+  __shared__ uint32_t cum[2 * kWinBins];  // points in lower bins
+  __shared__ unsigned s_wtot[2][16];
+  __shared__ int s_rng[2][8];
+  __shared__ double s_med[2][kWinBlkMed], s_ring[2][kWinBlkRing];
+  __shared__ unsigned s_cnt[4];
+  static_assert(kWinBins == 2 * kWinThreads, "two bins per thread");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 4) s_cnt[tid] = 0;
+  unsigned first[2], inc[2], tot[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const uint2 v = reinterpret_cast<const uint2 *>(whist + d * kWinBins)[tid];
+    first[d] = v.x;
+    tot[d] = v.x + v.y;
+    unsigned s = tot[d];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned t = __shfl_up(s, off);
+      if (lane >= off) s += t;
+    }
+    inc[d] = s;
+    if (lane == 63) s_wtot[d][wave] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    unsigned wbase = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) wbase += (w < wave) ? s_wtot[d][w] : 0u;
+    const unsigned base = wbase + inc[d] - tot[d];
+    cum[d * kWinBins + 2 * tid] = base;
+    cum[d * kWinBins + 2 * tid + 1] = base + first[d];
+  }
+  __syncthreads();
+  if (wave < 2) {  // one wave per dimension
+    const int d = wave;
+    WinRanges R = {};
+    unsigned med_base = 0, med_cnt = 0, inner = 0, ring_cnt = 0;
+    double range[4] = {0., 0., 0., 0.};
+    const bool ok = resolve_window(cum + d * kWinBins, n, P.d[d], R, med_base, med_cnt, inner, ring_cnt, range);
+    if (lane == 0) {
+      s_rng[d][0] = R.mlo;
+      s_rng[d][1] = R.mhi;
+      s_rng[d][2] = R.a0;
+      s_rng[d][3] = R.b1;
+      s_rng[d][4] = R.i0;
+      s_rng[d][5] = R.i1;
+      s_rng[d][6] = ok ? 0 : 1;
+      if (blockIdx.x == 0) {
+        st->med_base[d] = med_base;
+        st->med_cnt[d] = med_cnt;
+        st->ring_inner[d] = inner;
+        st->ring_cnt[d] = ring_cnt;
+        st->med_lo[d] = range[0];
+        st->med_hi[d] = range[1];
+        st->ring_lo[d] = range[2];
+        st->ring_hi[d] = range[3];
+      }
+    }
+  }
+  __syncthreads();
+  const bool fail = (s_rng[0][6] | s_rng[1][6]) != 0;
+  if (blockIdx.x == 0 && tid == 0) st->fail = fail ? 1u : 0u;
+  if (fail) return;
+  unsigned mlo[2], mhi[2], a0[2], b1[2], i0[2], i1[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    mlo[d] = (unsigned)s_rng[d][0];
+    mhi[d] = (unsigned)s_rng[d][1];
+    a0[d] = (unsigned)s_rng[d][2];
+    b1[d] = (unsigned)s_rng[d][3];
+    i0[d] = (unsigned)s_rng[d][4];
+    i1[d] = (unsigned)s_rng[d][5];
+  }
+  const unsigned G = gridDim.x * kWinThreads;
+  for (unsigned base = blockIdx.x * kWinThreads + tid; base < n; base += G * kWinBatch) {
+    double v[2][kWinBatch];
+#pragma unroll
+    for (int u = 0; u < kWinBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i < n) {
+        v[0][u] = rx[i];
+        v[1][u] = ry[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kWinBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i >= n) continue;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const double r = v[d][u];
+        const unsigned j = wbin(r, P.d[d]);
+        if (j >= mlo[d] && j <= mhi[d]) {
+          const unsigned pos = atomicAdd(&s_cnt[d], 1u);
+          if (pos < (unsigned)kWinBlkMed) s_med[d][pos] = r;
+        }
+        if (j >= a0[d] && j <= b1[d] && !(j >= i0[d] && j <= i1[d])) {
+          const unsigned pos = atomicAdd(&s_cnt[2 + d], 1u);
+          if (pos < (unsigned)kWinBlkRing) s_ring[d][pos] = r;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // one reservation per workgroup and list (the totals are known in advance, so the dense
+  // lists cannot overflow; a workgroup that ran out of staging slots leaves the total short,
+  // which A notices)
+  __shared__ unsigned s_base[4];
+  if (tid < 4) {
+    const unsigned cap = tid < 2 ? kWinBlkMed : kWinBlkRing;
+    const unsigned c = s_cnt[tid] < cap ? s_cnt[tid] : cap;
+    s_base[tid] = c ? atomicAdd(&st->list_cnt[tid][0], c) : 0u;
+  }
+  __syncthreads();
+  if (tid < 2 * kWinBlkMed) {
+    const int d = tid / kWinBlkMed, e = tid % kWinBlkMed;
+    const unsigned pos = s_base[d] + e;
+    if ((unsigned)e < s_cnt[d] && pos < (unsigned)kWinCapMed) wmed[(size_t)d * kWinCapMed + pos] = s_med[d][e];
+  } else if (tid < 2 * kWinBlkMed + 2 * kWinBlkRing) {
+    const int q = tid - 2 * kWinBlkMed, d = q / kWinBlkRing, e = q % kWinBlkRing;
+    const unsigned pos = s_base[2 + d] + e;
+    if ((unsigned)e < s_cnt[2 + d] && pos < (unsigned)kWinCapRing) wring[(size_t)d * kWinCapRing + pos] = s_ring[d][e];
+  }
+}
+
+// ---- A ------------------------------------------------------------------------------
+// exclusive prefix of v over the 512 threads of the workgroup; *total = the sum
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *total) {
+  __shared__ unsigned s_w[kReduceThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned s = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned t = __shfl_up(s, off);
+    if (lane >= off) s += t;
+  }
+  if (lane == 63) s_w[wave] = s;
+  __syncthreads();
+  unsigned before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kReduceThreads / 64; ++w) {
+    const unsigned x = s_w[w];
+    all += x;
+    before += (w < wave) ? x : 0u;
+  }
+  __syncthreads();
+  *total = all;
+  return before + s - v;
+}
+
+// Two exact selections at once (x and y), by the whole workgroup, on candidates that stay in
+// registers: thread t holds candidates t, t + 512, ... of the dense list of dimension d, cnt[d]
+// in all.  Wanted: the keys of ranks rlo[d] <= rhi[d] <= rlo[d] + 1 among them.  Linear sub-bins
+// over [lo[d], hi[d]] (monotone in the value; values outside clamp to the end bins) locate the
+// few keys around the ranks; those go to LDS and are ranked by counting on their
+// order-preserving keys.  fail (uniform): a rank outside the list, or more than kSmallCap keys
+// in the wanted sub-bins.
+template <int NV>
+__device__ __forceinline__ void select_pair(const double (&v)[2][NV], const unsigned (&cnt)[2],
+                                            const double (&lo)[2], const double (&hi)[2],
+                                            const long long (&rlo)[2], const long long (&rhi)[2],
+                                            unsigned long long (&out)[2][2], bool &fail) {
+  static_assert(kSubBins == 2 * kReduceThreads && kSmallCap * 2 == kReduceThreads, "geometry");
+  __shared__ unsigned s_hist[2][kSubBins];
+  __shared__ unsigned long long s_small[2][kSmallCap];
+  __shared__ unsigned s_nsmall[2], s_sb[2][2], s_below[2];
+  __shared__ unsigned long long s_out[2][2];
+  const unsigned tid = threadIdx.x;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) out[d][0] = out[d][1] = 0;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+    if (rlo[d] < 0 || rhi[d] >= (long long)cnt[d] || rhi[d] < rlo[d] || cnt[d] > 0xffffu) fail = true;
+  if (fail) return;  // uniform
+  for (unsigned i = tid; i < 2u * kSubBins; i += kReduceThreads) (&s_hist[0][0])[i] = 0;
+  if (tid < 2) {
+    s_nsmall[tid] = 0;
+    s_sb[tid][0] = s_sb[tid][1] = 0;
+    s_below[tid] = 0;
+    s_out[tid][0] = s_out[tid][1] = 0;
+  }
+  __syncthreads();
+  double scale[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) scale[d] = hi[d] > lo[d] ? (double)(kSubBins - 1) / (hi[d] - lo[d]) : 0.;
+  auto sub = [&](int d, double x) -> unsigned {
+    const double t = (x - lo[d]) * scale[d];  // monotone in x
+    const unsigned sb = t > 0. ? (unsigned)t : 0u;
+    return sb < (unsigned)kSubBins ? sb : (unsigned)(kSubBins - 1);
+  };
+  unsigned sbv[2][NV];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      sbv[d][u] = sub(d, v[d][u]);
+      if (tid + u * kReduceThreads < cnt[d]) atomicAdd(&s_hist[d][sbv[d][u]], 1u);
+    }
+  __syncthreads();
+  // one scan for both dimensions: 16 bits each (counts <= 65535, checked above)
+  const unsigned c0 = s_hist[0][2 * tid] | (s_hist[1][2 * tid] << 16);
+  const unsigned c1 = s_hist[0][2 * tid + 1] | (s_hist[1][2 * tid + 1] << 16);
+  unsigned total;
+  const unsigned e0 = block_excl_scan(c0 + c1, &total), e1 = e0 + c0;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int sh = 16 * d;
+    const unsigned E0 = (e0 >> sh) & 0xffffu, C0 = (c0 >> sh) & 0xffffu;
+    const unsigned E1 = (e1 >> sh) & 0xffffu, C1 = (c1 >> sh) & 0xffffu;
+    const unsigned rl = (unsigned)rlo[d], rh = (unsigned)rhi[d];
+    if (E0 <= rl && rl < E0 + C0) {
+      s_sb[d][0] = 2 * tid;
+      s_below[d] = E0;
+    }
+    if (E1 <= rl && rl < E1 + C1) {
+      s_sb[d][0] = 2 * tid + 1;
+      s_below[d] = E1;
+    }
+    if (E0 <= rh && rh < E0 + C0) s_sb[d][1] = 2 * tid;
+    if (E1 <= rh && rh < E1 + C1) s_sb[d][1] = 2 * tid + 1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const unsigned sb_lo = s_sb[d][0], sb_hi = s_sb[d][1];
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+      if (tid + u * kReduceThreads < cnt[d] && sbv[d][u] >= sb_lo && sbv[d][u] <= sb_hi) {
+        const unsigned pos = atomicAdd(&s_nsmall[d], 1u);
+        if (pos < (unsigned)kSmallCap) s_small[d][pos] = f2k(v[d][u]);
+      }
+  }
+  __syncthreads();
+  if (s_nsmall[0] > (unsigned)kSmallCap || s_nsmall[1] > (unsigned)kSmallCap) {
+    fail = true;  // uniform
+    return;
+  }
+  {
+    const int d = tid / kSmallCap;
+    const unsigned i = tid % kSmallCap, ns = s_nsmall[d];
+    if (i < ns) {
+      const unsigned long long ki = s_small[d][i];
+      unsigned less = s_below[d], eq = 0;
+      for (unsigned j = 0; j < ns; ++j) {
+        const unsigned long long kj = s_small[d][j];
+        less += kj < ki;
+        eq += kj == ki;
+      }
+      const unsigned rl = (unsigned)rlo[d], rh = (unsigned)rhi[d];
+      if (less <= rl && rl < less + eq) s_out[d][0] = ki;
+      if (less <= rh && rh < less + eq) s_out[d][1] = ki;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    out[d][0] = s_out[d][0];
+    out[d][1] = s_out[d][1];
+  }
+  __syncthreads();  // the next call reuses the LDS
+}
+
+__device__ __forceinline__ double middle_of(unsigned n, unsigned long long klo, unsigned long long khi) {
+  const double lo = k2f(klo), hi = k2f(khi);
+  return (n & 1) ? lo : (lo + hi) / 2.;  // src/stats.rs:18-27
+}
+
+__global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
+    const double2 *__restrict__ a, const double *__restrict__ rx, const double *__restrict__ ry, unsigned n, Pose T,
+    const WinState *__restrict__ st, const double *__restrict__ wmed, const double *__restrict__ wring,
+    GnScalars *scal, double *partials, uint32_t *whist, SelCtl *ctl, GnResult *res, unsigned seq) {
+  constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
+  static_assert(kWinCapMed % kReduceThreads == 0 && kWinCapRing % kReduceThreads == 0, "candidates per thread");
+  const unsigned tid = threadIdx.x;
+#ifdef ICP_WIN_DEBUG
+  long long stamp[8];
+  int ns_ = 0;
+#define STAMP() stamp[ns_++] = wall_clock64()
+#else
+#define STAMP()
+#endif
+  STAMP();
+  // every global load of the prologue is issued before the first use: one round trip
+  double vm[2][PM], vr[2][PR];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+#pragma unroll
+    for (int u = 0; u < PM; ++u) vm[d][u] = wmed[(size_t)d * kWinCapMed + tid + u * kReduceThreads];
+#pragma unroll
+    for (int u = 0; u < PR; ++u) vr[d][u] = wring[(size_t)d * kWinCapRing + tid + u * kReduceThreads];
+  }
+  const unsigned got[4] = {st->list_cnt[0][0], st->list_cnt[1][0], st->list_cnt[2][0], st->list_cnt[3][0]};
+  const unsigned em[2] = {st->med_cnt[0], st->med_cnt[1]}, er[2] = {st->ring_cnt[0], st->ring_cnt[1]};
+  const unsigned mbase[2] = {st->med_base[0], st->med_base[1]}, inner[2] = {st->ring_inner[0], st->ring_inner[1]};
+  const double m_lo[2] = {st->med_lo[0], st->med_lo[1]}, m_hi[2] = {st->med_hi[0], st->med_hi[1]};
+  const double r_lo[2] = {st->ring_lo[0], st->ring_lo[1]}, r_hi[2] = {st->ring_hi[0], st->ring_hi[1]};
+  // a workgroup of C that ran out of staging slots leaves a list short
+  bool fail = st->fail != 0 || got[0] != em[0] || got[1] != em[1] || got[2] != er[0] || got[3] != er[1];
+  STAMP();
+  const unsigned klo = (n - 1) / 2, khi = n / 2;
+  double med[2] = {0., 0.}, sig[2] = {0., 0.};
+  if (!fail) {
+    unsigned long long key[2][2];
+    const long long mlo[2] = {(long long)klo - mbase[0], (long long)klo - mbase[1]};
+    const long long mhi[2] = {(long long)khi - mbase[0], (long long)khi - mbase[1]};
+    select_pair<PM>(vm, em, m_lo, m_hi, mlo, mhi, key, fail);
+    STAMP();
+    if (!fail) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        med[d] = middle_of(n, key[d][0], key[d][1]);
+#pragma unroll
+        for (int u = 0; u < PR; ++u) vr[d][u] = fabs(vr[d][u] - med[d]);  // src/stats.rs:35
+      }
+      const long long dlo[2] = {(long long)klo - inner[0], (long long)klo - inner[1]};
+      const long long dhi[2] = {(long long)khi - inner[0], (long long)khi - inner[1]};
+      select_pair<PR>(vr, er, r_lo, r_hi, dlo, dhi, key, fail);
+      STAMP();
+      if (!fail) {
+        sig[0] = ICP_PPF34 * middle_of(n, key[0][0], key[0][1]);  // src/stats.rs:42-46
+        sig[1] = ICP_PPF34 * middle_of(n, key[1][0], key[1][1]);
+      }
+    }
+  }
+  double acc[kNAcc];
+#pragma unroll
+  for (int k = 0; k < kNAcc; ++k) acc[k] = 0.;
+  if (!fail) accumulate_points(a, rx, ry, n, T, sig, acc);
+  STAMP();
+  block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
+  // the histograms of the next evaluation start from zero (nobody reads them in this launch)
+  const unsigned G = gridDim.x * kReduceThreads;
+  for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x; i < 2u * kWinBins; i += G) whist[i] = 0;
+  STAMP();
+#ifdef ICP_WIN_DEBUG
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && seq % 64 == 50)
+    printf("[A blk %d] loads %lld sel1 %lld sel2 %lld acc %lld red %lld (x10ns)\n", blockIdx.x, stamp[1] - stamp[0],
+           stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4]);
+#endif
+
+  if (!last_block_arrives(&ctl->t[2])) return;
+  publish_result(partials, res, seq, sig, med, scal->nan_flag, fail ? 2 : 0);
+}
+
+// ---- host ---------------------------------------------------------------------------
+bool window_usable(const icp_handle *h, size_t n, WinParams *P) {
+  static const bool off = getenv("ICP_GN_NO_WIN") != nullptr;
+  // half-width of the fine windows in sigmas: the prediction may be off by about that much
+  static const double hw_sigmas = getenv("ICP_WIN_HW") ? atof(getenv("ICP_WIN_HW")) : 0.05;
+  const Workspace &w = h->ws;
+  if (off || !w.win_valid || n < kWinMinN || n > kWinMaxN) return false;
+  double f = hw_sigmas * (w.win_wide ? 4. : 1.);
+  if (n > 1000000) f *= 1e6 / (double)n;  // candidates per fine bin grow with n
+  if (f > 0.2) f = 0.2;                   // the windows must not overlap (MAD = 0.6745 sigma)
+  for (int d = 0; d < 2; ++d) {
+    const double s = w.win_sigma[d], m = w.win_med[d];
+    if (!(s > 0.) || !(s < 1e300) || !(fabs(m) < 1e300)) return false;
+    const double mad = s / ICP_PPF34, hw = f * s;
+    // the bracket's quarter-bin margins must dwarf the rounding of (r - x) * scale
+    if (!(2. * hw / kWinFine > 1e-10 * (fabs(m) + mad + hw))) return false;
+    WinDim &D = P->d[d];
+    D.x[0] = m - mad - hw;
+    D.x[1] = m - mad + hw;
+    D.x[2] = m - hw;
+    D.x[3] = m + hw;
+    D.x[4] = m + mad - hw;
+    D.x[5] = m + mad + hw;
+    if (!(D.x[1] < D.x[2] && D.x[3] < D.x[4])) return false;
+    D.sf = (double)kWinFine / (2. * hw);
+    D.sc = (double)kWinCoarse / (D.x[2] - D.x[1]);
+  }
+  return true;
+}
+
+hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double *d_b, size_t n_, const Pose &T,
+                                  const WinParams &P) {
+  Workspace &w = h->ws;
+  const unsigned n = (unsigned)n_;
+  const unsigned per = kWinThreads * kWinBatch;
+  unsigned hb = (n + per - 1) / per;
+  if (hb > (unsigned)kWinBlocks) hb = kWinBlocks;
+  const double2 *a = (const double2 *)d_a, *b = (const double2 *)d_b;
+  hipStream_t s = h->stream;
+  hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(kWinThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
+                     w.d_wstate, w.d_scal);
+  hipLaunchKernelGGL(k_win_compact, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
+                     (const double *)w.d_ry, n, P, (const uint32_t *)w.d_whist, w.d_wstate, w.d_wmed,
+                     w.d_wring);
+  int blocks, threads;
+  reduce_geometry(n_, &blocks, &threads);
+  hipLaunchKernelGGL(k_win_accumulate, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
+                     (const double *)w.d_ry, n, T, (const WinState *)w.d_wstate,
+                     (const double *)w.d_wmed, (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist,
+                     w.d_ctl, w.h_res, ++w.seq);
+  return hipGetLastError();
+}
+
+}  // namespace icp
