@@ -139,8 +139,9 @@ struct Workspace {
 struct GridParams {
   double lo[3];
   double hi[3];
-  double h, inv_h;
+  double h[3], inv_h[3];  // cell size per axis (x may be finer: rows are contiguous along x)
   int n[3];
+  int fx;        // x cells per y/z cell size: the cold search grows its block by fx cells along x per ring
   double scale;  // coordinate magnitude used for the rounding margin of the pruning bounds
 };
 

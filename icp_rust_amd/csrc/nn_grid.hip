@@ -60,7 +60,7 @@ __global__ void k_grid_count(const double *__restrict__ dst, unsigned m, int dim
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   int c[3] = {0, 0, 0};
-  for (int d = 0; d < dim; ++d) c[d] = cell_coord(dst[(size_t)i * dim + d], g.lo[d], g.inv_h, g.n[d]);
+  for (int d = 0; d < dim; ++d) c[d] = cell_coord(dst[(size_t)i * dim + d], g.lo[d], g.inv_h[d], g.n[d]);
   const uint32_t cell = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0] + c[0];
   cell_of[i] = cell;
   atomicAdd(&cnt[cell], 1u);
@@ -193,18 +193,24 @@ hipError_t build_grid(icp_handle *h) {
   static const double occ = getenv("ICP_GRID_OCC") ? atof(getenv("ICP_GRID_OCC")) : 2.;
   double hh = k > 0 ? pow(occ * vol / (double)m, 1. / k) : 1.;
   if (!(hh > 0.) || !std::isfinite(hh)) hh = 1.;
+  // ICP_GRID_FX: cells are that many times finer along x.  A row of cells along x is one
+  // contiguous run of records, so finer x cells clip the runs tighter around [qx - r, qx + r]
+  // without adding rows (dense surfaces put ~10 targets into a cubic cell of the average
+  // occupancy; the search radius there is a fraction of the cell).
+  static const double fx = getenv("ICP_GRID_FX") ? fmax(1., atof(getenv("ICP_GRID_FX"))) : 4.;
   for (;;) {
     double cells = 1.;
     for (int d = 0; d < 3; ++d) {
-      const double nd = (d < h->dim && ext[d] > 1e-9 * emax) ? floor(ext[d] / hh) + 1. : 1.;
-      g.n[d] = (int)fmin(nd, 4096.);
+      g.h[d] = d == 0 ? hh / fx : hh;
+      const double nd = (d < h->dim && ext[d] > 1e-9 * emax) ? floor(ext[d] / g.h[d]) + 1. : 1.;
+      g.n[d] = (int)fmin(nd, d == 0 ? 16384. : 4096.);
       cells *= g.n[d];
     }
     if (cells <= 16777216.) break;
     hh *= 1.26;
   }
-  g.h = hh;
-  g.inv_h = 1. / hh;
+  for (int d = 0; d < 3; ++d) g.inv_h[d] = 1. / g.h[d];
+  g.fx = (int)fmin(fmax(floor(fx + 0.5), 1.), 64.);
   g.scale = scale + hh;
   G.p = g;
   G.ncell = (uint32_t)g.n[0] * g.n[1] * g.n[2];
@@ -362,16 +368,19 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   // distance from q to the slab of cells [i0, i1] on axis d (0 inside); outermost cells
   // extend to infinity (targets are clamped into them)
   auto slab = [&](int d, int i0, int i1) -> double {
-    const double lo_b = (i0 <= 0) ? -__builtin_huge_val() : (g.lo[d] + i0 * g.h) - mg[d];
-    const double hi_b = (i1 >= g.n[d] - 1) ? __builtin_huge_val() : (g.lo[d] + (i1 + 1) * g.h) + mg[d];
+    const double lo_b = (i0 <= 0) ? -__builtin_huge_val() : (g.lo[d] + i0 * g.h[d]) - mg[d];
+    const double hi_b = (i1 >= g.n[d] - 1) ? __builtin_huge_val() : (g.lo[d] + (i1 + 1) * g.h[d]) + mg[d];
     const double v = fmax(lo_b - q[d], q[d] - hi_b);
     return v > 0. ? v : 0.;
   };
 
-  // Walk the rows (iy, iz) of the cell box [lo, hi] as ONE flat loop per lane: a lane refills
-  // from its next unpruned row when its current run is exhausted, so a wave's trip count is the
-  // largest per-lane total, not the sum of per-row maxima.  Rows whose box is strictly farther
-  // than the current best cannot win or tie and are skipped.
+  // Walk the rows (iy, iz) of the cell box [lo, hi] in groups of up to four unpruned rows: the
+  // bounds of a group are fetched together (one round trip), and its runs are then streamed
+  // as ONE flattened sequence, kBatch records in flight -- a typical warm box (2-4 rows of 4-6
+  // records) costs one bounds round trip and two record round trips instead of two per row.
+  // Rows whose box is strictly farther than the current best cannot win or tie and are skipped
+  // (in the warm search `best` starts at the previous match's distance, so the test is already
+  // tight when the rows are collected).
   auto walk_box = [&](const int lo[3], const int hi[3]) {
     const double dx = slab(0, lo[0], hi[0]);
     const double dx2 = dx * dx;
@@ -381,39 +390,64 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
       const double dz = slab(2, iz, iz);
       dz2 = dz * dz;
     }
-    uint32_t p = 0, e = 0;
     for (;;) {
-#ifdef ICP_NN_STATS
-      if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) st[4] += 1;
-#endif
-      if (p >= e) {
-        bool found = false;
-        while (iz <= hi[2]) {
-          if (iy > hi[1]) {
-            iy = lo[1];
-            ++iz;
-            if (DIM == 3 && iz <= hi[2]) {
-              const double dz = slab(2, iz, iz);
-              dz2 = dz * dz;
-            }
-            continue;
+      uint32_t rb0 = 0, rb1 = 0, rb2 = 0, rb3 = 0;
+      int nr = 0;
+      while (nr < 4 && iz <= hi[2]) {
+        if (iy > hi[1]) {
+          iy = lo[1];
+          ++iz;
+          if (DIM == 3 && iz <= hi[2]) {
+            const double dz = slab(2, iz, iz);
+            dz2 = dz * dz;
           }
-          const int cy = iy++;
-          const double dy = slab(1, cy, cy);
-          if (dx2 + (dy * dy + dz2) > best) continue;
-          const uint32_t row = ((uint32_t)iz * g.n[1] + cy) * g.n[0];
-          NN_STAT(1, 1);
-          p = start[row + lo[0]];
-          e = start[row + hi[0] + 1];
-          if (p < e) {
-            found = true;
-            break;
-          }
+          continue;
         }
-        if (!found) break;
+        const int cy = iy++;
+        const double dy = slab(1, cy, cy);
+        if (dx2 + (dy * dy + dz2) > best) continue;
+        const uint32_t rb = ((uint32_t)iz * g.n[1] + cy) * g.n[0];
+        if (nr == 0) rb0 = rb;
+        else if (nr == 1) rb1 = rb;
+        else if (nr == 2) rb2 = rb;
+        else rb3 = rb;
+        ++nr;
       }
-      batch(p, e);
-      p += kBatch;
+      if (nr == 0) break;
+      NN_STAT(1, nr);
+      if (nr < 2) rb1 = rb0;  // unused slots repeat row 0 (a cached address costs next to nothing)
+      if (nr < 3) rb2 = rb0;
+      if (nr < 4) rb3 = rb0;
+      const uint32_t s0 = start[rb0 + lo[0]], e0 = start[rb0 + hi[0] + 1];
+      const uint32_t s1 = start[rb1 + lo[0]], e1 = start[rb1 + hi[0] + 1];
+      const uint32_t s2 = start[rb2 + lo[0]], e2 = start[rb2 + hi[0] + 1];
+      const uint32_t s3 = start[rb3 + lo[0]], e3 = start[rb3 + hi[0] + 1];
+      const uint32_t o1 = e0 - s0;
+      const uint32_t o2 = o1 + (nr > 1 ? e1 - s1 : 0u);
+      const uint32_t o3 = o2 + (nr > 2 ? e2 - s2 : 0u);
+      const uint32_t R = o3 + (nr > 3 ? e3 - s3 : 0u);
+      for (uint32_t base = 0; base < R; base += kBatch) {
+#ifdef ICP_NN_STATS
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) st[4] += 1;
+#endif
+        NN_STAT(2, 1);
+        GridPoint t[kBatch];
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; ++u) {
+          const uint32_t j = min(base + u, R - 1);  // the tail re-reads the last record
+          uint32_t addr = s0 + j;
+          if (j >= o1) addr = s1 + (j - o1);
+          if (j >= o2) addr = s2 + (j - o2);
+          if (j >= o3) addr = s3 + (j - o3);
+          t[u] = pts[addr];
+        }
+        float sc[kBatch];
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; ++u) sc[u] = screen(t[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; ++u)
+          if (!(sc[u] > thr32)) consider(t[u].idx);
+      }
     }
   };
 
@@ -434,8 +468,8 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
         int lo_c[3] = {0, 0, 0}, hi_c[3] = {0, 0, 0};
 #pragma unroll
         for (int d = 0; d < DIM; ++d) {
-          lo_c[d] = cell_coord(q[d] - rad - mg[d], g.lo[d], g.inv_h, g.n[d]);
-          hi_c[d] = cell_coord(q[d] + rad + mg[d], g.lo[d], g.inv_h, g.n[d]);
+          lo_c[d] = cell_coord(q[d] - rad - mg[d], g.lo[d], g.inv_h[d], g.n[d]);
+          hi_c[d] = cell_coord(q[d] + rad + mg[d], g.lo[d], g.inv_h[d], g.n[d]);
         }
         walk_box(lo_c, hi_c);
         done = true;
@@ -446,19 +480,20 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   if (!done) {
     int c[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) c[d] = (d < DIM) ? cell_coord(q[d], g.lo[d], g.inv_h, g.n[d]) : 0;
+    for (int d = 0; d < 3; ++d) c[d] = (d < DIM) ? cell_coord(q[d], g.lo[d], g.inv_h[d], g.n[d]) : 0;
     // Rings 0 and 1 in one go: the block [c-1, c+1]^DIM, centre row first so that `best` is
     // tight early.
     {
-      const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, g.n[0] - 1);
+      const int x0 = max(c[0] - g.fx, 0), x1 = min(c[0] + g.fx, g.n[0] - 1);
       const uint32_t row = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0];
       const uint32_t s = start[row + x0], e = start[row + x1 + 1];
       for (uint32_t p = s; p < e; p += kBatch) batch(p, e);
       int lo_c[3], hi_c[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        lo_c[d] = max(c[d] - 1, 0);
-        hi_c[d] = min(c[d] + 1, g.n[d] - 1);
+        const int w = d == 0 ? g.fx : 1;
+        lo_c[d] = max(c[d] - w, 0);
+        hi_c[d] = min(c[d] + w, g.n[d] - 1);
       }
       walk_box(lo_c, hi_c);  // re-reads the centre row (cached); the other rows are pruned by `best`
     }
@@ -481,10 +516,14 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
             for (int run = 0; run < nruns; ++run) {
               int x0, x1;
               if (edge) {
-                x0 = c[0] - r;
-                x1 = c[0] + r;
+                x0 = c[0] - r * g.fx;
+                x1 = c[0] + r * g.fx;
+              } else if (run == 0) {
+                x0 = c[0] - r * g.fx;
+                x1 = c[0] - (r - 1) * g.fx - 1;
               } else {
-                x0 = x1 = (run == 0) ? c[0] - r : c[0] + r;
+                x0 = c[0] + (r - 1) * g.fx + 1;
+                x1 = c[0] + r * g.fx;
               }
               if (x1 < 0 || x0 > g.n[0] - 1) continue;
               x0 = max(x0, 0);
@@ -498,12 +537,13 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
           }
         }
       }
-      // can anything outside the visited block [c-r, c+r] still win or tie?
+      // can anything outside the visited block [c-r, c+r] (x: r * fx cells) still win or tie?
       double L = __builtin_huge_val();
 #pragma unroll
       for (int d = 0; d < DIM; ++d) {
-        if (c[d] - r > 0) L = fmin(L, (q[d] - (g.lo[d] + (c[d] - r) * g.h)) - mg[d]);
-        if (c[d] + r < g.n[d] - 1) L = fmin(L, ((g.lo[d] + (c[d] + r + 1) * g.h) - q[d]) - mg[d]);
+        const int w = d == 0 ? r * g.fx : r;
+        if (c[d] - w > 0) L = fmin(L, (q[d] - (g.lo[d] + (c[d] - w) * g.h[d])) - mg[d]);
+        if (c[d] + w < g.n[d] - 1) L = fmin(L, ((g.lo[d] + (c[d] + w + 1) * g.h[d]) - q[d]) - mg[d]);
       }
       if (L == __builtin_huge_val()) break;  // the whole grid has been visited
       if (L > 0. && best < L * L) break;     // every unvisited target is strictly farther
@@ -557,7 +597,7 @@ __global__ void k_query_count(const double *__restrict__ src, unsigned n, int di
   q[0] = nx;
   q[1] = ny;
   int c[3] = {0, 0, 0};
-  for (int d = 0; d < dim; ++d) c[d] = cell_coord(q[d], g.lo[d], g.inv_h, g.n[d]);
+  for (int d = 0; d < dim; ++d) c[d] = cell_coord(q[d], g.lo[d], g.inv_h[d], g.n[d]);
   const uint32_t cell = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0] + c[0];
   cell_of[i] = cell;
   atomicAdd(&cnt[cell], 1u);
