@@ -343,8 +343,9 @@ class _Icp:
         self.synchronize()
         return idx[: qq.shape[0]].cpu().numpy().view(np.uint32)
 
-    def profile_enable(self, on=True):
-        check(lib().icp_profile_enable(self._h, int(on)), "icp_profile_enable")
+    def profile_enable(self, every=1):
+        """Time every `every`-th NN search launch with HIP events (0 / False: off)."""
+        check(lib().icp_profile_enable(self._h, int(every)), "icp_profile_enable")
 
     def profile_read(self):
         """(summed NN-kernel device time in ms, launches) since the last read."""

@@ -293,7 +293,8 @@ extern "C" int icp_synchronize(icp_handle *h) {
 
 extern "C" int icp_profile_enable(icp_handle *h, int enable) {
   if (!h) return ICP_BAD_ARGUMENT;
-  h->profile = enable != 0;
+  h->profile = enable < 0 ? 0 : enable;
+  h->prof_seen = 0;
   return ICP_OK;
 }
 extern "C" int icp_profile_read(icp_handle *h, double *ms, uint64_t *launches) {
@@ -379,6 +380,10 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   static const bool force_radix = getenv("ICP_GN_RADIX") != nullptr;
   Workspace &w = h->ws;
   bool done = false, has_median = false;
+  if (w.gn_dirty) {  // first use, or the radix path / a NaN left its state behind (the short pipelines clean up after themselves)
+    HIP_TRY(launch_sel_init(h, n));
+    w.gn_dirty = false;
+  }
   if (!force_radix) {
     WinParams P;
     if (window_usable(h, n, &P)) {  // three launches around the previous evaluation's median and sigma
@@ -409,6 +414,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
     HIP_TRY(launch_sel_init(h, n));
     HIP_TRY(launch_weighted_gn(h, d_a, d_b, n, T));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    w.gn_dirty = true;
   }
   const GnResult &r = *w.h_res;
   w.win_valid = has_median;
@@ -417,7 +423,10 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
       w.win_med[d] = r.median[d];
       w.win_sigma[d] = r.sigma[d];
     }
-  if (r.nan_flag) return ICP_NAN_INPUT;
+  if (r.nan_flag) {
+    w.gn_dirty = true;
+    return ICP_NAN_INPUT;
+  }
   if (huber_err) *huber_err = r.acc[12];
   return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
 }
@@ -430,7 +439,8 @@ extern "C" int icp_estimate_transform_device(icp_handle *h, const double *d_a, c
   if (input_size_ok(n)) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(ensure_workspace(h, n, false));
-    HIP_TRY(launch_sel_init(h, n));
+    static const bool push = getenv("ICP_GN_PUSH") != nullptr;
+    if (push) h->ws.gn_dirty = true;  // the debugging pipeline expects a fresh search state per call
     double prev_error = DBL_MAX;  // f64::MAX, src/lib.rs:63
     for (int it = 0; it < ICP_INNER_MAX_ITER; ++it) {
       double delta[3], err = 0.;
@@ -543,7 +553,6 @@ extern "C" int icp_weighted_gauss_newton_update(const icp_pose *T, const double 
   if (rc != ICP_OK) return rc;
   if (!input_size_ok(n)) return ICP_NONE;  // src/lib.rs:225-228
   if ((rc = stage_pairs(h, a, b, n)) != ICP_OK) return rc;
-  HIP_TRY(launch_sel_init(h, n));
   return wgn_step(h, h->ws.d_a, h->ws.d_b, n, *T, delta, nullptr);
 }
 
@@ -602,6 +611,7 @@ extern "C" int icp_residual_stddevs(const icp_pose *T, const double *a, const do
   if ((rc = stage_pairs(h, a, b, n)) != ICP_OK) return rc;
   HIP_TRY(launch_sel_init(h, n));
   HIP_TRY(launch_stddevs(h, h->ws.d_a, h->ws.d_b, n, *T));
+  h->ws.gn_dirty = true;
   GnScalars s;
   HIP_TRY(hipMemcpyAsync(&s, h->ws.d_scal, sizeof(s), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));

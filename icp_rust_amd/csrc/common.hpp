@@ -124,6 +124,7 @@ struct Workspace {
   double *d_partials = nullptr; // kReduceMaxBlocks x (kNAcc+1)
   GnResult *h_res = nullptr;    // pinned coherent host memory, written by the last workgroup
   unsigned seq = 0;             // sequence number of the last fast evaluation launched
+  bool gn_dirty = true;         // selection scratch is not in its all-zero rest state: k_sel_init first
   // window path (gn_win.hip)
   uint32_t *d_whist = nullptr;  // 2 x kWinBins, zero between evaluations
   WinState *d_wstate = nullptr;
@@ -192,7 +193,8 @@ struct icp_handle {
   icp::Grid grid;
   icp::QuerySort qsort;
   // live kernel timing (icp_profile_*): event pairs around the NN search kernel
-  bool profile = false;
+  int profile = 0;         // 0: off; k: event pairs around every k-th search launch
+  unsigned prof_seen = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 };
 

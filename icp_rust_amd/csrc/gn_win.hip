@@ -74,8 +74,15 @@ __global__ __launch_bounds__(kWinThreads) void k_win_hist(const double2 *__restr
                                                           unsigned n, WinParams P, uint32_t *whist, WinState *st,
                                                           GnScalars *scal) {
   __shared__ uint32_t lh[2 * kWinBins];
+#ifdef ICP_WIN_DEBUG
+  long long wst[6];
+  wst[0] = wall_clock64();
+#endif
   for (unsigned i = threadIdx.x; i < 2u * kWinBins; i += kWinThreads) lh[i] = 0;
   __syncthreads();
+#ifdef ICP_WIN_DEBUG
+  wst[1] = wall_clock64();
+#endif
   unsigned edge[4] = {0u, 0u, 0u, 0u};  // {below, above} x {x, y}: one word each, kept out of the LDS atomics
   bool saw_nan = false;
   const unsigned G = gridDim.x * kWinThreads;
@@ -116,12 +123,25 @@ __global__ __launch_bounds__(kWinThreads) void k_win_hist(const double2 *__restr
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
   }
   if (saw_nan) atomicOr(&scal->nan_flag, 1);
+#ifdef ICP_WIN_DEBUG
+  wst[2] = wall_clock64();
+#endif
   __syncthreads();
+#ifdef ICP_WIN_DEBUG
+  wst[3] = wall_clock64();
+#endif
   for (unsigned i = threadIdx.x; i < 2u * kWinBins; i += kWinThreads) {  // dense flush: contiguous words
     const uint32_t c = lh[i];
     if (c) atomicAdd(&whist[i], c);
   }
   if (blockIdx.x == 0 && threadIdx.x < 4) st->list_cnt[threadIdx.x][0] = 0;  // the previous evaluation has read them
+#ifdef ICP_WIN_DEBUG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wst[4] = wall_clock64();
+  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && st->med_cnt[0] % 16 == 3)
+    printf("[W blk %d] zero %lld stream %lld barrier %lld flush %lld (x10ns)\n", blockIdx.x, wst[1] - wst[0],
+           wst[2] - wst[1], wst[3] - wst[2], wst[4] - wst[3]);
+#endif
 }
 
 // ---- C ------------------------------------------------------------------------------
@@ -236,6 +256,10 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
   __shared__ unsigned s_cnt[4];
   static_assert(kWinBins == 2 * kWinThreads, "two bins per thread");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef ICP_WIN_DEBUG
+  long long cst[6];
+  cst[0] = wall_clock64();
+#endif
   if (tid < 4) s_cnt[tid] = 0;
   unsigned first[2], inc[2], tot[2];
 #pragma unroll
@@ -263,6 +287,9 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
     cum[d * kWinBins + 2 * tid + 1] = base + first[d];
   }
   __syncthreads();
+#ifdef ICP_WIN_DEBUG
+  cst[1] = wall_clock64();
+#endif
   if (wave < 2) {  // one wave per dimension
     const int d = wave;
     WinRanges R = {};
@@ -290,6 +317,9 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
     }
   }
   __syncthreads();
+#ifdef ICP_WIN_DEBUG
+  cst[2] = wall_clock64();
+#endif
   const bool fail = (s_rng[0][6] | s_rng[1][6]) != 0;
   if (blockIdx.x == 0 && tid == 0) st->fail = fail ? 1u : 0u;
   if (fail) return;
@@ -334,6 +364,9 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
     }
   }
   __syncthreads();
+#ifdef ICP_WIN_DEBUG
+  cst[3] = wall_clock64();
+#endif
   // one reservation per workgroup and list (the totals are known in advance, so the dense
   // lists cannot overflow; a workgroup that ran out of staging slots leaves the total short,
   // which A notices)
@@ -353,6 +386,13 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
     const unsigned pos = s_base[2 + d] + e;
     if ((unsigned)e < s_cnt[2 + d] && pos < (unsigned)kWinCapRing) wring[(size_t)d * kWinCapRing + pos] = s_ring[d][e];
   }
+#ifdef ICP_WIN_DEBUG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  cst[4] = wall_clock64();
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && s_cnt[2] % 16 == 3)
+    printf("[C blk %d] scan %lld resolve %lld stream %lld append %lld (x10ns)\n", blockIdx.x, cst[1] - cst[0],
+           cst[2] - cst[1], cst[3] - cst[2], cst[4] - cst[3]);
+#endif
 }
 
 // ---- A ------------------------------------------------------------------------------

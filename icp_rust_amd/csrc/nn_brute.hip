@@ -415,7 +415,7 @@ hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n_, const 
   }
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (h->profile) {
+  if (h->profile > 0 && (h->prof_seen++ % (unsigned)h->profile) == 0) {
     if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
       (void)hipEventRecord(ev0, h->stream);
   }

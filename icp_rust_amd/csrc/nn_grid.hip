@@ -250,6 +250,7 @@ hipError_t build_grid(icp_handle *h) {
 // [2] record batches, [3] exact evaluations, [4] sum over waves of wave-level loop steps,
 // [5] sum over waves of lifetime in shader cycles, [6] waves, [7] warm queries.
 __device__ unsigned long long g_nn_stats[8];
+__device__ unsigned long long g_nn_hist[2][32];  // [0]: lanes by record chunks, [1]: waves by loop steps
 #define NN_STAT(i, v) (st[i] += (v))
 #else
 #define NN_STAT(i, v) ((void)0)
@@ -391,7 +392,8 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
       dz2 = dz * dz;
     }
     for (;;) {
-      uint32_t rb0 = 0, rb1 = 0, rb2 = 0, rb3 = 0;
+      uint32_t ra0 = 0, ra1 = 0, ra2 = 0, ra3 = 0;  // first / one-past-last cell of each collected row
+      uint32_t rz0 = 0, rz1 = 0, rz2 = 0, rz3 = 0;
       int nr = 0;
       while (nr < 4 && iz <= hi[2]) {
         if (iy > hi[1]) {
@@ -405,28 +407,41 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
         }
         const int cy = iy++;
         const double dy = slab(1, cy, cy);
-        if (dx2 + (dy * dy + dz2) > best) continue;
+        const double dyz = dy * dy + dz2;
+        if (dx2 + dyz > best) continue;
+        // a target of this row that can still win or tie has |x - qx| <= sqrt(best - dy^2 - dz^2):
+        // clip the run to those cells (the box is a cube, the candidates lie in a ball)
+        int xl = lo[0], xh = hi[0];
+        if (best < __builtin_huge_val()) {
+          const double hw = sqrt(best - dyz) * (1. + 1e-9) + mg[0];
+          xl = max(xl, cell_coord(q[0] - hw, g.lo[0], g.inv_h[0], g.n[0]));
+          xh = min(xh, cell_coord(q[0] + hw, g.lo[0], g.inv_h[0], g.n[0]));
+        }
         const uint32_t rb = ((uint32_t)iz * g.n[1] + cy) * g.n[0];
-        if (nr == 0) rb0 = rb;
-        else if (nr == 1) rb1 = rb;
-        else if (nr == 2) rb2 = rb;
-        else rb3 = rb;
+        const uint32_t ra = rb + xl, rz = rb + xh + 1;
+        if (nr == 0) ra0 = ra, rz0 = rz;
+        else if (nr == 1) ra1 = ra, rz1 = rz;
+        else if (nr == 2) ra2 = ra, rz2 = rz;
+        else ra3 = ra, rz3 = rz;
         ++nr;
       }
       if (nr == 0) break;
       NN_STAT(1, nr);
-      if (nr < 2) rb1 = rb0;  // unused slots repeat row 0 (a cached address costs next to nothing)
-      if (nr < 3) rb2 = rb0;
-      if (nr < 4) rb3 = rb0;
-      const uint32_t s0 = start[rb0 + lo[0]], e0 = start[rb0 + hi[0] + 1];
-      const uint32_t s1 = start[rb1 + lo[0]], e1 = start[rb1 + hi[0] + 1];
-      const uint32_t s2 = start[rb2 + lo[0]], e2 = start[rb2 + hi[0] + 1];
-      const uint32_t s3 = start[rb3 + lo[0]], e3 = start[rb3 + hi[0] + 1];
+      if (nr < 2) ra1 = ra0, rz1 = rz0;  // unused slots repeat row 0 (a cached address costs next to nothing)
+      if (nr < 3) ra2 = ra0, rz2 = rz0;
+      if (nr < 4) ra3 = ra0, rz3 = rz0;
+      const uint32_t s0 = start[ra0], e0 = start[rz0];
+      const uint32_t s1 = start[ra1], e1 = start[rz1];
+      const uint32_t s2 = start[ra2], e2 = start[rz2];
+      const uint32_t s3 = start[ra3], e3 = start[rz3];
       const uint32_t o1 = e0 - s0;
       const uint32_t o2 = o1 + (nr > 1 ? e1 - s1 : 0u);
       const uint32_t o3 = o2 + (nr > 2 ? e2 - s2 : 0u);
       const uint32_t R = o3 + (nr > 3 ? e3 - s3 : 0u);
       for (uint32_t base = 0; base < R; base += kBatch) {
+#ifdef ICP_HACK_CAP
+        if (base >= 24) break;
+#endif
 #ifdef ICP_NN_STATS
         if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) st[4] += 1;
 #endif
@@ -556,6 +571,12 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
       if (j != 4) atomicAdd(&g_nn_stats[j], (unsigned long long)st[j]);
     atomicAdd(&g_nn_stats[4], (unsigned long long)st[4]);
     atomicAdd(&g_nn_stats[7], (unsigned long long)st[7]);
+    atomicAdd(&g_nn_hist[0][st[2] < 31 ? st[2] : 31], 1ull);
+    {
+      unsigned mx = st[2];
+      for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+      if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&g_nn_hist[1][mx < 31 ? mx : 31], 1ull);
+    }
     if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) {
       atomicAdd(&g_nn_stats[5], t_end - t_begin);
       atomicAdd(&g_nn_stats[6], 1ull);
@@ -676,7 +697,7 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   const uint32_t *q_perm = sorted ? Q.d_perm : nullptr;
   PrevMatch *q_prev = sorted ? Q.d_prev : nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (h->profile) {
+  if (h->profile > 0 && (h->prof_seen++ % (unsigned)h->profile) == 0) {
     if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
       (void)hipEventRecord(ev0, h->stream);
   }
@@ -699,6 +720,15 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
 }
 
 #ifdef ICP_NN_STATS
+extern "C" int icp_debug_nn_hist(unsigned long long out[64], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_hist), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_nn_hist), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+
 extern "C" int icp_debug_nn_stats(unsigned long long out[8], int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (reset) {

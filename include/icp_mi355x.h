@@ -173,10 +173,11 @@ int icp_estimate_transform_device(icp_handle *h, const double *d_a_xy, const dou
 int icp_nn_search_device(icp_handle *h, const double *d_q, size_t n, uint32_t *d_idx);
 int icp_synchronize(icp_handle *h);
 
-/* Live kernel timing for the benchmark: while enabled, HIP events bracket every launch
- * of the nearest-neighbour search kernel on the handle's stream.  icp_profile_read
- * synchronises the stream, returns the summed device time (ms) and launch count since
- * the last read, and clears them. */
+/* Live kernel timing for the benchmark: with enable = k > 0, HIP events bracket every
+ * k-th launch of the nearest-neighbour search kernel on the handle's stream (an event pair
+ * costs a few us of stream time, so the benchmark samples instead of timing every launch);
+ * 0 switches it off.  icp_profile_read synchronises the stream, returns the summed device
+ * time (ms) of the timed launches and their count since the last read, and clears them. */
 int icp_profile_enable(icp_handle *h, int enable);
 int icp_profile_read(icp_handle *h, double *nn_kernel_ms, uint64_t *nn_kernel_launches);
 

@@ -13,14 +13,19 @@ icp = I.Icp3d(d_dst)
 drv = ShardedIcp(HipStages(icp), n)
 L = I.lib(); L.icp_debug_nn_stats.argtypes = [C.POINTER(C.c_uint64), C.c_int]
 out = (C.c_uint64 * 8)()
+L.icp_debug_nn_hist.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+hist = (C.c_uint64 * 64)()
 T = I.Transform(); drv.stages.prepare(d_src, T)
 names = ["queries", "row_bound_fetches", "record_batches", "exact_evals", "wave_loop_steps", "wave_cycles", "waves", "warm_queries"]
-for it in range(4):
-    L.icp_debug_nn_stats(out, 1)
+for it in range(16):
+    L.icp_debug_nn_stats(out, 1); L.icp_debug_nn_hist(hist, 1)
     T, k = drv.step(d_src, T); torch.cuda.synchronize()
     L.icp_debug_nn_stats(out, 0)
     v = list(out); q = max(v[0], 1); w = max(v[6], 1)
     print(f"iter {it}:", {nm: x for nm, x in zip(names, v)})
+    if it not in (0, 1, 3, 15): continue
+    L.icp_debug_nn_hist(hist, 0); hv = list(hist)
+    print("   lanes by chunks:", hv[:32]); print("   waves by max chunks:", hv[32:])
     print(f"   per query: rows {v[1]/q:.2f} batches {v[2]/q:.2f} exact {v[3]/q:.2f} | per wave: loop steps {v[4]/w:.1f} lifetime {v[5]/w:.0f} cycles")
 
 # phase times of the histogram kernels (diagnostic stamps)
