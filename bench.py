@@ -32,26 +32,38 @@ def cpu_baseline(src, dst, iters):
     """The oracle (kd-tree exact NN + the reference-order inner loop), single thread, timed on
     this host: `iters` outer iterations of the same workload from the identity pose.  This is
     the only place bench.py touches oracle/ -- as the reported baseline, never as the thing
-    measured."""
+    measured.  `all_cores` repeats it with the queries of each search split over every host core
+    (the reference itself is single-threaded; SURVEY.md 8(d) asks for both)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi as O
 
     t0 = time.perf_counter()
     tree = O.KdTree(dst)
     t_build = time.perf_counter() - t0
-    T = O.transform_identity()
-    times = []
-    for _ in range(iters):
-        t0 = time.perf_counter()
-        rc, T, _, _ = tree.estimate(src, T, 1)
-        times.append(time.perf_counter() - t0)
-        assert rc == O.OK
-    per_iter = float(np.mean(times))
+
+    def run(threads):
+        O.set_threads(threads)
+        tree.search(src[:4096])  # thread start-up is not part of the sample
+        T = O.transform_identity()
+        times = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            rc, T, _, _ = tree.estimate(src, T, 1)
+            times.append(time.perf_counter() - t0)
+            assert rc == O.OK
+        O.set_threads(1)
+        return float(np.mean(times))
+
+    per_iter = run(1)
+    cores = os.cpu_count() or 1
+    per_iter_all = run(cores) if cores > 1 else per_iter
     return {
         "value": 1.0 / per_iter,
         "unit": "iterations/s",
         "cores": 1,
         "kind": "port",
+        "all_cores": {"value": 1.0 / per_iter_all, "cores": cores,
+                      "note": "kd-tree queries split over all host cores, inner Gauss-Newton loop serial"},
         "sample": f"{iters} outer iterations of the same {len(src)}x{len(dst)} pair from the identity pose "
                   f"(oracle restatement, not the Rust binary; kd-tree build {t_build:.2f} s not included)",
         "kdtree_build_s": t_build,

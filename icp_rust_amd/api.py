@@ -248,6 +248,14 @@ def reduce_geometry(n):
     return b.value, t.value
 
 
+def gn_path_counters(icp=None):
+    """(window started, window missed, short pipeline, radix path) evaluation counts of a handle
+    (default: the scratch handle behind the free functions)."""
+    out = (C.c_uint64 * 4)()
+    check(lib().icp_gn_path_counters(icp._h if icp is not None else None, out), "icp_gn_path_counters")
+    return tuple(int(x) for x in out)
+
+
 class _Icp:
     DIM = 0
 

@@ -403,6 +403,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
       }
     }
     if (!done) {
+      ++w.short_evals;
       HIP_TRY(launch_weighted_gn_fast(h, d_a, d_b, n, T));
       HIP_TRY(wait_result(h));
       done = !w.h_res->overflow;
@@ -411,6 +412,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
     }
   }
   if (!done) {  // heavy duplicates around a median: the general 6-pass radix select
+    ++w.radix_evals;
     HIP_TRY(launch_sel_init(h, n));
     HIP_TRY(launch_weighted_gn(h, d_a, d_b, n, T));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -532,6 +534,20 @@ int stage_pairs(icp_handle *h, const double *a, const double *b, size_t n) {
 }
 
 }  // namespace
+
+extern "C" int icp_gn_path_counters(icp_handle *h, uint64_t out[4]) {
+  if (!out) return ICP_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!h) {
+    const int rc = scratch_handle(&h);
+    if (rc != ICP_OK) return rc;
+  }
+  out[0] = h->ws.win_tried;
+  out[1] = h->ws.win_missed;
+  out[2] = h->ws.short_evals;
+  out[3] = h->ws.radix_evals;
+  return ICP_OK;
+}
 
 extern "C" int icp_estimate_transform(const double *a, const double *b, size_t n, icp_pose *out,
                                       uint32_t *inner_iters) {

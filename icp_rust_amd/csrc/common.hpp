@@ -133,7 +133,7 @@ struct Workspace {
   bool win_valid = false;       // median/sigma of the previous evaluation are known
   bool win_wide = false;        // the last window missed: use wider fine windows until it settles
   double win_med[2] = {0., 0.}, win_sigma[2] = {0., 0.};
-  unsigned long long win_tried = 0, win_missed = 0;
+  unsigned long long win_tried = 0, win_missed = 0, short_evals = 0, radix_evals = 0;
 };
 
 // ---- uniform grid over the target cloud (nn_grid.hip) ------------------------------

@@ -32,7 +32,7 @@ namespace icp {
 constexpr int kWinThreads = 1024;
 constexpr int kWinBatch = 4;
 constexpr int kSubBins = 1024;   // select_pair: linear sub-bins over the candidates
-constexpr int kSmallCap = 256;   // select_pair: keys ranked by counting, per dimension
+constexpr int kSmallCap = 1024;  // select_pair: keys ranked by counting, per dimension (a run of equal keys lands here)
 constexpr size_t kWinMinN = 1u << 15;
 constexpr size_t kWinMaxN = 1u << 22;
 
@@ -217,6 +217,11 @@ __device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, co
   const int tmax = (int)((w.x[5] - w.x[0]) * w.sf) + 2;
   const int t1 = wave_last_true(0, tmax, [&](int t) { return n_possible(t) <= klo; });
   const int t2 = wave_last_true(0, tmax, [&](int t) { return n_inside(t) <= khi; }) + 1;
+#ifdef ICP_WIN_DEBUG
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+    printf("[C resolve] n %u jlo %d jhi %d t1 %d t2 %d tmax %d mL %.6g mU %.6g cnt[jlo] %u x0 %.6g x5 %.6g\n", n, jlo, jhi, t1,
+           t2, tmax, mL, mU, C(jlo + 1) - c[jlo], w.x[0], w.x[5]);
+#endif
   if (t1 < 0 || t2 > tmax) return false;
   int is, ie, ps, pe;
   inside_bins((double)t1 * fine - 2. * q, is, ie);
@@ -238,6 +243,10 @@ __device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, co
   med_base = c[jlo];
   med_cnt = C(jhi + 1) - c[jlo];
   ring_cnt = (C(pe) - C(ps)) - inner;
+#ifdef ICP_WIN_DEBUG
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+    printf("[C resolve] ring [%d,%d) inner [%d,%d) med_cnt %u ring_cnt %u inner %u\n", ps, pe, is, ie, med_cnt, ring_cnt, inner);
+#endif
   range[0] = mL;  // every median candidate lies in [mL, mU]
   range[1] = mU;
   range[2] = t1 > 0 ? (double)(t1 - 1) * fine : 0.;  // the MAD lies in (t1, t2] fine bins
@@ -352,13 +361,25 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
       for (int d = 0; d < 2; ++d) {
         const double r = v[d][u];
         const unsigned j = wbin(r, P.d[d]);
+        // staged in LDS; a workgroup that meets more candidates than it can stage (a run of
+        // neighbouring points with equal residuals) appends the excess one by one
         if (j >= mlo[d] && j <= mhi[d]) {
           const unsigned pos = atomicAdd(&s_cnt[d], 1u);
-          if (pos < (unsigned)kWinBlkMed) s_med[d][pos] = r;
+          if (pos < (unsigned)kWinBlkMed) {
+            s_med[d][pos] = r;
+          } else {
+            const unsigned g = atomicAdd(&st->list_cnt[d][0], 1u);
+            if (g < (unsigned)kWinCapMed) wmed[(size_t)d * kWinCapMed + g] = r;
+          }
         }
         if (j >= a0[d] && j <= b1[d] && !(j >= i0[d] && j <= i1[d])) {
           const unsigned pos = atomicAdd(&s_cnt[2 + d], 1u);
-          if (pos < (unsigned)kWinBlkRing) s_ring[d][pos] = r;
+          if (pos < (unsigned)kWinBlkRing) {
+            s_ring[d][pos] = r;
+          } else {
+            const unsigned g = atomicAdd(&st->list_cnt[2 + d][0], 1u);
+            if (g < (unsigned)kWinCapRing) wring[(size_t)d * kWinCapRing + g] = r;
+          }
         }
       }
     }
@@ -368,8 +389,7 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
   cst[3] = wall_clock64();
 #endif
   // one reservation per workgroup and list (the totals are known in advance, so the dense
-  // lists cannot overflow; a workgroup that ran out of staging slots leaves the total short,
-  // which A notices)
+  // lists cannot overflow)
   __shared__ unsigned s_base[4];
   if (tid < 4) {
     const unsigned cap = tid < 2 ? kWinBlkMed : kWinBlkRing;
@@ -432,7 +452,7 @@ __device__ __forceinline__ void select_pair(const double (&v)[2][NV], const unsi
                                             const double (&lo)[2], const double (&hi)[2],
                                             const long long (&rlo)[2], const long long (&rhi)[2],
                                             unsigned long long (&out)[2][2], bool &fail) {
-  static_assert(kSubBins == 2 * kReduceThreads && kSmallCap * 2 == kReduceThreads, "geometry");
+  static_assert(kSubBins == 2 * kReduceThreads, "geometry");
   __shared__ unsigned s_hist[2][kSubBins];
   __shared__ unsigned long long s_small[2][kSmallCap];
   __shared__ unsigned s_nsmall[2], s_sb[2][2], s_below[2];
@@ -507,10 +527,11 @@ __device__ __forceinline__ void select_pair(const double (&v)[2][NV], const unsi
     fail = true;  // uniform
     return;
   }
-  {
-    const int d = tid / kSmallCap;
-    const unsigned i = tid % kSmallCap, ns = s_nsmall[d];
-    if (i < ns) {
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const unsigned ns = s_nsmall[d];
+    const unsigned rl = (unsigned)rlo[d], rh = (unsigned)rhi[d];
+    for (unsigned i = tid; i < ns; i += kReduceThreads) {
       const unsigned long long ki = s_small[d][i];
       unsigned less = s_below[d], eq = 0;
       for (unsigned j = 0; j < ns; ++j) {
@@ -518,7 +539,6 @@ __device__ __forceinline__ void select_pair(const double (&v)[2][NV], const unsi
         less += kj < ki;
         eq += kj == ki;
       }
-      const unsigned rl = (unsigned)rlo[d], rh = (unsigned)rhi[d];
       if (less <= rl && rl < less + eq) s_out[d][0] = ki;
       if (less <= rh && rh < less + eq) s_out[d][1] = ki;
     }
@@ -566,8 +586,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
   const unsigned mbase[2] = {st->med_base[0], st->med_base[1]}, inner[2] = {st->ring_inner[0], st->ring_inner[1]};
   const double m_lo[2] = {st->med_lo[0], st->med_lo[1]}, m_hi[2] = {st->med_hi[0], st->med_hi[1]};
   const double r_lo[2] = {st->ring_lo[0], st->ring_lo[1]}, r_hi[2] = {st->ring_hi[0], st->ring_hi[1]};
-  // a workgroup of C that ran out of staging slots leaves a list short
+  // (the appended counts are cross-checked against the histogram: a mismatch is a miss)
   bool fail = st->fail != 0 || got[0] != em[0] || got[1] != em[1] || got[2] != er[0] || got[3] != er[1];
+#ifdef ICP_WIN_DEBUG
+  if (blockIdx.x == 0 && tid == 0 && fail)
+    printf("[A] fail: st %u got %u %u %u %u want %u %u %u %u\n", st->fail, got[0], got[1], got[2], got[3], em[0], em[1], er[0], er[1]);
+#endif
   STAMP();
   const unsigned klo = (n - 1) / 2, khi = n / 2;
   double med[2] = {0., 0.}, sig[2] = {0., 0.};

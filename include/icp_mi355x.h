@@ -186,6 +186,14 @@ int icp_profile_read(icp_handle *h, double *nn_kernel_ms, uint64_t *nn_kernel_la
  * reproduce the exact association order (DESIGN.md "GN reduction order"). */
 void icp_reduce_geometry(size_t n, int *blocks, int *threads);
 
+/* Observability for tests: which pipeline served the weighted Gauss-Newton evaluations of
+ * this handle (NULL: the scratch handle behind the free functions) since it was created.
+ * out[0] evaluations started with the three-launch window pipeline, out[1] how many of those
+ * missed their window and were repeated, out[2] evaluations by the seven-launch (or
+ * single-workgroup) pipeline, out[3] by the general radix-select path.  All pipelines return
+ * the same bits; the counters only show that a test exercised the path it meant to. */
+int icp_gn_path_counters(icp_handle *h, uint64_t out[4]);
+
 #ifdef __cplusplus
 }
 #endif

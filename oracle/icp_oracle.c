@@ -627,8 +627,15 @@ static void kd_search(const orc_kdtree *t, size_t lo, size_t hi, const double *q
   }
 }
 
+/* The reference is single-threaded (no_std, no rayon); threads > 1 only splits the
+ * independent queries of one search over host cores for bench.py's "all cores" baseline
+ * (SURVEY.md 8(d)).  Results do not depend on it. */
+static int g_threads = 1;
+void orc_set_threads(int threads) { g_threads = threads > 1 ? threads : 1; }
+
 int orc_kdtree_search(const orc_kdtree *t, const double *q, size_t n, uint32_t *idx) {
   if (t->m == 0) return ORC_EMPTY_DST;
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(g_threads) if (g_threads > 1)
   for (size_t i = 0; i < n; ++i) {
     double best = INFINITY;
     uint32_t bi = 0xffffffffu;

@@ -92,6 +92,7 @@ int orc_nn_brute(const double *dst, size_t m, int dim, const double *q, size_t n
 typedef struct orc_kdtree orc_kdtree;
 orc_kdtree *orc_kdtree_build(const double *dst, size_t m, int dim);  /* KdTree::new(dst, 1) */
 void orc_kdtree_free(orc_kdtree *t);
+void orc_set_threads(int threads); /* queries of one kd search over host cores (default 1, as the reference) */
 int orc_kdtree_search(const orc_kdtree *t, const double *q, size_t n, uint32_t *idx);
 
 /* --- ICP driver (src/lib.rs:91-174) ------------------------------------------------ */

@@ -92,6 +92,7 @@ def lib():
     sig("orc_kdtree_build", C.c_void_p, dp, sz, C.c_int)
     sig("orc_kdtree_free", None, C.c_void_p)
     sig("orc_kdtree_search", C.c_int, C.c_void_p, dp, sz, u32p)
+    sig("orc_set_threads", None, C.c_int)
     sig("orc_icp_estimate", C.c_int, C.c_int, dp, sz, dp, sz, pp, sz, C.POINTER(IcpOpts), pp, u32p,
         u32p)
     sig("orc_icp_estimate_tree", C.c_int, C.c_void_p, dp, sz, dp, sz, pp, sz, C.POINTER(IcpOpts), pp,
@@ -257,6 +258,11 @@ def nn_brute(dst, q):
     idx, ip = _u32(q.shape[0])
     rc = lib().orc_nn_brute(dp_, dst.shape[0], dim, qp, q.shape[0], ip)
     return rc, idx[: q.shape[0]]
+
+
+def set_threads(threads):
+    """Split the queries of a kd search over `threads` host cores (1 = the reference's behaviour)."""
+    lib().orc_set_threads(int(threads))
 
 
 class KdTree:

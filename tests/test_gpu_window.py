@@ -1,0 +1,149 @@
+"""The three-launch "window" evaluation (gn_win.hip): it predicts the median and sigma of the
+residuals from the previous evaluation of the same handle and must return the same bits as every
+other pipeline -- on a hit, on a miss (repeat with the seven-launch pipeline), with the widened
+windows after a miss, and when duplicates overload a fine bin.  The path counters of the C ABI
+(icp_gn_path_counters) prove that each case took the path it is meant to test.
+
+The checker is the oracle's tree variant (same association order): bit-exact comparisons."""
+import numpy as np
+import pytest
+
+import icp_rust_amd as I
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+def opose(T):
+    return O.Pose(*[float(x) for x in T.as_array()])
+
+
+def pairs(n, seed, shift=(0.0, 0.0), spread=0.05, outliers=True):
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(n, 2)) * 20
+    Tt = O.transform_new(np.array([0.4, -0.3, 0.02]))
+    b = O.transform_apply_many(Tt, a) + rng.normal(size=(n, 2)) * spread + np.asarray(shift)
+    if outliers:
+        k = rng.integers(0, n, size=n // 10)
+        b[k] += rng.normal(size=(len(k), 2)) * 5
+    return a, b
+
+
+def check(T, a, b):
+    got = I.weighted_gauss_newton_update(T, a, b)
+    blocks, threads = I.reduce_geometry(len(a))
+    rc, want, _ = O.weighted_gauss_newton_update_tree(opose(T), a, b, blocks, threads)
+    assert rc == O.OK and got is not None
+    assert np.array_equal(got, want), (got, want)
+
+
+def delta(before, after):
+    return tuple(y - x for x, y in zip(before, after))
+
+
+@pytest.mark.parametrize("n", [40_000, 262_144, 1_000_003])
+def test_window_hit_is_bit_exact(n):
+    a, b = pairs(n, n)
+    T = I.Transform([0.39, -0.31, 0.0199])
+    check(T, a, b)  # whatever ran, the next evaluation has a prediction
+    c0 = I.gn_path_counters()
+    # a slightly different pose: the residuals move by ~1e-2 sigma, as between inner iterations
+    for k in range(3):
+        check(I.Transform([0.39 + 1e-4 * k, -0.31, 0.0199 + 1e-6 * k]), a, b)
+    tried, missed, short, radix = delta(c0, I.gn_path_counters())
+    assert tried == 3 and missed == 0 and short == 0 and radix == 0
+
+
+def test_window_miss_falls_back_and_recentres():
+    n = 200_000
+    a, b = pairs(n, 11)
+    T = I.Transform([0.39, -0.31, 0.0199])
+    check(T, a, b)
+    c0 = I.gn_path_counters()
+    # the whole residual distribution jumps by ~20 sigma: every order statistic leaves its window
+    a2, b2 = pairs(n, 11, shift=(1.5, -2.0))
+    check(T, a2, b2)
+    tried, missed, short, radix = delta(c0, I.gn_path_counters())
+    assert tried == 1 and missed == 1 and short == 1 and radix == 0
+    # the repeat re-centred the prediction: the next evaluations hit again (wide windows first)
+    c1 = I.gn_path_counters()
+    check(I.Transform([0.3901, -0.31, 0.0199]), a2, b2)
+    check(I.Transform([0.3902, -0.31, 0.0199]), a2, b2)
+    check(I.Transform([0.3903, -0.31, 0.0199]), a2, b2)
+    tried, missed, short, radix = delta(c1, I.gn_path_counters())
+    assert tried == 3 and missed == 0
+
+
+def test_window_with_changing_scale():
+    """sigma doubles between evaluations: the MAD leaves its fine windows -> miss, repeat, then hits."""
+    n = 150_000
+    a, b = pairs(n, 5, spread=0.05, outliers=False)
+    T = I.Transform([0.4, -0.3, 0.02])
+    check(T, a, b)
+    a2, b2 = pairs(n, 5, spread=0.11, outliers=False)
+    c0 = I.gn_path_counters()
+    check(T, a2, b2)
+    check(T, a2, b2)
+    tried, missed, _, _ = delta(c0, I.gn_path_counters())
+    assert tried == 2 and missed == 1
+
+
+def test_window_duplicates_overload_a_bin():
+    """30 % of the x residuals are one exact value on the median: more candidates in the median
+    bin than the window pipeline keeps -> it reports a miss; the seven-launch pipeline overflows
+    too and the radix path serves the evaluation.  Same bits."""
+    n = 200_001
+    rng = np.random.default_rng(n)
+    a = rng.normal(size=(n, 2)) * 10
+    r = rng.normal(size=(n, 2)) * 0.2
+    T = I.Transform()
+    check(T, a, a - r)  # prediction from a clean distribution of the same scale
+    k = int(0.3 * n)
+    r[:k, 0] = 0.0
+    r[k:k + (n - k) // 2, 0] = -np.abs(r[k:k + (n - k) // 2, 0]) - 1e-3
+    r[k + (n - k) // 2:, 0] = np.abs(r[k + (n - k) // 2:, 0]) + 1e-3
+    c0 = I.gn_path_counters()
+    check(T, a, a - r)
+    tried, missed, short, radix = delta(c0, I.gn_path_counters())
+    assert tried == 1 and missed == 1 and radix == 1
+    # and the pipelines are back in their rest state afterwards
+    a2, b2 = pairs(n, 3)
+    check(I.Transform([0.39, -0.31, 0.0199]), a2, b2)
+    check(I.Transform([0.39, -0.31, 0.0199]), a2, b2)
+
+
+def test_window_even_and_odd_counts_and_signed_zero_medians():
+    for n in (65_536, 65_537):
+        rng = np.random.default_rng(n)
+        a = rng.normal(size=(n, 2)) * 10
+        r = rng.normal(size=(n, 2)) * 0.1
+        # a run of +-0 sits exactly on the median of y, the rest splits evenly around it
+        z = 301
+        h = (n - z) // 2
+        r[:z, 1] = np.where(np.arange(z) % 2 == 0, 0.0, -0.0)
+        r[z:z + h, 1] = -np.abs(r[z:z + h, 1]) - 1e-6
+        r[z + h:, 1] = np.abs(r[z + h:, 1]) + 1e-6
+        T = I.Transform()
+        c0 = I.gn_path_counters()
+        check(T, a, a - r)
+        check(T, a, a - r)
+        check(T, a, a - r)
+        tried, missed, _, _ = delta(c0, I.gn_path_counters())
+        assert tried >= 2 and tried - missed >= 1  # at least one evaluation was served by the window pipeline
+
+
+def test_estimate_uses_the_window_pipeline_and_stays_bit_exact():
+    from icp_rust_amd import synth
+    n = m = 120_000
+    src, dst = synth.synthetic_pair(n, m)
+    icp = I.Icp3d(dst)
+    T, idx, inner = icp.estimate(src, I.Transform(), 8, return_info=True)
+    tried, missed, short, radix = I.gn_path_counters(icp)
+    assert tried > 8 and missed <= tried // 2
+    blocks, threads = I.reduce_geometry(n)
+    rc, oT, oidx, oinner = O.icp_estimate(3, dst, src, O.transform_identity(), 8, use_kdtree=True,
+                                           sum_mode=1, reduce_blocks=blocks, reduce_threads=threads)
+    assert rc == O.OK
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(inner, oinner)
+    assert np.array_equal(T.as_array(), oT.as_array())
