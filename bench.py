@@ -52,11 +52,11 @@ def cpu_baseline(src, dst, iters):
             times.append(time.perf_counter() - t0)
             assert rc == O.OK
         O.set_threads(1)
-        return float(np.mean(times))
+        return float(np.mean(times)), times
 
-    per_iter = run(1)
+    per_iter, times = run(1)
     cores = os.cpu_count() or 1
-    per_iter_all = run(cores) if cores > 1 else per_iter
+    per_iter_all = run(cores)[0] if cores > 1 else per_iter
     return {
         "value": 1.0 / per_iter,
         "unit": "iterations/s",
