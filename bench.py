@@ -146,14 +146,24 @@ def main():
         barrier()
         t0 = time.perf_counter()
         inner = []
-        for k_step in range(steps):
-            if k_step % MAX_ITER == 0:
-                # a new Icp3d::estimate(src, identity, 20) call, as examples/scan3d.rs:131 issues per
-                # frame: its per-call setup (cell-sorted snapshot of the source cloud) is timed too
-                T = I.Transform()
-                driver.stages.prepare(d_src, T)
-            T, k = driver.step(d_src, T)
-            inner.append(int(k))
+        if world == 1:
+            # one rank: the library's own outer loop (icp_estimate_device), one call per 20 steps as
+            # examples/scan3d.rs:131 issues per frame; its per-call setup (cell-sorted snapshot of
+            # the source cloud) is timed too
+            done = 0
+            while done < steps:
+                k_iters = min(MAX_ITER, steps - done)
+                T, k = icp.estimate(d_src, I.Transform(), k_iters, return_info="inner")
+                inner.extend(int(x) for x in k[:k_iters])
+                done += k_iters
+        else:
+            # N ranks: the same iteration as stage calls around one collective (icp_rust_amd/dist.py)
+            for k_step in range(steps):
+                if k_step % MAX_ITER == 0:
+                    T = I.Transform()
+                    driver.stages.prepare(d_src, T)
+                T, k = driver.step(d_src, T)
+                inner.append(int(k))
         barrier()
         elapsed = time.perf_counter() - t0
         nn_ms, nn_launches = icp.profile_read()

@@ -281,18 +281,23 @@ class _Icp:
 
     # -- the reference's method ------------------------------------------------------
     def estimate(self, src, initial_transform, max_iter, return_info=False):
-        """Icp2d::estimate / Icp3d::estimate (src/lib.rs:105-130, 148-173)."""
+        """Icp2d::estimate / Icp3d::estimate (src/lib.rs:105-130, 148-173).  return_info=True also
+        returns the last correspondence indices and the inner-iteration counts; "inner" only the
+        counts (no index buffer, no device-to-host copy)."""
         o = Transform()
         inner = np.zeros(max(max_iter, 1), dtype=np.uint32)
         if _is_device_tensor(src):
             import torch
 
             n = src.shape[0]
-            idx = torch.empty(max(n, 1), dtype=torch.int32, device=src.device) if return_info else None
+            want_idx = return_info is True
+            idx = torch.empty(max(n, 1), dtype=torch.int32, device=src.device) if want_idx else None
             check(lib().icp_estimate_device(self._h, C.c_void_p(src.data_ptr()), n,
                                             C.byref(initial_transform.pose), max_iter, C.byref(o.pose),
-                                            C.c_void_p(idx.data_ptr()) if return_info else None,
+                                            C.c_void_p(idx.data_ptr()) if want_idx else None,
                                             C.c_void_p(inner.ctypes.data)), "icp_estimate_device")
+            if return_info == "inner":
+                return o, inner[:max_iter]
             if return_info:
                 return o, idx[:n].cpu().numpy().view(np.uint32), inner[:max_iter]
             return o
