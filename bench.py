@@ -133,11 +133,17 @@ def main():
     def measure(mode, steps, warmup):
         """K timed outer iterations = one Icp3d::estimate(src, T, K) call on resident data."""
         icp = I.Icp3d(d_dst, device=local_rank, nn_mode=mode)
-        driver = ShardedIcp(HipStages(icp), n, rank, world, src_full=d_src_full)
         T = I.Transform()
-        driver.stages.prepare(d_src, T)
-        for _ in range(warmup):
-            T, _ = driver.step(d_src, T)
+        if world == 1:
+            # one rank: the handle keeps its own streams (the library overlaps the next search with the
+            # evaluation that decides it); nothing else is enqueued on them
+            if warmup > 0:
+                icp.estimate(d_src, T, warmup)
+        else:
+            driver = ShardedIcp(HipStages(icp), n, rank, world, src_full=d_src_full)
+            driver.stages.prepare(d_src, T)
+            for _ in range(warmup):
+                T, _ = driver.step(d_src, T)
         # HIP events around every 3rd search launch (every launch on short runs): an event pair costs a
         # few us of stream time.  3 is coprime with the 20-step cycle, so the cold first search of each
         # estimate call is sampled at its true share.

@@ -52,6 +52,8 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_src);
   (void)hipFree(w.d_a);
   (void)hipFree(w.d_b);
+  (void)hipFree(w.d_a2);
+  (void)hipFree(w.d_b2);
   (void)hipFree(w.d_rx);
   (void)hipFree(w.d_ry);
   (void)hipFree(w.d_idx);
@@ -68,6 +70,11 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_wmed);
   (void)hipFree(w.d_wring);
   if (w.h_res) (void)hipHostFree(w.h_res);
+  if (w.spec_event) (void)hipEventDestroy(w.spec_event);
+  if (w.spec_stream) {
+    (void)hipStreamSynchronize(w.spec_stream);
+    (void)hipStreamDestroy(w.spec_stream);
+  }
   w = Workspace();
 }
 
@@ -95,6 +102,8 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     if ((e = hipMemsetAsync(w.d_wstate, 0, sizeof(WinState), h->stream)) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_wmed, (size_t)2 * kWinCapMed * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_wring, (size_t)2 * kWinCapRing * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithFlags(&w.spec_stream, hipStreamNonBlocking)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&w.spec_event, hipEventDisableTiming)) != hipSuccess) return e;
     if ((e = hipHostMalloc(&w.h_res, sizeof(GnResult), hipHostMallocCoherent)) != hipSuccess) return e;
     memset(w.h_res, 0, sizeof(GnResult));
   }
@@ -106,6 +115,8 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     w.d_src = nullptr;
     if ((e = grow(w.d_a, cap * 2)) != hipSuccess) return e;
     if ((e = grow(w.d_b, cap * 2)) != hipSuccess) return e;
+    if ((e = grow(w.d_a2, cap * 2)) != hipSuccess) return e;
+    if ((e = grow(w.d_b2, cap * 2)) != hipSuccess) return e;
     if ((e = grow(w.d_rx, cap)) != hipSuccess) return e;
     if ((e = grow(w.d_ry, cap)) != hipSuccess) return e;
     if ((e = grow(w.d_idx, cap)) != hipSuccess) return e;
@@ -230,7 +241,8 @@ extern "C" void icp_destroy(icp_handle *h) {
     (void)hipEventDestroy(ev.second);
   }
   if (getenv("ICP_DBG_WIN") && h->ws.win_tried)
-    fprintf(stderr, "[icp] window evaluations: %llu tried, %llu missed\n", h->ws.win_tried, h->ws.win_missed);
+    fprintf(stderr, "[icp] window evaluations: %llu tried, %llu missed; speculative searches: %llu hit, %llu missed\n",
+            h->ws.win_tried, h->ws.win_missed, h->ws.spec_hits, h->ws.spec_misses);
   free_workspace(h->ws);
   if (h->owns_dst) (void)hipFree(const_cast<double *>(h->d_dst));
   (void)hipFree(h->d_dst_soa);
@@ -375,11 +387,14 @@ static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
 
 // weighted_gauss_newton_update on device pairs (src/lib.rs:218-261); also yields the
 // Huber error of the same T (src/lib.rs:75), which shares the pass.
+// `after_launch` (optional) runs once, right after the first attempt's kernels have been enqueued
+// and before the host waits for them: the place to enqueue work that does not depend on the result.
+template <typename Hook>
 static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
-                    double delta[3], double *huber_err) {
+                    double delta[3], double *huber_err, Hook &&after_launch) {
   static const bool force_radix = getenv("ICP_GN_RADIX") != nullptr;
   Workspace &w = h->ws;
-  bool done = false, has_median = false;
+  bool done = false, has_median = false, hooked = false;
   if (w.gn_dirty) {  // first use, or the radix path / a NaN left its state behind (the short pipelines clean up after themselves)
     HIP_TRY(launch_sel_init(h, n));
     w.gn_dirty = false;
@@ -389,6 +404,8 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
     if (window_usable(h, n, &P)) {  // three launches around the previous evaluation's median and sigma
       ++w.win_tried;
       HIP_TRY(launch_weighted_gn_win(h, d_a, d_b, n, T, P));
+      HIP_TRY(after_launch());
+      hooked = true;
       HIP_TRY(wait_result(h));
       done = has_median = !w.h_res->overflow;
       if (!done) {
@@ -405,6 +422,8 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
     if (!done) {
       ++w.short_evals;
       HIP_TRY(launch_weighted_gn_fast(h, d_a, d_b, n, T));
+      if (!hooked) HIP_TRY(after_launch());
+      hooked = true;
       HIP_TRY(wait_result(h));
       done = !w.h_res->overflow;
       static const bool push = getenv("ICP_GN_PUSH") != nullptr;
@@ -415,6 +434,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
     ++w.radix_evals;
     HIP_TRY(launch_sel_init(h, n));
     HIP_TRY(launch_weighted_gn(h, d_a, d_b, n, T));
+    if (!hooked) HIP_TRY(after_launch());
     HIP_TRY(hipStreamSynchronize(h->stream));
     w.gn_dirty = true;
   }
@@ -432,21 +452,28 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   if (huber_err) *huber_err = r.acc[12];
   return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
 }
+static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
+                    double delta[3], double *huber_err) {
+  return wgn_step(h, d_a, d_b, n, T, delta, huber_err, [] { return hipSuccess; });
+}
 
-extern "C" int icp_estimate_transform_device(icp_handle *h, const double *d_a, const double *d_b, size_t n,
-                                             icp_pose *out, uint32_t *inner_iters) {
-  if (!h || !out || (n > 0 && (!d_a || !d_b)) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+// estimate_transform (src/lib.rs:59-84) on device pairs.  `second_eval_hook(T1)` (optional) is
+// called when the evaluation at the once-updated pose T1 has been enqueued: if that evaluation
+// ends the loop -- the usual case once a registration has settled -- T1 is the result, so the
+// caller may start work for it while the device is still evaluating.
+template <typename Hook>
+static int estimate_transform_loop(icp_handle *h, const double *d_a, const double *d_b, size_t n, Pose *out,
+                                   uint32_t *inner_iters, Hook &&second_eval_hook) {
   Pose T = transform_identity();
   uint32_t applied = 0;
   if (input_size_ok(n)) {
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(ensure_workspace(h, n, false));
     static const bool push = getenv("ICP_GN_PUSH") != nullptr;
     if (push) h->ws.gn_dirty = true;  // the debugging pipeline expects a fresh search state per call
     double prev_error = DBL_MAX;  // f64::MAX, src/lib.rs:63
     for (int it = 0; it < ICP_INNER_MAX_ITER; ++it) {
       double delta[3], err = 0.;
-      const int rc = wgn_step(h, d_a, d_b, n, T, delta, &err);
+      const int rc = (it == 1) ? wgn_step(h, d_a, d_b, n, T, delta, &err, [&] { return second_eval_hook(T); })
+                               : wgn_step(h, d_a, d_b, n, T, delta, &err);
       if (rc == ICP_NONE) break;           // src/lib.rs:67-69
       if (rc != ICP_OK) return rc;
       if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD)
@@ -462,26 +489,94 @@ extern "C" int icp_estimate_transform_device(icp_handle *h, const double *d_a, c
   return ICP_OK;
 }
 
+extern "C" int icp_estimate_transform_device(icp_handle *h, const double *d_a, const double *d_b, size_t n,
+                                             icp_pose *out, uint32_t *inner_iters) {
+  if (!h || !out || (n > 0 && (!d_a || !d_b)) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  if (input_size_ok(n)) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(ensure_workspace(h, n, false));
+  }
+  return estimate_transform_loop(h, d_a, d_b, n, out, inner_iters, [](const Pose &) { return hipSuccess; });
+}
+
+// Icp{2,3}d::estimate (src/lib.rs:105-130, 148-173) on a device-resident source cloud.
+//
+// Speculative search: once the inner loop has needed exactly one update in the previous outer
+// iteration, the next pose is known as soon as that update is (T_next = Exp(delta_1) * T, provided
+// the evaluation at the updated pose ends the loop).  The search for T_next is then enqueued
+// right behind that evaluation's kernels, into the second pair buffer, instead of after the host
+// has seen its result: the host round trip between two outer iterations disappears from the
+// device's timeline.  The guess is verified bit for bit (the pose the loop really returns must
+// equal the speculated one); on a mismatch the speculative pairs are ignored and the search runs
+// again for the true pose.  Results cannot depend on it.
 extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *init,
                                    size_t max_iter, icp_pose *out, uint32_t *d_last_idx,
                                    uint32_t *inner_iters) {
   if (!h || !init || !out || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(ensure_workspace(h, n, false));
+  static const bool no_spec = getenv("ICP_NO_SPECULATION") != nullptr;
+  // two internal streams take turns; with a caller-supplied stream everything stays on that stream
+  static const bool same_stream_env = getenv("ICP_SPEC_SAME_STREAM") != nullptr;
+  const bool same_stream = same_stream_env || h->stream != h->own_stream;
+  struct StreamRoles {  // whatever happens below, the handle leaves with its own stream in place
+    icp_handle *h;
+    ~StreamRoles() {
+      if (h->stream != h->own_stream && h->ws.spec_stream == h->own_stream) std::swap(h->stream, h->ws.spec_stream);
+    }
+  } restore_roles{h};
+  Workspace &w = h->ws;
   Pose T = *init;
   if (max_iter > 0) {
     const int prc = icp_prepare_source_device(h, d_src, n, init);
     if (prc != ICP_OK) return prc;
   }
+  double *A[2] = {w.d_a, w.d_a2}, *B[2] = {w.d_b, w.d_b2};
+  int cur = 0;
+  bool spec_valid = false;
+  Pose spec_pose = T;
+  uint32_t prev_inner = 0xffffffffu;
   for (size_t it = 0; it < max_iter; ++it) {
-    uint32_t *idx_out = (it + 1 == max_iter) ? d_last_idx : nullptr;
-    int rc = icp_correspond_device(h, d_src, n, &T, h->ws.d_a, h->ws.d_b, idx_out);
-    if (rc != ICP_OK) return rc;
+    if (spec_valid && memcmp(&spec_pose, &T, sizeof(Pose)) == 0) {
+      cur ^= 1;  // the pairs of this pose are already in (or on their way into) the other buffers
+      ++w.spec_hits;
+      // the iteration continues on the stream the search runs on (no cross-queue dependency:
+      // resolving one costs ~12 us on this chip); everything else it touches was complete when
+      // the host saw the last evaluation's result
+      if (!same_stream) std::swap(h->stream, w.spec_stream);
+    } else {
+      if (spec_valid) {
+        ++w.spec_misses;
+        if (!same_stream) HIP_TRY(hipStreamWaitEvent(h->stream, w.spec_event, 0));
+      }
+      uint32_t *idx_out = (it + 1 == max_iter) ? d_last_idx : nullptr;
+      const int rc = icp_correspond_device(h, d_src, n, &T, A[cur], B[cur], idx_out);
+      if (rc != ICP_OK) return rc;
+    }
+    spec_valid = false;
+    const bool speculate = !no_spec && n > 0 && h->m > 0 && it + 1 < max_iter && prev_inner == 1;
+    auto hook = [&](const Pose &T1) -> hipError_t {
+      if (!speculate) return hipSuccess;
+      spec_pose = transform_mul(T1, T);  // src/lib.rs:127, 170 -- what the outer loop will compute
+      uint32_t *idx_out = (it + 2 == max_iter) ? d_last_idx : nullptr;
+      spec_valid = true;
+      if (same_stream) return launch_nn(h, d_src, n, &spec_pose, A[cur ^ 1], B[cur ^ 1], idx_out);
+      // on its own stream: the search (latency-bound, 4 waves/SIMD) and the evaluation it bets on
+      // (one workgroup per CU) share the CUs instead of queueing behind each other.  Everything
+      // the search reads was complete when the host saw the previous evaluation's result.
+      hipStream_t main_stream = h->stream;
+      h->stream = w.spec_stream;
+      hipError_t e = launch_nn(h, d_src, n, &spec_pose, A[cur ^ 1], B[cur ^ 1], idx_out);
+      h->stream = main_stream;
+      if (e == hipSuccess) e = hipEventRecord(w.spec_event, w.spec_stream);
+      return e;
+    };
     Pose dT;
     uint32_t inner = 0;
-    rc = icp_estimate_transform_device(h, h->ws.d_a, h->ws.d_b, n, &dT, &inner);
+    const int rc = estimate_transform_loop(h, A[cur], B[cur], n, &dT, &inner, hook);
     if (rc != ICP_OK) return rc;
     if (inner_iters) inner_iters[it] = inner;
+    prev_inner = inner;
     T = transform_mul(dT, T);  // src/lib.rs:127, 170
   }
   HIP_TRY(hipStreamSynchronize(h->stream));

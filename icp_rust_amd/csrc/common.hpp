@@ -108,6 +108,11 @@ struct Workspace {
   double *d_src = nullptr; // staged source cloud (host API), cap_n x dim
   double *d_a = nullptr;   // transformed source xy, cap_n x 2
   double *d_b = nullptr;   // matched target xy, cap_n x 2
+  double *d_a2 = nullptr;  // second pair buffers: the speculative search of the next outer iteration
+  double *d_b2 = nullptr;
+  unsigned long long spec_hits = 0, spec_misses = 0;
+  hipStream_t spec_stream = nullptr;  // the speculative search runs beside the evaluation it bets on
+  hipEvent_t spec_event = nullptr;
   double *d_rx = nullptr;  // residual x, cap_n
   double *d_ry = nullptr;  // residual y, cap_n
   uint32_t *d_idx = nullptr;

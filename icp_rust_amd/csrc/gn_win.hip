@@ -217,7 +217,7 @@ __device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, co
   const int tmax = (int)((w.x[5] - w.x[0]) * w.sf) + 2;
   const int t1 = wave_last_true(0, tmax, [&](int t) { return n_possible(t) <= klo; });
   const int t2 = wave_last_true(0, tmax, [&](int t) { return n_inside(t) <= khi; }) + 1;
-#ifdef ICP_WIN_DEBUG
+#ifdef ICP_WIN_DEBUG_RESOLVE
   if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
     printf("[C resolve] n %u jlo %d jhi %d t1 %d t2 %d tmax %d mL %.6g mU %.6g cnt[jlo] %u x0 %.6g x5 %.6g\n", n, jlo, jhi, t1,
            t2, tmax, mL, mU, C(jlo + 1) - c[jlo], w.x[0], w.x[5]);
@@ -243,7 +243,7 @@ __device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, co
   med_base = c[jlo];
   med_cnt = C(jhi + 1) - c[jlo];
   ring_cnt = (C(pe) - C(ps)) - inner;
-#ifdef ICP_WIN_DEBUG
+#ifdef ICP_WIN_DEBUG_RESOLVE
   if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
     printf("[C resolve] ring [%d,%d) inner [%d,%d) med_cnt %u ring_cnt %u inner %u\n", ps, pe, is, ie, med_cnt, ring_cnt, inner);
 #endif
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
 #ifdef ICP_WIN_DEBUG
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   cst[4] = wall_clock64();
-  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && s_cnt[2] % 16 == 3)
+  if (tid == 0 && blockIdx.x == 100)
     printf("[C blk %d] scan %lld resolve %lld stream %lld append %lld (x10ns)\n", blockIdx.x, cst[1] - cst[0],
            cst[2] - cst[1], cst[3] - cst[2], cst[4] - cst[3]);
 #endif
