@@ -249,9 +249,9 @@ def reduce_geometry(n):
 
 
 def gn_path_counters(icp=None):
-    """(window started, window missed, short pipeline, radix path) evaluation counts of a handle
-    (default: the scratch handle behind the free functions)."""
-    out = (C.c_uint64 * 4)()
+    """(window started, window missed, short pipeline, radix path, speculative searches confirmed,
+    discarded) counts of a handle (default: the scratch handle behind the free functions)."""
+    out = (C.c_uint64 * 6)()
     check(lib().icp_gn_path_counters(icp._h if icp is not None else None, out), "icp_gn_path_counters")
     return tuple(int(x) for x in out)
 

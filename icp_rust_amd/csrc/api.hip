@@ -630,7 +630,7 @@ int stage_pairs(icp_handle *h, const double *a, const double *b, size_t n) {
 
 }  // namespace
 
-extern "C" int icp_gn_path_counters(icp_handle *h, uint64_t out[4]) {
+extern "C" int icp_gn_path_counters(icp_handle *h, uint64_t out[6]) {
   if (!out) return ICP_BAD_ARGUMENT;
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   if (!h) {
@@ -641,6 +641,8 @@ extern "C" int icp_gn_path_counters(icp_handle *h, uint64_t out[4]) {
   out[1] = h->ws.win_missed;
   out[2] = h->ws.short_evals;
   out[3] = h->ws.radix_evals;
+  out[4] = h->ws.spec_hits;
+  out[5] = h->ws.spec_misses;
   return ICP_OK;
 }
 

@@ -190,9 +190,10 @@ void icp_reduce_geometry(size_t n, int *blocks, int *threads);
  * this handle (NULL: the scratch handle behind the free functions) since it was created.
  * out[0] evaluations started with the three-launch window pipeline, out[1] how many of those
  * missed their window and were repeated, out[2] evaluations by the seven-launch (or
- * single-workgroup) pipeline, out[3] by the general radix-select path.  All pipelines return
- * the same bits; the counters only show that a test exercised the path it meant to. */
-int icp_gn_path_counters(icp_handle *h, uint64_t out[4]);
+ * single-workgroup) pipeline, out[3] by the general radix-select path; out[4] / out[5]
+ * speculative searches of icp_estimate[_device] whose pose was confirmed / discarded.  Every
+ * path returns the same bits; the counters only show that a test exercised what it meant to. */
+int icp_gn_path_counters(icp_handle *h, uint64_t out[6]);
 
 #ifdef __cplusplus
 }

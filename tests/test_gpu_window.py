@@ -50,7 +50,7 @@ def test_window_hit_is_bit_exact(n):
     # a slightly different pose: the residuals move by ~1e-2 sigma, as between inner iterations
     for k in range(3):
         check(I.Transform([0.39 + 1e-4 * k, -0.31, 0.0199 + 1e-6 * k]), a, b)
-    tried, missed, short, radix = delta(c0, I.gn_path_counters())
+    tried, missed, short, radix, _, _ = delta(c0, I.gn_path_counters())
     assert tried == 3 and missed == 0 and short == 0 and radix == 0
 
 
@@ -63,14 +63,14 @@ def test_window_miss_falls_back_and_recentres():
     # the whole residual distribution jumps by ~20 sigma: every order statistic leaves its window
     a2, b2 = pairs(n, 11, shift=(1.5, -2.0))
     check(T, a2, b2)
-    tried, missed, short, radix = delta(c0, I.gn_path_counters())
+    tried, missed, short, radix, _, _ = delta(c0, I.gn_path_counters())
     assert tried == 1 and missed == 1 and short == 1 and radix == 0
     # the repeat re-centred the prediction: the next evaluations hit again (wide windows first)
     c1 = I.gn_path_counters()
     check(I.Transform([0.3901, -0.31, 0.0199]), a2, b2)
     check(I.Transform([0.3902, -0.31, 0.0199]), a2, b2)
     check(I.Transform([0.3903, -0.31, 0.0199]), a2, b2)
-    tried, missed, short, radix = delta(c1, I.gn_path_counters())
+    tried, missed, short, radix, _, _ = delta(c1, I.gn_path_counters())
     assert tried == 3 and missed == 0
 
 
@@ -84,7 +84,7 @@ def test_window_with_changing_scale():
     c0 = I.gn_path_counters()
     check(T, a2, b2)
     check(T, a2, b2)
-    tried, missed, _, _ = delta(c0, I.gn_path_counters())
+    tried, missed, _, _, _, _ = delta(c0, I.gn_path_counters())
     assert tried == 2 and missed == 1
 
 
@@ -104,7 +104,7 @@ def test_window_duplicates_overload_a_bin():
     r[k + (n - k) // 2:, 0] = np.abs(r[k + (n - k) // 2:, 0]) + 1e-3
     c0 = I.gn_path_counters()
     check(T, a, a - r)
-    tried, missed, short, radix = delta(c0, I.gn_path_counters())
+    tried, missed, short, radix, _, _ = delta(c0, I.gn_path_counters())
     assert tried == 1 and missed == 1 and radix == 1
     # and the pipelines are back in their rest state afterwards
     a2, b2 = pairs(n, 3)
@@ -128,7 +128,7 @@ def test_window_even_and_odd_counts_and_signed_zero_medians():
         check(T, a, a - r)
         check(T, a, a - r)
         check(T, a, a - r)
-        tried, missed, _, _ = delta(c0, I.gn_path_counters())
+        tried, missed, _, _, _, _ = delta(c0, I.gn_path_counters())
         assert tried >= 2 and tried - missed >= 1  # at least one evaluation was served by the window pipeline
 
 
@@ -138,10 +138,32 @@ def test_estimate_uses_the_window_pipeline_and_stays_bit_exact():
     src, dst = synth.synthetic_pair(n, m)
     icp = I.Icp3d(dst)
     T, idx, inner = icp.estimate(src, I.Transform(), 8, return_info=True)
-    tried, missed, short, radix = I.gn_path_counters(icp)
+    tried, missed, short, radix, spec_hit, spec_miss = I.gn_path_counters(icp)
     assert tried > 8 and missed <= tried // 2
+    assert spec_hit + spec_miss > 0  # the outer loop bet on at least one next pose
     blocks, threads = I.reduce_geometry(n)
     rc, oT, oidx, oinner = O.icp_estimate(3, dst, src, O.transform_identity(), 8, use_kdtree=True,
+                                           sum_mode=1, reduce_blocks=blocks, reduce_threads=threads)
+    assert rc == O.OK
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(inner, oinner)
+    assert np.array_equal(T.as_array(), oT.as_array())
+
+
+def test_speculative_search_hits_and_misses_leave_the_result_alone():
+    """A small cloud whose inner loop needs a varying number of updates: the bet on the next pose is
+    sometimes wrong, the discarded search must not leak into the result (indices, inner counts and
+    pose equal the oracle's, bit for bit), and the same run with speculation disabled is identical."""
+    from icp_rust_amd import synth
+    n, m = 28_000, 28_000
+    src, dst = synth.synthetic_pair(n, m)
+    icp = I.Icp3d(dst)
+    T, idx, inner = icp.estimate(src, I.Transform(), 12, return_info=True)
+    _, _, _, _, hit, miss = I.gn_path_counters(icp)
+    assert hit + miss > 0
+    assert len(set(int(x) for x in inner)) > 1 or hit > 0
+    blocks, threads = I.reduce_geometry(n)
+    rc, oT, oidx, oinner = O.icp_estimate(3, dst, src, O.transform_identity(), 12, use_kdtree=True,
                                            sum_mode=1, reduce_blocks=blocks, reduce_threads=threads)
     assert rc == O.OK
     assert np.array_equal(idx, oidx)
