@@ -102,7 +102,9 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     if ((e = hipMemsetAsync(w.d_wstate, 0, sizeof(WinState), h->stream)) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_wmed, (size_t)2 * kWinCapMed * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc(&w.d_wring, (size_t)2 * kWinCapRing * sizeof(double))) != hipSuccess) return e;
-    if ((e = hipStreamCreateWithFlags(&w.spec_stream, hipStreamNonBlocking)) != hipSuccess) return e;
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if ((e = hipStreamCreateWithPriority(&w.spec_stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&w.spec_event, hipEventDisableTiming)) != hipSuccess) return e;
     if ((e = hipHostMalloc(&w.h_res, sizeof(GnResult), hipHostMallocCoherent)) != hipSuccess) return e;
     memset(w.h_res, 0, sizeof(GnResult));
@@ -461,9 +463,13 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
 // called when the evaluation at the once-updated pose T1 has been enqueued: if that evaluation
 // ends the loop -- the usual case once a registration has settled -- T1 is the result, so the
 // caller may start work for it while the device is still evaluating.
+// With `eval_stream` set, the evaluations after the first run on that stream (see
+// icp_estimate_device); `hook_first` calls the hook before that evaluation is enqueued instead of
+// after.
 template <typename Hook>
 static int estimate_transform_loop(icp_handle *h, const double *d_a, const double *d_b, size_t n, Pose *out,
-                                   uint32_t *inner_iters, Hook &&second_eval_hook) {
+                                   uint32_t *inner_iters, Hook &&second_eval_hook,
+                                   hipStream_t eval_stream = nullptr, bool hook_first = false) {
   Pose T = transform_identity();
   uint32_t applied = 0;
   if (input_size_ok(n)) {
@@ -472,8 +478,19 @@ static int estimate_transform_loop(icp_handle *h, const double *d_a, const doubl
     double prev_error = DBL_MAX;  // f64::MAX, src/lib.rs:63
     for (int it = 0; it < ICP_INNER_MAX_ITER; ++it) {
       double delta[3], err = 0.;
-      const int rc = (it == 1) ? wgn_step(h, d_a, d_b, n, T, delta, &err, [&] { return second_eval_hook(T); })
-                               : wgn_step(h, d_a, d_b, n, T, delta, &err);
+      hipStream_t first_stream = h->stream;
+      if (it >= 1 && eval_stream) h->stream = eval_stream;
+      if (it == 1 && hook_first) {
+        const hipError_t he = second_eval_hook(T);
+        if (he != hipSuccess) {
+          h->stream = first_stream;
+          return map_hip(he);
+        }
+      }
+      const int rc = (it == 1 && !hook_first)
+                         ? wgn_step(h, d_a, d_b, n, T, delta, &err, [&] { return second_eval_hook(T); })
+                         : wgn_step(h, d_a, d_b, n, T, delta, &err);
+      h->stream = first_stream;
       if (rc == ICP_NONE) break;           // src/lib.rs:67-69
       if (rc != ICP_OK) return rc;
       if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD)
@@ -504,11 +521,17 @@ extern "C" int icp_estimate_transform_device(icp_handle *h, const double *d_a, c
 // Speculative search: once the inner loop has needed exactly one update in the previous outer
 // iteration, the next pose is known as soon as that update is (T_next = Exp(delta_1) * T, provided
 // the evaluation at the updated pose ends the loop).  The search for T_next is then enqueued
-// right behind that evaluation's kernels, into the second pair buffer, instead of after the host
-// has seen its result: the host round trip between two outer iterations disappears from the
-// device's timeline.  The guess is verified bit for bit (the pose the loop really returns must
-// equal the speculated one); on a mismatch the speculative pairs are ignored and the search runs
-// again for the true pose.  Results cannot depend on it.
+// together with that evaluation instead of after the host has seen its result, into the second
+// pair buffer.  The guess is verified bit for bit (the pose the loop really returns must equal
+// the speculated one); on a mismatch the speculative pairs are ignored and the search runs again
+// for the true pose.  Results cannot depend on it.
+//
+// Two streams with fixed roles and no device-side dependency between them (resolving a
+// cross-queue event costs ~12 us here; every hand-over below goes through a host wait that the
+// loop needs anyway):  the handle's stream runs search -> first evaluation -> search -> ...; the
+// second, high-priority stream runs the later evaluations of an inner loop.  The search
+// (latency-bound, 4 waves/SIMD) and the evaluation it bets on (one workgroup per CU) then share
+// the CUs instead of queueing behind each other.
 extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *init,
                                    size_t max_iter, icp_pose *out, uint32_t *d_last_idx,
                                    uint32_t *inner_iters) {
@@ -516,16 +539,11 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(ensure_workspace(h, n, false));
   static const bool no_spec = getenv("ICP_NO_SPECULATION") != nullptr;
-  // two internal streams take turns; with a caller-supplied stream everything stays on that stream
-  static const bool same_stream_env = getenv("ICP_SPEC_SAME_STREAM") != nullptr;
-  const bool same_stream = same_stream_env || h->stream != h->own_stream;
-  struct StreamRoles {  // whatever happens below, the handle leaves with its own stream in place
-    icp_handle *h;
-    ~StreamRoles() {
-      if (h->stream != h->own_stream && h->ws.spec_stream == h->own_stream) std::swap(h->stream, h->ws.spec_stream);
-    }
-  } restore_roles{h};
+  static const bool one_stream_env = getenv("ICP_SPEC_SAME_STREAM") != nullptr;
+  static const bool nn_first = getenv("ICP_SPEC_NN_LAST") == nullptr;
   Workspace &w = h->ws;
+  // with a caller-supplied stream everything stays on that stream
+  const bool two_streams = !no_spec && !one_stream_env && h->stream == h->own_stream;
   Pose T = *init;
   if (max_iter > 0) {
     const int prc = icp_prepare_source_device(h, d_src, n, init);
@@ -536,50 +554,43 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   bool spec_valid = false;
   Pose spec_pose = T;
   uint32_t prev_inner = 0xffffffffu;
+  hipStream_t search_stream = h->stream;
   for (size_t it = 0; it < max_iter; ++it) {
     if (spec_valid && memcmp(&spec_pose, &T, sizeof(Pose)) == 0) {
       cur ^= 1;  // the pairs of this pose are already in (or on their way into) the other buffers
       ++w.spec_hits;
-      // the iteration continues on the stream the search runs on (no cross-queue dependency:
-      // resolving one costs ~12 us on this chip); everything else it touches was complete when
-      // the host saw the last evaluation's result
-      if (!same_stream) std::swap(h->stream, w.spec_stream);
     } else {
-      if (spec_valid) {
-        ++w.spec_misses;
-        if (!same_stream) HIP_TRY(hipStreamWaitEvent(h->stream, w.spec_event, 0));
-      }
+      if (spec_valid) ++w.spec_misses;  // the discarded search precedes this one on the same stream
       uint32_t *idx_out = (it + 1 == max_iter) ? d_last_idx : nullptr;
       const int rc = icp_correspond_device(h, d_src, n, &T, A[cur], B[cur], idx_out);
       if (rc != ICP_OK) return rc;
     }
     spec_valid = false;
     const bool speculate = !no_spec && n > 0 && h->m > 0 && it + 1 < max_iter && prev_inner == 1;
-    auto hook = [&](const Pose &T1) -> hipError_t {
-      if (!speculate) return hipSuccess;
+    auto launch_spec = [&](const Pose &T1) -> hipError_t {
       spec_pose = transform_mul(T1, T);  // src/lib.rs:127, 170 -- what the outer loop will compute
       uint32_t *idx_out = (it + 2 == max_iter) ? d_last_idx : nullptr;
       spec_valid = true;
-      if (same_stream) return launch_nn(h, d_src, n, &spec_pose, A[cur ^ 1], B[cur ^ 1], idx_out);
-      // on its own stream: the search (latency-bound, 4 waves/SIMD) and the evaluation it bets on
-      // (one workgroup per CU) share the CUs instead of queueing behind each other.  Everything
-      // the search reads was complete when the host saw the previous evaluation's result.
-      hipStream_t main_stream = h->stream;
-      h->stream = w.spec_stream;
-      hipError_t e = launch_nn(h, d_src, n, &spec_pose, A[cur ^ 1], B[cur ^ 1], idx_out);
-      h->stream = main_stream;
-      if (e == hipSuccess) e = hipEventRecord(w.spec_event, w.spec_stream);
+      hipStream_t eval_stream = h->stream;  // the hook runs inside the second evaluation
+      h->stream = search_stream;
+      const hipError_t e = launch_nn(h, d_src, n, &spec_pose, A[cur ^ 1], B[cur ^ 1], idx_out);
+      h->stream = eval_stream;
       return e;
     };
+    auto hook = [&](const Pose &T1) -> hipError_t { return speculate ? launch_spec(T1) : hipSuccess; };
     Pose dT;
     uint32_t inner = 0;
-    const int rc = estimate_transform_loop(h, A[cur], B[cur], n, &dT, &inner, hook);
+    // two streams: the search is enqueued first; the evaluation's workgroups arrive on the
+    // high-priority stream and are placed as soon as a CU has room
+    const int rc = estimate_transform_loop(h, A[cur], B[cur], n, &dT, &inner, hook,
+                                           two_streams ? w.spec_stream : nullptr, two_streams && nn_first);
     if (rc != ICP_OK) return rc;
     if (inner_iters) inner_iters[it] = inner;
     prev_inner = inner;
     T = transform_mul(dT, T);  // src/lib.rs:127, 170
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (two_streams) HIP_TRY(hipStreamSynchronize(w.spec_stream));
   h->qsort.valid = false;  // the caller may reuse or rewrite the source buffer
   *out = T;
   return ICP_OK;

@@ -359,15 +359,18 @@ __global__ __launch_bounds__(kReduceThreads) void k_pull_accumulate(const double
   block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
   // clear what the next evaluation accumulates into (nobody reads these in this launch)
   const unsigned G = gridDim.x * kReduceThreads;
+  // (write-through: the next evaluation may run on the handle's other stream before this
+  // kernel's end-of-kernel write-back, see gn_win.hip)
   for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x;
        i < (unsigned)(kSelRoles * kSelProblems * kSelBins); i += G)
-    hist[i] = 0;
-  if (blockIdx.x == 0 && threadIdx.x < kSelProblems) ctl->cand_cnt_pull[0][threadIdx.x] = 0;
+    __hip_atomic_store(&hist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (blockIdx.x == 0 && threadIdx.x < kSelProblems)
+    __hip_atomic_store(&ctl->cand_cnt_pull[0][threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   if (!last_block_arrives(&ctl->t[2])) return;
   const int nan_flag = scal->nan_flag, overflow = scal->overflow | (over ? 1 : 0);
   const double med[2] = {scal->median[0], scal->median[1]};
-  if (threadIdx.x == 0) scal->overflow = 0;
+  if (threadIdx.x == 0) __hip_atomic_store(&scal->overflow, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   publish_result(partials, res, seq, sig, med, nan_flag, overflow);
 }
 

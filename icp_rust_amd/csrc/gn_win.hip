@@ -304,7 +304,11 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
     WinRanges R = {};
     unsigned med_base = 0, med_cnt = 0, inner = 0, ring_cnt = 0;
     double range[4] = {0., 0., 0., 0.};
-    const bool ok = resolve_window(cum + d * kWinBins, n, P.d[d], R, med_base, med_cnt, inner, ring_cnt, range);
+    unsigned counted = 0;  // every point is in exactly one bin: anything else means the histogram is not
+#pragma unroll             // this evaluation's (defence in depth for the hand-over between streams)
+    for (int w = 0; w < 16; ++w) counted += s_wtot[d][w];
+    const bool ok = counted == n &&
+                    resolve_window(cum + d * kWinBins, n, P.d[d], R, med_base, med_cnt, inner, ring_cnt, range);
     if (lane == 0) {
       s_rng[d][0] = R.mlo;
       s_rng[d][1] = R.mhi;
@@ -624,9 +628,13 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
   if (!fail) accumulate_points(a, rx, ry, n, T, sig, acc);
   STAMP();
   block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
-  // the histograms of the next evaluation start from zero (nobody reads them in this launch)
+  // the histograms of the next evaluation start from zero (nobody reads them in this launch).
+  // Write-through stores: the next evaluation may run on the handle's other stream, handed over
+  // by the host as soon as it sees this kernel's result -- i.e. possibly before this kernel's
+  // end-of-kernel write-back, so nothing it must see may linger in an XCD's L2.
   const unsigned G = gridDim.x * kReduceThreads;
-  for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x; i < 2u * kWinBins; i += G) whist[i] = 0;
+  for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x; i < 2u * kWinBins; i += G)
+    __hip_atomic_store(&whist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   STAMP();
 #ifdef ICP_WIN_DEBUG
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && seq % 64 == 50)
