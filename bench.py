@@ -71,6 +71,50 @@ def cpu_baseline(src, dst, iters):
     }
 
 
+def gn_large(npts):
+    """the Gauss-Newton reduce kernels alone on a pair list far larger than the
+    256 MiB Infinity Cache, where HBM bandwidth -- not launch latency -- is what they run against.
+    One estimate_transform call on `npts` device-generated pairs; bytes per evaluation as SURVEY
+    prices them (96 B/point: 32 in + 16 out for the residual pass, 48 in for the accumulate pass;
+    the selection passes in between are implementation-defined and not counted)."""
+    import torch
+    import icp_rust_amd as I
+
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    a = (torch.rand((npts, 2), dtype=torch.float64, device="cuda", generator=g) - 0.5) * 80.0
+    c, s_ = np.cos(0.015), np.sin(0.015)
+    b = torch.empty_like(a)
+    b[:, 0] = c * a[:, 0] - s_ * a[:, 1] + 0.3
+    b[:, 1] = s_ * a[:, 0] + c * a[:, 1] - 0.2
+    b += torch.randn((npts, 2), dtype=torch.float64, device="cuda", generator=g) * 0.05
+    icp = I.Icp3d(torch.zeros((1, 3), dtype=torch.float64, device="cuda"))
+    icp.estimate_transform_device(a, b)  # warm-up: allocations, first-touch
+    torch.cuda.synchronize()
+    c0 = I.gn_path_counters(icp)
+    t0 = time.perf_counter()
+    _, applied = icp.estimate_transform_device(a, b)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c1 = I.gn_path_counters(icp)
+    evals = sum(c1[k] - c0[k] for k in (0, 2, 3))  # evaluations launched (a window miss counts twice)
+    icp.close()
+    per_eval = dt / max(evals, 1)
+    gbs = 96.0 * npts / per_eval / 1e9
+    window = c1[0] > c0[0]
+    digits = 2 if npts <= (4 << 20) else 3
+    # bytes the launches really stream per point: residual pass 32 in + 16 out, every further selection
+    # pass 16 in, accumulate 32 in
+    streamed = (48 + 16 + 32) if window else (48 + 16 * (2 * (digits + 1) - 1) + 32)
+    return {"points": npts, "evaluations": int(evals), "inner_iterations": int(applied),
+            "ms_per_evaluation": 1e3 * per_eval, "algorithmic_bytes_per_evaluation": 96 * npts,
+            "achieved_GBs": gbs, "peak_GBs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+            "streamed_bytes_per_point": streamed, "streamed_GBs": streamed * npts / per_eval / 1e9,
+            "streamed_frac": streamed * npts / per_eval / 1e9 / HBM_PEAK_GBS,
+            "pipeline": "window (3 launches)" if window else f"radix digits ({2 * (digits + 1) + 1} launches)",
+            "note": "reduce kernels alone on pairs past the 256 MiB Infinity Cache (SURVEY 8(d)(i)); bytes as SURVEY "
+                    "prices them, selection passes not counted"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +128,8 @@ def main():
     ap.add_argument("--brute-steps", type=int, default=3,
                     help="outer iterations of the brute-force sweep measured alongside (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=3, help="outer iterations of the CPU baseline (0 = skip)")
+    ap.add_argument("--gn-points", type=int, default=64 * 1024 * 1024,
+                    help="pairs of the separate 'reduce kernels alone, past the Infinity Cache' line (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -265,6 +311,8 @@ def main():
                 "value": brute["steps"] / brute["elapsed"], "unit": "iterations/s", "steps": brute["steps"],
                 "ms_per_step": 1e3 * brute["elapsed"] / brute["steps"], "roofline": nn_roofline(brute, n_shard),
             }
+        if world == 1 and args.gn_points > 0:
+            out["gn_large"] = gn_large(args.gn_points)
         if world == 1 and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(src_np, dst_np, args.cpu_iters)
         else:

@@ -17,7 +17,7 @@ constexpr int kNAcc = 13;             // jtj[9], jtr[3], huber error
 constexpr int kSelProblems = 4;       // {x, y} x {lower, upper middle order statistic}
 constexpr int kSelBins = 4096;        // 12-bit radix digits
 constexpr int kSelPasses = 6;         // 12+12+12+12+12+4 bits
-constexpr int kSelRoles = 4;          // fast path: histogram buffers {median, MAD} x {pass 0, pass 1}
+constexpr int kSelRoles = 6;          // fast path: histogram buffers {median, MAD} x {digit 0, 1, 2}
 constexpr int kSelCap = 1024;         // fast path: candidates kept per problem after two passes
 // window path (gn_win.hip): one piecewise-linear histogram per dimension instead of radix digits
 constexpr int kWinFine = 512;         // bins of each of the three fine windows (median, median -+ MAD)

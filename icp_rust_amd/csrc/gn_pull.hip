@@ -235,9 +235,14 @@ __global__ __launch_bounds__(kPullThreads) void k_pull_hist(const double2 *__res
       med0 = scal->median[0];
       med1 = scal->median[1];
     }
-    init_state(st, n);
-    if (pass == 1) {
-      resolve_hist(lh, hist_prev, st, 0, false, over);
+    if (pass >= 2) {  // third digit (large n): continue from the state the previous launch recorded
+#pragma unroll
+      for (int p = 0; p < kSelProblems; ++p) st[p] = sel_in[p];
+    } else {
+      init_state(st, n);
+    }
+    if (pass >= 1) {
+      resolve_hist(lh, hist_prev, st, pass - 1, false, over);
       if (blockIdx.x == 0 && threadIdx.x == 0)
 #pragma unroll
         for (int p = 0; p < kSelProblems; ++p) sel_out[p] = st[p];
@@ -284,13 +289,15 @@ __global__ __launch_bounds__(kPullThreads) void k_pull_hist(const double2 *__res
       }
 }
 
-// C: resolve digit 1, then append the keys sharing the 24-bit prefix to the candidate lists
+// C: resolve the last digit (the 2nd, or the 3rd for large n), then append the keys sharing the
+// 24- resp. 36-bit prefix to the candidate lists
 template <int MODE>
 __global__ __launch_bounds__(kPullThreads) void k_pull_compact(const double2 *__restrict__ a,
                                                                const double2 *__restrict__ b, Pose T,
                                                                double *__restrict__ rx, double *__restrict__ ry,
-                                                               unsigned n, int stage, const SelState *sel_in,
-                                                               SelState *sel_out, GnScalars *scal,
+                                                               unsigned n, int stage, int digits,
+                                                               const SelState *sel_in, SelState *sel_out,
+                                                               GnScalars *scal,
                                                                const uint32_t *__restrict__ hist_prev,
                                                                unsigned long long *cand, SelCtl *ctl) {
   __shared__ uint32_t lh[kSelProblems * kPullPad];
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(kPullThreads) void k_pull_compact(const double2 *__
   }
 #pragma unroll
   for (int p = 0; p < kSelProblems; ++p) st[p] = sel_in[p];
-  resolve_hist(lh, hist_prev, st, 1, true, over);
+  resolve_hist(lh, hist_prev, st, digits - 1, true, over);
   // the resolved state goes to the OTHER half of the state buffer: workgroups of this launch
   // that start later must still read the input state
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -319,13 +326,14 @@ __global__ __launch_bounds__(kPullThreads) void k_pull_compact(const double2 *__
     prefix[p] = st[p].prefix;
   }
   bool saw_nan = false;
+  const int cshift = 64 - 12 * digits;  // keys sharing the digits resolved so far
   unsigned *cnt = ctl->cand_cnt_pull[stage];
   stream_keys<MODE>(a, b, T, rx, ry, n, med0, med1, saw_nan, [&](unsigned long long k0, unsigned long long k1) {
 #pragma unroll
     for (int p = 0; p < kSelProblems; ++p) {
       if (!active[p]) continue;
       const unsigned long long key = (p < 2) ? k0 : k1;
-      if ((key >> 40) == (prefix[p] >> 40)) {
+      if ((key >> cshift) == (prefix[p] >> cshift)) {
         const unsigned pos = atomicAdd(&cnt[p], 1u);
         if (pos < (unsigned)kSelCap) cand[p * kSelCap + pos] = key;
       }
@@ -380,33 +388,56 @@ hipError_t launch_weighted_gn_pull(icp_handle *h, const double *d_a, const doubl
   const unsigned per = kPullThreads * kPullBatch;
   unsigned hb = (n + per - 1) / per;
   if (hb > 256) hb = 256;  // one workgroup per CU
-  const unsigned hb1 = hb / 2 > 0 ? hb / 2 : 1;  // digit-1 passes flush dense histograms: fewer, fatter workgroups
+  const unsigned hb1 = hb / 2 > 0 ? hb / 2 : 1;  // later digits flush dense histograms: fewer, fatter workgroups
+  // two 12-bit digits leave ~1e-4 n keys per prefix; beyond a few million points a third digit
+  // keeps the candidate lists short (n <= 2^32)
+  static const size_t three_from = getenv("ICP_PULL_3DIGITS_FROM") ? (size_t)atoll(getenv("ICP_PULL_3DIGITS_FROM")) : ((size_t)4 << 20);
+  const int digits = n_ > three_from ? 3 : 2;
   const double2 *a = (const double2 *)d_a, *b = (const double2 *)d_b;
   hipStream_t s = h->stream;
   const size_t role = (size_t)kSelProblems * kSelBins;
   uint32_t *H = w.d_hist;
   unsigned long long *C0 = w.d_cand, *C1 = w.d_cand + (size_t)kSelProblems * kSelCap;
   const dim3 bt(kPullThreads);
-  SelState *SA = w.d_sel, *SB = w.d_sel + kSelProblems;  // ping-pong: a launch never rewrites what it reads
-  hipLaunchKernelGGL(k_pull_hist<0>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 0, (const SelState *)SB, SA,
-                     w.d_scal, (const uint32_t *)nullptr, H + 0 * role, (const unsigned long long *)nullptr,
+  SelState *S[2] = {w.d_sel, w.d_sel + kSelProblems};  // ping-pong: a launch never rewrites what it reads
+  const unsigned long long *no_cand = nullptr;
+  const uint32_t *no_hist = nullptr;
+  int cur = 1;  // S[cur] = what the next launch reads, S[cur ^ 1] = what it records
+  // ---- median stage
+  hipLaunchKernelGGL(k_pull_hist<0>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 0, (const SelState *)S[cur],
+                     S[cur ^ 1], w.d_scal, no_hist, H + 0 * role, no_cand, w.d_ctl);
+  hipLaunchKernelGGL(k_pull_hist<1>, dim3(hb1), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 1, (const SelState *)S[cur],
+                     S[cur ^ 1], w.d_scal, (const uint32_t *)(H + 0 * role), H + 1 * role, no_cand, w.d_ctl);
+  cur ^= 1;
+  if (digits == 3) {
+    hipLaunchKernelGGL(k_pull_hist<1>, dim3(hb1), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 2, (const SelState *)S[cur],
+                       S[cur ^ 1], w.d_scal, (const uint32_t *)(H + 1 * role), H + 2 * role, no_cand, w.d_ctl);
+    cur ^= 1;
+  }
+  hipLaunchKernelGGL(k_pull_compact<1>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 0, digits,
+                     (const SelState *)S[cur], S[cur ^ 1], w.d_scal, (const uint32_t *)(H + (digits - 1) * role), C0,
                      w.d_ctl);
-  hipLaunchKernelGGL(k_pull_hist<1>, dim3(hb1), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 1, (const SelState *)SB, SA,
-                     w.d_scal, (const uint32_t *)(H + 0 * role), H + 1 * role,
-                     (const unsigned long long *)nullptr, w.d_ctl);
-  hipLaunchKernelGGL(k_pull_compact<1>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 0, (const SelState *)SA,
-                     SB, w.d_scal, (const uint32_t *)(H + 1 * role), C0, w.d_ctl);
-  hipLaunchKernelGGL(k_pull_hist<2>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 0, (const SelState *)SB, SA,
-                     w.d_scal, (const uint32_t *)nullptr, H + 2 * role, (const unsigned long long *)C0, w.d_ctl);
-  hipLaunchKernelGGL(k_pull_hist<2>, dim3(hb1), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 1, (const SelState *)SB, SA,
-                     w.d_scal, (const uint32_t *)(H + 2 * role), H + 3 * role,
-                     (const unsigned long long *)nullptr, w.d_ctl);
-  hipLaunchKernelGGL(k_pull_compact<2>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 1, (const SelState *)SA,
-                     SB, w.d_scal, (const uint32_t *)(H + 3 * role), C1, w.d_ctl);
+  cur ^= 1;
+  // ---- MAD stage (its first launch turns the median candidates into the median)
+  hipLaunchKernelGGL(k_pull_hist<2>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 0, (const SelState *)S[cur],
+                     S[cur ^ 1], w.d_scal, no_hist, H + 3 * role, (const unsigned long long *)C0, w.d_ctl);
+  hipLaunchKernelGGL(k_pull_hist<2>, dim3(hb1), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 1, (const SelState *)S[cur],
+                     S[cur ^ 1], w.d_scal, (const uint32_t *)(H + 3 * role), H + 4 * role, no_cand, w.d_ctl);
+  cur ^= 1;
+  if (digits == 3) {
+    hipLaunchKernelGGL(k_pull_hist<2>, dim3(hb1), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 2, (const SelState *)S[cur],
+                       S[cur ^ 1], w.d_scal, (const uint32_t *)(H + 4 * role), H + 5 * role, no_cand, w.d_ctl);
+    cur ^= 1;
+  }
+  hipLaunchKernelGGL(k_pull_compact<2>, dim3(hb), bt, 0, s, a, b, T, w.d_rx, w.d_ry, n, 1, digits,
+                     (const SelState *)S[cur], S[cur ^ 1], w.d_scal, (const uint32_t *)(H + (3 + digits - 1) * role), C1,
+                     w.d_ctl);
+  cur ^= 1;
   int blocks, threads;
   reduce_geometry(n_, &blocks, &threads);
   hipLaunchKernelGGL(k_pull_accumulate, dim3(blocks), dim3(threads), 0, s, a, w.d_rx, w.d_ry, n, T,
-                     (const SelState *)SB, w.d_scal, (const unsigned long long *)C1, w.d_partials, w.d_hist, w.d_ctl, w.h_res, ++w.seq);
+                     (const SelState *)S[cur], w.d_scal, (const unsigned long long *)C1, w.d_partials, w.d_hist, w.d_ctl,
+                     w.h_res, ++w.seq);
   return hipGetLastError();
 }
 
