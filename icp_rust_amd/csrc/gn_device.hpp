@@ -95,7 +95,7 @@ __device__ __forceinline__ bool last_block_arrives(TicketSet *t) {
 
 // src/lib.rs:238-255 (+ :45-50) over this thread's points g, g + G, ... in index order (the
 // first level of the fixed reduction tree); residuals come from the arrays the first launch wrote
-constexpr int kAccBatch = 4;
+template <int kAccBatch = 4>
 __device__ __forceinline__ void accumulate_points(const double2 *__restrict__ a, const double *__restrict__ rx,
                                                   const double *__restrict__ ry, unsigned n, const Pose &T,
                                                   const double (&sig)[2], double (&acc)[kNAcc]) {

@@ -29,8 +29,9 @@
 
 namespace icp {
 
-constexpr int kWinThreads = 1024;
+constexpr int kWinThreads = 512;  // workgroups small enough to be placed beside the search kernel's waves
 constexpr int kWinBatch = 4;
+constexpr int kWinAccBatch = 4;  // loads in flight per lane in A (2 saves 16 VGPRs but loses more than the better placement gains)
 constexpr int kSubBins = 1024;   // select_pair: linear sub-bins over the candidates
 constexpr int kSmallCap = 1024;  // select_pair: keys ranked by counting, per dimension (a run of equal keys lands here)
 constexpr size_t kWinMinN = 1u << 15;
@@ -263,19 +264,31 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
   __shared__ int s_rng[2][8];
   __shared__ double s_med[2][kWinBlkMed], s_ring[2][kWinBlkRing];
   __shared__ unsigned s_cnt[4];
-  static_assert(kWinBins == 2 * kWinThreads, "two bins per thread");
+  constexpr int PER = kWinBins / kWinThreads, NW = kWinThreads / 64;
+  static_assert(PER * kWinThreads == kWinBins && (PER == 2 || PER == 4), "bins per thread");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef ICP_WIN_DEBUG
   long long cst[6];
   cst[0] = wall_clock64();
 #endif
   if (tid < 4) s_cnt[tid] = 0;
-  unsigned first[2], inc[2], tot[2];
+  unsigned v[2][PER], inc[2], tot[2];
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
-    const uint2 v = reinterpret_cast<const uint2 *>(whist + d * kWinBins)[tid];
-    first[d] = v.x;
-    tot[d] = v.x + v.y;
+    if (PER == 2) {
+      const uint2 x = reinterpret_cast<const uint2 *>(whist + d * kWinBins)[tid];
+      v[d][0] = x.x;
+      v[d][1] = x.y;
+    } else {
+      const uint4 x = reinterpret_cast<const uint4 *>(whist + d * kWinBins)[tid];
+      v[d][0] = x.x;
+      v[d][1] = x.y;
+      v[d][PER - 2] = x.z;
+      v[d][PER - 1] = x.w;
+    }
+    tot[d] = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) tot[d] += v[d][i];
     unsigned s = tot[d];
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -290,10 +303,13 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
   for (int d = 0; d < 2; ++d) {
     unsigned wbase = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) wbase += (w < wave) ? s_wtot[d][w] : 0u;
-    const unsigned base = wbase + inc[d] - tot[d];
-    cum[d * kWinBins + 2 * tid] = base;
-    cum[d * kWinBins + 2 * tid + 1] = base + first[d];
+    for (int w = 0; w < NW; ++w) wbase += (w < wave) ? s_wtot[d][w] : 0u;
+    unsigned run = wbase + inc[d] - tot[d];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      cum[d * kWinBins + PER * tid + i] = run;
+      run += v[d][i];
+    }
   }
   __syncthreads();
 #ifdef ICP_WIN_DEBUG
@@ -306,7 +322,7 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
     double range[4] = {0., 0., 0., 0.};
     unsigned counted = 0;  // every point is in exactly one bin: anything else means the histogram is not
 #pragma unroll             // this evaluation's (defence in depth for the hand-over between streams)
-    for (int w = 0; w < 16; ++w) counted += s_wtot[d][w];
+    for (int w = 0; w < NW; ++w) counted += s_wtot[d][w];
     const bool ok = counted == n &&
                     resolve_window(cum + d * kWinBins, n, P.d[d], R, med_base, med_cnt, inner, ring_cnt, range);
     if (lane == 0) {
@@ -625,7 +641,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
   double acc[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; ++k) acc[k] = 0.;
-  if (!fail) accumulate_points(a, rx, ry, n, T, sig, acc);
+  if (!fail) accumulate_points<kWinAccBatch>(a, rx, ry, n, T, sig, acc);
   STAMP();
   block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
   // the histograms of the next evaluation start from zero (nobody reads them in this launch).
