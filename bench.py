@@ -220,6 +220,22 @@ def main():
         elapsed = time.perf_counter() - t0
         nn_ms, nn_launches = icp.profile_read()
         icp.profile_enable(0)
+        alone_ms = None
+        if world == 1 and steps >= 20:
+            # outside the timed region: the same search kernel with nothing beside it (stage calls on one
+            # stream: no speculative overlap), for comparison with the overlapped duration above
+            solo = ShardedIcp(HipStages(icp), n, 0, 1)
+            Ts = I.Transform()
+            solo.stages.prepare(d_src, Ts)
+            for _ in range(3):
+                Ts, _ = solo.step(d_src, Ts)
+            icp.profile_enable(1)
+            icp.profile_read()
+            for _ in range(12):
+                Ts, _ = solo.step(d_src, Ts)
+            a_ms, a_n = icp.profile_read()
+            icp.profile_enable(0)
+            alone_ms = a_ms / max(a_n, 1)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -227,7 +243,7 @@ def main():
         engine = {I.NN_BRUTE: "brute", I.NN_GRID: "grid"}[I.lib().icp_get_nn_mode(icp._h)]
         icp.close()
         return dict(elapsed=elapsed, steps=steps, inner=inner, nn_ms=nn_ms, nn_launches=nn_launches, T=T,
-                    engine=engine)
+                    engine=engine, alone_ms=alone_ms)
 
     def nn_roofline(r, n_shard):
         """Roofline of the dominant kernel (the NN search) from the live HIP-event timing."""
@@ -259,7 +275,12 @@ def main():
                 "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": "profiles/r01_traffic_pmc.json (separate rocprofv3 --pmc passes)",
                 "avg_launch_ms": 1e3 * avg_s,
-                "launches": int(r["nn_launches"]), "algorithmic_bytes_per_launch": nn_bytes}
+                "launches": int(r["nn_launches"]), "algorithmic_bytes_per_launch": nn_bytes,
+                # in the timed region the kernel shares the CUs with the Gauss-Newton evaluation that decides
+                # its pose (speculative search); alone it is shorter:
+                "alone": None if not r.get("alone_ms") else {
+                    "avg_launch_ms": r["alone_ms"], "achieved": nn_bytes / (1e-3 * r["alone_ms"]) / 1e9,
+                    "frac": nn_bytes / (1e-3 * r["alone_ms"]) / 1e9 / HBM_PEAK_GBS}}
 
     res = measure(nn_mode, args.steps, args.warmup)
     brute = None
