@@ -193,3 +193,15 @@ def test_two_stream_estimate_equals_single_stream_stage_calls_repeatedly():
         assert inner.tolist() == inner_ref.tolist(), rep
     hit, miss = I.gn_path_counters(fused)[4:]
     assert hit > 0
+
+
+def test_three_digit_radix_pipeline_beyond_4m_points():
+    """Above 4M pairs the window pipeline stands down and the radix pipeline takes a third 12-bit
+    digit per stage (candidate lists would overflow after two); same bits as the oracle's tree."""
+    n = 4_500_000
+    a, b = pairs(n, 99)
+    T = I.Transform([0.39, -0.31, 0.0199])
+    c0 = I.gn_path_counters()
+    check(T, a, b)
+    tried, missed, short, radix, _, _ = delta(c0, I.gn_path_counters())
+    assert tried == 0 and short == 1 and radix == 0
