@@ -255,6 +255,7 @@ extern "C" void icp_destroy(icp_handle *h) {
   (void)hipFree(h->qsort.d_start);
   (void)hipFree(h->qsort.d_btot);
   (void)hipFree(h->qsort.d_cell_of);
+  (void)hipFree(h->qsort.d_rank_of);
   (void)hipFree(h->qsort.d_perm);
   (void)hipFree(h->qsort.d_sorted);
   (void)hipFree(h->qsort.d_prev);

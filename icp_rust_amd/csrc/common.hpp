@@ -175,7 +175,8 @@ struct QuerySort {
   const double *src = nullptr;  // the device buffer this snapshot was taken from
   size_t n = 0, cap = 0;
   uint32_t *d_cnt = nullptr, *d_start = nullptr, *d_btot = nullptr;
-  uint32_t *d_cell_of = nullptr, *d_perm = nullptr;
+  uint32_t *d_cell_of = nullptr, *d_rank_of = nullptr, *d_perm = nullptr;
+  bool have_prev = false;      // d_prev holds the matches of an earlier search of this snapshot
   PrevMatch *d_prev = nullptr; // per sorted slot: the last match (idx = ~0u: none)
   double *d_sorted = nullptr;
 };

@@ -256,14 +256,15 @@ __device__ unsigned long long g_nn_hist[2][32];  // [0]: lanes by record chunks,
 #define NN_STAT(i, v) ((void)0)
 #endif
 
-template <int DIM, bool XFORM>
+// COLD: no previous matches exist (first search of a source snapshot, or unsorted queries)
+template <int DIM, bool XFORM, bool COLD>
 __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
                                                  const uint32_t *__restrict__ perm, unsigned n, Pose T,
                                                  GridParams g, const uint32_t *__restrict__ start,
                                                  const GridPoint *__restrict__ pts,
                                                  const double *__restrict__ dst, uint32_t *__restrict__ idx,
                                                  double2 *__restrict__ a, double2 *__restrict__ b,
-                                                 PrevMatch *__restrict__ prev) {
+                                                 const PrevMatch *__restrict__ prev, PrevMatch *prev_out) {
 #ifdef ICP_NN_STATS
   unsigned st[8] = {1, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -353,6 +354,26 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   // evaluating a target twice cannot change the winner, and a repeated address costs next to
   // nothing -- divergent control flow is what is expensive here)
   constexpr uint32_t kBatch = 8;
+  // Exact evaluation of the records of one batch that pass the screen.  In the cold search no
+  // tight bound exists at first (thr32 = +inf: every record passes, and each exact evaluation is
+  // a dependent gather from dst), so the record with the smallest screened distance goes first:
+  // it almost always is the batch's winner and its bound then rejects the rest.  (A macro, not
+  // a lambda: arrays passed by reference end up in scratch memory.)
+#define ICP_EXAMINE(t, sc)                                                        \
+  do {                                                                            \
+    if (COLD && thr32 == __builtin_huge_valf()) {                                 \
+      float sm_ = sc[0];                                                          \
+      uint32_t ti_ = t[0].idx;                                                    \
+      _Pragma("unroll") for (uint32_t u_ = 1; u_ < kBatch; ++u_) {                \
+        const bool lt_ = sc[u_] < sm_;                                            \
+        sm_ = lt_ ? sc[u_] : sm_;                                                 \
+        ti_ = lt_ ? t[u_].idx : ti_;                                              \
+      }                                                                           \
+      consider(ti_);                                                              \
+    }                                                                             \
+    _Pragma("unroll") for (uint32_t u_ = 0; u_ < kBatch; ++u_)                    \
+      if (!(sc[u_] > thr32)) consider(t[u_].idx);                                 \
+  } while (0)
   auto batch = [&](uint32_t p, uint32_t e) {
     NN_STAT(2, 1);
     const uint32_t last = e - 1;
@@ -362,9 +383,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
     float sc[kBatch];
 #pragma unroll
     for (uint32_t u = 0; u < kBatch; ++u) sc[u] = screen(t[u]);
-#pragma unroll
-    for (uint32_t u = 0; u < kBatch; ++u)
-      if (!(sc[u] > thr32)) consider(t[u].idx);
+    ICP_EXAMINE(t, sc);
   };
   // distance from q to the slab of cells [i0, i1] on axis d (0 inside); outermost cells
   // extend to infinity (targets are clamped into them)
@@ -459,9 +478,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
         float sc[kBatch];
 #pragma unroll
         for (uint32_t u = 0; u < kBatch; ++u) sc[u] = screen(t[u]);
-#pragma unroll
-        for (uint32_t u = 0; u < kBatch; ++u)
-          if (!(sc[u] > thr32)) consider(t[u].idx);
+        ICP_EXAMINE(t, sc);
       }
     }
   };
@@ -473,7 +490,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   // of the 3^DIM block.  The previous match is a real target and every cell that can hold a
   // closer-or-equal one is visited, so the result is the same exact minimum by (d^2, index).
   bool done = false;
-  if (prev) {
+  if (!COLD && prev) {
     const PrevMatch pm = prev[k];  // coalesced per-slot record (index + exact coordinates), not a gather
     if (pm.idx != 0xffffffffu) {
       NN_STAT(7, 1);
@@ -503,17 +520,30 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
       const uint32_t row = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0];
       const uint32_t s = start[row + x0], e = start[row + x1 + 1];
       for (uint32_t p = s; p < e; p += kBatch) batch(p, e);
-      int lo_c[3], hi_c[3];
+      int lo_c[3] = {0, 0, 0}, hi_c[3] = {0, 0, 0};
+      if (best < __builtin_huge_val()) {
+        // the centre row gave a candidate at distance r: every target that can beat or tie it lies
+        // in the cell box of the ball, exactly as in the warm search -- one walk instead of shells
+        const double rad = sqrt(best) * (1. + 1e-9);
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const int w = d == 0 ? g.fx : 1;
-        lo_c[d] = max(c[d] - w, 0);
-        hi_c[d] = min(c[d] + w, g.n[d] - 1);
+        for (int d = 0; d < DIM; ++d) {
+          lo_c[d] = cell_coord(q[d] - rad - mg[d], g.lo[d], g.inv_h[d], g.n[d]);
+          hi_c[d] = cell_coord(q[d] + rad + mg[d], g.lo[d], g.inv_h[d], g.n[d]);
+        }
+        walk_box(lo_c, hi_c);
+        done = true;
+      } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const int w = d == 0 ? g.fx : 1;
+          lo_c[d] = max(c[d] - w, 0);
+          hi_c[d] = min(c[d] + w, g.n[d] - 1);
+        }
+        walk_box(lo_c, hi_c);  // the other rows of the block are pruned by `best` as it appears
       }
-      walk_box(lo_c, hi_c);  // re-reads the centre row (cached); the other rows are pruned by `best`
     }
     const int rmax = max(max(g.n[0], g.n[1]), g.n[2]);
-    for (int r = 1; r <= rmax; ++r) {
+    for (int r = 1; r <= rmax && !done; ++r) {
       if (r >= 2) {  // shell r of the general walk (rings 0 and 1 were handled above)
         const int z0 = DIM == 3 ? max(c[2] - r, 0) : 0, z1 = DIM == 3 ? min(c[2] + r, g.n[2] - 1) : 0;
         const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
@@ -583,14 +613,14 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
     }
   }
 #endif
-  if (prev) {
+  if (prev_out) {
     PrevMatch pm;
     pm.x = bx;
     pm.y = by;
     pm.z = bz;
     pm.idx = bi;
     pm.pad = 0;
-    prev[k] = pm;
+    prev_out[k] = pm;
   }
   if (bi == 0xffffffffu) {  // no finite distance at all (NaN query): index 0, as a scan from 0 would
     bi = 0;
@@ -609,7 +639,8 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
 // nothing downstream can tell the difference -- except the memory system: a wave's 64
 // queries now walk the same few cells.
 __global__ void k_query_count(const double *__restrict__ src, unsigned n, int dim, Pose T, GridParams g,
-                              uint32_t *__restrict__ cell_of, uint32_t *__restrict__ cnt) {
+                              uint32_t *__restrict__ cell_of, uint32_t *__restrict__ rank_of,
+                              uint32_t *__restrict__ cnt) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double q[3] = {src[(size_t)i * dim], src[(size_t)i * dim + 1], dim == 3 ? src[(size_t)i * dim + 2] : 0.};
@@ -621,17 +652,16 @@ __global__ void k_query_count(const double *__restrict__ src, unsigned n, int di
   for (int d = 0; d < dim; ++d) c[d] = cell_coord(q[d], g.lo[d], g.inv_h[d], g.n[d]);
   const uint32_t cell = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0] + c[0];
   cell_of[i] = cell;
-  atomicAdd(&cnt[cell], 1u);
+  rank_of[i] = atomicAdd(&cnt[cell], 1u);  // arrival order inside the cell: the scatter needs no second counter
 }
 
 __global__ void k_query_scatter(const double *__restrict__ src, unsigned n, int dim,
-                                const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ start,
-                                uint32_t *__restrict__ cursor, double *__restrict__ sorted,
+                                const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ rank_of,
+                                const uint32_t *__restrict__ start, double *__restrict__ sorted,
                                 uint32_t *__restrict__ perm) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t cell = cell_of[i];
-  const uint32_t pos = start[cell] + atomicAdd(&cursor[cell], 1u);
+  const uint32_t pos = start[cell_of[i]] + rank_of[i];
   perm[pos] = i;
   for (int d = 0; d < dim; ++d) sorted[(size_t)pos * dim + d] = src[(size_t)i * dim + d];
 }
@@ -654,14 +684,16 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   if (n_ > Q.cap) {
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     (void)hipFree(Q.d_cell_of);
+    (void)hipFree(Q.d_rank_of);
     (void)hipFree(Q.d_perm);
     (void)hipFree(Q.d_sorted);
     (void)hipFree(Q.d_prev);
     Q.d_prev = nullptr;
-    Q.d_cell_of = Q.d_perm = nullptr;
+    Q.d_cell_of = Q.d_perm = Q.d_rank_of = nullptr;
     Q.d_sorted = nullptr;
     Q.cap = 0;
     if ((e = hipMalloc(&Q.d_cell_of, n_ * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&Q.d_rank_of, n_ * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_perm, n_ * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_sorted, n_ * h->dim * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_prev, n_ * sizeof(PrevMatch))) != hipSuccess) return e;
@@ -669,14 +701,14 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   }
   if ((e = hipMemsetAsync(Q.d_cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_query_count, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, T, G.p,
-                     Q.d_cell_of, Q.d_cnt);
+                     Q.d_cell_of, Q.d_rank_of, Q.d_cnt);
   hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, s, Q.d_cnt, Q.d_start, nscan, Q.d_btot);
   hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, Q.d_btot, nb, Q.d_btot + nb);
   hipLaunchKernelGGL(k_scan_add, dim3((nscan + 255) / 256), dim3(256), 0, s, Q.d_start, nscan, Q.d_btot);
-  if ((e = hipMemsetAsync(Q.d_cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, Q.d_cell_of,
-                     Q.d_start, Q.d_cnt, Q.d_sorted, Q.d_perm);
-  if ((e = hipMemsetAsync(Q.d_prev, 0xff, n_ * sizeof(PrevMatch), s)) != hipSuccess) return e;  // idx = ~0u: none yet
+  hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim,
+                     (const uint32_t *)Q.d_cell_of, (const uint32_t *)Q.d_rank_of, (const uint32_t *)Q.d_start,
+                     Q.d_sorted, Q.d_perm);
+  Q.have_prev = false;  // the first search of this snapshot reads no previous matches, it only records them
   if ((e = hipGetLastError()) != hipSuccess) return e;
   Q.src = d_src;
   Q.n = n_;
@@ -695,7 +727,9 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   const bool sorted = xform && Q.valid && Q.src == d_src && Q.n == n_;
   const double *q_src = sorted ? Q.d_sorted : d_src;
   const uint32_t *q_perm = sorted ? Q.d_perm : nullptr;
-  PrevMatch *q_prev = sorted ? Q.d_prev : nullptr;
+  PrevMatch *q_prev_out = sorted ? Q.d_prev : nullptr;
+  const PrevMatch *q_prev = (sorted && Q.have_prev) ? Q.d_prev : nullptr;
+  if (sorted) h->qsort.have_prev = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (h->profile > 0 && (h->prof_seen++ % (unsigned)h->profile) == 0) {
     if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
@@ -703,14 +737,20 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   }
   const unsigned blocks = (n + 255) / 256;
 #define GRID(DIM, XF)                                                                                   \
-  hipLaunchKernelGGL((k_nn_grid<DIM, XF>), dim3(blocks), dim3(256), 0, h->stream, q_src, q_perm, n, T,   \
-                     G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, q_prev)
+  if (q_prev)                                                                                           \
+    GRID2(DIM, XF, false);                                                                              \
+  else                                                                                                  \
+    GRID2(DIM, XF, true)
+#define GRID2(DIM, XF, CD)                                                                              \
+  hipLaunchKernelGGL((k_nn_grid<DIM, XF, CD>), dim3(blocks), dim3(256), 0, h->stream, q_src, q_perm, n, T, \
+                     G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, q_prev, q_prev_out)
   if (h->dim == 3) {
-    if (xform) GRID(3, true); else GRID(3, false);
+    if (xform) { GRID(3, true); } else { GRID(3, false); }
   } else {
-    if (xform) GRID(2, true); else GRID(2, false);
+    if (xform) { GRID(2, true); } else { GRID(2, false); }
   }
 #undef GRID
+#undef GRID2
   hipError_t e = hipGetLastError();
   if (ev0 && ev1) {
     (void)hipEventRecord(ev1, h->stream);
