@@ -32,8 +32,8 @@ namespace icp {
 constexpr int kWinThreads = 512;  // workgroups small enough to be placed beside the search kernel's waves
 constexpr int kWinBatch = 4;
 constexpr int kWinAccBatch = 4;  // loads in flight per lane in A (2 saves 16 VGPRs but loses more than the better placement gains)
-constexpr int kSubBins = 1024;   // select_pair: linear sub-bins over the candidates
-constexpr int kSmallCap = 1024;  // select_pair: keys ranked by counting, per dimension (a run of equal keys lands here)
+constexpr int kSubBins = 1024;   // select_n: linear sub-bins over the candidates
+constexpr int kSmallCap = 1024;  // select_n: keys ranked by counting, per dimension (a run of equal keys lands here)
 constexpr size_t kWinMinN = 1u << 15;
 constexpr size_t kWinMaxN = 1u << 22;
 
@@ -460,49 +460,50 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *total)
   return before + s - v;
 }
 
-// Two exact selections at once (x and y), by the whole workgroup, on candidates that stay in
+// ND (1 or 2) exact selections at once, by the whole workgroup, on candidates that stay in
 // registers: thread t holds candidates t, t + 512, ... of the dense list of dimension d, cnt[d]
 // in all.  Wanted: the keys of ranks rlo[d] <= rhi[d] <= rlo[d] + 1 among them.  Linear sub-bins
 // over [lo[d], hi[d]] (monotone in the value; values outside clamp to the end bins) locate the
 // few keys around the ranks; those go to LDS and are ranked by counting on their
 // order-preserving keys.  fail (uniform): a rank outside the list, or more than kSmallCap keys
 // in the wanted sub-bins.
-template <int NV>
-__device__ __forceinline__ void select_pair(const double (&v)[2][NV], const unsigned (&cnt)[2],
-                                            const double (&lo)[2], const double (&hi)[2],
-                                            const long long (&rlo)[2], const long long (&rhi)[2],
-                                            unsigned long long (&out)[2][2], bool &fail) {
+template <int ND, int NV>
+__device__ __forceinline__ void select_n(const double (&v)[ND][NV], const unsigned (&cnt)[ND],
+                                         const double (&lo)[ND], const double (&hi)[ND],
+                                         const long long (&rlo)[ND], const long long (&rhi)[ND],
+                                         unsigned long long (&out)[ND][2], bool &fail) {
+  static_assert(ND == 1 || ND == 2, "one or two lists");
   static_assert(kSubBins == 2 * kReduceThreads, "geometry");
-  __shared__ unsigned s_hist[2][kSubBins];
-  __shared__ unsigned long long s_small[2][kSmallCap];
-  __shared__ unsigned s_nsmall[2], s_sb[2][2], s_below[2];
-  __shared__ unsigned long long s_out[2][2];
+  __shared__ unsigned s_hist[ND][kSubBins];
+  __shared__ unsigned long long s_small[ND][kSmallCap];
+  __shared__ unsigned s_nsmall[ND], s_sb[ND][2], s_below[ND];
+  __shared__ unsigned long long s_out[ND][2];
   const unsigned tid = threadIdx.x;
 #pragma unroll
-  for (int d = 0; d < 2; ++d) out[d][0] = out[d][1] = 0;
+  for (int d = 0; d < ND; ++d) out[d][0] = out[d][1] = 0;
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+  for (int d = 0; d < ND; ++d)
     if (rlo[d] < 0 || rhi[d] >= (long long)cnt[d] || rhi[d] < rlo[d] || cnt[d] > 0xffffu) fail = true;
   if (fail) return;  // uniform
-  for (unsigned i = tid; i < 2u * kSubBins; i += kReduceThreads) (&s_hist[0][0])[i] = 0;
-  if (tid < 2) {
+  for (unsigned i = tid; i < (unsigned)ND * kSubBins; i += kReduceThreads) (&s_hist[0][0])[i] = 0;
+  if (tid < (unsigned)ND) {
     s_nsmall[tid] = 0;
     s_sb[tid][0] = s_sb[tid][1] = 0;
     s_below[tid] = 0;
     s_out[tid][0] = s_out[tid][1] = 0;
   }
   __syncthreads();
-  double scale[2];
+  double scale[ND];
 #pragma unroll
-  for (int d = 0; d < 2; ++d) scale[d] = hi[d] > lo[d] ? (double)(kSubBins - 1) / (hi[d] - lo[d]) : 0.;
+  for (int d = 0; d < ND; ++d) scale[d] = hi[d] > lo[d] ? (double)(kSubBins - 1) / (hi[d] - lo[d]) : 0.;
   auto sub = [&](int d, double x) -> unsigned {
     const double t = (x - lo[d]) * scale[d];  // monotone in x
     const unsigned sb = t > 0. ? (unsigned)t : 0u;
     return sb < (unsigned)kSubBins ? sb : (unsigned)(kSubBins - 1);
   };
-  unsigned sbv[2][NV];
+  unsigned sbv[ND][NV];
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+  for (int d = 0; d < ND; ++d)
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       sbv[d][u] = sub(d, v[d][u]);
@@ -510,12 +511,12 @@ __device__ __forceinline__ void select_pair(const double (&v)[2][NV], const unsi
     }
   __syncthreads();
   // one scan for both dimensions: 16 bits each (counts <= 65535, checked above)
-  const unsigned c0 = s_hist[0][2 * tid] | (s_hist[1][2 * tid] << 16);
-  const unsigned c1 = s_hist[0][2 * tid + 1] | (s_hist[1][2 * tid + 1] << 16);
+  const unsigned c0 = s_hist[0][2 * tid] | (ND == 2 ? s_hist[ND - 1][2 * tid] << 16 : 0u);
+  const unsigned c1 = s_hist[0][2 * tid + 1] | (ND == 2 ? s_hist[ND - 1][2 * tid + 1] << 16 : 0u);
   unsigned total;
   const unsigned e0 = block_excl_scan(c0 + c1, &total), e1 = e0 + c0;
 #pragma unroll
-  for (int d = 0; d < 2; ++d) {
+  for (int d = 0; d < ND; ++d) {
     const int sh = 16 * d;
     const unsigned E0 = (e0 >> sh) & 0xffffu, C0 = (c0 >> sh) & 0xffffu;
     const unsigned E1 = (e1 >> sh) & 0xffffu, C1 = (c1 >> sh) & 0xffffu;
@@ -533,7 +534,7 @@ __device__ __forceinline__ void select_pair(const double (&v)[2][NV], const unsi
   }
   __syncthreads();
 #pragma unroll
-  for (int d = 0; d < 2; ++d) {
+  for (int d = 0; d < ND; ++d) {
     const unsigned sb_lo = s_sb[d][0], sb_hi = s_sb[d][1];
 #pragma unroll
     for (int u = 0; u < NV; ++u)
@@ -543,12 +544,12 @@ __device__ __forceinline__ void select_pair(const double (&v)[2][NV], const unsi
       }
   }
   __syncthreads();
-  if (s_nsmall[0] > (unsigned)kSmallCap || s_nsmall[1] > (unsigned)kSmallCap) {
+  if (s_nsmall[0] > (unsigned)kSmallCap || s_nsmall[ND - 1] > (unsigned)kSmallCap) {
     fail = true;  // uniform
     return;
   }
 #pragma unroll
-  for (int d = 0; d < 2; ++d) {
+  for (int d = 0; d < ND; ++d) {
     const unsigned ns = s_nsmall[d];
     const unsigned rl = (unsigned)rlo[d], rh = (unsigned)rhi[d];
     for (unsigned i = tid; i < ns; i += kReduceThreads) {
@@ -565,7 +566,7 @@ __device__ __forceinline__ void select_pair(const double (&v)[2][NV], const unsi
   }
   __syncthreads();
 #pragma unroll
-  for (int d = 0; d < 2; ++d) {
+  for (int d = 0; d < ND; ++d) {
     out[d][0] = s_out[d][0];
     out[d][1] = s_out[d][1];
   }
@@ -577,10 +578,72 @@ __device__ __forceinline__ double middle_of(unsigned n, unsigned long long klo, 
   return (n & 1) ? lo : (lo + hi) / 2.;  // src/stats.rs:18-27
 }
 
+// The order statistics of one evaluation from its candidate lists, one workgroup per dimension
+// (half the registers of doing both at once): the co-resident variant of the pipeline runs this
+// as its own tiny launch so that the accumulate kernel stays small.
+__global__ __launch_bounds__(kReduceThreads) void k_win_select(unsigned n, WinState *st,
+                                                               const double *__restrict__ wmed,
+                                                               const double *__restrict__ wring, GnScalars *scal) {
+  constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
+  const unsigned tid = threadIdx.x;
+  const int d = blockIdx.x;
+  const unsigned klo = (n - 1) / 2, khi = n / 2;
+  double med = 0., sig = 0.;
+  bool fail = false;
+  if (st->fail == 0) {  // (written by k_win_compact; this kernel only ever raises it)
+    double vm[1][PM], vr[1][PR];
+#pragma unroll
+    for (int u = 0; u < PM; ++u) vm[0][u] = wmed[(size_t)d * kWinCapMed + tid + u * kReduceThreads];
+#pragma unroll
+    for (int u = 0; u < PR; ++u) vr[0][u] = wring[(size_t)d * kWinCapRing + tid + u * kReduceThreads];
+    const unsigned em[1] = {st->med_cnt[d]}, er[1] = {st->ring_cnt[d]};
+    // (the appended counts are cross-checked against the histogram: a mismatch is a miss)
+    fail = st->list_cnt[d][0] != em[0] || st->list_cnt[2 + d][0] != er[0];
+    const double m_lo[1] = {st->med_lo[d]}, m_hi[1] = {st->med_hi[d]};
+    const double r_lo[1] = {st->ring_lo[d]}, r_hi[1] = {st->ring_hi[d]};
+    const long long mlo[1] = {(long long)klo - st->med_base[d]}, mhi[1] = {(long long)khi - st->med_base[d]};
+    const long long dlo[1] = {(long long)klo - st->ring_inner[d]}, dhi[1] = {(long long)khi - st->ring_inner[d]};
+    unsigned long long key[1][2];
+    if (!fail) select_n<1, PM>(vm, em, m_lo, m_hi, mlo, mhi, key, fail);
+    if (!fail) {
+      med = middle_of(n, key[0][0], key[0][1]);
+#pragma unroll
+      for (int u = 0; u < PR; ++u) vr[0][u] = fabs(vr[0][u] - med);  // src/stats.rs:35
+      select_n<1, PR>(vr, er, r_lo, r_hi, dlo, dhi, key, fail);
+      if (!fail) sig = ICP_PPF34 * middle_of(n, key[0][0], key[0][1]);  // src/stats.rs:42-46
+    }
+  }
+  if (tid == 0) {  // the accumulate kernel is the next launch on this stream
+    scal->median[d] = med;
+    scal->sigma[d] = sig;
+    if (fail) atomicOr(&st->fail, 1u);
+  }
+}
+
+// INLINE_SELECT: every workgroup derives the order statistics itself (lowest latency: the
+// evaluation the host is waiting for).  Otherwise k_win_select has left them in `scal`, and this
+// kernel needs few enough registers (68) to be placed beside three search waves per SIMD.
+template <bool INLINE_SELECT>
 __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
     const double2 *__restrict__ a, const double *__restrict__ rx, const double *__restrict__ ry, unsigned n, Pose T,
     const WinState *__restrict__ st, const double *__restrict__ wmed, const double *__restrict__ wring,
     GnScalars *scal, double *partials, uint32_t *whist, SelCtl *ctl, GnResult *res, unsigned seq) {
+  if (!INLINE_SELECT) {
+    const bool failed = st->fail != 0;
+    const double med0[2] = {scal->median[0], scal->median[1]};
+    const double sig0[2] = {scal->sigma[0], scal->sigma[1]};
+    double acc[kNAcc];
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k) acc[k] = 0.;
+    if (!failed) accumulate_points<2>(a, rx, ry, n, T, sig0, acc);
+    block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
+    const unsigned G0 = gridDim.x * kReduceThreads;  // (write-through, see below)
+    for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x; i < 2u * kWinBins; i += G0)
+      __hip_atomic_store(&whist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!last_block_arrives(&ctl->t[2])) return;
+    publish_result(partials, res, seq, sig0, med0, scal->nan_flag, failed ? 2 : 0);
+    return;
+  }
   constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
   static_assert(kWinCapMed % kReduceThreads == 0 && kWinCapRing % kReduceThreads == 0, "candidates per thread");
   const unsigned tid = threadIdx.x;
@@ -619,7 +682,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
     unsigned long long key[2][2];
     const long long mlo[2] = {(long long)klo - mbase[0], (long long)klo - mbase[1]};
     const long long mhi[2] = {(long long)khi - mbase[0], (long long)khi - mbase[1]};
-    select_pair<PM>(vm, em, m_lo, m_hi, mlo, mhi, key, fail);
+    select_n<2, PM>(vm, em, m_lo, m_hi, mlo, mhi, key, fail);
     STAMP();
     if (!fail) {
 #pragma unroll
@@ -630,7 +693,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
       }
       const long long dlo[2] = {(long long)klo - inner[0], (long long)klo - inner[1]};
       const long long dhi[2] = {(long long)khi - inner[0], (long long)khi - inner[1]};
-      select_pair<PR>(vr, er, r_lo, r_hi, dlo, dhi, key, fail);
+      select_n<2, PR>(vr, er, r_lo, r_hi, dlo, dhi, key, fail);
       STAMP();
       if (!fail) {
         sig[0] = ICP_PPF34 * middle_of(n, key[0][0], key[0][1]);  // src/stats.rs:42-46
@@ -701,6 +764,10 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
   if (hb > (unsigned)kWinBlocks) hb = kWinBlocks;
   const double2 *a = (const double2 *)d_a, *b = (const double2 *)d_b;
   hipStream_t s = h->stream;
+  // on the evaluation stream this runs beside a speculative search: the variant whose every
+  // workgroup fits next to three search waves per SIMD (one extra tiny launch; latency is hidden)
+  static const bool no_co = getenv("ICP_WIN_NO_CORESIDENT") != nullptr;
+  const bool coresident = !no_co && h->stream == w.spec_stream;
   hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(kWinThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
                      w.d_wstate, w.d_scal);
   hipLaunchKernelGGL(k_win_compact, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
@@ -708,10 +775,17 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
                      w.d_wring);
   int blocks, threads;
   reduce_geometry(n_, &blocks, &threads);
-  hipLaunchKernelGGL(k_win_accumulate, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
-                     (const double *)w.d_ry, n, T, (const WinState *)w.d_wstate,
-                     (const double *)w.d_wmed, (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist,
-                     w.d_ctl, w.h_res, ++w.seq);
+  if (coresident) {
+    hipLaunchKernelGGL(k_win_select, dim3(2), dim3(kReduceThreads), 0, s, n, w.d_wstate, (const double *)w.d_wmed,
+                       (const double *)w.d_wring, w.d_scal);
+    hipLaunchKernelGGL(k_win_accumulate<false>, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
+                       (const double *)w.d_ry, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
+                       (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, ++w.seq);
+  } else {
+    hipLaunchKernelGGL(k_win_accumulate<true>, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
+                       (const double *)w.d_ry, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
+                       (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, ++w.seq);
+  }
   return hipGetLastError();
 }
 
