@@ -48,34 +48,62 @@ hipError_t grow(Tp *&p, size_t count) {
   return hipMalloc(&p, (count ? count : 1) * sizeof(Tp));
 }
 
+void free_ctx(GnCtx &c) {
+  (void)hipFree(c.d_rx);
+  (void)hipFree(c.d_ry);
+  (void)hipFree(c.d_hist);
+  (void)hipFree(c.d_cand);
+  (void)hipFree(c.d_ctl);
+  (void)hipFree(c.d_sel);
+  (void)hipFree(c.d_scal);
+  (void)hipFree(c.d_partials);
+  (void)hipFree(c.d_whist);
+  (void)hipFree(c.d_wstate);
+  (void)hipFree(c.d_wmed);
+  (void)hipFree(c.d_wring);
+  if (c.h_res) (void)hipHostFree(c.h_res);
+}
+
 void free_workspace(Workspace &w) {
   (void)hipFree(w.d_src);
   (void)hipFree(w.d_a);
   (void)hipFree(w.d_b);
   (void)hipFree(w.d_a2);
   (void)hipFree(w.d_b2);
-  (void)hipFree(w.d_rx);
-  (void)hipFree(w.d_ry);
   (void)hipFree(w.d_idx);
   (void)hipFree(w.d_part_d);
   (void)hipFree(w.d_part_i);
-  (void)hipFree(w.d_hist);
-  (void)hipFree(w.d_cand);
-  (void)hipFree(w.d_ctl);
-  (void)hipFree(w.d_sel);
-  (void)hipFree(w.d_scal);
-  (void)hipFree(w.d_partials);
-  (void)hipFree(w.d_whist);
-  (void)hipFree(w.d_wstate);
-  (void)hipFree(w.d_wmed);
-  (void)hipFree(w.d_wring);
-  if (w.h_res) (void)hipHostFree(w.h_res);
+  free_ctx(w);
+  free_ctx(w.alt);
   if (w.spec_event) (void)hipEventDestroy(w.spec_event);
   if (w.spec_stream) {
     (void)hipStreamSynchronize(w.spec_stream);
     (void)hipStreamDestroy(w.spec_stream);
   }
   w = Workspace();
+}
+
+hipError_t alloc_ctx(GnCtx &c, hipStream_t s) {
+  hipError_t e;
+  const size_t hist_bytes = (size_t)kSelRoles * kSelProblems * kSelBins * sizeof(uint32_t);
+  if ((e = hipMalloc(&c.d_hist, hist_bytes)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(c.d_hist, 0, hist_bytes, s)) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_cand, (size_t)2 * kSelProblems * kSelCap * sizeof(unsigned long long))) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_ctl, sizeof(SelCtl))) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(c.d_ctl, 0, sizeof(SelCtl), s)) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_sel, 2 * kSelProblems * sizeof(SelState))) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_scal, sizeof(GnScalars))) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_partials, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double))) != hipSuccess) return e;
+  const size_t whist_bytes = (size_t)2 * kWinBins * sizeof(uint32_t);
+  if ((e = hipMalloc(&c.d_whist, whist_bytes)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(c.d_whist, 0, whist_bytes, s)) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_wstate, sizeof(WinState))) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(c.d_wstate, 0, sizeof(WinState), s)) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_wmed, (size_t)2 * kWinCapMed * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_wring, (size_t)2 * kWinCapRing * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipHostMalloc(&c.h_res, sizeof(GnResult), hipHostMallocCoherent)) != hipSuccess) return e;
+  memset(c.h_res, 0, sizeof(GnResult));
+  return hipSuccess;
 }
 
 }  // namespace
@@ -86,32 +114,19 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
   Workspace &w = h->ws;
   hipError_t e;
   if (!w.d_hist) {
-    const size_t hist_bytes = (size_t)kSelRoles * kSelProblems * kSelBins * sizeof(uint32_t);
-    if ((e = hipMalloc(&w.d_hist, hist_bytes)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(w.d_hist, 0, hist_bytes, h->stream)) != hipSuccess) return e;
-    if ((e = hipMalloc(&w.d_cand, (size_t)2 * kSelProblems * kSelCap * sizeof(unsigned long long))) != hipSuccess) return e;
-    if ((e = hipMalloc(&w.d_ctl, sizeof(SelCtl))) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(w.d_ctl, 0, sizeof(SelCtl), h->stream)) != hipSuccess) return e;
-    if ((e = hipMalloc(&w.d_sel, 2 * kSelProblems * sizeof(SelState))) != hipSuccess) return e;
-    if ((e = hipMalloc(&w.d_scal, sizeof(GnScalars))) != hipSuccess) return e;
-    if ((e = hipMalloc(&w.d_partials, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double))) != hipSuccess) return e;
-    const size_t whist_bytes = (size_t)2 * kWinBins * sizeof(uint32_t);
-    if ((e = hipMalloc(&w.d_whist, whist_bytes)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(w.d_whist, 0, whist_bytes, h->stream)) != hipSuccess) return e;
-    if ((e = hipMalloc(&w.d_wstate, sizeof(WinState))) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(w.d_wstate, 0, sizeof(WinState), h->stream)) != hipSuccess) return e;
-    if ((e = hipMalloc(&w.d_wmed, (size_t)2 * kWinCapMed * sizeof(double))) != hipSuccess) return e;
-    if ((e = hipMalloc(&w.d_wring, (size_t)2 * kWinCapRing * sizeof(double))) != hipSuccess) return e;
+    if ((e = alloc_ctx(w, h->stream)) != hipSuccess) return e;
+    if ((e = alloc_ctx(w.alt, h->stream)) != hipSuccess) return e;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if ((e = hipStreamCreateWithPriority(&w.spec_stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&w.spec_event, hipEventDisableTiming)) != hipSuccess) return e;
-    if ((e = hipHostMalloc(&w.h_res, sizeof(GnResult), hipHostMallocCoherent)) != hipSuccess) return e;
-    memset(w.h_res, 0, sizeof(GnResult));
+    // the memsets above must have landed before either stream uses the scratch
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
   }
   if (n > w.cap_n) {
     // in-flight work may still read the old buffers
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(w.spec_stream)) != hipSuccess) return e;
     size_t cap = n + n / 8;
     (void)hipFree(w.d_src);
     w.d_src = nullptr;
@@ -121,6 +136,8 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     if ((e = grow(w.d_b2, cap * 2)) != hipSuccess) return e;
     if ((e = grow(w.d_rx, cap)) != hipSuccess) return e;
     if ((e = grow(w.d_ry, cap)) != hipSuccess) return e;
+    if ((e = grow(w.alt.d_rx, cap)) != hipSuccess) return e;
+    if ((e = grow(w.alt.d_ry, cap)) != hipSuccess) return e;
     if ((e = grow(w.d_idx, cap)) != hipSuccess) return e;
     w.cap_n = cap;
   }
@@ -243,8 +260,10 @@ extern "C" void icp_destroy(icp_handle *h) {
     (void)hipEventDestroy(ev.second);
   }
   if (getenv("ICP_DBG_WIN") && h->ws.win_tried)
-    fprintf(stderr, "[icp] window evaluations: %llu tried, %llu missed; speculative searches: %llu hit, %llu missed\n",
-            h->ws.win_tried, h->ws.win_missed, h->ws.spec_hits, h->ws.spec_misses);
+    fprintf(stderr,
+            "[icp] window evaluations: %llu tried, %llu missed; speculative searches: %llu hit, %llu missed; "
+            "first evaluations launched ahead: %llu\n",
+            h->ws.win_tried, h->ws.win_missed, h->ws.spec_hits, h->ws.spec_misses, h->ws.pre_evals);
   free_workspace(h->ws);
   if (h->owns_dst) (void)hipFree(const_cast<double *>(h->d_dst));
   (void)hipFree(h->d_dst_soa);
@@ -392,9 +411,11 @@ static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
 // Huber error of the same T (src/lib.rs:75), which shares the pass.
 // `after_launch` (optional) runs once, right after the first attempt's kernels have been enqueued
 // and before the host waits for them: the place to enqueue work that does not depend on the result.
+// `pre_launched`: the window pipeline for exactly this evaluation is already in flight on this
+// stream (icp_estimate_device enqueued it behind the speculative search); only its result is awaited.
 template <typename Hook>
 static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
-                    double delta[3], double *huber_err, Hook &&after_launch) {
+                    double delta[3], double *huber_err, Hook &&after_launch, bool pre_launched = false) {
   static const bool force_radix = getenv("ICP_GN_RADIX") != nullptr;
   Workspace &w = h->ws;
   bool done = false, has_median = false, hooked = false;
@@ -404,11 +425,13 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   }
   if (!force_radix) {
     WinParams P;
-    if (window_usable(h, n, &P)) {  // three launches around the previous evaluation's median and sigma
-      ++w.win_tried;
-      HIP_TRY(launch_weighted_gn_win(h, d_a, d_b, n, T, P));
-      HIP_TRY(after_launch());
-      hooked = true;
+    if (pre_launched || window_usable(h, n, &P)) {  // three launches around the previous evaluation's median and sigma
+      if (!pre_launched) {
+        ++w.win_tried;
+        HIP_TRY(launch_weighted_gn_win(h, d_a, d_b, n, T, P));
+        HIP_TRY(after_launch());
+        hooked = true;
+      }
       HIP_TRY(wait_result(h));
       done = has_median = !w.h_res->overflow;
       if (!done) {
@@ -456,8 +479,8 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
 }
 static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
-                    double delta[3], double *huber_err) {
-  return wgn_step(h, d_a, d_b, n, T, delta, huber_err, [] { return hipSuccess; });
+                    double delta[3], double *huber_err, bool pre_launched = false) {
+  return wgn_step(h, d_a, d_b, n, T, delta, huber_err, [] { return hipSuccess; }, pre_launched);
 }
 
 // estimate_transform (src/lib.rs:59-84) on device pairs.  `second_eval_hook(T1)` (optional) is
@@ -470,7 +493,8 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
 template <typename Hook>
 static int estimate_transform_loop(icp_handle *h, const double *d_a, const double *d_b, size_t n, Pose *out,
                                    uint32_t *inner_iters, Hook &&second_eval_hook,
-                                   hipStream_t eval_stream = nullptr, bool hook_first = false) {
+                                   hipStream_t eval_stream = nullptr, bool hook_first = false,
+                                   bool first_pre_launched = false) {
   Pose T = transform_identity();
   uint32_t applied = 0;
   if (input_size_ok(n)) {
@@ -480,18 +504,28 @@ static int estimate_transform_loop(icp_handle *h, const double *d_a, const doubl
     for (int it = 0; it < ICP_INNER_MAX_ITER; ++it) {
       double delta[3], err = 0.;
       hipStream_t first_stream = h->stream;
-      if (it >= 1 && eval_stream) h->stream = eval_stream;
+      const bool on_eval_stream = it >= 1 && eval_stream;
+      if (on_eval_stream) {  // the other stream and its own evaluation scratch
+        h->stream = eval_stream;
+        h->ws.swap_ctx();
+      }
       if (it == 1 && hook_first) {
         const hipError_t he = second_eval_hook(T);
         if (he != hipSuccess) {
-          h->stream = first_stream;
+          if (on_eval_stream) {
+            h->stream = first_stream;
+            h->ws.swap_ctx();
+          }
           return map_hip(he);
         }
       }
       const int rc = (it == 1 && !hook_first)
                          ? wgn_step(h, d_a, d_b, n, T, delta, &err, [&] { return second_eval_hook(T); })
-                         : wgn_step(h, d_a, d_b, n, T, delta, &err);
-      h->stream = first_stream;
+                         : wgn_step(h, d_a, d_b, n, T, delta, &err, it == 0 && first_pre_launched);
+      if (on_eval_stream) {
+        h->stream = first_stream;
+        h->ws.swap_ctx();
+      }
       if (rc == ICP_NONE) break;           // src/lib.rs:67-69
       if (rc != ICP_OK) return rc;
       if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD)
@@ -552,29 +586,54 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   }
   double *A[2] = {w.d_a, w.d_a2}, *B[2] = {w.d_b, w.d_b2};
   int cur = 0;
-  bool spec_valid = false;
+  bool spec_valid = false, pre_valid = false, first_pre_launched = false;
+  static const bool no_pre = getenv("ICP_NO_PRE_EVAL") != nullptr;
   Pose spec_pose = T;
-  uint32_t prev_inner = 0xffffffffu;
+  // the bet needs "the inner loop took exactly one update last time"; across calls the handle
+  // remembers how its previous call ended (a new frame usually behaves like the last one)
+  uint32_t prev_inner = w.last_inner;
   hipStream_t search_stream = h->stream;
   for (size_t it = 0; it < max_iter; ++it) {
     if (spec_valid && memcmp(&spec_pose, &T, sizeof(Pose)) == 0) {
       cur ^= 1;  // the pairs of this pose are already in (or on their way into) the other buffers
       ++w.spec_hits;
+      first_pre_launched = pre_valid;
     } else {
+      first_pre_launched = false;  // (a pre-launched evaluation of discarded pairs just runs out; nobody reads it)
       if (spec_valid) ++w.spec_misses;  // the discarded search precedes this one on the same stream
       uint32_t *idx_out = (it + 1 == max_iter) ? d_last_idx : nullptr;
       const int rc = icp_correspond_device(h, d_src, n, &T, A[cur], B[cur], idx_out);
       if (rc != ICP_OK) return rc;
     }
     spec_valid = false;
+    pre_valid = false;
     const bool speculate = !no_spec && n > 0 && h->m > 0 && it + 1 < max_iter && prev_inner == 1;
     auto launch_spec = [&](const Pose &T1) -> hipError_t {
       spec_pose = transform_mul(T1, T);  // src/lib.rs:127, 170 -- what the outer loop will compute
       uint32_t *idx_out = (it + 2 == max_iter) ? d_last_idx : nullptr;
       spec_valid = true;
+      pre_valid = false;
       hipStream_t eval_stream = h->stream;  // the hook runs inside the second evaluation
       h->stream = search_stream;
-      const hipError_t e = launch_nn(h, d_src, n, &spec_pose, A[cur ^ 1], B[cur ^ 1], idx_out);
+      hipError_t e = launch_nn(h, d_src, n, &spec_pose, A[cur ^ 1], B[cur ^ 1], idx_out);
+      if (e == hipSuccess && two_streams && !no_pre) {
+        // ... and the next iteration's FIRST evaluation (inner pose = identity) right behind it,
+        // in the search stream's own evaluation scratch: if the bet holds, its result is waiting
+        // when the host gets there
+        WinParams P;
+        w.swap_ctx();
+        if (w.gn_dirty) {
+          e = launch_sel_init(h, n);
+          w.gn_dirty = false;
+        }
+        if (e == hipSuccess && window_usable(h, n, &P)) {
+          ++w.win_tried;
+          ++w.pre_evals;
+          e = launch_weighted_gn_win(h, A[cur ^ 1], B[cur ^ 1], n, transform_identity(), P);
+          pre_valid = true;
+        }
+        w.swap_ctx();
+      }
       h->stream = eval_stream;
       return e;
     };
@@ -584,10 +643,12 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     // two streams: the search is enqueued first; the evaluation's workgroups arrive on the
     // high-priority stream and are placed as soon as a CU has room
     const int rc = estimate_transform_loop(h, A[cur], B[cur], n, &dT, &inner, hook,
-                                           two_streams ? w.spec_stream : nullptr, two_streams && nn_first);
+                                           two_streams ? w.spec_stream : nullptr, two_streams && nn_first,
+                                           first_pre_launched);
     if (rc != ICP_OK) return rc;
     if (inner_iters) inner_iters[it] = inner;
     prev_inner = inner;
+    w.last_inner = inner;
     T = transform_mul(dT, T);  // src/lib.rs:127, 170
   }
   HIP_TRY(hipStreamSynchronize(h->stream));

@@ -103,23 +103,13 @@ struct GnResult {
   unsigned pad;
 };
 
-struct Workspace {
-  size_t cap_n = 0;        // points the per-point buffers hold
-  double *d_src = nullptr; // staged source cloud (host API), cap_n x dim
-  double *d_a = nullptr;   // transformed source xy, cap_n x 2
-  double *d_b = nullptr;   // matched target xy, cap_n x 2
-  double *d_a2 = nullptr;  // second pair buffers: the speculative search of the next outer iteration
-  double *d_b2 = nullptr;
-  unsigned long long spec_hits = 0, spec_misses = 0;
-  hipStream_t spec_stream = nullptr;  // the speculative search runs beside the evaluation it bets on
-  hipEvent_t spec_event = nullptr;
+// Scratch of ONE Gauss-Newton evaluation in flight.  A handle has two of them, one per stream of
+// icp_estimate_device (an evaluation that decides a speculated pose and the speculated next
+// iteration's first evaluation are in flight together); `Workspace` derives from the active one,
+// so the launchers simply see `w.d_rx` etc., and switching the stream swaps it with `alt`.
+struct GnCtx {
   double *d_rx = nullptr;  // residual x, cap_n
   double *d_ry = nullptr;  // residual y, cap_n
-  uint32_t *d_idx = nullptr;
-  // brute-force NN partial minima when the target range is split over blockIdx.y
-  size_t cap_part = 0;
-  double *d_part_d = nullptr;
-  uint32_t *d_part_i = nullptr;
   // selection + reduction scratch (fixed size)
   uint32_t *d_hist = nullptr;   // kSelRoles x kSelProblems x kSelBins (role 0 also serves the radix path)
   unsigned long long *d_cand = nullptr;  // 2 stages x kSelProblems x kSelCap candidate keys
@@ -135,6 +125,27 @@ struct Workspace {
   WinState *d_wstate = nullptr;
   double *d_wmed = nullptr;     // 2 x kWinCapMed residuals
   double *d_wring = nullptr;    // 2 x kWinCapRing residuals
+};
+
+struct Workspace : GnCtx {
+  GnCtx alt;               // the other stream's evaluation scratch
+  void swap_ctx() { std::swap(static_cast<GnCtx &>(*this), alt); }
+  size_t cap_n = 0;        // points the per-point buffers hold
+  double *d_src = nullptr; // staged source cloud (host API), cap_n x dim
+  double *d_a = nullptr;   // transformed source xy, cap_n x 2
+  double *d_b = nullptr;   // matched target xy, cap_n x 2
+  double *d_a2 = nullptr;  // second pair buffers: the speculative search of the next outer iteration
+  double *d_b2 = nullptr;
+  unsigned long long spec_hits = 0, spec_misses = 0, pre_evals = 0;
+  uint32_t last_inner = 0xffffffffu;  // updates the inner loop applied in the last outer iteration of the previous call
+  hipStream_t spec_stream = nullptr;  // later evaluations of an inner loop run beside the speculative search
+  hipEvent_t spec_event = nullptr;
+  uint32_t *d_idx = nullptr;
+  // brute-force NN partial minima when the target range is split over blockIdx.y
+  size_t cap_part = 0;
+  double *d_part_d = nullptr;
+  uint32_t *d_part_i = nullptr;
+  // prediction for the window path (host state, shared by both contexts)
   bool win_valid = false;       // median/sigma of the previous evaluation are known
   bool win_wide = false;        // the last window missed: use wider fine windows until it settles
   double win_med[2] = {0., 0.}, win_sigma[2] = {0., 0.};
