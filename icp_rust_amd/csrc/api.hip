@@ -452,8 +452,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
       hooked = true;
       HIP_TRY(wait_result(h));
       done = !w.h_res->overflow;
-      static const bool push = getenv("ICP_GN_PUSH") != nullptr;
-      has_median = done && n > 1024 && !push;  // only gn_pull.hip reports the median
+      has_median = done && n > 1024;  // gn_pull.hip reports the median, the single-workgroup kernel does not
     }
   }
   if (!done) {  // heavy duplicates around a median: the general 6-pass radix select
@@ -498,8 +497,6 @@ static int estimate_transform_loop(icp_handle *h, const double *d_a, const doubl
   Pose T = transform_identity();
   uint32_t applied = 0;
   if (input_size_ok(n)) {
-    static const bool push = getenv("ICP_GN_PUSH") != nullptr;
-    if (push) h->ws.gn_dirty = true;  // the debugging pipeline expects a fresh search state per call
     double prev_error = DBL_MAX;  // f64::MAX, src/lib.rs:63
     for (int it = 0; it < ICP_INNER_MAX_ITER; ++it) {
       double delta[3], err = 0.;

@@ -64,7 +64,6 @@ struct TicketSet {
 // Tickets and candidate counters of the fast selection path (all zero between launches).
 struct SelCtl {
   TicketSet t[3];
-  unsigned cand_cnt[kSelProblems];
   unsigned cand_cnt_pull[2][kSelProblems];  // gn_pull.hip: candidates per stage (median, MAD)
   unsigned pad[20];
 };

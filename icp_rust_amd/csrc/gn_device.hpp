@@ -1,4 +1,4 @@
-// Device helpers shared by the Gauss-Newton kernels (gn.hip, gn_fast.hip).
+// Device helpers shared by the Gauss-Newton kernels (gn.hip, gn_fast.hip, gn_pull.hip, gn_win.hip).
 #pragma once
 #include "common.hpp"
 

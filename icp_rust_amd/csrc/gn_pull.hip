@@ -1,14 +1,14 @@
 // "Pull" variant of the short pipeline for one inner Gauss-Newton evaluation
-// (src/lib.rs:218-261 + :45-50): the same seven launches as gn_fast.hip,
+// (src/lib.rs:218-261 + :45-50): seven launches,
 //     H(median, digit 0)  H(median, digit 1)  C(median)  H(MAD, digit 0)  H(MAD, digit 1)  C(MAD)  A
-// but nobody waits for a last workgroup any more.  In gn_fast.hip every selection launch ends
+// and nobody waits for a last workgroup.  In the first ("push") version every selection launch ended
 // with a serial tail (arrival ticket -> one workgroup scans the histograms / ranks the
 // candidates: 3.5-8 us per launch by in-kernel stamps).  Here the NEXT launch resolves the
 // previous launch's output in its prologue, redundantly in every workgroup (a 2 x 4096-bin
 // histogram or a <= 1024-key candidate list is a few us of L2-resident reads, all workgroups
 // in parallel): the kernel boundary is the only synchronisation, and workgroup 0 records the
 // resolved state for the launch after next.  Only A, which must produce ONE sum, keeps a
-// last-workgroup tail.  Results are bit-identical to gn_fast.hip / gn.hip: integer
+// last-workgroup tail.  Results are bit-identical to gn.hip: integer
 // histograms, exact rank counting, the same reduction tree.
 #include "common.hpp"
 #include "gn_device.hpp"
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kPullThreads) void k_pull_compact(const double2 *__
 }
 
 // A: sigma from the MAD candidates, then src/lib.rs:238-255 (+ :45-50) in the fixed tree; the
-// last workgroup folds the block sums and publishes to the host (as in gn_fast.hip).
+// last workgroup folds the block sums and publishes to the host.
 __global__ __launch_bounds__(kReduceThreads) void k_pull_accumulate(const double2 *__restrict__ a,
                                                                     const double *__restrict__ rx,
                                                                     const double *__restrict__ ry,

@@ -17,7 +17,7 @@
 // and appends both candidate sets while re-reading the residuals once.  A ranks the median
 // candidates, turns the ring into distances to that exact median, ranks those behind |I|, and
 // accumulates.  Every order statistic is the exact one, so the results are bit-identical to
-// gn_pull.hip / gn_fast.hip / gn.hip and to the oracle's tree variant.  When the prediction
+// gn_pull.hip / gn.hip and to the oracle's tree variant.  When the prediction
 // is off (an order statistic outside its fine window, too many candidates) the evaluation
 // reports `overflow = 2` and the host repeats it with gn_pull.hip, which also re-centres the
 // windows.  (A single fine histogram over the whole range needs ~2 scattered global atomics per

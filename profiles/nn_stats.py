@@ -28,19 +28,3 @@ for it in range(16):
     print("   lanes by chunks:", hv[:32]); print("   waves by max chunks:", hv[32:])
     print(f"   per query: rows {v[1]/q:.2f} batches {v[2]/q:.2f} exact {v[3]/q:.2f} | per wave: loop steps {v[4]/w:.1f} lifetime {v[5]/w:.0f} cycles")
 
-# phase times of the histogram kernels (diagnostic stamps)
-L.icp_debug_hist_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
-hs = (C.c_uint64 * 48)()
-L.icp_debug_hist_stamps(hs, 1)
-for it in range(3):
-    T, k = drv.step(d_src, T)
-torch.cuda.synchronize()
-L.icp_debug_hist_stamps(hs, 0)
-v = list(hs)
-for row, nm in enumerate(["H0 (MODE0 p0)", "H1 (MODE1 p1)", "H0' (MODE2 p0)", "H1' (MODE2 p1)"]):
-    r = v[row * 8: row * 8 + 8]
-    wg, tails = max(r[5], 1), max(r[6], 1)
-    print(f"{nm}: per workgroup cycles: zero {r[0]/wg:.0f} stream {r[1]/wg:.0f} flush {r[2]/wg:.0f} ticket {r[3]/wg:.0f} | tail {r[4]/tails:.0f} (launches {r[6]})")
-r = v[4 * 8: 4 * 8 + 8]
-wg, tails = max(r[5], 1), max(r[6], 1)
-print(f"A (accumulate): per workgroup cycles: stream+math {r[0]/wg:.0f} block reduce {r[1]/wg:.0f} zero+ticket {r[2]/wg:.0f} | tail {r[4]/tails:.0f} (launches {r[6]})")
