@@ -36,7 +36,7 @@ def residuals(rng, n, kind):
 KINDS = ["gauss", "heavy", "skew", "bimodal", "ties", "mixed_scale"]
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(18))
 def test_random_sequences_of_evaluations(seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(33_000, 400_000))
@@ -68,7 +68,7 @@ def test_random_sequences_of_evaluations(seed):
     assert tried + short + radix >= 5
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(6))
 def test_random_registrations_equal_the_oracle(seed):
     """Whole estimate calls on random sub-clouds of the synthetic pair: indices, inner counts and
     pose bit-equal to the oracle in tree order (speculation hits and misses included)."""
