@@ -75,7 +75,6 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_part_i);
   free_ctx(w);
   free_ctx(w.alt);
-  if (w.spec_event) (void)hipEventDestroy(w.spec_event);
   if (w.spec_stream) {
     (void)hipStreamSynchronize(w.spec_stream);
     (void)hipStreamDestroy(w.spec_stream);
@@ -119,7 +118,6 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if ((e = hipStreamCreateWithPriority(&w.spec_stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&w.spec_event, hipEventDisableTiming)) != hipSuccess) return e;
     // the memsets above must have landed before either stream uses the scratch
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
   }

@@ -138,7 +138,6 @@ struct Workspace : GnCtx {
   unsigned long long spec_hits = 0, spec_misses = 0, pre_evals = 0;
   uint32_t last_inner = 0xffffffffu;  // updates the inner loop applied in the last outer iteration of the previous call
   hipStream_t spec_stream = nullptr;  // later evaluations of an inner loop run beside the speculative search
-  hipEvent_t spec_event = nullptr;
   uint32_t *d_idx = nullptr;
   // brute-force NN partial minima when the target range is split over blockIdx.y
   size_t cap_part = 0;
