@@ -86,6 +86,7 @@ SIGNATURES = {
     "icp_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_uint64)]),
     "icp_reduce_geometry": (None, [_sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "icp_gn_path_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "icp_trim_pool": (None, []),
 }
 
 _lib = None

@@ -198,6 +198,8 @@ extern "C" int icp_inverse3x3(const double m[9], double out[9]) {
 extern "C" void icp_reduce_geometry(size_t n, int *blocks, int *threads) { reduce_geometry(n, blocks, threads); }
 
 // ---------------------------------------------------------------- handle ---------
+static icp_handle *pool_take(int device);
+
 static int create_common(icp_handle **out, int dim, const double *dst, size_t m, int device, bool dst_on_device) {
   if (!out || (dim != 2 && dim != 3) || (m > 0 && !dst) || m >= 0xffffffffull) return ICP_BAD_ARGUMENT;
   *out = nullptr;
@@ -206,7 +208,10 @@ static int create_common(icp_handle **out, int dim, const double *dst, size_t m,
   if (device < 0) HIP_TRY(hipGetDevice(&device));
   if (device >= count) return ICP_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(device));
-  icp_handle *h = new (std::nothrow) icp_handle();
+  // the reference builds a new Icp per frame (examples/scan3d.rs:130): a destroyed handle's device
+  // buffers, streams and pinned memory wait in a small pool for the next create on the same device
+  icp_handle *h = pool_take(device);
+  if (!h) h = new (std::nothrow) icp_handle();
   if (!h) return ICP_OUT_OF_MEMORY;
   h->dim = dim;
   h->m = m;
@@ -214,17 +219,17 @@ static int create_common(icp_handle **out, int dim, const double *dst, size_t m,
   int rc = ICP_OK;
   do {
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { rc = map_hip(e); break; }
+    if (!h->own_stream &&
+        (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { rc = map_hip(e); break; }
     h->stream = h->own_stream;
     if (dst_on_device || m == 0) {
       h->d_dst = dst;
       h->owns_dst = false;
     } else {
-      double *p = nullptr;
-      if ((e = hipMalloc(&p, m * dim * sizeof(double))) != hipSuccess) { rc = map_hip(e); break; }
-      h->d_dst = p;
+      if ((e = reserve(h->d_dst_own, h->cap_dst_own, m * dim)) != hipSuccess) { rc = map_hip(e); break; }
+      h->d_dst = h->d_dst_own;
       h->owns_dst = true;
-      if ((e = hipMemcpyAsync(p, dst, m * dim * sizeof(double), hipMemcpyHostToDevice, h->stream)) != hipSuccess) { rc = map_hip(e); break; }
+      if ((e = hipMemcpyAsync(h->d_dst_own, dst, m * dim * sizeof(double), hipMemcpyHostToDevice, h->stream)) != hipSuccess) { rc = map_hip(e); break; }
     }
     if ((e = build_target_soa(h)) != hipSuccess) { rc = map_hip(e); break; }
     if ((e = build_grid(h)) != hipSuccess) { rc = map_hip(e); break; }
@@ -248,26 +253,20 @@ extern "C" int icp_create_device(icp_handle **out, int dim, const double *d_dst,
   return create_common(out, dim, d_dst, m, device, true);
 }
 
-extern "C" void icp_destroy(icp_handle *h) {
-  if (!h) return;
+namespace {
+
+void free_handle(icp_handle *h) {  // really release everything
   (void)hipSetDevice(h->device);
-  if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-  if (h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);  // work enqueued on a caller's stream
-  for (auto &ev : h->prof_events) {
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
-  }
-  if (getenv("ICP_DBG_WIN") && h->ws.win_tried)
-    fprintf(stderr,
-            "[icp] window evaluations: %llu tried, %llu missed; speculative searches: %llu hit, %llu missed; "
-            "first evaluations launched ahead: %llu\n",
-            h->ws.win_tried, h->ws.win_missed, h->ws.spec_hits, h->ws.spec_misses, h->ws.pre_evals);
   free_workspace(h->ws);
-  if (h->owns_dst) (void)hipFree(const_cast<double *>(h->d_dst));
+  (void)hipFree(h->d_dst_own);
   (void)hipFree(h->d_dst_soa);
   (void)hipFree(h->d_dst_f32);
   (void)hipFree(h->grid.d_start);
   (void)hipFree(h->grid.d_pts);
+  (void)hipFree(h->grid.t_cell_of);
+  (void)hipFree(h->grid.t_cnt);
+  (void)hipFree(h->grid.t_btot);
+  (void)hipFree(h->grid.t_part);
   (void)hipFree(h->qsort.d_cnt);
   (void)hipFree(h->qsort.d_start);
   (void)hipFree(h->qsort.d_btot);
@@ -278,6 +277,76 @@ extern "C" void icp_destroy(icp_handle *h) {
   (void)hipFree(h->qsort.d_prev);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
+}
+
+constexpr size_t kPoolMax = 2;  // per process; a frame loop needs one
+std::mutex g_pool_mu;
+std::vector<icp_handle *> g_pool;
+
+}  // namespace
+
+static icp_handle *pool_take(int device) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (size_t i = 0; i < g_pool.size(); ++i)
+    if (g_pool[i]->device == device) {
+      icp_handle *h = g_pool[i];
+      g_pool.erase(g_pool.begin() + i);
+      return h;
+    }
+  return nullptr;
+}
+
+extern "C" void icp_destroy(icp_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  if (h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);  // work enqueued on a caller's stream
+  if (h->ws.spec_stream) (void)hipStreamSynchronize(h->ws.spec_stream);
+  for (auto &ev : h->prof_events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  h->prof_events.clear();
+  if (getenv("ICP_DBG_WIN") && h->ws.win_tried)
+    fprintf(stderr,
+            "[icp] window evaluations: %llu tried, %llu missed; speculative searches: %llu hit, %llu missed; "
+            "first evaluations launched ahead: %llu\n",
+            h->ws.win_tried, h->ws.win_missed, h->ws.spec_hits, h->ws.spec_misses, h->ws.pre_evals);
+  static const bool no_pool = getenv("ICP_NO_POOL") != nullptr;
+  if (!no_pool) {
+    // back to the state of a fresh handle, buffers kept (everything logical is reset here; the
+    // evaluation scratch is in its rest state unless gn_dirty says otherwise)
+    Workspace &w = h->ws;
+    h->m = 0;
+    h->d_dst = nullptr;
+    h->owns_dst = false;
+    h->nn_mode = ICP_NN_AUTO;
+    h->stream = h->own_stream;
+    h->profile = 0;
+    h->prof_seen = 0;
+    h->grid.built = false;
+    h->qsort.valid = false;
+    h->qsort.have_prev = false;
+    w.win_valid = w.win_wide = false;
+    w.win_tried = w.win_missed = w.short_evals = w.radix_evals = 0;
+    w.spec_hits = w.spec_misses = w.pre_evals = 0;
+    w.last_inner = 0xffffffffu;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool.size() < kPoolMax) {
+      g_pool.push_back(h);
+      return;
+    }
+  }
+  free_handle(h);
+}
+
+extern "C" void icp_trim_pool(void) {
+  std::vector<icp_handle *> take;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    take.swap(g_pool);
+  }
+  for (icp_handle *h : take) free_handle(h);
 }
 
 extern "C" int icp_set_nn_mode(icp_handle *h, int mode) {

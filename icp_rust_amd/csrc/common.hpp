@@ -171,6 +171,11 @@ struct Grid {
   uint32_t ncell = 0;
   uint32_t *d_start = nullptr;  // ncell + 1 cell offsets into d_pts
   GridPoint *d_pts = nullptr;   // m targets sorted by cell
+  // capacities (elements) and build temporaries: kept, so that a pooled handle rebuilds without allocating
+  size_t cap_start = 0, cap_pts = 0;
+  uint32_t *t_cell_of = nullptr, *t_cnt = nullptr, *t_btot = nullptr;
+  size_t cap_tcell = 0, cap_tcnt = 0, cap_tbtot = 0;
+  double *t_part = nullptr;     // bounding-box partials
 };
 
 struct PrevMatch {  // a query's previous nearest neighbour, stored per sorted slot (coalesced)
@@ -182,7 +187,7 @@ struct PrevMatch {  // a query's previous nearest neighbour, stored per sorted s
 struct QuerySort {
   bool valid = false;
   const double *src = nullptr;  // the device buffer this snapshot was taken from
-  size_t n = 0, cap = 0;
+  size_t n = 0, cap = 0, cap_cells = 0, cap_btot = 0;
   uint32_t *d_cnt = nullptr, *d_start = nullptr, *d_btot = nullptr;
   uint32_t *d_cell_of = nullptr, *d_rank_of = nullptr, *d_perm = nullptr;
   bool have_prev = false;      // d_prev holds the matches of an earlier search of this snapshot
@@ -198,7 +203,9 @@ struct icp_handle {
   int device = 0;
   int nn_mode = ICP_NN_AUTO;
   bool owns_dst = false;
-  const double *d_dst = nullptr; // AoS m x dim (owned or borrowed)
+  const double *d_dst = nullptr; // AoS m x dim (the owned copy below, or borrowed)
+  double *d_dst_own = nullptr;   // buffer for a host-supplied target cloud
+  size_t cap_dst_own = 0, cap_soa = 0, cap_f32 = 0;  // capacities in elements (buffers survive in the handle pool)
   double *d_dst_soa = nullptr;   // x[m_pad] | y[m_pad] | z[m_pad], padded with +inf
   float *d_dst_f32 = nullptr;    // fl32(p - bbox lo), same layout: the sweep's f32 screen
   size_t m_pad = 0;
@@ -214,6 +221,21 @@ struct icp_handle {
 };
 
 namespace icp {
+
+// grow-only device buffer: reallocates (with 1/8 headroom) when `need` elements exceed `cap`
+template <typename Tp>
+inline hipError_t reserve(Tp *&p, size_t &cap, size_t need) {
+  if (need <= cap && p) return hipSuccess;
+  if (p) {
+    (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  const size_t want = need + need / 8 + 1;
+  const hipError_t e = hipMalloc(&p, want * sizeof(Tp));
+  if (e == hipSuccess) cap = want;
+  return e;
+}
 
 // ---- launchers (each enqueues on h->stream and returns the HIP error) ---------------
 hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src);

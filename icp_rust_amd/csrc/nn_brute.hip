@@ -316,7 +316,7 @@ __global__ void k_build_soa_f32(const double *__restrict__ dst, unsigned m, unsi
 // needs the target bounding box (build_grid); without one the plain f64 sweep serves
 hipError_t build_target_screen(icp_handle *h) {
   if (!h->grid.built || h->m_pad == 0) return hipSuccess;
-  hipError_t e = hipMalloc(&h->d_dst_f32, 3 * h->m_pad * sizeof(float));
+  hipError_t e = reserve(h->d_dst_f32, h->cap_f32, 3 * h->m_pad);
   if (e != hipSuccess) return e;
   const GridParams &g = h->grid.p;
   hipLaunchKernelGGL(k_build_soa_f32, dim3((unsigned)((h->m_pad + 255) / 256)), dim3(256), 0, h->stream, h->d_dst,
@@ -328,7 +328,7 @@ hipError_t build_target_soa(icp_handle *h) {
   const size_t m_pad = ((h->m + kNnTile - 1) / kNnTile) * kNnTile;
   h->m_pad = m_pad;
   if (m_pad == 0) return hipSuccess;
-  hipError_t e = hipMalloc(&h->d_dst_soa, 3 * m_pad * sizeof(double));
+  hipError_t e = reserve(h->d_dst_soa, h->cap_soa, 3 * m_pad);
   if (e != hipSuccess) return e;
   const unsigned blocks = (unsigned)((m_pad + 255) / 256);
   hipLaunchKernelGGL(k_build_soa, dim3(blocks), dim3(256), 0, h->stream, h->d_dst, (unsigned)h->m,

@@ -154,13 +154,11 @@ hipError_t build_grid(icp_handle *h) {
   hipStream_t s = h->stream;
   // 1. bounding box
   const int bb = 256;
-  double *d_part = nullptr;
-  if ((e = hipMalloc(&d_part, bb * 6 * sizeof(double))) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_grid_bbox, dim3(bb), dim3(256), 0, s, h->d_dst, m, h->dim, d_part);
+  if (!G.t_part && (e = hipMalloc(&G.t_part, bb * 6 * sizeof(double))) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_grid_bbox, dim3(bb), dim3(256), 0, s, h->d_dst, m, h->dim, G.t_part);
   double part[bb * 6];
-  e = hipMemcpyAsync(part, d_part, sizeof(part), hipMemcpyDeviceToHost, s);
+  e = hipMemcpyAsync(part, G.t_part, sizeof(part), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(d_part);
   if (e != hipSuccess) return e;
   GridParams g;
   for (int d = 0; d < 3; ++d) {
@@ -215,15 +213,15 @@ hipError_t build_grid(icp_handle *h) {
   G.p = g;
   G.ncell = (uint32_t)g.n[0] * g.n[1] * g.n[2];
   // 3. counting sort of the targets by cell
-  uint32_t *cell_of = nullptr, *cnt = nullptr, *btot = nullptr;
   const unsigned nscan = G.ncell + 1;
   const unsigned nb = (nscan + kScanItems - 1) / kScanItems;
   do {
-    if ((e = hipMalloc(&cell_of, (size_t)m * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&cnt, (size_t)nscan * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&btot, ((size_t)nb + 1) * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&G.d_start, (size_t)nscan * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&G.d_pts, (size_t)m * sizeof(GridPoint))) != hipSuccess) break;
+    if ((e = reserve(G.t_cell_of, G.cap_tcell, (size_t)m)) != hipSuccess) break;
+    if ((e = reserve(G.t_cnt, G.cap_tcnt, (size_t)nscan)) != hipSuccess) break;
+    if ((e = reserve(G.t_btot, G.cap_tbtot, (size_t)nb + 1)) != hipSuccess) break;
+    if ((e = reserve(G.d_start, G.cap_start, (size_t)nscan)) != hipSuccess) break;
+    if ((e = reserve(G.d_pts, G.cap_pts, (size_t)m)) != hipSuccess) break;
+    uint32_t *cell_of = G.t_cell_of, *cnt = G.t_cnt, *btot = G.t_btot;
     if ((e = hipMemsetAsync(cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) break;
     hipLaunchKernelGGL(k_grid_count, dim3((m + 255) / 256), dim3(256), 0, s, h->d_dst, m, h->dim, g, cell_of, cnt);
     hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, s, cnt, G.d_start, nscan, btot);
@@ -232,12 +230,8 @@ hipError_t build_grid(icp_handle *h) {
     if ((e = hipMemsetAsync(cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) break;
     hipLaunchKernelGGL(k_grid_scatter, dim3((m + 255) / 256), dim3(256), 0, s, h->d_dst, m, h->dim, cell_of,
                        G.d_start, cnt, g, G.d_pts);
-    if ((e = hipGetLastError()) != hipSuccess) break;
-    e = hipStreamSynchronize(s);
+    e = hipGetLastError();  // stream order is all the later kernels need; create_common synchronises once at the end
   } while (0);
-  (void)hipFree(cell_of);
-  (void)hipFree(cnt);
-  (void)hipFree(btot);
   if (e != hipSuccess) return e;
   G.built = true;
   return hipSuccess;
@@ -676,10 +670,13 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   hipStream_t s = h->stream;
   const unsigned nscan = G.ncell + 1;
   const unsigned nb = (nscan + kScanItems - 1) / kScanItems;
-  if (!Q.d_cnt) {
-    if ((e = hipMalloc(&Q.d_cnt, (size_t)nscan * 4)) != hipSuccess) return e;
-    if ((e = hipMalloc(&Q.d_start, (size_t)nscan * 4)) != hipSuccess) return e;
-    if ((e = hipMalloc(&Q.d_btot, ((size_t)nb + 1) * 4)) != hipSuccess) return e;
+  if ((size_t)nscan > Q.cap_cells || (size_t)nb + 1 > Q.cap_btot) {
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    size_t c1 = Q.cap_cells, c2 = Q.cap_cells;
+    if ((e = reserve(Q.d_cnt, c1, (size_t)nscan)) != hipSuccess) return e;
+    if ((e = reserve(Q.d_start, c2, (size_t)nscan)) != hipSuccess) return e;
+    Q.cap_cells = c1 < c2 ? c1 : c2;
+    if ((e = reserve(Q.d_btot, Q.cap_btot, (size_t)nb + 1)) != hipSuccess) return e;
   }
   if (n_ > Q.cap) {
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;

@@ -195,6 +195,12 @@ void icp_reduce_geometry(size_t n, int *blocks, int *threads);
  * path returns the same bits; the counters only show that a test exercised what it meant to. */
 int icp_gn_path_counters(icp_handle *h, uint64_t out[6]);
 
+/* The reference builds a new Icp per frame (examples/scan2d.rs:87, scan3d.rs:130), so icp_destroy
+ * keeps the device buffers, streams and pinned memory of up to two handles per process for the
+ * next icp_create on the same device (a create then costs its kernels, not its allocations).
+ * icp_trim_pool releases them. */
+void icp_trim_pool(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -205,3 +205,44 @@ def test_three_digit_radix_pipeline_beyond_4m_points():
     check(T, a, b)
     tried, missed, short, radix, _, _ = delta(c0, I.gn_path_counters())
     assert tried == 0 and short == 1 and radix == 0
+
+
+def test_pooled_handles_start_clean():
+    """icp_destroy parks a handle's buffers for the next icp_create.  Whatever the previous owner
+    did -- another size, another dimension, a window prediction, previous matches -- the next
+    handle must behave like a fresh one (bit-equal to the oracle), before and after icp_trim_pool."""
+    from icp_rust_amd import synth
+    from icp_rust_amd.scans import load_scan2d
+    import os
+
+    def check3d(n, m, seed, iters):
+        src, dst = synth.synthetic_pair(n, m, seed=synth.SEED + seed)
+        icp = I.Icp3d(dst)
+        T, idx, inner = icp.estimate(src, I.Transform(), iters, return_info=True)
+        icp.close()
+        b, t = I.reduce_geometry(n)
+        rc, oT, oidx, oinner = O.icp_estimate(3, dst, src, O.transform_identity(), iters, use_kdtree=True,
+                                               sum_mode=1, reduce_blocks=b, reduce_threads=t)
+        assert rc == O.OK
+        assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
+        assert np.array_equal(T.as_array(), oT.as_array())
+
+    def check2d():
+        d = os.path.join(os.path.dirname(__file__), "golden", "scans2d")
+        src, dst = load_scan2d(os.path.join(d, "001.txt")), load_scan2d(os.path.join(d, "002.txt"))
+        icp = I.Icp2d(dst)
+        T, idx, inner = icp.estimate(src, I.Transform(), 6, return_info=True)
+        icp.close()
+        b, t = I.reduce_geometry(len(src))
+        rc, oT, oidx, oinner = O.icp_estimate(2, dst, src, O.transform_identity(), 6, use_kdtree=True,
+                                               sum_mode=1, reduce_blocks=b, reduce_threads=t)
+        assert rc == O.OK
+        assert np.array_equal(inner, oinner)
+        assert np.array_equal(T.as_array(), oT.as_array())
+
+    check3d(120_000, 90_000, 1, 5)   # leaves a big pooled handle with predictions and matches
+    check2d()                         # tiny 2-D problem on the pooled buffers
+    check3d(40_000, 150_000, 2, 4)    # more targets than the pooled grid held
+    check3d(70_000, 20_000, 3, 4)
+    I.lib().icp_trim_pool()
+    check3d(50_000, 50_000, 4, 3)
