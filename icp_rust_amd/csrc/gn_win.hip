@@ -34,7 +34,7 @@ constexpr int kWinBatch = 4;
 constexpr int kWinAccBatch = 4;  // loads in flight per lane in A (2 saves 16 VGPRs but loses more than the better placement gains)
 constexpr int kSubBins = 1024;   // select_n: linear sub-bins over the candidates
 constexpr int kSmallCap = 1024;  // select_n: keys ranked by counting, per dimension (a run of equal keys lands here)
-constexpr size_t kWinMinN = 1u << 15;
+constexpr size_t kWinMinN = 1u << 12;
 constexpr size_t kWinMaxN = 1u << 22;
 
 // first bin of each region
