@@ -26,7 +26,9 @@ namespace icp {
 constexpr int kNnThreads = 256;
 constexpr int kNnTile = 1024;  // targets per LDS tile
 
-template <int DIM, int R, bool XFORM>
+// FULL: every chunk is whole tiles (compile-time trip count, unrolled); otherwise chunks are whole
+// 64-target granules of a tile (small clouds)
+template <int DIM, int R, bool XFORM, bool FULL = true>
 __global__ __launch_bounds__(kNnThreads) void k_nn_brute(
     const double *__restrict__ src, unsigned n, const double *__restrict__ tx,
     const double *__restrict__ ty, const double *__restrict__ tz, unsigned m_pad, unsigned chunk,
@@ -63,15 +65,15 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute(
   const unsigned t_begin = blockIdx.y * chunk;
   const unsigned t_end = min(m_pad, t_begin + chunk);
   for (unsigned t0 = t_begin; t0 < t_end; t0 += kNnTile) {
+    const unsigned len = FULL ? (unsigned)kNnTile : min((unsigned)kNnTile, t_end - t0);  // a multiple of 64
     __syncthreads();
-    for (unsigned k = threadIdx.x; k < kNnTile; k += kNnThreads) {
+    for (unsigned k = threadIdx.x; k < len; k += kNnThreads) {
       sx[k] = tx[t0 + k];
       sy[k] = ty[t0 + k];
       if (DIM == 3) sz[k] = tz[t0 + k];
     }
     __syncthreads();
-#pragma unroll 4
-    for (unsigned k = 0; k < kNnTile; ++k) {
+auto pair_step = [&](unsigned k) {
       const double px = sx[k], py = sy[k];
       const double pz = (DIM == 3) ? sz[k] : 0.;
 #pragma unroll
@@ -88,6 +90,12 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute(
           bi[r] = t0 + k;
         }
       }
+    };
+    if (FULL) {
+#pragma unroll 4
+      for (unsigned k = 0; k < (unsigned)kNnTile; ++k) pair_step(k);
+    } else {
+      for (unsigned k = 0; k < len; ++k) pair_step(k);
     }
   }
 
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute(
 // neither win nor tie -- and every other pair is evaluated exactly with the contract's f64
 // formula, in the same ascending target order with the same strict `<`.  Same indices, bit
 // for bit; ~8 f32 instead of ~12 f64-rate instructions for all but ~ln(M) pairs per query.
-template <int DIM, int R, bool XFORM>
+template <int DIM, int R, bool XFORM, bool FULL = true>
 __global__ __launch_bounds__(kNnThreads) void k_nn_brute_scr(
     const double *__restrict__ src, unsigned n, const double *__restrict__ tx,
     const double *__restrict__ ty, const double *__restrict__ tz, const float *__restrict__ fx,
@@ -158,8 +166,9 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute_scr(
   const unsigned t_begin = blockIdx.y * chunk;
   const unsigned t_end = min(m_pad, t_begin + chunk);
   for (unsigned t0 = t_begin; t0 < t_end; t0 += kNnTile) {
+    const unsigned len = FULL ? (unsigned)kNnTile : min((unsigned)kNnTile, t_end - t0);  // a multiple of 64
     __syncthreads();
-    for (unsigned k = threadIdx.x; k < kNnTile; k += kNnThreads) {
+    for (unsigned k = threadIdx.x; k < len; k += kNnThreads) {
       sx[k] = tx[t0 + k];
       sy[k] = ty[t0 + k];
       gx[k] = fx[t0 + k];
@@ -170,8 +179,7 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute_scr(
       }
     }
     __syncthreads();
-#pragma unroll 4
-    for (unsigned k = 0; k < kNnTile; ++k) {
+auto pair_step = [&](unsigned k) {
       const float px = gx[k], py = gy[k];
       const float pz = (DIM == 3) ? gz[k] : 0.f;
       float s[R];
@@ -209,6 +217,12 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute_scr(
           }
         }
       }
+    };
+    if (FULL) {
+#pragma unroll 4
+      for (unsigned k = 0; k < (unsigned)kNnTile; ++k) pair_step(k);
+    } else {
+      for (unsigned k = 0; k < len; ++k) pair_step(k);
     }
   }
 
@@ -344,18 +358,28 @@ static int env_int(const char *name, int dflt) {
 template <int DIM, int R, bool XFORM>
 static void launch_one(icp_handle *h, const double *d_src, unsigned n, const Pose &T, unsigned qblocks,
                        unsigned chunks, unsigned chunk) {
+  const bool full = chunk % kNnTile == 0;
   const double *tx = h->d_dst_soa, *ty = tx + h->m_pad, *tz = ty + h->m_pad;
   static const bool no_screen = getenv("ICP_NN_NO_SCREEN") != nullptr;
   if (h->d_dst_f32 && !no_screen) {
     const float *fx = h->d_dst_f32, *fy = fx + h->m_pad, *fz = fy + h->m_pad;
     const GridParams &g = h->grid.p;
-    hipLaunchKernelGGL((k_nn_brute_scr<DIM, R, XFORM>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
-                       d_src, n, tx, ty, tz, fx, fy, fz, (unsigned)h->m_pad, chunk, T, g.lo[0], g.lo[1], g.lo[2],
-                       g.scale, h->ws.d_part_d, h->ws.d_part_i);
+    if (full)
+      hipLaunchKernelGGL((k_nn_brute_scr<DIM, R, XFORM, true>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
+                         d_src, n, tx, ty, tz, fx, fy, fz, (unsigned)h->m_pad, chunk, T, g.lo[0], g.lo[1], g.lo[2],
+                         g.scale, h->ws.d_part_d, h->ws.d_part_i);
+    else
+      hipLaunchKernelGGL((k_nn_brute_scr<DIM, R, XFORM, false>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
+                         d_src, n, tx, ty, tz, fx, fy, fz, (unsigned)h->m_pad, chunk, T, g.lo[0], g.lo[1], g.lo[2],
+                         g.scale, h->ws.d_part_d, h->ws.d_part_i);
     return;
   }
-  hipLaunchKernelGGL((k_nn_brute<DIM, R, XFORM>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
-                     d_src, n, tx, ty, tz, (unsigned)h->m_pad, chunk, T, h->ws.d_part_d, h->ws.d_part_i);
+  if (full)
+    hipLaunchKernelGGL((k_nn_brute<DIM, R, XFORM, true>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
+                       d_src, n, tx, ty, tz, (unsigned)h->m_pad, chunk, T, h->ws.d_part_d, h->ws.d_part_i);
+  else
+    hipLaunchKernelGGL((k_nn_brute<DIM, R, XFORM, false>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
+                       d_src, n, tx, ty, tz, (unsigned)h->m_pad, chunk, T, h->ws.d_part_d, h->ws.d_part_i);
 }
 
 template <int DIM, bool XFORM>
@@ -385,19 +409,22 @@ hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n_, const 
   else if (n >= 256u * 1024u) R = 2;
   if (forced_r == 1 || forced_r == 2 || forced_r == 4 || forced_r == 8) R = forced_r;
   const unsigned qblocks = (n + kNnThreads * R - 1) / (kNnThreads * R);
-  const unsigned tiles = (unsigned)(h->m_pad / kNnTile);
-  // split the targets when the query blocks alone cannot fill the chip
+  // split the targets when the query blocks alone cannot fill the chip: chunks of whole 64-target
+  // granules (a tile is 16 of them), so that even a 650-point scan spreads over ~11 workgroups per
+  // query block instead of one lane looping over a whole padded tile
   static const int forced_chunks = env_int("ICP_NN_CHUNKS", 0);
+  const unsigned granules = (unsigned)((h->m + 63) / 64);  // beyond them the SoA holds only +inf padding
   unsigned chunks = 1;
   const unsigned want_blocks = 2048;
   if (qblocks < want_blocks) chunks = (want_blocks + qblocks - 1) / qblocks;
   if (forced_chunks > 0) chunks = (unsigned)forced_chunks;
-  if (chunks > tiles) chunks = tiles;
+  if (chunks > granules) chunks = granules;
   if (chunks > 64) chunks = 64;
   if (chunks < 1) chunks = 1;
-  const unsigned tiles_per_chunk = (tiles + chunks - 1) / chunks;
-  chunks = (tiles + tiles_per_chunk - 1) / tiles_per_chunk;
-  const unsigned chunk = tiles_per_chunk * kNnTile;
+  unsigned granules_per_chunk = (granules + chunks - 1) / chunks;
+  if (granules_per_chunk >= 16) granules_per_chunk = (granules_per_chunk + 15) / 16 * 16;  // whole tiles: unrolled kernel
+  chunks = (granules + granules_per_chunk - 1) / granules_per_chunk;
+  const unsigned chunk = granules_per_chunk * 64;
 
   // partial buffers
   const size_t need = (size_t)chunks * n;
