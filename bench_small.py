@@ -37,3 +37,11 @@ t0=time.perf_counter(); tree3 = O.KdTree(d3); tb=time.perf_counter()-t0
 t0 = time.perf_counter()
 for _ in range(3): rc, oT, _, oin = tree3.estimate(s3, O.transform_identity(), 20)
 print(f"   CPU oracle estimate(20 it) {1e3*(time.perf_counter()-t0)/3:.3f} ms (+ kd build {tb*1e3:.2f} ms), inner {oin.tolist()}")
+# the reference's frame loop itself (examples/scan3d.rs:104-158): a new Icp3d per frame, warm-started
+# estimate(src, T, 20); handle turnover comes out of the pool after the first frame
+pk = synth.synthetic_scan3d_packets(75 * 9)
+harness.run_scan3d(pk[:75 * 3])
+t0 = time.perf_counter()
+Ts, inv, path = harness.run_scan3d(pk)
+nf = len(Ts)
+print(f"scan3d frame loop ({nf} frames of ~28k points): {1e3*(time.perf_counter()-t0)/nf:.3f} ms per frame (Icp3d::new + estimate(20) + drop)")
