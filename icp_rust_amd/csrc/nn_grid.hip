@@ -250,7 +250,9 @@ __device__ unsigned long long g_nn_hist[2][32];  // [0]: lanes by record chunks,
 #define NN_STAT(i, v) ((void)0)
 #endif
 
-// COLD: no previous matches exist (first search of a source snapshot, or unsorted queries)
+// COLD: no previous matches exist (first search of a source snapshot, or unsorted queries).
+// Register budget of the warm 3-D instantiation: 120 VGPRs -- three of its waves plus two waves of an
+// evaluation kernel (<= 72) share a SIMD during the speculative overlap (tests/test_registers.py).
 template <int DIM, bool XFORM, bool COLD>
 __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
                                                  const uint32_t *__restrict__ perm, unsigned n, Pose T,
