@@ -187,46 +187,68 @@ struct WinRanges {  // bins, per dimension
 // and of the edges -- the host refuses windows whose fine bins are narrower than 1e-10 of the
 // coordinates -- so neither rounding nor the evaluation of edges can create ties or misplace
 // a bin; the bins probed are additionally shrunk / widened by q).
-__device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, const WinDim &w, WinRanges &R,
-                                               unsigned &med_base, unsigned &med_cnt, unsigned &inner,
-                                               unsigned &ring_cnt, double (&range)[4]) {
+struct WinGeom {  // what both halves of the bracket search need, per dimension
+  int jlo, jhi;
+  double mL, mU, fine, q;
+  int tmax;
+  bool ok;
+};
+
+// bins of the two middle ranks and the median's interval
+__device__ __forceinline__ WinGeom window_geometry(const uint32_t *c, unsigned n, const WinDim &w) {
   auto C = [&](int j) -> unsigned { return j >= kWinBins ? n : c[j]; };  // points in bins < j
   const unsigned klo = (n - 1) / 2, khi = n / 2;                          // src/stats.rs:18-27
-  const int jlo = wave_last_true(0, kWinBins - 1, [&](int j) { return c[j] <= klo; });
-  const int jhi = wave_last_true(0, kWinBins - 1, [&](int j) { return c[j] <= khi; });
-  if (jlo < 1 || jhi > kWinBins - 2) return false;  // a middle rank outside the windows
-  const double mL = wedge(jlo, w), mU = wedge(jhi + 1, w);
-  const double fine = 1. / w.sf, q = 0.25 * fine;
-  auto inside_bins = [&](double d, int &s, int &e) {  // [s, e): regular bins only
-    s = (int)wbin(mU - d + q, w) + 1;
-    e = (int)wbin(mL + d - q, w);
-  };
-  auto possible_bins = [&](double d, int &s, int &e) {  // [s, e): may include the catch-all bins
-    s = (int)wbin(mL - d - q, w);
-    e = (int)wbin(mU + d + q, w) + 1;
-  };
-  auto n_possible = [&](int t) -> unsigned {
-    int s, e;
-    possible_bins((double)t * fine, s, e);
-    return C(e) - C(s);
-  };
-  auto n_inside = [&](int t) -> unsigned {
-    int s, e;
-    inside_bins((double)t * fine, s, e);
-    return s < e ? C(e) - C(s) : 0u;
-  };
-  const int tmax = (int)((w.x[5] - w.x[0]) * w.sf) + 2;
-  const int t1 = wave_last_true(0, tmax, [&](int t) { return n_possible(t) <= klo; });
-  const int t2 = wave_last_true(0, tmax, [&](int t) { return n_inside(t) <= khi; }) + 1;
-#ifdef ICP_WIN_DEBUG_RESOLVE
-  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
-    printf("[C resolve] n %u jlo %d jhi %d t1 %d t2 %d tmax %d mL %.6g mU %.6g cnt[jlo] %u x0 %.6g x5 %.6g\n", n, jlo, jhi, t1,
-           t2, tmax, mL, mU, C(jlo + 1) - c[jlo], w.x[0], w.x[5]);
-#endif
-  if (t1 < 0 || t2 > tmax) return false;
+  WinGeom g;
+  g.jlo = wave_last_true(0, kWinBins - 1, [&](int j) { return c[j] <= klo; });
+  // khi is klo or klo + 1: almost always the same bin
+  g.jhi = (C(g.jlo + 1) > khi) ? g.jlo : wave_last_true(0, kWinBins - 1, [&](int j) { return c[j] <= khi; });
+  g.ok = !(g.jlo < 1 || g.jhi > kWinBins - 2);  // else: a middle rank outside the windows
+  g.mL = g.ok ? wedge(g.jlo, w) : 0.;
+  g.mU = g.ok ? wedge(g.jhi + 1, w) : 0.;
+  g.fine = 1. / w.sf;
+  g.q = 0.25 * g.fine;
+  g.tmax = (int)((w.x[5] - w.x[0]) * w.sf) + 2;
+  return g;
+}
+
+__device__ __forceinline__ void inside_bins(const WinGeom &g, const WinDim &w, double d, int &s, int &e) {
+  s = (int)wbin(g.mU - d + g.q, w) + 1;  // [s, e): regular bins only
+  e = (int)wbin(g.mL + d - g.q, w);
+}
+__device__ __forceinline__ void possible_bins(const WinGeom &g, const WinDim &w, double d, int &s, int &e) {
+  s = (int)wbin(g.mL - d - g.q, w);      // [s, e): may include the catch-all bins
+  e = (int)wbin(g.mU + d + g.q, w) + 1;
+}
+
+// one half of the bracket: role 0 -> t1 = max{t: #possible(d_t) <= klo}, role 1 -> t2 = min{t: #inside(d_t) > khi}
+__device__ __forceinline__ int bracket_search(const uint32_t *c, unsigned n, const WinDim &w, const WinGeom &g,
+                                              int role) {
+  auto C = [&](int j) -> unsigned { return j >= kWinBins ? n : c[j]; };
+  const unsigned klo = (n - 1) / 2, khi = n / 2;
+  if (role == 0)
+    return wave_last_true(0, g.tmax, [&](int t) {
+      int s, e;
+      possible_bins(g, w, (double)t * g.fine, s, e);
+      return C(e) - C(s) <= klo;
+    });
+  return wave_last_true(0, g.tmax, [&](int t) {
+           int s, e;
+           inside_bins(g, w, (double)t * g.fine, s, e);
+           return (s < e ? C(e) - C(s) : 0u) <= khi;
+         }) + 1;
+}
+
+__device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, const WinDim &w, const WinGeom &g,
+                                               int t1, int t2, WinRanges &R, unsigned &med_base,
+                                               unsigned &med_cnt, unsigned &inner, unsigned &ring_cnt,
+                                               double (&range)[4]) {
+  auto C = [&](int j) -> unsigned { return j >= kWinBins ? n : c[j]; };
+  if (!g.ok || t1 < 0 || t2 > g.tmax) return false;
+  const int jlo = g.jlo, jhi = g.jhi;
+  const double fine = g.fine, q = g.q;
   int is, ie, ps, pe;
-  inside_bins((double)t1 * fine - 2. * q, is, ie);
-  possible_bins((double)t2 * fine + 2. * q, ps, pe);
+  inside_bins(g, w, (double)t1 * fine - 2. * q, is, ie);
+  possible_bins(g, w, (double)t2 * fine + 2. * q, ps, pe);
   if (ps < 1 || pe > kWinBins - 1) return false;  // the ring reaches a catch-all bin
   R.mlo = jlo;
   R.mhi = jhi;
@@ -244,12 +266,8 @@ __device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, co
   med_base = c[jlo];
   med_cnt = C(jhi + 1) - c[jlo];
   ring_cnt = (C(pe) - C(ps)) - inner;
-#ifdef ICP_WIN_DEBUG_RESOLVE
-  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
-    printf("[C resolve] ring [%d,%d) inner [%d,%d) med_cnt %u ring_cnt %u inner %u\n", ps, pe, is, ie, med_cnt, ring_cnt, inner);
-#endif
-  range[0] = mL;  // every median candidate lies in [mL, mU]
-  range[1] = mU;
+  range[0] = g.mL;  // every median candidate lies in [mL, mU]
+  range[1] = g.mU;
   range[2] = t1 > 0 ? (double)(t1 - 1) * fine : 0.;  // the MAD lies in (t1, t2] fine bins
   range[3] = (double)(t2 + 1) * fine;
   return med_cnt <= (unsigned)kWinCapMed && ring_cnt <= (unsigned)kWinCapRing;
@@ -315,6 +333,15 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
 #ifdef ICP_WIN_DEBUG
   cst[1] = wall_clock64();
 #endif
+  __shared__ int s_t[2][2];
+  WinGeom geo = {};
+  if (wave < 4) {  // waves 0,1: t1 of x,y; waves 2,3: t2 of x,y -- the two halves of the bracket side by side
+    const int d = wave & 1, role = wave >> 1;
+    geo = window_geometry(cum + d * kWinBins, n, P.d[d]);
+    const int t = geo.ok ? bracket_search(cum + d * kWinBins, n, P.d[d], geo, role) : -1;
+    if (lane == 0) s_t[role][d] = t;
+  }
+  __syncthreads();
   if (wave < 2) {  // one wave per dimension
     const int d = wave;
     WinRanges R = {};
@@ -323,8 +350,8 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
     unsigned counted = 0;  // every point is in exactly one bin: anything else means the histogram is not
 #pragma unroll             // this evaluation's (defence in depth for the hand-over between streams)
     for (int w = 0; w < NW; ++w) counted += s_wtot[d][w];
-    const bool ok = counted == n &&
-                    resolve_window(cum + d * kWinBins, n, P.d[d], R, med_base, med_cnt, inner, ring_cnt, range);
+    const bool ok = counted == n && resolve_window(cum + d * kWinBins, n, P.d[d], geo, s_t[0][d], s_t[1][d], R,
+                                                   med_base, med_cnt, inner, ring_cnt, range);
     if (lane == 0) {
       s_rng[d][0] = R.mlo;
       s_rng[d][1] = R.mhi;
