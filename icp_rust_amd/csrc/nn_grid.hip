@@ -486,8 +486,10 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   // of the 3^DIM block.  The previous match is a real target and every cell that can hold a
   // closer-or-equal one is visited, so the result is the same exact minimum by (d^2, index).
   bool done = false;
+  uint32_t prev_bi = 0xfffffffeu;  // never a target index (icp_create refuses m >= 2^32 - 1)
   if (!COLD && prev) {
     const PrevMatch pm = prev[k];  // coalesced per-slot record (index + exact coordinates), not a gather
+    prev_bi = pm.idx;
     if (pm.idx != 0xffffffffu) {
       NN_STAT(7, 1);
       eval(pm.idx, pm.x, pm.y, pm.z);
@@ -609,7 +611,9 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
     }
   }
 #endif
-  if (prev_out) {
+  // prev and prev_out are the same per-slot array: a slot whose match did not change already
+  // holds this record (32 B of write traffic per query saved once the registration settles)
+  if (prev_out && bi != prev_bi) {
     PrevMatch pm;
     pm.x = bx;
     pm.y = by;

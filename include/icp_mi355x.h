@@ -201,6 +201,32 @@ int icp_gn_path_counters(icp_handle *h, uint64_t out[6]);
  * icp_trim_pool releases them. */
 void icp_trim_pool(void);
 
+/* ================================================================================
+ * 6. EXTENSION (not in the reference): a target cloud that grows -- scan-to-map
+ * ==============================================================================
+ * BASELINE.json configs[4] registers each scan against a map that the
+ * registered scans are appended to.  The reference has no such thing: its Icp borrows a fixed
+ * `dst` (src/lib.rs:97-102, 139-144).  What the reference does define is the registration of a
+ * scan against ANY target cloud, so a map handle is an ordinary handle whose target cloud can
+ * be extended; after an append every result is, bit for bit, that of a fresh icp_create on the
+ * concatenated cloud (target indices = position in the concatenation).  Point-to-plane
+ * residuals, also named by configs[4], have no definition in the reference (no normals
+ * anywhere in src/) and are not built.
+ *
+ * icp_append_targets[_device]: append k points (AoS, the handle's dim) to the target cloud;
+ * with T != NULL the points are first moved by T exactly as Transform::transform does
+ * (transform.rs:22-24: x' = (r00 x + r01 y) + tx, y' = (r10 x + r11 y) + ty, z kept; no FMA),
+ * i.e. "append the scan at its registered pose".  A handle made by icp_create_device stops
+ * borrowing the caller's buffer at its first append (the cloud moves into storage the handle
+ * owns, grown geometrically).  The search structures are rebuilt on the device.
+ * icp_reserve_targets sizes that storage ahead of time; icp_target_count reports m. */
+int icp_append_targets(icp_handle *h, const double *pts, size_t k, const icp_pose *T);
+int icp_append_targets_device(icp_handle *h, const double *d_pts, size_t k, const icp_pose *T);
+int icp_reserve_targets(icp_handle *h, size_t capacity);
+size_t icp_target_count(const icp_handle *h);
+/* copy target points [first, first + k) back to the host (AoS), e.g. to save the map */
+int icp_read_targets(icp_handle *h, size_t first, size_t k, double *out);
+
 #ifdef __cplusplus
 }
 #endif
