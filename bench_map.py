@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""EXTENSION beyond the reference (BASELINE.json configs[4], scan-to-growing-map; include/icp_mi355x.h
+section 6): frames of 28 800 points registered with the reference's estimator (Icp3d::estimate, 20
+iterations, warm-started) against a map of more than 10 M points that every registered frame is
+appended to.  One GPU; the map is device resident.  Not the headline benchmark (bench.py) -- there is
+no reference number for it, and point-to-plane (no definition in the reference) is not built.
+
+Prints one JSON line: per-frame registration time, per-frame append time (= rebuilding the search
+grid over the whole map), map build time, frames/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--map-points", type=int, default=10_000_000)
+    ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--frame-points", type=int, default=75 * 384)
+    ap.add_argument("--max-iter", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+
+    import icp_rust_amd as I
+    from icp_rust_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_map.py needs a GPU: the product path has no CPU fallback")
+    I.build()
+    m0 = args.map_points
+    chunk = 1 << 20
+    d_map = torch.empty((m0, 3), dtype=torch.float64, device="cuda")
+    for first in range(0, m0, chunk):
+        cnt = min(chunk, m0 - first)
+        d_map[first:first + cnt] = torch.from_numpy(synth.box_cloud(synth.SEED + 200, cnt, first=first)).cuda()
+    motion = np.array([0.02, -0.01, 0.001])
+    scans = []
+    for k in range(1, args.frames + 1):
+        # a fresh sample of the same world, seen from the sensor pose Exp(k * motion), with sensor noise
+        s, _ = synth.synthetic_pair(args.frame_points, 1, seed=synth.SEED + 300 + 2 * k, param=tuple(k * motion))
+        scans.append(torch.from_numpy(s).cuda())
+    torch.cuda.synchronize()
+
+    t0 = time.perf_counter()
+    world = I.Icp3d(d_map)
+    world.synchronize()
+    t_build = time.perf_counter() - t0
+    world.reserve(m0 + (args.frames + 1) * args.frame_points)
+    del d_map
+    # untimed: first-call allocations (workspace for one frame)
+    world.estimate(scans[0], I.Transform(), 1)
+
+    T = I.Transform()
+    est_ms, app_ms, inner_all, err = [], [], [], []
+    for k, scan in enumerate(scans, start=1):
+        t0 = time.perf_counter()
+        T, inner = world.estimate(scan, T, args.max_iter, return_info="inner")
+        t1 = time.perf_counter()
+        world.append(scan, T)
+        t2 = time.perf_counter()
+        est_ms.append(1e3 * (t1 - t0))
+        app_ms.append(1e3 * (t2 - t1))
+        inner_all.append(int(inner.sum()))
+        truth = I.Transform(tuple(k * motion)).as_array()
+        err.append(float(np.max(np.abs(T.as_array() - truth))))
+    frame_ms = float(np.mean(est_ms) + np.mean(app_ms))
+    out = {
+        "metric": "scan-to-growing-map frames/s (EXTENSION: not a reference workload)",
+        "value": 1e3 / frame_ms, "unit": "frames/s", "n_gpus": 1,
+        "config": {"workload": "BASELINE.json configs[4] stand-in: synthetic frames registered against a growing map, "
+                               "point-to-point (the reference's estimator); point-to-plane is not built",
+                   "map_points_start": m0, "map_points_end": world.target_count,
+                   "frame_points": args.frame_points, "frames": args.frames, "max_iter": args.max_iter},
+        "ms_per_frame": frame_ms,
+        "estimate_ms": {"mean": float(np.mean(est_ms)), "min": float(np.min(est_ms)), "max": float(np.max(est_ms))},
+        "append_ms": {"mean": float(np.mean(app_ms)), "min": float(np.min(app_ms)), "max": float(np.max(app_ms)),
+                      "note": "transform + append + rebuild of the search grid over the whole map"},
+        "map_build_ms": 1e3 * t_build,
+        "inner_updates_per_frame": inner_all,
+        "pose_abs_err_vs_truth_last_frame": err[-1],
+        "dtype": "f64", "data": "synthetic",
+    }
+    print(json.dumps(out), flush=True)
+    world.close()
+
+
+if __name__ == "__main__":
+    main()

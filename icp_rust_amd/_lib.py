@@ -87,6 +87,11 @@ SIGNATURES = {
     "icp_reduce_geometry": (None, [_sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "icp_gn_path_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_trim_pool": (None, []),
+    "icp_append_targets": (C.c_int, [_vp, _vp, _sz, _pp]),
+    "icp_append_targets_device": (C.c_int, [_vp, _vp, _sz, _pp]),
+    "icp_reserve_targets": (C.c_int, [_vp, _sz]),
+    "icp_target_count": (_sz, [_vp]),
+    "icp_read_targets": (C.c_int, [_vp, _sz, _sz, _vp]),
 }
 
 _lib = None

@@ -356,6 +356,38 @@ class _Icp:
         self.synchronize()
         return idx[: qq.shape[0]].cpu().numpy().view(np.uint32)
 
+    # -- EXTENSION (not in the reference): a target cloud that grows, for scan-to-map ------
+    def append(self, points, transform=None):
+        """Append `points` to the target cloud, moved by `transform` first if given (exactly
+        Transform::transform on xy, z kept).  Afterwards the handle behaves like a fresh
+        Icp*::new on the concatenated cloud (include/icp_mi355x.h section 6)."""
+        tp = C.byref(transform.pose) if transform is not None else None
+        if _is_device_tensor(points):
+            if points.dim() != 2 or points.shape[1] != self.DIM or str(points.dtype) != "torch.float64" \
+                    or not points.is_contiguous():
+                raise ValueError(f"expected a contiguous (k, {self.DIM}) float64 CUDA tensor")
+            check(lib().icp_append_targets_device(self._h, C.c_void_p(points.data_ptr()), points.shape[0], tp),
+                  "icp_append_targets_device")
+        else:
+            p = _host(points, self.DIM)
+            check(lib().icp_append_targets(self._h, _ptr(p), p.shape[0], tp), "icp_append_targets")
+        self._keep = None  # the cloud now lives in the handle's own storage
+        self.m = self.target_count
+
+    def reserve(self, capacity):
+        check(lib().icp_reserve_targets(self._h, int(capacity)), "icp_reserve_targets")
+        self._keep = None if capacity > self.m else self._keep
+
+    @property
+    def target_count(self):
+        return int(lib().icp_target_count(self._h))
+
+    def read_targets(self, first=0, count=None):
+        count = self.target_count - first if count is None else count
+        out = np.empty((count, self.DIM), dtype=np.float64)
+        check(lib().icp_read_targets(self._h, first, count, C.c_void_p(out.ctypes.data)), "icp_read_targets")
+        return out
+
     def profile_enable(self, every=1):
         """Time every `every`-th NN search launch with HIP events (0 / False: off)."""
         check(lib().icp_profile_enable(self._h, int(every)), "icp_profile_enable")

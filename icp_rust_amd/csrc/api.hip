@@ -870,3 +870,128 @@ extern "C" int icp_residual_stddevs(const icp_pose *T, const double *a, const do
   sigma[1] = s.sigma[1];
   return ICP_OK;
 }
+
+// ------------------------------------------- EXTENSION: a growing target cloud ----
+// Scan-to-map (BASELINE.json configs[4]; not in the reference, see include/icp_mi355x.h section 6).
+// After an append the handle is indistinguishable from a fresh icp_create on the concatenated
+// cloud: same target indices, same search results, same poses.
+namespace {
+
+// Transform::transform on every appended point (transform.rs:22-24; products, add, then + t; the
+// library is compiled with -ffp-contract=off), z carried through as in transform_xy (lib.rs:52-57)
+template <int DIM>
+__global__ void k_append_targets(const double *__restrict__ pts, unsigned k, Pose T, bool xform,
+                                 double *__restrict__ out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  double x = pts[(size_t)i * DIM], y = pts[(size_t)i * DIM + 1];
+  if (xform) {
+    const double nx = (T.r00 * x + T.r01 * y) + T.tx;
+    const double ny = (T.r10 * x + T.r11 * y) + T.ty;
+    x = nx;
+    y = ny;
+  }
+  out[(size_t)i * DIM] = x;
+  out[(size_t)i * DIM + 1] = y;
+  if (DIM == 3) out[(size_t)i * DIM + 2] = pts[(size_t)i * DIM + 2];
+}
+
+int quiesce(icp_handle *h) {
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->own_stream) HIP_TRY(hipStreamSynchronize(h->own_stream));
+  if (h->stream != h->own_stream) HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->ws.spec_stream) HIP_TRY(hipStreamSynchronize(h->ws.spec_stream));
+  return ICP_OK;
+}
+
+// make the target cloud live in storage the handle owns, with room for `points` points
+int own_targets(icp_handle *h, size_t points) {
+  const size_t need = points * (size_t)h->dim;
+  if (h->owns_dst && need <= h->cap_dst_own) return ICP_OK;
+  if (!h->owns_dst && need <= h->cap_dst_own && h->d_dst_own) {
+    // a pooled buffer is large enough: move the borrowed cloud in
+    if (h->m > 0)
+      HIP_TRY(hipMemcpyAsync(h->d_dst_own, h->d_dst, h->m * h->dim * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    // grow geometrically: a map that gains one scan per frame is copied O(log) times
+    size_t cap = h->owns_dst ? h->cap_dst_own * 2 : 0;
+    if (cap < need) cap = need + need / 8 + 1;
+    double *p = nullptr;
+    HIP_TRY(hipMalloc(&p, cap * sizeof(double)));
+    if (h->m > 0) {
+      const hipError_t e =
+          hipMemcpyAsync(p, h->d_dst, h->m * h->dim * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+      if (e != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+        (void)hipFree(p);
+        return ICP_HIP_ERROR;
+      }
+    }
+    (void)hipFree(h->d_dst_own);
+    h->d_dst_own = p;
+    h->cap_dst_own = cap;
+  }
+  h->d_dst = h->d_dst_own;
+  h->owns_dst = true;
+  return ICP_OK;
+}
+
+int append_common(icp_handle *h, const double *pts, size_t k, const icp_pose *T, bool on_device) {
+  if (!h || (k > 0 && !pts) || h->m + k >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  if (k == 0) return ICP_OK;
+  int rc = quiesce(h);
+  if (rc != ICP_OK) return rc;
+  const double *d_pts = pts;
+  if (!on_device) {
+    // stage through the handle's source buffer (the same one icp_estimate stages a scan in)
+    HIP_TRY(ensure_workspace(h, k, true));
+    HIP_TRY(hipMemcpyAsync(h->ws.d_src, pts, k * h->dim * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    d_pts = h->ws.d_src;
+  }
+  if ((rc = own_targets(h, h->m + k)) != ICP_OK) return rc;
+  double *tail = h->d_dst_own + h->m * h->dim;
+  const Pose P = T ? *T : transform_identity();
+  const unsigned blocks = (unsigned)((k + 255) / 256);
+  if (h->dim == 3)
+    hipLaunchKernelGGL(k_append_targets<3>, dim3(blocks), dim3(256), 0, h->stream, d_pts, (unsigned)k, P, T != nullptr, tail);
+  else
+    hipLaunchKernelGGL(k_append_targets<2>, dim3(blocks), dim3(256), 0, h->stream, d_pts, (unsigned)k, P, T != nullptr, tail);
+  HIP_TRY(hipGetLastError());
+  h->m += k;
+  // the grid is what a map-sized cloud is searched with; the sweep's structures (SoA + f32 screen,
+  // 36 B per target) are rebuilt right away only where the sweep is the engine in use
+  HIP_TRY(build_grid(h));
+  h->brute_valid = h->screen_valid = false;
+  if (resolved_nn_mode(h) == ICP_NN_BRUTE) {
+    HIP_TRY(build_target_soa(h));
+    HIP_TRY(build_target_screen(h));
+  }
+  h->qsort.valid = false;  // snapshots and previous matches refer to the old grid
+  h->qsort.have_prev = false;
+  HIP_TRY(hipStreamSynchronize(h->stream));  // host `pts` may be freed; later calls may use another stream
+  return ICP_OK;
+}
+
+}  // namespace
+
+extern "C" int icp_append_targets(icp_handle *h, const double *pts, size_t k, const icp_pose *T) {
+  return append_common(h, pts, k, T, false);
+}
+extern "C" int icp_append_targets_device(icp_handle *h, const double *d_pts, size_t k, const icp_pose *T) {
+  return append_common(h, d_pts, k, T, true);
+}
+extern "C" int icp_reserve_targets(icp_handle *h, size_t capacity) {
+  if (!h || capacity >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  if (capacity <= h->m) return ICP_OK;
+  const int rc = quiesce(h);
+  if (rc != ICP_OK) return rc;
+  return own_targets(h, capacity);
+}
+extern "C" size_t icp_target_count(const icp_handle *h) { return h ? h->m : 0; }
+extern "C" int icp_read_targets(icp_handle *h, size_t first, size_t k, double *out) {
+  if (!h || first > h->m || k > h->m - first || (k > 0 && !out)) return ICP_BAD_ARGUMENT;
+  if (k == 0) return ICP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(out, h->d_dst + first * h->dim, k * h->dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ICP_OK;
+}

@@ -209,6 +209,8 @@ struct icp_handle {
   double *d_dst_soa = nullptr;   // x[m_pad] | y[m_pad] | z[m_pad], padded with +inf
   float *d_dst_f32 = nullptr;    // fl32(p - bbox lo), same layout: the sweep's f32 screen
   size_t m_pad = 0;
+  bool brute_valid = false;      // d_dst_soa describes the current target cloud (else launch_nn_brute rebuilds it)
+  bool screen_valid = false;     // d_dst_f32 too (needs the grid's bounding box: finite targets only)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   icp::Workspace ws;

@@ -329,21 +329,28 @@ __global__ void k_build_soa_f32(const double *__restrict__ dst, unsigned m, unsi
 
 // needs the target bounding box (build_grid); without one the plain f64 sweep serves
 hipError_t build_target_screen(icp_handle *h) {
+  h->screen_valid = false;  // a pooled handle may still hold the previous cloud's screen
   if (!h->grid.built || h->m_pad == 0) return hipSuccess;
   hipError_t e = reserve(h->d_dst_f32, h->cap_f32, 3 * h->m_pad);
   if (e != hipSuccess) return e;
   const GridParams &g = h->grid.p;
   hipLaunchKernelGGL(k_build_soa_f32, dim3((unsigned)((h->m_pad + 255) / 256)), dim3(256), 0, h->stream, h->d_dst,
                      (unsigned)h->m, (unsigned)h->m_pad, h->dim, g.lo[0], g.lo[1], g.lo[2], h->d_dst_f32);
+  h->screen_valid = true;
   return hipGetLastError();
 }
 
 hipError_t build_target_soa(icp_handle *h) {
   const size_t m_pad = ((h->m + kNnTile - 1) / kNnTile) * kNnTile;
   h->m_pad = m_pad;
-  if (m_pad == 0) return hipSuccess;
+  h->brute_valid = h->screen_valid = false;
+  if (m_pad == 0) {
+    h->brute_valid = true;  // nothing to describe
+    return hipSuccess;
+  }
   hipError_t e = reserve(h->d_dst_soa, h->cap_soa, 3 * m_pad);
   if (e != hipSuccess) return e;
+  h->brute_valid = true;
   const unsigned blocks = (unsigned)((m_pad + 255) / 256);
   hipLaunchKernelGGL(k_build_soa, dim3(blocks), dim3(256), 0, h->stream, h->d_dst, (unsigned)h->m,
                      (unsigned)m_pad, h->dim, h->d_dst_soa);
@@ -361,7 +368,7 @@ static void launch_one(icp_handle *h, const double *d_src, unsigned n, const Pos
   const bool full = chunk % kNnTile == 0;
   const double *tx = h->d_dst_soa, *ty = tx + h->m_pad, *tz = ty + h->m_pad;
   static const bool no_screen = getenv("ICP_NN_NO_SCREEN") != nullptr;
-  if (h->d_dst_f32 && !no_screen) {
+  if (h->screen_valid && !no_screen) {
     const float *fx = h->d_dst_f32, *fy = fx + h->m_pad, *fz = fy + h->m_pad;
     const GridParams &g = h->grid.p;
     if (full)
@@ -399,6 +406,14 @@ hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n_, const 
   const unsigned n = (unsigned)n_;
   const bool xform = Tp != nullptr;
   const Pose T = xform ? *Tp : transform_identity();
+  if (!h->brute_valid) {
+    // a grown map (icp_append_targets) rebuilds only the grid; the sweep's structures follow on
+    // first use.  Synchronised: later launches may come from another stream.
+    hipError_t e = build_target_soa(h);
+    if (e == hipSuccess) e = build_target_screen(h);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return e;
+  }
 
   // queries per lane: enough waves to cover 1024 SIMDs several times over, then as
   // many registers-resident queries as that allows (fewer LDS reads per pair)

@@ -67,3 +67,28 @@ def run_scan3d(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=None):
         inverses.append(inv)
         path.append(inv.t.copy())
     return transforms, inverses, np.array(path).reshape(-1, 2)
+
+
+def run_scan_to_map(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=None, max_frames=None):
+    """EXTENSION, not in the reference (BASELINE.json configs[4]): the
+    scan3d frames registered against a map that grows.  The map starts as frame 0 (filtered as
+    examples/scan3d.rs:63-69 does); every later frame is registered against the whole map with
+    the reference's own estimator (Icp3d::estimate, warm-started with the previous pose as
+    scan3d.rs:131 does) and then appended at its registered pose.  The pose maps the scan into
+    the map frame, so the path is its translation directly (no inverse()).
+    `icp_factory(dst)` must return an object with .estimate and .append(points, transform).
+    Returns (transforms, path_xy, map_handle)."""
+    icp_factory = icp_factory or Icp3d
+    packets = np.asarray(packets, dtype=np.float64)
+    world = icp_factory(remove_invalid_values(packets[0:step]))
+    transform = Transform.identity()
+    transforms, path = [], []
+    index = step
+    while index + step <= packets.shape[0] and (max_frames is None or len(transforms) < max_frames):
+        scan = remove_invalid_values(packets[index:index + step])
+        index += step
+        transform = world.estimate(scan, transform, max_iter)
+        world.append(scan, transform)
+        transforms.append(transform)
+        path.append(transform.t.copy())
+    return transforms, np.array(path).reshape(-1, 2), world
