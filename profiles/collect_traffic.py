@@ -1,8 +1,8 @@
 """Aggregate two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as
 MI355X_MICROARCH.md prescribes) into the per-kernel traffic summary bench.py reads.
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 6 --warmup 2 --brute-steps 0 --cpu-iters 0
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 6 --warmup 2 --brute-steps 0 --cpu-iters 0
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 40 --warmup 2 --brute-steps 0 --cpu-iters 0 --gn-points 0
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 40 --warmup 2 --brute-steps 0 --cpu-iters 0 --gn-points 0
     python profiles/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_traffic_pmc.json
 """
 import csv
@@ -46,17 +46,37 @@ def main():
             e["launches_WRITE_SIZE"] = write[k][1]
         kernels[k] = e
     note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, MI355X_MICROARCH.md "
-            "'HBM' + 'rocprofv3 PMC slots'), python bench.py --steps 6 --warmup 2 --brute-steps 0 --cpu-iters 0, "
+            "'HBM' + 'rocprofv3 PMC slots'), python bench.py --steps 40 --warmup 2 --brute-steps 0 --cpu-iters 0 --gn-points 0, "
             "1M x 1M. Units: KB per launch. gfx950 correction: FETCH_SIZE reads exactly 1/2 of wide coalesced "
             "streaming reads -> to be doubled for the streaming GN kernels; k_nn_grid issues narrow per-lane "
             "gathers (uncalibrated width): reported uncorrected. Infinity-Cache hits are counted by these "
             "fabric-side counters, so at this 1M size (working set < 256 MiB) they are an upper bound on HBM bytes.")
     doc = {"note": note, "kernels": kernels}
-    g = kernels.get("icp::k_nn_grid<3, true>") or kernels.get("icp::k_nn_grid<3, true>".replace(" ", ""))
-    if g and "FETCH_SIZE_KB_avg_per_launch" in g and "WRITE_SIZE_KB_avg_per_launch" in g:
-        fb, wb = g["FETCH_SIZE_KB_avg_per_launch"] * 1024, g["WRITE_SIZE_KB_avg_per_launch"] * 1024
+    # the search kernel: warm <3, true, false> and cold <3, true, true> instantiations, launch-weighted
+    # (the benchmark's timed region holds one cold search per 20 launches; a short PMC run holds more)
+    tot = {"f": 0.0, "w": 0.0, "nf": 0, "nw": 0}
+    for k, e in kernels.items():
+        if not k.startswith("icp::k_nn_grid<3, true"):
+            continue
+        tot["f"] += e.get("FETCH_SIZE_KB_avg_per_launch", 0.0) * e.get("launches_FETCH_SIZE", 0)
+        tot["nf"] += e.get("launches_FETCH_SIZE", 0)
+        tot["w"] += e.get("WRITE_SIZE_KB_avg_per_launch", 0.0) * e.get("launches_WRITE_SIZE", 0)
+        tot["nw"] += e.get("launches_WRITE_SIZE", 0)
+    if tot["nf"] and tot["nw"]:
+        fb, wb = tot["f"] / tot["nf"] * 1024, tot["w"] / tot["nw"] * 1024
         doc["k_nn_grid"] = {"traffic_bytes_per_launch": fb + wb, "fetch_bytes": fb, "write_bytes": wb,
-                            "corrected": False}
+                            "corrected": False, "launches": tot["nf"]}
+        warm = kernels.get("icp::k_nn_grid<3, true, false>")
+        if warm and "FETCH_SIZE_KB_avg_per_launch" in warm and "WRITE_SIZE_KB_avg_per_launch" in warm:
+            wb_ = 1024 * (warm["FETCH_SIZE_KB_avg_per_launch"] + warm["WRITE_SIZE_KB_avg_per_launch"])
+            doc["k_nn_grid"]["warm_only_bytes_per_launch"] = wb_
+            cold = kernels.get("icp::k_nn_grid<3, true, true>")
+            if cold and "FETCH_SIZE_KB_avg_per_launch" in cold and "WRITE_SIZE_KB_avg_per_launch" in cold:
+                cb_ = 1024 * (cold["FETCH_SIZE_KB_avg_per_launch"] + cold["WRITE_SIZE_KB_avg_per_launch"])
+                doc["k_nn_grid"]["cold_only_bytes_per_launch"] = cb_
+                # bench.py's timed region: estimate calls of 20 outer iterations = 1 cold + 19 warm searches
+                doc["k_nn_grid"]["traffic_bytes_per_launch"] = (19 * wb_ + cb_) / 20
+                doc["k_nn_grid"]["weighting"] = "19 warm + 1 cold search per 20 launches, as in bench.py's timed region"
     json.dump(doc, open(out, "w"), indent=1)
     for k, e in kernels.items():
         print(k, e)
