@@ -328,6 +328,7 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->qsort.valid = false;
     h->qsort.have_prev = false;
     w.win_valid = w.win_wide = false;
+    w.win_kind[0] = w.win_kind[1] = Workspace::WinPred();
     w.win_tried = w.win_missed = w.short_evals = w.radix_evals = 0;
     w.spec_hits = w.spec_misses = w.pre_evals = 0;
     w.last_inner = 0xffffffffu;
@@ -482,17 +483,27 @@ static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
 // stream (icp_estimate_device enqueued it behind the speculative search); only its result is awaited.
 template <typename Hook>
 static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
-                    double delta[3], double *huber_err, Hook &&after_launch, bool pre_launched = false) {
+                    double delta[3], double *huber_err, Hook &&after_launch, bool pre_launched = false,
+                    int kind = 2) {
   static const bool force_radix = getenv("ICP_GN_RADIX") != nullptr;
   Workspace &w = h->ws;
   bool done = false, has_median = false, hooked = false;
+  // the prediction this evaluation's window is (or, pre-launched, was) centred on: its own kind's
+  // previous evaluation if there is one, else the most recent evaluation (window_usable)
+  const bool own = kind >= 0 && kind < 2 && w.win_kind[kind].valid;
+  bool &wide = own ? w.win_kind[kind].wide : w.win_wide;
+  double p_med[2], p_sigma[2];
+  for (int d = 0; d < 2; ++d) {
+    p_med[d] = own ? w.win_kind[kind].med[d] : w.win_med[d];
+    p_sigma[d] = own ? w.win_kind[kind].sigma[d] : w.win_sigma[d];
+  }
   if (w.gn_dirty) {  // first use, or the radix path / a NaN left its state behind (the short pipelines clean up after themselves)
     HIP_TRY(launch_sel_init(h, n));
     w.gn_dirty = false;
   }
   if (!force_radix) {
     WinParams P;
-    if (pre_launched || window_usable(h, n, &P)) {  // three launches around the previous evaluation's median and sigma
+    if (pre_launched || window_usable(h, n, &P, kind)) {  // three launches around the predicted median and sigma
       if (!pre_launched) {
         ++w.win_tried;
         HIP_TRY(launch_weighted_gn_win(h, d_a, d_b, n, T, P));
@@ -503,13 +514,12 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
       done = has_median = !w.h_res->overflow;
       if (!done) {
         ++w.win_missed;
-        w.win_wide = true;
-      } else if (w.win_wide) {  // back to narrow windows once the statistics have settled
+        wide = true;
+      } else if (wide) {  // back to narrow windows once the statistics have settled
         double shift = 0.;
         for (int d = 0; d < 2; ++d)
-          shift = fmax(shift, (fabs(w.h_res->median[d] - w.win_med[d]) + fabs(w.h_res->sigma[d] - w.win_sigma[d])) /
-                                  w.win_sigma[d]);
-        if (shift < 0.01) w.win_wide = false;
+          shift = fmax(shift, (fabs(w.h_res->median[d] - p_med[d]) + fabs(w.h_res->sigma[d] - p_sigma[d])) / p_sigma[d]);
+        if (shift < 0.01) wide = false;
       }
     }
     if (!done) {
@@ -532,10 +542,15 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   }
   const GnResult &r = *w.h_res;
   w.win_valid = has_median;
+  if (kind >= 0 && kind < 2) w.win_kind[kind].valid = has_median;
   if (has_median)
     for (int d = 0; d < 2; ++d) {
       w.win_med[d] = r.median[d];
       w.win_sigma[d] = r.sigma[d];
+      if (kind >= 0 && kind < 2) {
+        w.win_kind[kind].med[d] = r.median[d];
+        w.win_kind[kind].sigma[d] = r.sigma[d];
+      }
     }
   if (r.nan_flag) {
     w.gn_dirty = true;
@@ -545,8 +560,8 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
 }
 static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
-                    double delta[3], double *huber_err, bool pre_launched = false) {
-  return wgn_step(h, d_a, d_b, n, T, delta, huber_err, [] { return hipSuccess; }, pre_launched);
+                    double delta[3], double *huber_err, bool pre_launched = false, int kind = 2) {
+  return wgn_step(h, d_a, d_b, n, T, delta, huber_err, [] { return hipSuccess; }, pre_launched, kind);
 }
 
 // estimate_transform (src/lib.rs:59-84) on device pairs.  `second_eval_hook(T1)` (optional) is
@@ -584,8 +599,8 @@ static int estimate_transform_loop(icp_handle *h, const double *d_a, const doubl
         }
       }
       const int rc = (it == 1 && !hook_first)
-                         ? wgn_step(h, d_a, d_b, n, T, delta, &err, [&] { return second_eval_hook(T); })
-                         : wgn_step(h, d_a, d_b, n, T, delta, &err, it == 0 && first_pre_launched);
+                         ? wgn_step(h, d_a, d_b, n, T, delta, &err, [&] { return second_eval_hook(T); }, false, 1)
+                         : wgn_step(h, d_a, d_b, n, T, delta, &err, it == 0 && first_pre_launched, it < 2 ? it : 2);
       if (on_eval_stream) {
         h->stream = first_stream;
         h->ws.swap_ctx();
@@ -690,7 +705,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
           e = launch_sel_init(h, n);
           w.gn_dirty = false;
         }
-        if (e == hipSuccess && window_usable(h, n, &P)) {
+        if (e == hipSuccess && window_usable(h, n, &P, 0)) {
           ++w.win_tried;
           ++w.pre_evals;
           e = launch_weighted_gn_win(h, A[cur ^ 1], B[cur ^ 1], n, transform_identity(), P);

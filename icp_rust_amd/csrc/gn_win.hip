@@ -753,17 +753,22 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
 }
 
 // ---- host ---------------------------------------------------------------------------
-bool window_usable(const icp_handle *h, size_t n, WinParams *P) {
+bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind) {
   static const bool off = getenv("ICP_GN_NO_WIN") != nullptr;
   // half-width of the fine windows in sigmas: the prediction may be off by about that much
   static const double hw_sigmas = getenv("ICP_WIN_HW") ? atof(getenv("ICP_WIN_HW")) : 0.05;
   const Workspace &w = h->ws;
-  if (off || !w.win_valid || n < kWinMinN || n > kWinMaxN) return false;
-  double f = hw_sigmas * (w.win_wide ? 4. : 1.);
+  if (off || n < kWinMinN || n > kWinMaxN) return false;
+  // the evaluation's own kind first (common.hpp, Workspace::win_kind), else the most recent evaluation
+  const bool own = kind >= 0 && kind < 2 && w.win_kind[kind].valid;
+  if (!own && !w.win_valid) return false;
+  const double *p_med = own ? w.win_kind[kind].med : w.win_med;
+  const double *p_sigma = own ? w.win_kind[kind].sigma : w.win_sigma;
+  double f = hw_sigmas * ((own ? w.win_kind[kind].wide : w.win_wide) ? 4. : 1.);
   if (n > 1000000) f *= 1e6 / (double)n;  // candidates per fine bin grow with n
   if (f > 0.2) f = 0.2;                   // the windows must not overlap (MAD = 0.6745 sigma)
   for (int d = 0; d < 2; ++d) {
-    const double s = w.win_sigma[d], m = w.win_med[d];
+    const double s = p_sigma[d], m = p_med[d];
     if (!(s > 0.) || !(s < 1e300) || !(fabs(m) < 1e300)) return false;
     const double mad = s / ICP_PPF34, hw = f * s;
     // the bracket's quarter-bin margins must dwarf the rounding of (r - x) * scale
