@@ -253,7 +253,15 @@ __device__ unsigned long long g_nn_hist[2][32];  // [0]: lanes by record chunks,
 // COLD: no previous matches exist (first search of a source snapshot, or unsorted queries).
 // Register budget of the warm 3-D instantiation: 120 VGPRs -- three of its waves plus two waves of an
 // evaluation kernel (<= 72) share a SIMD during the speculative overlap (tests/test_registers.py).
-template <int DIM, bool XFORM, bool COLD>
+//
+// L lanes per query (1, or 4 for clouds of tens of thousands of points, where a one-lane-per-query
+// launch leaves most of the chip idle and lasts exactly as long as its slowest wave): the lanes of
+// a query share the rows of walk_box's cell box -- lane `sub` takes rows sub, sub + L, ... in the
+// order the box enumerates them -- and exchange their winners by (d^2, index) at the end.  Every
+// lane prunes with the distance of a real target of the SAME query (a valid bound, merely less
+// tight than the group's), every row is some lane's, and the lexicographic minimum over the lanes
+// is the minimum over all records visited: same result as L = 1.
+template <int DIM, bool XFORM, bool COLD, int L>
 __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
                                                  const uint32_t *__restrict__ perm, unsigned n, Pose T,
                                                  GridParams g, const uint32_t *__restrict__ start,
@@ -265,8 +273,9 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   unsigned st[8] = {1, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
-  const unsigned k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= n) return;
+  const unsigned k = (blockIdx.x * 256 + threadIdx.x) / L;
+  const unsigned sub = (blockIdx.x * 256 + threadIdx.x) % L;  // lane within the query's group (aligned: L divides 64)
+  if (k >= n) return;  // whole groups leave together
   // perm != null: src is the cell-sorted copy made by prepare_queries (neighbouring lanes
   // search neighbouring cells); results go back to the original positions
   const unsigned i = perm ? perm[k] : k;
@@ -334,6 +343,29 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   auto consider = [&](uint32_t ti) {
     if (ti == bi) return;
     eval(ti, dst[(size_t)ti * DIM + 0], dst[(size_t)ti * DIM + 1], DIM == 3 ? dst[(size_t)ti * DIM + 2] : 0.);
+  };
+  // L > 1: adopt the best (d^2, index) any lane of the group holds.  Called where the group's lanes
+  // have reconverged (after walk_box's loop).
+  auto share_best = [&]() {
+    if (L == 1) return;
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) {
+      const double ob = __shfl_xor(best, off);
+      const uint32_t obi = (uint32_t)__shfl_xor((int)bi, off);
+      const double ox = __shfl_xor(bx, off), oy = __shfl_xor(by, off), oz = DIM == 3 ? __shfl_xor(bz, off) : 0.;
+      if (ob < best || (ob == best && obi < bi)) {
+        best = ob;
+        bi = obi;
+        bx = ox;
+        by = oy;
+        bz = oz;
+      }
+    }
+    if (best < __builtin_huge_val()) {
+      const double r = sqrt(best) + ec;
+      thr32 = (float)(r * r * 1.000004);
+      thr32 = thr32 * 1.000001f + 1e-37f;
+    }
   };
   auto screen = [&](const GridPoint &t) -> float {
     const float fx = qf[0] - t.x, fy = qf[1] - t.y;
@@ -406,6 +438,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
       const double dz = slab(2, iz, iz);
       dz2 = dz * dz;
     }
+    unsigned rowno = 0;  // L > 1: rows are dealt round-robin to the lanes of the group
     for (;;) {
       uint32_t ra0 = 0, ra1 = 0, ra2 = 0, ra3 = 0;  // first / one-past-last cell of each collected row
       uint32_t rz0 = 0, rz1 = 0, rz2 = 0, rz3 = 0;
@@ -421,6 +454,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
           continue;
         }
         const int cy = iy++;
+        if (L > 1 && (rowno++ % L) != sub) continue;  // another lane's row
         const double dy = slab(1, cy, cy);
         const double dyz = dy * dy + dz2;
         if (dx2 + dyz > best) continue;
@@ -477,6 +511,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
         ICP_EXAMINE(t, sc);
       }
     }
+    share_best();  // the group agrees again (nothing below may depend on which lane took which row)
   };
 
   // Warm start (second and later outer iterations of one estimate call): the pose moved a
@@ -581,15 +616,15 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
         }
       }
       // can anything outside the visited block [c-r, c+r] (x: r * fx cells) still win or tie?
-      double L = __builtin_huge_val();
+      double Lb = __builtin_huge_val();
 #pragma unroll
       for (int d = 0; d < DIM; ++d) {
         const int w = d == 0 ? r * g.fx : r;
-        if (c[d] - w > 0) L = fmin(L, (q[d] - (g.lo[d] + (c[d] - w) * g.h[d])) - mg[d]);
-        if (c[d] + w < g.n[d] - 1) L = fmin(L, ((g.lo[d] + (c[d] + w + 1) * g.h[d]) - q[d]) - mg[d]);
+        if (c[d] - w > 0) Lb = fmin(Lb, (q[d] - (g.lo[d] + (c[d] - w) * g.h[d])) - mg[d]);
+        if (c[d] + w < g.n[d] - 1) Lb = fmin(Lb, ((g.lo[d] + (c[d] + w + 1) * g.h[d]) - q[d]) - mg[d]);
       }
-      if (L == __builtin_huge_val()) break;  // the whole grid has been visited
-      if (L > 0. && best < L * L) break;     // every unvisited target is strictly farther
+      if (Lb == __builtin_huge_val()) break;  // the whole grid has been visited
+      if (Lb > 0. && best < Lb * Lb) break;   // every unvisited target is strictly farther
     }
   }
 #ifdef ICP_NN_STATS
@@ -613,6 +648,7 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
 #endif
   // prev and prev_out are the same per-slot array: a slot whose match did not change already
   // holds this record (32 B of write traffic per query saved once the registration settles)
+  if (L > 1 && sub != 0) return;  // the group agrees (walk_box ends on share_best); one lane reports
   if (prev_out && bi != prev_bi) {
     PrevMatch pm;
     pm.x = bx;
@@ -738,14 +774,29 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
     if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
       (void)hipEventRecord(ev0, h->stream);
   }
-  const unsigned blocks = (n + 255) / 256;
-#define GRID(DIM, XF)                                                                                   \
-  if (q_prev)                                                                                           \
-    GRID2(DIM, XF, false);                                                                              \
-  else                                                                                                  \
-    GRID2(DIM, XF, true)
-#define GRID2(DIM, XF, CD)                                                                              \
-  hipLaunchKernelGGL((k_nn_grid<DIM, XF, CD>), dim3(blocks), dim3(256), 0, h->stream, q_src, q_perm, n, T, \
+  // four lanes per query while one lane per query cannot fill the chip (8 lanes measured the same, 16
+  // slower; ICP_NN_COOP_MAX_N: largest n that gets them, 0 = never)
+  static const long coop_max = getenv("ICP_NN_COOP_MAX_N") ? atol(getenv("ICP_NN_COOP_MAX_N")) : 65536;
+  const bool coop = (long)n <= coop_max;
+  const unsigned blocks = (unsigned)(((size_t)n * (coop ? 4 : 1) + 255) / 256);
+#define GRID(DIM, XF)                       \
+  do {                                      \
+    if (q_prev) {                           \
+      GRID2(DIM, XF, false);                \
+    } else {                                \
+      GRID2(DIM, XF, true);                 \
+    }                                       \
+  } while (0)
+#define GRID2(DIM, XF, CD)                  \
+  do {                                      \
+    if (coop) {                             \
+      GRID3(DIM, XF, CD, 4);                \
+    } else {                                \
+      GRID3(DIM, XF, CD, 1);                \
+    }                                       \
+  } while (0)
+#define GRID3(DIM, XF, CD, LN)                                                                          \
+  hipLaunchKernelGGL((k_nn_grid<DIM, XF, CD, LN>), dim3(blocks), dim3(256), 0, h->stream, q_src, q_perm, n, T, \
                      G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, q_prev, q_prev_out)
   if (h->dim == 3) {
     if (xform) { GRID(3, true); } else { GRID(3, false); }
@@ -754,6 +805,7 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   }
 #undef GRID
 #undef GRID2
+#undef GRID3
   hipError_t e = hipGetLastError();
   if (ev0 && ev1) {
     (void)hipEventRecord(ev1, h->stream);

@@ -354,6 +354,34 @@ def test_grid_nn_equals_brute_force_and_oracle(name):
     assert np.array_equal(g, want)
 
 
+@pytest.mark.parametrize("name", ["far3", "lattice3", "clusters3", "lattice2", "line3"])
+def test_grid_nn_both_lane_layouts_agree(name):
+    """up to 65536 queries the grid search gives every query four lanes (they share the rows of its
+    cell box), beyond that one: the same queries, repeated past that size, must get the same indices"""
+    dst, q = _grid_cases()[name]
+    reps = 65536 // len(q) + 1
+    big = np.ascontiguousarray(np.tile(q, (reps, 1)))
+    assert len(q) <= 65536 < len(big)
+    icp = (I.Icp3d if dst.shape[1] == 3 else I.Icp2d)(dst, nn_mode=I.NN_GRID)
+    small = icp.nn_search(q)
+    assert np.array_equal(icp.nn_search(big), np.tile(small, reps))
+    rc, want = O.KdTree(dst).search(q)
+    assert rc == O.OK and np.array_equal(small, want)
+
+
+def test_warm_search_with_four_lanes_per_query_tracks_the_oracle_over_a_large_motion():
+    """the pose moves a lot in the first iterations: boxes of many rows, dealt to the four lanes"""
+    pk = synth.synthetic_scan3d_packets(150)
+    s3, d3 = synth.remove_invalid_values(pk[:75]), synth.remove_invalid_values(pk[75:150])
+    T, idx, inner = I.Icp3d(d3).estimate(s3, I.Transform(), 8, return_info=True)
+    b, t = I.reduce_geometry(len(s3))
+    rc, oT, oidx, oinner = O.icp_estimate(3, d3, s3, O.transform_identity(), 8, use_kdtree=True, sum_mode=1,
+                                          reduce_blocks=b, reduce_threads=t)
+    assert rc == O.OK
+    assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
+    assert np.array_equal(T.as_array(), oT.as_array())
+
+
 def test_grid_nn_full_size_vs_kdtree():
     """BASELINE's 1M x 1M synthetic pair: every correspondence index equals the oracle's."""
     src, dst = synth.synthetic_pair(1_000_000, 1_000_000)
