@@ -9,6 +9,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def run2d():
+    import icp_rust_amd as I
+    from icp_rust_amd.scans import load_scan2d
+    G = os.path.join(ROOT, "tests", "golden", "scans2d")
+    src = load_scan2d(f"{G}/001.txt"); dst = load_scan2d(f"{G}/002.txt")
+    icp = I.Icp2d(dst)
+    for _ in range(3):
+        icp.estimate(src, I.Transform(), 20)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        inner = icp.estimate(src, I.Transform(), 20, return_info=True)[-1]
+    print(f"2-D scan: {1e3 * (time.perf_counter() - t0) / 10:.3f} ms per estimate(20), inner {inner.tolist()}")
+
+
 def run():
     import numpy as np
     import icp_rust_amd as I
@@ -32,7 +46,10 @@ def analyze(d):
     rows.sort()
     # the last estimate call: from the last k_query_count on
     starts = [i for i, r in enumerate(rows) if r[2].startswith("k_query_count")]
-    seg = rows[starts[-1]:]
+    if starts:
+        seg = rows[starts[-1]:]
+    else:  # small clouds take no snapshot: show the tail of the trace
+        seg = rows[-int(os.environ.get("TAIL", "260")):]
     t0 = seg[0][0]
     busy = 0
     prev_end = t0
@@ -49,5 +66,7 @@ def analyze(d):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--analyze":
         analyze(sys.argv[2])
+    elif len(sys.argv) > 1 and sys.argv[1] == "--scan2d":
+        run2d()
     else:
         run()
