@@ -202,8 +202,13 @@ __global__ __launch_bounds__(1024) void k_tiny_eval(const double2 *__restrict__ 
     acc[12] = acc[12] + huber_rho(r[0] * r[0] + r[1] * r[1]);
   }
   TSTAMP();
-  // stage 1: virtual blocks of 512 threads (8 waves each)
-  group_reduce<kNAcc + 1>(acc, sm, wave);
+  // stage 1: virtual blocks of 512 threads (8 waves each); a wave without points sums to +0.0
+  if ((unsigned)wave * 64u < n) {
+    group_reduce<kNAcc + 1>(acc, sm, wave);
+  } else if ((tid & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < kNAcc + 1; ++k) sm[wave][k] = 0.;
+  }
   __syncthreads();
   if (tid < 2 * (kNAcc + 1)) {
     const int vb = tid / (kNAcc + 1), k = tid % (kNAcc + 1);
@@ -212,19 +217,15 @@ __global__ __launch_bounds__(1024) void k_tiny_eval(const double2 *__restrict__ 
     part[vb][k] = v;
   }
   __syncthreads();
-  // stage 2: one block of 512 threads over the `blocks` block sums
-  double tot[kNAcc + 1];
-#pragma unroll
-  for (int k = 0; k < kNAcc + 1; ++k) tot[k] = 0.;
-  if (tid < (unsigned)blocks)
-#pragma unroll
-    for (int k = 0; k < kNAcc; ++k) tot[k] = tot[k] + part[tid][k];
-  if (tid < 512) group_reduce<kNAcc + 1>(tot, sm, wave);
-  __syncthreads();
+  // stage 2: one block of 512 threads over the `blocks` (<= 2) block sums.  Only threads 0 and 1 of
+  // that block hold anything: every other operand of its wave tree and of the fold over its wave
+  // sums is +0.0, and x + 0.0 is x (a -0.0 becomes +0.0, once and for all).  So lane 0 of wave 0
+  // ends with (p0 + 0.0) + (p1 + 0.0) -- lane 1 joins at the last step -- and the fold adds zeros:
+  // the same bits as the general path without its 84 shuffles.
   if (tid < kNAcc + 1) {
-    double v = sm[0][tid];
-    for (int w = 1; w < 8; ++w) v = v + sm[w][tid];
-    res->acc[tid] = v;
+    const double p0 = (0. + part[0][tid]) + 0.;
+    const double p1 = blocks > 1 ? (0. + part[1][tid]) + 0. : 0.;
+    res->acc[tid] = tid < kNAcc ? (p0 + p1) + 0. : 0.;
   }
   TSTAMP();
   __threadfence_system();
