@@ -66,11 +66,16 @@ def main():
         fb, wb = tot["f"] / tot["nf"] * 1024, tot["w"] / tot["nw"] * 1024
         doc["k_nn_grid"] = {"traffic_bytes_per_launch": fb + wb, "fetch_bytes": fb, "write_bytes": wb,
                             "corrected": False, "launches": tot["nf"]}
-        warm = kernels.get("icp::k_nn_grid<3, true, false>")
+        def pick(prefix):  # (a trailing template argument: lanes per query)
+            for k, e in kernels.items():
+                if k.startswith(prefix) and "FETCH_SIZE_KB_avg_per_launch" in e and "WRITE_SIZE_KB_avg_per_launch" in e:
+                    return e
+            return None
+        warm = pick("icp::k_nn_grid<3, true, false")
         if warm and "FETCH_SIZE_KB_avg_per_launch" in warm and "WRITE_SIZE_KB_avg_per_launch" in warm:
             wb_ = 1024 * (warm["FETCH_SIZE_KB_avg_per_launch"] + warm["WRITE_SIZE_KB_avg_per_launch"])
             doc["k_nn_grid"]["warm_only_bytes_per_launch"] = wb_
-            cold = kernels.get("icp::k_nn_grid<3, true, true>")
+            cold = pick("icp::k_nn_grid<3, true, true")
             if cold and "FETCH_SIZE_KB_avg_per_launch" in cold and "WRITE_SIZE_KB_avg_per_launch" in cold:
                 cb_ = 1024 * (cold["FETCH_SIZE_KB_avg_per_launch"] + cold["WRITE_SIZE_KB_avg_per_launch"])
                 doc["k_nn_grid"]["cold_only_bytes_per_launch"] = cb_
