@@ -4,9 +4,10 @@
 // bit for bit: d^2 = ((dx*dx + dy*dy) + dz*dz) in f64 without FMA contraction, ties ->
 // lowest target index.  It replaces the reference's kd-tree (nearest_neighbor::KdTree,
 // src/lib.rs:99,121,141,164) the MI355X way: instead of a pointer-chasing tree, targets
-// are counting-sorted into cells (32-B records: x, y, z, original index), a query walks
-// Chebyshev shells of cells around its own cell and stops as soon as no unvisited cell
-// can hold a closer-or-equal point.  Exactness does not depend on the cell size or on
+// are counting-sorted into cells (16-B screening records: f32 offsets + original index; the exact
+// f64 coordinates stay in dst), a query walks the cell box of the ball around its previous match
+// (warm) or Chebyshev shells of cells around its own cell (cold) and stops as soon as no
+// unvisited cell can hold a closer-or-equal point.  Exactness does not depend on the cell size or on
 // floating-point rounding of the cell assignment: every pruning bound is relaxed by a
 // margin that is orders of magnitude above the rounding of the cell arithmetic, so a
 // bound can only cause extra visits, never a missed candidate; candidates are compared
@@ -376,8 +377,6 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
     }
     return s;
   };
-  // four records of a contiguous run in flight per lane (the tail re-reads the last record:
-  // evaluating a target twice cannot change the winner)
   // kBatch records of a contiguous run in flight per lane (the tail re-reads the last record:
   // evaluating a target twice cannot change the winner, and a repeated address costs next to
   // nothing -- divergent control flow is what is expensive here)
