@@ -92,3 +92,37 @@ def run_scan_to_map(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=No
         transforms.append(transform)
         path.append(transform.t.copy())
     return transforms, np.array(path).reshape(-1, 2), world
+
+
+def main(argv=None):
+    """Headless stand-ins for the reference's two example binaries: the trajectory they draw,
+    printed.  `scan2d DIR` reads DIR/001.txt, 002.txt, ... (examples/scan2d.rs); `scan3d` runs the
+    synthetic packet stream in the scans.hdf5 layout (the file itself is absent from the reference
+    mount); `scan2map` is the growing-map extension on the same stream."""
+    import argparse
+
+    from . import synth
+
+    ap = argparse.ArgumentParser(prog="python -m icp_rust_amd.harness", description=main.__doc__)
+    ap.add_argument("loop", choices=["scan2d", "scan3d", "scan2map"])
+    ap.add_argument("scan_dir", nargs="?", help="scan2d: directory with 001.txt, 002.txt, ...")
+    ap.add_argument("--frames", type=int, default=8, help="scan3d / scan2map: synthetic frames")
+    ap.add_argument("--max-iter", type=int, default=20)
+    args = ap.parse_args(argv)
+    if args.loop == "scan2d":
+        if not args.scan_dir:
+            ap.error("scan2d needs the scan directory")
+        _, _, path = run_scan2d(args.scan_dir, max_iter=args.max_iter)
+    elif args.loop == "scan3d":
+        _, _, path = run_scan3d(synth.synthetic_scan3d_packets(PACKETS_PER_FRAME * args.frames), max_iter=args.max_iter)
+    else:
+        _, path, world = run_scan_to_map(synth.synthetic_scan3d_packets(PACKETS_PER_FRAME * (args.frames + 1)),
+                                         max_iter=args.max_iter)
+        print(f"# map: {world.target_count} points")
+    for k, (x, y) in enumerate(path):
+        print(f"{k:4d} {x:+.9f} {y:+.9f}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

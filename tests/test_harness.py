@@ -91,3 +91,15 @@ def test_scan3d_trajectory_on_gpu_matches_oracle_bit_for_bit():
     assert len(Ts) == 4
     for a, b in zip(Ts, Os):
         assert np.array_equal(a.as_array(), b.as_array())
+
+
+@pytest.mark.gpu
+def test_cli_prints_the_trajectories(capsys):
+    assert harness.main(["scan2d", GOLDEN, "--max-iter", "5"]) == 0
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln and not ln.startswith("#")]
+    Ts, _, path = harness.run_scan2d(GOLDEN, max_iter=5)
+    assert len(out) == len(path) == 4
+    assert [float(v) for v in out[-1].split()[1:]] == pytest.approx(list(path[-1]), abs=1e-9)
+    assert harness.main(["scan2map", "--frames", "2", "--max-iter", "3"]) == 0
+    out = capsys.readouterr().out.splitlines()
+    assert out[0].startswith("# map:") and len(out) == 3
