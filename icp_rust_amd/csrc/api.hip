@@ -71,6 +71,11 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_a2);
   (void)hipFree(w.d_b2);
   (void)hipFree(w.d_idx);
+  (void)hipFree(w.d_sa);
+  (void)hipFree(w.d_sb);
+  if (w.h_whist) (void)hipHostFree(w.h_whist);
+  (void)hipFree(w.d_rlist);
+  (void)hipFree(w.d_rlist_len);
   (void)hipFree(w.d_part_d);
   (void)hipFree(w.d_part_i);
   free_ctx(w);
@@ -310,8 +315,9 @@ extern "C" void icp_destroy(icp_handle *h) {
   if (getenv("ICP_DBG_WIN") && h->ws.win_tried)
     fprintf(stderr,
             "[icp] window evaluations: %llu tried, %llu missed; speculative searches: %llu hit, %llu missed; "
-            "first evaluations launched ahead: %llu\n",
-            h->ws.win_tried, h->ws.win_missed, h->ws.spec_hits, h->ws.spec_misses, h->ws.pre_evals);
+            "first evaluations launched ahead: %llu; refined windows (n > 4M): %llu tried, %llu missed\n",
+            h->ws.win_tried, h->ws.win_missed, h->ws.spec_hits, h->ws.spec_misses, h->ws.pre_evals,
+            h->ws.refine_tried, h->ws.refine_missed);
   static const bool no_pool = getenv("ICP_NO_POOL") != nullptr;
   if (!no_pool) {
     // back to the state of a fresh handle, buffers kept (everything logical is reset here; the
@@ -331,6 +337,7 @@ extern "C" void icp_destroy(icp_handle *h) {
     w.win_kind[0] = w.win_kind[1] = Workspace::WinPred();
     w.win_tried = w.win_missed = w.short_evals = w.radix_evals = 0;
     w.spec_hits = w.spec_misses = w.pre_evals = 0;
+    w.refine_tried = w.refine_missed = 0;
     w.last_inner = 0xffffffffu;
     std::lock_guard<std::mutex> lk(g_pool_mu);
     if (g_pool.size() < kPoolMax) {
@@ -521,6 +528,35 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
           shift = fmax(shift, (fabs(w.h_res->median[d] - p_med[d]) + fabs(w.h_res->sigma[d] - p_sigma[d])) / p_sigma[d]);
         if (shift < 0.01) wide = false;
       }
+    }
+    if (!done && refine_applies(n)) {
+      // beyond 4M points: windows refined in two passes (gn_win.hip).  The exact statistics of a
+      // strided 1M-pair sample centre the first pass ...
+      ++w.refine_tried;
+      HIP_TRY(launch_sample_pairs(h, d_a, d_b, n));
+      HIP_TRY(launch_weighted_gn_pull(h, w.d_sa, w.d_sb, kRefineSample, T));
+      HIP_TRY(wait_result(h));
+      WinParams P1, P2;
+      bool ok = !w.h_res->overflow && !w.h_res->nan_flag;
+      if (ok) {
+        const double m[2] = {w.h_res->median[0], w.h_res->median[1]}, sg[2] = {w.h_res->sigma[0], w.h_res->sigma[1]};
+        ok = make_window(m, sg, 0.02, &P1);
+      }
+      if (ok) {  // ... whose counts place the windows of the second
+        HIP_TRY(launch_win_first_pass(h, d_a, d_b, n, T, P1));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        ok = refine_window(w.h_whist, n, P1, &P2);
+      }
+      if (ok) {
+        ++w.win_tried;
+        HIP_TRY(launch_win_second_pass(h, d_a, n, T, P2));
+        if (!hooked) HIP_TRY(after_launch());
+        hooked = true;
+        HIP_TRY(wait_result(h));
+        done = has_median = !w.h_res->overflow;
+        if (!done) ++w.win_missed;
+      }
+      if (!done) ++w.refine_missed;
     }
     if (!done) {
       ++w.short_evals;

@@ -139,6 +139,12 @@ struct Workspace : GnCtx {
   uint32_t last_inner = 0xffffffffu;  // updates the inner loop applied in the last outer iteration of the previous call
   hipStream_t spec_stream = nullptr;  // later evaluations of an inner loop run beside the speculative search
   uint32_t *d_idx = nullptr;
+  // refined windows (n > 4M, gn_win.hip): a strided sample of the pairs and a host copy of the histograms
+  double *d_sa = nullptr, *d_sb = nullptr;
+  uint32_t *h_whist = nullptr;
+  double *d_rlist = nullptr;        // 2 x kRefineListCap: the residuals inside the second pass' fine windows
+  unsigned *d_rlist_len = nullptr;  // [2]
+  unsigned long long refine_tried = 0, refine_missed = 0;
   // brute-force NN partial minima when the target range is split over blockIdx.y
   size_t cap_part = 0;
   double *d_part_d = nullptr;
@@ -281,6 +287,17 @@ hipError_t launch_weighted_gn_pull(icp_handle *h, const double *d_a, const doubl
 bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind = 2);
 hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double *d_b, size_t n,
                                   const Pose &T, const WinParams &P);
+// n > 4M: the window is found in two passes (gn_win.hip, "refined windows"); the host part of the
+// orchestration (two waits) lives in api.hip:wgn_step
+constexpr size_t kRefineListCap = 1u << 21;  // expected: ~4e5 per dimension
+constexpr size_t kRefineSample = 1u << 18;  // standard error of its median: 0.0025 sigma (1M: 0.0012, 60 us more)
+bool refine_applies(size_t n);
+bool make_window(const double med[2], const double sigma[2], double f, WinParams *P);
+hipError_t launch_sample_pairs(icp_handle *h, const double *d_a, const double *d_b, size_t n);
+hipError_t launch_win_first_pass(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
+                                 const WinParams &P1);  // + copy of the histograms into h->ws.h_whist
+bool refine_window(const uint32_t *hist, size_t n, const WinParams &P1, WinParams *P2);
+hipError_t launch_win_second_pass(icp_handle *h, const double *d_a, size_t n, const Pose &T, const WinParams &P2);
 // unweighted accumulation (gauss_newton_update / error / huber_error)
 hipError_t launch_plain_gn(icp_handle *h, const double *d_a, const double *d_b, size_t n,
                            const Pose &T);

@@ -145,6 +145,95 @@ __global__ __launch_bounds__(kWinThreads) void k_win_hist(const double2 *__restr
 #endif
 }
 
+// ---- W' (refined windows, n > 4M): the histograms again for new windows, from the stored residuals
+// ... and the points inside the three fine windows of each dimension (where every candidate of the
+// compaction will be) go to two dense lists: staged in LDS, one reservation per workgroup and list.
+constexpr unsigned kRehistStage = 1024;
+__global__ __launch_bounds__(kWinThreads) void k_win_rehist(const double *__restrict__ rx,
+                                                            const double *__restrict__ ry, unsigned n, WinParams P,
+                                                            uint32_t *whist, WinState *st, double *lx, double *ly,
+                                                            unsigned lcap, unsigned *llen) {
+  __shared__ uint32_t lh[2 * kWinBins];
+  __shared__ double s_stage[2][kRehistStage];
+  __shared__ unsigned s_n[2], s_base[2];
+  for (unsigned i = threadIdx.x; i < 2u * kWinBins; i += kWinThreads) lh[i] = 0;
+  if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+  __syncthreads();
+  auto fine = [](unsigned j) {
+    return (j >= (unsigned)kF0 && j < (unsigned)kC0) || (j >= (unsigned)kF1 && j < (unsigned)kC1) ||
+           (j >= (unsigned)kF2 && j < (unsigned)(kWinBins - 1));
+  };
+  auto keep = [&](int d, double v) {
+    const unsigned pos = atomicAdd(&s_n[d], 1u);
+    if (pos < kRehistStage) {
+      s_stage[d][pos] = v;
+    } else {  // more than the stage holds: one by one
+      const unsigned g = atomicAdd(&llen[d], 1u);
+      if (g < lcap) (d ? ly : lx)[g] = v;
+    }
+  };
+  unsigned edge[4] = {0u, 0u, 0u, 0u};
+  const unsigned G = gridDim.x * kWinThreads;
+  for (unsigned base = blockIdx.x * kWinThreads + threadIdx.x; base < n; base += G * kWinBatch) {
+    double v0[kWinBatch], v1[kWinBatch];
+#pragma unroll
+    for (int u = 0; u < kWinBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i < n) {
+        v0[u] = rx[i];
+        v1[u] = ry[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kWinBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i >= n) continue;
+      const unsigned j0 = wbin(v0[u], P.d[0]), j1 = wbin(v1[u], P.d[1]);
+      if (j0 == 0u) ++edge[0];
+      else if (j0 == (unsigned)(kWinBins - 1)) ++edge[1];
+      else atomicAdd(&lh[j0], 1u);
+      if (j1 == 0u) ++edge[2];
+      else if (j1 == (unsigned)(kWinBins - 1)) ++edge[3];
+      else atomicAdd(&lh[kWinBins + j1], 1u);
+      if (fine(j0)) keep(0, v0[u]);
+      if (fine(j1)) keep(1, v1[u]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned v = edge[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < 2u * kWinBins; i += kWinThreads) {
+    const uint32_t c = lh[i];
+    if (c) atomicAdd(&whist[i], c);
+  }
+  if (threadIdx.x < 2) {
+    const unsigned c = s_n[threadIdx.x] < kRehistStage ? s_n[threadIdx.x] : kRehistStage;
+    s_base[threadIdx.x] = c ? atomicAdd(&llen[threadIdx.x], c) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const unsigned c = s_n[d] < kRehistStage ? s_n[d] : kRehistStage;
+    for (unsigned e = threadIdx.x; e < c; e += kWinThreads)
+      if (s_base[d] + e < lcap) (d ? ly : lx)[s_base[d] + e] = s_stage[d][e];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4) st->list_cnt[threadIdx.x][0] = 0;
+}
+
+// every (n / count)-th pair: the sample whose exact statistics centre the first pass
+__global__ void k_sample_pairs(const double2 *__restrict__ a, const double2 *__restrict__ b, unsigned stride,
+                               unsigned count, double2 *__restrict__ sa, double2 *__restrict__ sb) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  sa[i] = a[(size_t)i * stride];
+  sb[i] = b[(size_t)i * stride];
+}
+
 // ---- C ------------------------------------------------------------------------------
 // largest t in [lo, hi] with pred(t), for a predicate that holds on a prefix of the range
 // (lo - 1 if nowhere); the 64 lanes of a wave probe 64 positions per round
@@ -273,10 +362,16 @@ __device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, co
   return med_cnt <= (unsigned)kWinCapMed && ring_cnt <= (unsigned)kWinCapRing;
 }
 
+// LISTS (second pass of the refined windows, n > 4M): rx / ry are not the n residuals but the lists
+// k_win_rehist made of the points inside the three fine windows (llen[d] entries, at most lcap) --
+// every median or MAD candidate is among them once the bins resolved below are checked to lie inside
+// those windows -- so the compaction streams a few hundred thousand values instead of n.
+template <bool LISTS>
 __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__restrict__ rx,
                                                              const double *__restrict__ ry, unsigned n,
                                                              WinParams P, const uint32_t *__restrict__ whist,
-                                                             WinState *st, double *wmed, double *wring) {
+                                                             WinState *st, double *wmed, double *wring,
+                                                             const unsigned *__restrict__ llen, unsigned lcap) {
   __shared__ uint32_t cum[2 * kWinBins];  // points in lower bins
   __shared__ unsigned s_wtot[2][16];
   __shared__ int s_rng[2][8];
@@ -350,8 +445,11 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
     unsigned counted = 0;  // every point is in exactly one bin: anything else means the histogram is not
 #pragma unroll             // this evaluation's (defence in depth for the hand-over between streams)
     for (int w = 0; w < NW; ++w) counted += s_wtot[d][w];
-    const bool ok = counted == n && resolve_window(cum + d * kWinBins, n, P.d[d], geo, s_t[0][d], s_t[1][d], R,
-                                                   med_base, med_cnt, inner, ring_cnt, range);
+    bool ok = counted == n && resolve_window(cum + d * kWinBins, n, P.d[d], geo, s_t[0][d], s_t[1][d], R,
+                                             med_base, med_cnt, inner, ring_cnt, range);
+    if (LISTS && ok)  // the median bins in the middle window, the two arcs of the ring in the outer ones
+      ok = llen[d] <= lcap && R.mlo >= kF1 && R.mhi < kC1 && R.i0 <= R.i1 && R.a0 >= kF0 && R.i0 - 1 < kC0 &&
+           R.i1 + 1 >= kF2 && R.b1 <= kWinBins - 2;
     if (lane == 0) {
       s_rng[d][0] = R.mlo;
       s_rng[d][1] = R.mhi;
@@ -390,22 +488,23 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
     i1[d] = (unsigned)s_rng[d][5];
   }
   const unsigned G = gridDim.x * kWinThreads;
-  for (unsigned base = blockIdx.x * kWinThreads + tid; base < n; base += G * kWinBatch) {
+  const unsigned lim[2] = {LISTS ? llen[0] : n, LISTS ? llen[1] : n};
+  const unsigned nmax = lim[0] > lim[1] ? lim[0] : lim[1];
+  for (unsigned base = blockIdx.x * kWinThreads + tid; base < nmax; base += G * kWinBatch) {
     double v[2][kWinBatch];
 #pragma unroll
     for (int u = 0; u < kWinBatch; ++u) {
       const unsigned i = base + u * G;
-      if (i < n) {
-        v[0][u] = rx[i];
-        v[1][u] = ry[i];
-      }
+      if (i < lim[0]) v[0][u] = rx[i];
+      if (i < lim[1]) v[1][u] = ry[i];
     }
 #pragma unroll
     for (int u = 0; u < kWinBatch; ++u) {
       const unsigned i = base + u * G;
-      if (i >= n) continue;
+      if (i >= nmax) continue;
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
+        if (LISTS && i >= lim[d]) continue;
         const double r = v[d][u];
         const unsigned j = wbin(r, P.d[d]);
         // staged in LDS; a workgroup that meets more candidates than it can stage (a run of
@@ -767,8 +866,13 @@ bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind) {
   double f = hw_sigmas * ((own ? w.win_kind[kind].wide : w.win_wide) ? 4. : 1.);
   if (n > 1000000) f *= 1e6 / (double)n;  // candidates per fine bin grow with n
   if (f > 0.2) f = 0.2;                   // the windows must not overlap (MAD = 0.6745 sigma)
+  return make_window(p_med, p_sigma, f, P);
+}
+
+// the bins of both dimensions for fine windows of half-width f * sigma around med and med -+ MAD
+bool make_window(const double med[2], const double sigma[2], double f, WinParams *P) {
   for (int d = 0; d < 2; ++d) {
-    const double s = p_sigma[d], m = p_med[d];
+    const double s = sigma[d], m = med[d];
     if (!(s > 0.) || !(s < 1e300) || !(fabs(m) < 1e300)) return false;
     const double mad = s / ICP_PPF34, hw = f * s;
     // the bracket's quarter-bin margins must dwarf the rounding of (r - x) * scale
@@ -802,9 +906,9 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
   const bool coresident = !no_co && h->stream == w.spec_stream;
   hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(kWinThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
                      w.d_wstate, w.d_scal);
-  hipLaunchKernelGGL(k_win_compact, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
+  hipLaunchKernelGGL(k_win_compact<false>, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
                      (const double *)w.d_ry, n, P, (const uint32_t *)w.d_whist, w.d_wstate, w.d_wmed,
-                     w.d_wring);
+                     w.d_wring, (const unsigned *)nullptr, 0u);
   int blocks, threads;
   reduce_geometry(n_, &blocks, &threads);
   if (coresident) {
@@ -818,6 +922,148 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
                        (const double *)w.d_ry, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
                        (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, ++w.seq);
   }
+  return hipGetLastError();
+}
+
+// ---- refined windows: n > kWinMaxN ---------------------------------------------------
+// Beyond 4M points a window wide enough to survive a prediction error holds more candidates than
+// the lists take, so the radix pipeline used to serve alone: nine launches that stream 192 B per
+// point.  Two window passes stream 112: the exact statistics of a 256k-point strided sample centre
+// a first histogram pass (fine windows of 0.02 sigma: eight standard errors of the sample
+// median); its counts place the median and the MAD to within a fine bin (8e-5 sigma), and a second
+// histogram pass over the stored residuals, with windows as narrow as the lists require, is then
+// resolved by the usual C and A launches -- which verify everything by exact counts, so a bad
+// sample can only cost a repeat with the radix pipeline, never a different result.
+bool refine_applies(size_t n) {
+  static const bool off = getenv("ICP_GN_NO_WIN") != nullptr || getenv("ICP_GN_NO_REFINE") != nullptr;
+  return !off && n > kWinMaxN && n / kRefineSample >= 1 && n < 0xffffffffull;
+}
+
+hipError_t launch_sample_pairs(icp_handle *h, const double *d_a, const double *d_b, size_t n) {
+  Workspace &w = h->ws;
+  hipError_t e;
+  if (!w.d_sa) {
+    if ((e = hipMalloc(&w.d_sa, kRefineSample * 2 * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_sb, kRefineSample * 2 * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipHostMalloc(&w.h_whist, (size_t)2 * kWinBins * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_rlist, 2 * kRefineListCap * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_rlist_len, 2 * sizeof(unsigned))) != hipSuccess) return e;
+  }
+  const unsigned stride = (unsigned)(n / kRefineSample);
+  hipLaunchKernelGGL(k_sample_pairs, dim3((unsigned)(kRefineSample / 256)), dim3(256), 0, h->stream, (const double2 *)d_a,
+                     (const double2 *)d_b, stride, (unsigned)kRefineSample, (double2 *)w.d_sa, (double2 *)w.d_sb);
+  return hipGetLastError();
+}
+
+// These launches run against HBM bandwidth, not launch latency: four workgroups per CU (one per CU
+// keeps 32 KB of 8-byte loads in flight per CU: 3 TB/s measured for the second histogram pass and the
+// compaction on 64M pairs; the flush of 4 x 4096 histogram words per CU is noise at this size)
+static unsigned win_hist_blocks(unsigned n) {
+  const unsigned per = kWinThreads * kWinBatch;
+  unsigned hb = (n + per - 1) / per;
+  return hb > 4u * (unsigned)kWinBlocks ? 4u * (unsigned)kWinBlocks : hb;
+}
+
+hipError_t launch_win_first_pass(icp_handle *h, const double *d_a, const double *d_b, size_t n_, const Pose &T,
+                                 const WinParams &P1) {
+  Workspace &w = h->ws;
+  const unsigned n = (unsigned)n_;
+  hipLaunchKernelGGL(k_win_hist, dim3(win_hist_blocks(n)), dim3(kWinThreads), 0, h->stream, (const double2 *)d_a,
+                     (const double2 *)d_b, T, w.d_rx, w.d_ry, n, P1, w.d_whist, w.d_wstate, w.d_scal);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = hipMemcpyAsync(w.h_whist, w.d_whist, (size_t)2 * kWinBins * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+  if (e != hipSuccess) return e;
+  // the second pass starts from empty histograms and empty lists
+  if ((e = hipMemsetAsync(w.d_rlist_len, 0, 2 * sizeof(unsigned), h->stream)) != hipSuccess) return e;
+  return hipMemsetAsync(w.d_whist, 0, (size_t)2 * kWinBins * sizeof(uint32_t), h->stream);
+}
+
+// host twin of wedge(): value range [lo, hi) of regular bin j
+static void bin_range(int j, const WinDim &w, double *lo, double *hi) {
+  auto edge = [&](int k) -> double {
+    if (k >= kWinBins - 1) return w.x[5];
+    if (k >= kF2) return w.x[4] + (double)(k - kF2) / w.sf;
+    if (k >= kC1) return w.x[3] + (double)(k - kC1) / w.sc;
+    if (k >= kF1) return w.x[2] + (double)(k - kF1) / w.sf;
+    if (k >= kC0) return w.x[1] + (double)(k - kC0) / w.sc;
+    return w.x[0] + (double)(k - kF0) / w.sf;
+  };
+  *lo = edge(j);
+  *hi = edge(j + 1);
+}
+
+// From the first pass' counts: the bin of the median -> its centre; bins taken outwards from there in
+// the order of their distance until half of the points are in -> the MAD.  Windows for the second
+// pass: as wide as the candidate lists allow (~256 points per fine bin), at least four first-pass
+// bins.  Nothing here needs to be exact: the second pass is verified by counts like any window.
+bool refine_window(const uint32_t *hist, size_t n, const WinParams &P1, WinParams *P2) {
+  double med[2], sigma[2];
+  for (int d = 0; d < 2; ++d) {
+    const uint32_t *c = hist + (size_t)d * kWinBins;
+    const WinDim &w = P1.d[d];
+    const size_t half = (n - 1) / 2;
+    size_t run = 0;
+    int jm = -1;
+    for (int j = 0; j < kWinBins; ++j) {
+      if (run + c[j] > half) {
+        jm = j;
+        break;
+      }
+      run += c[j];
+    }
+    if (jm < 1 || jm > kWinBins - 2) return false;  // the median is outside the first pass' windows
+    double lo, hi;
+    bin_range(jm, w, &lo, &hi);
+    const double m = 0.5 * (lo + hi);
+    // sweep outwards: the next bin on the left or on the right, whichever centre is closer
+    size_t in = c[jm];
+    int l = jm - 1, r = jm + 1;
+    double mad = 0.5 * (hi - lo);
+    while (in <= n / 2) {
+      double ll = 0., lh = 0., rl = 0., rh = 0.;
+      if (l < 1 || r > kWinBins - 2) return false;  // the MAD reaches a catch-all bin
+      bin_range(l, w, &ll, &lh);
+      bin_range(r, w, &rl, &rh);
+      const double dl = m - 0.5 * (ll + lh), dr = 0.5 * (rl + rh) - m;
+      if (dl <= dr) {
+        in += c[l--];
+        mad = dl;
+      } else {
+        in += c[r++];
+        mad = dr;
+      }
+    }
+    med[d] = m;
+    sigma[d] = ICP_PPF34 * mad;
+    if (!(sigma[d] > 0.)) return false;
+  }
+  double f = 256. * kWinFine / (2. * 0.4 * (double)n);    // ~256 points per fine bin at the median
+  const double f_min = 4. * (2. * 0.02 / kWinFine);       // four fine bins of the first pass
+  if (f < f_min) f = f_min;
+  if (f > 0.02) f = 0.02;
+  return make_window(med, sigma, f, P2);
+}
+
+hipError_t launch_win_second_pass(icp_handle *h, const double *d_a, size_t n_, const Pose &T, const WinParams &P2) {
+  Workspace &w = h->ws;
+  const unsigned n = (unsigned)n_;
+  const unsigned hb = win_hist_blocks(n);
+  hipStream_t s = h->stream;
+  // (a list longer than kRefineListCap -- a distribution far denser at its quartiles than a bell -- is a miss)
+  double *lx = w.d_rlist, *ly = w.d_rlist + kRefineListCap;
+  hipLaunchKernelGGL(k_win_rehist, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx, (const double *)w.d_ry, n,
+                     P2, w.d_whist, w.d_wstate, lx, ly, (unsigned)kRefineListCap, w.d_rlist_len);
+  const unsigned cb = hb < (unsigned)kWinBlocks ? hb : (unsigned)kWinBlocks;  // a few hundred thousand values: one workgroup per CU
+  hipLaunchKernelGGL(k_win_compact<true>, dim3(cb), dim3(kWinThreads), 0, s, (const double *)lx, (const double *)ly, n,
+                     P2, (const uint32_t *)w.d_whist, w.d_wstate, w.d_wmed, w.d_wring, (const unsigned *)w.d_rlist_len,
+                     (unsigned)kRefineListCap);
+  int blocks, threads;
+  reduce_geometry(n_, &blocks, &threads);
+  hipLaunchKernelGGL(k_win_accumulate<true>, dim3(blocks), dim3(threads), 0, s, (const double2 *)d_a,
+                     (const double *)w.d_rx, (const double *)w.d_ry, n, T, (const WinState *)w.d_wstate,
+                     (const double *)w.d_wmed, (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl,
+                     w.h_res, ++w.seq);
   return hipGetLastError();
 }
 

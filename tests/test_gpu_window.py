@@ -195,16 +195,44 @@ def test_two_stream_estimate_equals_single_stream_stage_calls_repeatedly():
     assert hit > 0
 
 
-def test_three_digit_radix_pipeline_beyond_4m_points():
-    """Above 4M pairs the window pipeline stands down and the radix pipeline takes a third 12-bit
-    digit per stage (candidate lists would overflow after two); same bits as the oracle's tree."""
+def test_refined_windows_beyond_4m_points():
+    """Above 4M pairs a window that survives a prediction error would overflow the candidate lists:
+    the window is found in two passes instead (sample -> first histogram pass -> second pass), and
+    resolved by the usual compaction / accumulate launches.  Same bits as the oracle's tree; several
+    distributions, one of them heavy-tailed with a far-off median."""
     n = 4_500_000
-    a, b = pairs(n, 99)
     T = I.Transform([0.39, -0.31, 0.0199])
-    c0 = I.gn_path_counters()
-    check(T, a, b)
-    tried, missed, short, radix, _, _ = delta(c0, I.gn_path_counters())
-    assert tried == 0 and short == 1 and radix == 0
+    for seed, kw in ((99, {}), (7, dict(shift=(3.0, -1.0), spread=0.5)), (8, dict(spread=1e-3, outliers=False))):
+        a, b = pairs(n, seed, **kw)
+        c0 = I.gn_path_counters()
+        check(T, a, b)
+        tried, missed, short, radix, _, _ = delta(c0, I.gn_path_counters())
+        assert tried == 1 and missed == 0 and short == 0 and radix == 0, (seed, tried, missed, short, radix)
+
+
+def test_three_digit_radix_pipeline_beyond_4m_points():
+    """With the refined windows switched off (ICP_GN_NO_REFINE, read once per process: a child
+    process) the radix pipeline serves alone beyond 4M pairs and takes a third 12-bit digit per stage
+    (candidate lists would overflow after two); it is also what a failed refinement falls back to."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import icp_rust_amd as I\n"
+        "import test_gpu_window as W\n"
+        "a, b = W.pairs(4_500_000, 99)\n"
+        "c0 = I.gn_path_counters()\n"
+        "W.check(I.Transform([0.39, -0.31, 0.0199]), a, b)\n"
+        "tried, missed, short, radix, _, _ = W.delta(c0, I.gn_path_counters())\n"
+        "assert tried == 0 and short == 1 and radix == 0, (tried, short, radix)\n"
+        "print('radix-ok')\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ICP_GN_NO_REFINE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "radix-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_pooled_handles_start_clean():

@@ -17,7 +17,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 BUDGET = {  # demangled-name fragment -> max VGPRs
     "k_nn_gridILi3ELb1ELb0E": 120,       # warm 3-D search with the pose applied
     "k_win_hist": 56,
-    "k_win_compact": 56,
+    "k_win_compactILb0E": 56,            # (the list variant of the refined windows runs alone)
     "k_win_select": 72,
     "k_win_accumulateILb0E": 72,
 }
