@@ -210,6 +210,23 @@ def test_refined_windows_beyond_4m_points():
         assert tried == 1 and missed == 0 and short == 0 and radix == 0, (seed, tried, missed, short, radix)
 
 
+def test_refined_windows_fall_back_on_degenerate_residuals():
+    """4.5M pairs whose residuals are almost all exactly equal (quantised noise: a few thousand
+    distinct values, heavy runs of duplicates at the median): whatever the sample and the two passes
+    make of it, the evaluation must end with the oracle's bits -- through the refined windows or
+    through the pipelines they fall back to."""
+    n = 4_500_000
+    rng = np.random.default_rng(5)
+    a = rng.normal(size=(n, 2)) * 20
+    q = np.round(rng.normal(size=(n, 2)) * 8) / 64.0  # steps of 1/64: exact in binary
+    b = a + q
+    T = I.Transform()  # identity: the residuals are -q exactly
+    c0 = I.gn_path_counters()
+    check(T, a, b)
+    tried, missed, short, radix, _, _ = delta(c0, I.gn_path_counters())
+    assert tried + short + radix >= 1
+
+
 def test_three_digit_radix_pipeline_beyond_4m_points():
     """With the refined windows switched off (ICP_GN_NO_REFINE, read once per process: a child
     process) the radix pipeline serves alone beyond 4M pairs and takes a third 12-bit digit per stage
