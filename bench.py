@@ -132,7 +132,8 @@ def main():
                          "at this size); all engines return bit-identical correspondences")
     ap.add_argument("--brute-steps", type=int, default=3,
                     help="outer iterations of the brute-force sweep measured alongside (0 = skip)")
-    ap.add_argument("--cpu-iters", type=int, default=3, help="outer iterations of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=10,
+                    help="outer iterations of the CPU baseline: ~7 s on one core + ~3 s with all cores (0 = skip)")
     ap.add_argument("--gn-points", type=int, default=64 * 1024 * 1024,
                     help="pairs of the separate 'reduce kernels alone, past the Infinity Cache' line (0 = skip)")
     args = ap.parse_args()
