@@ -120,6 +120,44 @@ def gn_large(npts):
                     "prices them, selection passes not counted"}
 
 
+def reference_sized():
+    """BASELINE configs[0] / configs[1] at the reference's own sizes, next to the single-thread CPU
+    oracle: a 650-point 2-D scan pair of the reference's scans/2d and a 28.8k-point 3-D frame in the
+    scans.hdf5 packet layout (synthetic stand-in: the file is absent from the reference mount), each as
+    one estimate(src, identity, 20) from host buffers -- what examples/scan2d / scan3d call per frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import icp_rust_amd as I
+    import oracle_ffi as O
+    from icp_rust_amd import synth
+    from icp_rust_amd.scans import load_scan2d
+
+    def timed(f, reps):
+        f()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f()
+        return 1e3 * (time.perf_counter() - t0) / reps
+
+    out = {}
+    g = os.path.join(ROOT, "tests", "golden", "scans2d")
+    s2, d2 = load_scan2d(os.path.join(g, "001.txt")), load_scan2d(os.path.join(g, "002.txt"))
+    icp2 = I.Icp2d(d2)
+    tree2 = O.KdTree(d2)
+    out["scan2d_pair"] = {"points": [len(s2), len(d2)],
+                          "gpu_ms_per_estimate20": timed(lambda: icp2.estimate(s2, I.Transform(), 20), 10),
+                          "cpu_oracle_ms_per_estimate20": timed(lambda: tree2.estimate(s2, O.transform_identity(), 20), 5)}
+    icp2.close()
+    pk = synth.synthetic_scan3d_packets(150)
+    s3, d3 = synth.remove_invalid_values(pk[:75]), synth.remove_invalid_values(pk[75:150])
+    icp3 = I.Icp3d(d3)
+    tree3 = O.KdTree(d3)
+    out["scan3d_frame"] = {"points": [len(s3), len(d3)],
+                           "gpu_ms_per_estimate20": timed(lambda: icp3.estimate(s3, I.Transform(), 20), 10),
+                           "cpu_oracle_ms_per_estimate20": timed(lambda: tree3.estimate(s3, O.transform_identity(), 20), 1)}
+    icp3.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,6 +380,7 @@ def main():
             out["gn_large"] = gn_large(args.gn_points)
         if world == 1 and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(src_np, dst_np, args.cpu_iters)
+            out["reference_sized"] = reference_sized()
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
