@@ -273,6 +273,57 @@ __global__ __launch_bounds__(256) void k_nn_finalize(
   if (b) b[q] = make_double2(tx[bi], ty[bi]);
 }
 
+// Tiny clouds (the reference's 2-D scans: ~650 x ~650 points): the tiled sweep + the merge of its
+// partial minima are two launches of ~17 + 5 us, all of it latency.  Here 16 lanes share a query --
+// lane `sub` scans targets sub, sub + 16, ... straight from the AoS cloud (it sits in L1 after the
+// first query of the workgroup) with the contract's formula -- and the lanes merge their minima by
+// (d^2, index): one launch, same results.
+template <int DIM, bool XFORM>
+__global__ __launch_bounds__(256) void k_nn_tiny(const double *__restrict__ src, unsigned n, Pose T,
+                                                 const double *__restrict__ dst, unsigned m,
+                                                 uint32_t *__restrict__ idx, double2 *__restrict__ a,
+                                                 double2 *__restrict__ b) {
+  const unsigned t = blockIdx.x * 256 + threadIdx.x;
+  const unsigned q = t >> 4, sub = t & 15u;
+  if (q >= n) return;  // whole groups leave together
+  double qx = src[(size_t)q * DIM + 0], qy = src[(size_t)q * DIM + 1];
+  const double qz = DIM == 3 ? src[(size_t)q * DIM + 2] : 0.;
+  if (XFORM) {  // Transform::transform, src/transform.rs:22-24
+    const double nx = (T.r00 * qx + T.r01 * qy) + T.tx;
+    const double ny = (T.r10 * qx + T.r11 * qy) + T.ty;
+    qx = nx;
+    qy = ny;
+  }
+  double best = __builtin_huge_val();
+  uint32_t bi = 0xffffffffu;
+  for (unsigned j = sub; j < m; j += 16) {
+    const double dx = qx - dst[(size_t)j * DIM + 0], dy = qy - dst[(size_t)j * DIM + 1];
+    double dd = dx * dx + dy * dy;
+    if (DIM == 3) {
+      const double dz = qz - dst[(size_t)j * DIM + 2];
+      dd = dd + dz * dz;
+    }
+    if (dd < best) {  // ascending j: the lowest index of a tie stays
+      best = dd;
+      bi = j;
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) {
+    const double ob = __shfl_xor(best, off);
+    const uint32_t obi = (uint32_t)__shfl_xor((int)bi, off);
+    if (ob < best || (ob == best && obi < bi)) {
+      best = ob;
+      bi = obi;
+    }
+  }
+  if (sub != 0) return;
+  if (bi == 0xffffffffu) bi = 0;  // no finite distance at all: index 0, as a scan from 0 would
+  if (idx) idx[q] = bi;
+  if (a) a[q] = make_double2(qx, qy);
+  if (b) b[q] = make_double2(dst[(size_t)bi * DIM + 0], dst[(size_t)bi * DIM + 1]);
+}
+
 // pairs from given indices: a = xy(T.src) (Transform::transform, src/transform.rs:22-24),
 // b = xy(dst[idx]) (get_xy, src/lib.rs:86-89)
 template <int DIM>
@@ -441,8 +492,10 @@ hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n_, const 
   chunks = (granules + granules_per_chunk - 1) / granules_per_chunk;
   const unsigned chunk = granules_per_chunk * 64;
 
+  static const bool no_tiny = getenv("ICP_NN_NO_TINY") != nullptr;
+  const bool tiny = !no_tiny && n <= 2048u && h->m <= 2048;
   // partial buffers
-  const size_t need = (size_t)chunks * n;
+  const size_t need = tiny ? 0 : (size_t)chunks * n;
   if (need > h->ws.cap_part) {
     if (h->ws.d_part_d) (void)hipFree(h->ws.d_part_d);
     if (h->ws.d_part_i) (void)hipFree(h->ws.d_part_i);
@@ -461,7 +514,18 @@ hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n_, const 
     if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
       (void)hipEventRecord(ev0, h->stream);
   }
-  if (h->dim == 3) {
+  if (tiny) {
+    const unsigned tb = (n * 16u + 255u) / 256u;
+#define TINY(DIM, XF)                                                                                          \
+  hipLaunchKernelGGL((k_nn_tiny<DIM, XF>), dim3(tb), dim3(256), 0, h->stream, d_src, n, T, h->d_dst, (unsigned)h->m, \
+                     d_idx, (double2 *)d_a, (double2 *)d_b)
+    if (h->dim == 3) {
+      if (xform) TINY(3, true); else TINY(3, false);
+    } else {
+      if (xform) TINY(2, true); else TINY(2, false);
+    }
+#undef TINY
+  } else if (h->dim == 3) {
     if (xform) launch_r<3, true>(h, R, d_src, n, T, qblocks, chunks, chunk);
     else       launch_r<3, false>(h, R, d_src, n, T, qblocks, chunks, chunk);
   } else {
@@ -473,7 +537,7 @@ hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n_, const 
     (void)hipEventRecord(ev1, h->stream);
     h->prof_events.emplace_back(ev0, ev1);
   }
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess || tiny) return e;
 
   const double *tx = h->d_dst_soa, *ty = tx + h->m_pad;
   const unsigned fblocks = (n + 255) / 256;
