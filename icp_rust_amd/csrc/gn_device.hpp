@@ -165,18 +165,22 @@ __device__ __forceinline__ void publish_result(const double *partials, GnResult 
 #pragma unroll
     for (int k = 0; k < kNAcc; ++k) tot[k] = tot[k] + v[k];
   }
-  block_reduce_store<kNAcc + 1>(tot, res->acc);
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    res->sigma[0] = sig[0];
-    res->sigma[1] = sig[1];
-    res->median[0] = med[0];
-    res->median[1] = med[1];
-    res->nan_flag = nan_flag;
-    res->overflow = overflow;
+  block_reduce_store<kNAcc + 1>(tot, res->acc);  // (its stores come from lanes of wave 0)
+  // everything the host reads is stored by lanes of wave 0: that wave's fence orders it before the
+  // sequence number; the other waves have nothing to publish
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == kNAcc + 1) {
+      res->sigma[0] = sig[0];
+      res->sigma[1] = sig[1];
+      res->median[0] = med[0];
+      res->median[1] = med[1];
+    }
+    if (threadIdx.x == kNAcc + 2) {
+      res->nan_flag = nan_flag;
+      res->overflow = overflow;
+    }
     __threadfence_system();
-    __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

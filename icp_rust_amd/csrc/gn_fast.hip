@@ -228,16 +228,20 @@ __global__ __launch_bounds__(1024) void k_tiny_eval(const double2 *__restrict__ 
     res->acc[tid] = tid < kNAcc ? (p0 + p1) + 0. : 0.;
   }
   TSTAMP();
-  __threadfence_system();
-  __syncthreads();
-  TSTAMP();
-  if (tid == 0) {
-    res->sigma[0] = sig[0];
-    res->sigma[1] = sig[1];
-    res->nan_flag = s_nan;
-    res->overflow = 0;
+  // everything the host reads is stored by lanes of wave 0, so one wave's fence orders it before
+  // the sequence number (a system-scope fence in all sixteen waves cost 2 us)
+  if (wave == 0) {
+    if (tid == kNAcc + 1) {
+      res->sigma[0] = sig[0];
+      res->sigma[1] = sig[1];
+    }
+    if (tid == kNAcc + 2) {
+      res->nan_flag = s_nan;
+      res->overflow = 0;
+    }
     __threadfence_system();
-    __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    TSTAMP();
+    if (tid == 0) __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 #ifdef ICP_TINY_DEBUG
   TSTAMP();
