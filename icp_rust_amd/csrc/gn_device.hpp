@@ -30,6 +30,41 @@ __device__ __forceinline__ double huber_drho(double e) {
 }
 
 // ------------------------------------------------------------- reductions --------
+// v[l + OFF] for the wave tree below.  Offsets below 16 stay inside a row of 16 lanes for every lane
+// whose result is still needed (after the step with offset OFF only lanes < OFF matter, and they read
+// lanes < 2 OFF <= 16): a DPP row shift, one v_mov per dword, instead of a trip through the LDS
+// crossbar (ds_bpermute).  Lanes whose source falls outside their row get zeros, and are never read
+// again.
+template <int OFF>
+__device__ __forceinline__ double tree_down(double v) {
+  if constexpr (OFF >= 16) {
+    return __shfl_down(v, OFF);
+  } else {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x100 + OFF, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x100 + OFF, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+  }
+}
+template <int N, int OFF>
+__device__ __forceinline__ void tree_step(double (&acc)[N]) {
+  double t[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) t[k] = tree_down<OFF>(acc[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) acc[k] = acc[k] + t[k];
+}
+// the six steps, step-major (the N shuffles of one step are independent and pipeline)
+template <int N>
+__device__ __forceinline__ void wave_tree(double (&acc)[N]) {
+  tree_step<N, 32>(acc);
+  tree_step<N, 16>(acc);
+  tree_step<N, 8>(acc);
+  tree_step<N, 4>(acc);
+  tree_step<N, 2>(acc);
+  tree_step<N, 1>(acc);
+}
+
 // Fixed association order (mirrored by the oracle's *_tree variant): a wave folds with
 // v[l] += v[l+off], off = 32..1; thread 0 left-folds the wave sums from wave 0.
 template <int N, bool SC1 = false>
@@ -39,14 +74,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double *__r
   // step-major: the N shuffles of one step are independent and pipeline through the LDS
   // crossbar; accumulator-major code runs N dependent 6-step chains one after the other
   // (measured: 14k cycles for N = 13).  Same association order per accumulator either way.
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    double t[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) t[k] = __shfl_down(acc[k], off);
-#pragma unroll
-    for (int k = 0; k < N; ++k) acc[k] = acc[k] + t[k];
-  }
+  wave_tree<N>(acc);
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < N; ++k) sm[wave][k] = acc[k];

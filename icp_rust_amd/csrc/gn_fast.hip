@@ -105,14 +105,7 @@ __device__ __forceinline__ void mad_ranks(const unsigned long long *S, unsigned 
 template <int N>
 __device__ __forceinline__ void group_reduce(double (&acc)[N], double (*sm)[N], int wave) {
   const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {  // step-major: see block_reduce_store
-    double t[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) t[k] = __shfl_down(acc[k], off);
-#pragma unroll
-    for (int k = 0; k < N; ++k) acc[k] = acc[k] + t[k];
-  }
+  wave_tree<N>(acc);  // see block_reduce_store
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < N; ++k) sm[wave][k] = acc[k];
