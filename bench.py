@@ -121,8 +121,8 @@ def gn_large(npts):
 
 
 def reference_sized():
-    """BASELINE configs[0] / configs[1] at the reference's own sizes, next to the single-thread CPU
-    oracle: a 650-point 2-D scan pair of the reference's scans/2d and a 28.8k-point 3-D frame in the
+    """Part of the CPU-baseline leg.  BASELINE configs[0] / configs[1] at the reference's own sizes,
+    next to the single-thread CPU oracle: a 650-point 2-D scan pair of the reference's scans/2d and a 28.8k-point 3-D frame in the
     scans.hdf5 packet layout (synthetic stand-in: the file is absent from the reference mount), each as
     one estimate(src, identity, 20) from host buffers -- what examples/scan2d / scan3d call per frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -380,7 +380,8 @@ def main():
             out["gn_large"] = gn_large(args.gn_points)
         if world == 1 and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(src_np, dst_np, args.cpu_iters)
-            out["reference_sized"] = reference_sized()
+            # (the CPU side of these is the oracle too: part of the same baseline leg)
+            out["cpu_baseline"]["reference_sized"] = reference_sized()
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
