@@ -1,0 +1,66 @@
+"""Extended randomised parity run (manual; the fixed-seed subset lives in tests/test_gpu_fuzz.py):
+evaluation sequences over all pipelines and registrations across the size thresholds of the search
+engines, everything bit-exact against the oracle's tree variant.  Prints one line per failure.
+
+    python3 profiles/extended_fuzz.py [first_seed] [count]
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import icp_rust_amd as I
+import oracle_ffi as O
+import test_gpu_fuzz as F
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad = 0
+t0 = time.time()
+# 1. single evaluations: sizes around every pipeline threshold (2, 1024, 4096, 65536, 4M is covered by tests)
+for seed in range(first, first + count):
+    rng = np.random.default_rng(50_000 + seed)
+    n = int(rng.choice([2, 3, 7, 64, 65, 511, 512, 513, 1023, 1024, 1025, 2047, 4095, 4096, 4097, 9999, 65535, 65537,
+                        int(rng.integers(2, 3000)), int(rng.integers(3000, 300_000))]))
+    a = rng.normal(size=(n, 2)) * rng.uniform(1.0, 40.0)
+    blocks, threads = I.reduce_geometry(n)
+    kind = F.KINDS[seed % len(F.KINDS)]
+    r = F.residuals(rng, n, kind)
+    for step in range(4):
+        r = r + rng.normal(size=2) * 1e-3 * (np.abs(r).mean() + 1e-6) if step != 2 else F.residuals(rng, n, F.KINDS[(seed + 1) % 6])
+        T = I.Transform(rng.normal(size=3) * np.array([1e-3, 1e-3, 1e-5]))
+        Tp = F.opose(T)
+        Ta = np.stack([(Tp.r00 * a[:, 0] + Tp.r01 * a[:, 1]) + Tp.tx, (Tp.r10 * a[:, 0] + Tp.r11 * a[:, 1]) + Tp.ty], axis=1)
+        b = Ta - r
+        got = I.weighted_gauss_newton_update(T, a, b)
+        rc, want, _ = O.weighted_gauss_newton_update_tree(Tp, a, b, blocks, threads)
+        ok = (got is None and rc != O.OK) or (got is not None and rc == O.OK and np.array_equal(got, want))
+        if not ok:
+            bad += 1
+            print("EVAL MISMATCH seed", seed, "n", n, "kind", kind, "step", step, got, want)
+# 2. registrations across the search-engine thresholds
+for seed in range(first, first + count):
+    rng = np.random.default_rng(70_000 + seed)
+    dim = 2 if seed % 4 == 0 else 3
+    n = int(rng.choice([5, 100, 2047, 2048, 2049, 5000, 16383, 16384, 65535, 65536, 65537, int(rng.integers(50, 90_000))]))
+    m = int(rng.choice([1, 2, 700, 2048, 2049, 8191, 8192, 8193, int(rng.integers(50, 60_000))]))
+    dst = rng.normal(size=(m, dim)) * np.array([10.0, 10.0, 1.0][:dim])
+    if seed % 5 == 0:
+        dst = np.round(dst * 4) / 4  # lattice: ties and duplicates
+    pick = rng.integers(0, m, size=n)
+    src = dst[pick] + rng.normal(size=(n, dim)) * 0.05
+    p = np.array([0.2, -0.1, 0.03]) * rng.uniform(0.2, 1.0)
+    Tt = O.transform_new(p)
+    src[:, :2] = O.transform_apply_many(O.transform_inverse(Tt), np.ascontiguousarray(src[:, :2]))
+    iters = int(rng.integers(1, 7))
+    icp = (I.Icp3d if dim == 3 else I.Icp2d)(dst)
+    T, idx, inner = icp.estimate(src, I.Transform(), iters, return_info=True)
+    icp.close()
+    b, t = I.reduce_geometry(n)
+    rc, oT, oidx, oinner = O.icp_estimate(dim, dst, src, O.transform_identity(), iters, use_kdtree=True, sum_mode=1,
+                                          reduce_blocks=b, reduce_threads=t)
+    if rc != O.OK or not (np.array_equal(idx, oidx) and np.array_equal(inner, oinner) and np.array_equal(T.as_array(), oT.as_array())):
+        bad += 1
+        print("REGISTRATION MISMATCH seed", seed, "dim", dim, "n", n, "m", m, "iters", iters, "rc", rc,
+              "idx diff", int(np.sum(idx != oidx)) if rc == O.OK else None, inner.tolist(), None if rc != O.OK else oinner.tolist())
+print(f"extended fuzz: seeds {first}..{first + count - 1}, {bad} mismatches, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
