@@ -733,7 +733,9 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     if ((e = hipMalloc(&Q.d_cell_of, n_ * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_rank_of, n_ * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_perm, n_ * 4)) != hipSuccess) return e;
-    if ((e = hipMalloc(&Q.d_sorted, n_ * h->dim * sizeof(double))) != hipSuccess) return e;
+    // three doubles per point whatever this handle's dimension: the buffers outlive it in the handle
+    // pool, and a 2-D owner followed by a 3-D one of the same size must not find them short
+    if ((e = hipMalloc(&Q.d_sorted, n_ * 3 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_prev, n_ * sizeof(PrevMatch))) != hipSuccess) return e;
     Q.cap = n_;
   }

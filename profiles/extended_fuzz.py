@@ -12,6 +12,13 @@ import icp_rust_amd as I
 import oracle_ffi as O
 import test_gpu_fuzz as F
 
+LOG = open(os.path.join(ROOT, "gpurun_out", "extended_fuzz_progress.log"), "w") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else sys.stderr
+
+
+def note(*a):  # what is about to run: a device fault leaves its configuration behind
+    print(*a, file=LOG, flush=True)
+
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
@@ -25,6 +32,7 @@ for seed in range(first, first + count):
     blocks, threads = I.reduce_geometry(n)
     kind = F.KINDS[seed % len(F.KINDS)]
     r = F.residuals(rng, n, kind)
+    note("eval seed", seed, "n", n, kind)
     for step in range(4):
         r = r + rng.normal(size=2) * 1e-3 * (np.abs(r).mean() + 1e-6) if step != 2 else F.residuals(rng, n, F.KINDS[(seed + 1) % 6])
         T = I.Transform(rng.normal(size=3) * np.array([1e-3, 1e-3, 1e-5]))
@@ -52,6 +60,7 @@ for seed in range(first, first + count):
     Tt = O.transform_new(p)
     src[:, :2] = O.transform_apply_many(O.transform_inverse(Tt), np.ascontiguousarray(src[:, :2]))
     iters = int(rng.integers(1, 7))
+    note("registration seed", seed, "dim", dim, "n", n, "m", m, "iters", iters)
     icp = (I.Icp3d if dim == 3 else I.Icp2d)(dst)
     T, idx, inner = icp.estimate(src, I.Transform(), iters, return_info=True)
     icp.close()

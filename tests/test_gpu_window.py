@@ -291,3 +291,26 @@ def test_pooled_handles_start_clean():
     check3d(70_000, 20_000, 3, 4)
     I.lib().icp_trim_pool()
     check3d(50_000, 50_000, 4, 3)
+
+
+def test_a_pooled_handle_changes_dimension():
+    """regression (found by profiles/extended_fuzz.py as a device memory fault): the cell-sorted copy
+    of the source cloud was sized n * dim doubles but its capacity remembered as n points, so a 3-D
+    handle that took over a 2-D handle's buffers from the pool wrote past their end"""
+    from icp_rust_amd import synth
+
+    I.lib().icp_trim_pool()
+    rng = np.random.default_rng(4)
+    n, m = 30_000, 20_000
+    for dim in (2, 3, 2, 3):
+        dst = rng.normal(size=(m, dim)) * 10
+        src = dst[rng.integers(0, m, size=n)] + rng.normal(size=(n, dim)) * 0.05
+        icp = (I.Icp3d if dim == 3 else I.Icp2d)(dst)
+        T, idx, inner = icp.estimate(src, I.Transform([0.05, -0.03, 0.01]), 3, return_info=True)
+        icp.close()  # parked: the next handle, of the other dimension, reuses its buffers
+        b, t = I.reduce_geometry(n)
+        rc, oT, oidx, oinner = O.icp_estimate(dim, dst, src, opose(I.Transform([0.05, -0.03, 0.01])), 3, use_kdtree=True,
+                                              sum_mode=1, reduce_blocks=b, reduce_threads=t)
+        assert rc == O.OK
+        assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
+        assert np.array_equal(T.as_array(), oT.as_array())
