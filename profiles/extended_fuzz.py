@@ -71,5 +71,54 @@ for seed in range(first, first + count):
         bad += 1
         print("REGISTRATION MISMATCH seed", seed, "dim", dim, "n", n, "m", m, "iters", iters, "rc", rc,
               "idx diff", int(np.sum(idx != oidx)) if rc == O.OK else None, inner.tolist(), None if rc != O.OK else oinner.tolist())
+# 3. one long-lived handle: clouds of changing size, appends, engine switches, host and device buffers
+import torch
+for seed in range(first, first + max(count // 4, 1)):
+    rng = np.random.default_rng(90_000 + seed)
+    dim = 2 if seed % 3 == 0 else 3
+    cls = I.Icp3d if dim == 3 else I.Icp2d
+    scale = np.array([10.0, 10.0, 1.0][:dim])
+    m = int(rng.choice([300, 2048, 2049, 8192, 9000, 30_000]))
+    dst = rng.normal(size=(m, dim)) * scale
+    on_device = bool(rng.integers(0, 2))
+    keep = torch.from_numpy(dst).cuda() if on_device else None
+    icp = cls(keep if on_device else dst)
+    T = I.Transform([0.02, -0.01, 0.004])
+    for step in range(5):
+        act = int(rng.integers(0, 4))
+        note("handle seed", seed, "dim", dim, "m", len(dst), "step", step, "act", act, "device", on_device)
+        if act == 0:  # append (with or without a pose)
+            k = int(rng.choice([1, 50, 3000, 9000]))
+            extra = rng.normal(size=(k, dim)) * scale
+            Ta = I.Transform(rng.normal(size=3) * 0.1) if rng.integers(0, 2) else None
+            icp.append(torch.from_numpy(extra).cuda() if rng.integers(0, 2) else extra, Ta)
+            if Ta is not None:
+                r00, r10, r01, r11, tx, ty = Ta.pose.as_tuple()
+                x, y = extra[:, 0].copy(), extra[:, 1].copy()
+                extra[:, 0] = (r00 * x + r01 * y) + tx
+                extra[:, 1] = (r10 * x + r11 * y) + ty
+            dst = np.ascontiguousarray(np.concatenate([dst, extra]))
+            continue
+        if act == 1:  # engine switch
+            mode = int(rng.choice([I.NN_AUTO, I.NN_BRUTE, I.NN_GRID]))
+            I._lib.check(I.lib().icp_set_nn_mode(icp._h, mode), "icp_set_nn_mode")
+            continue
+        n = int(rng.choice([3, 900, 2048, 5000, 16384, 20_000, 65536, 70_000]))
+        src = dst[rng.integers(0, len(dst), size=n)] + rng.normal(size=(n, dim)) * 0.05
+        iters = int(rng.integers(0, 5))
+        if act == 2:
+            Tn, idx, inner = icp.estimate(src, T, iters, return_info=True)
+        else:
+            Tn, idx, inner = icp.estimate(torch.from_numpy(src).cuda(), T, iters, return_info=True)
+        b, t = I.reduce_geometry(n)
+        rc, oT, oidx, oinner = O.icp_estimate(dim, dst, src, O.Pose(*T.pose.as_tuple()), iters, use_kdtree=True, sum_mode=1,
+                                              reduce_blocks=b, reduce_threads=t)
+        same = rc == O.OK and np.array_equal(Tn.as_array(), oT.as_array()) and np.array_equal(inner, oinner[:len(inner)]) \
+            and (iters == 0 or np.array_equal(idx, oidx))
+        if not same:
+            bad += 1
+            print("HANDLE MISMATCH seed", seed, "dim", dim, "m", len(dst), "n", n, "iters", iters, "act", act, "rc", rc)
+        T = Tn
+    icp.close()
 print(f"extended fuzz: seeds {first}..{first + count - 1}, {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
