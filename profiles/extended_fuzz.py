@@ -120,5 +120,41 @@ for seed in range(first, first + max(count // 4, 1)):
             print("HANDLE MISMATCH seed", seed, "dim", dim, "m", len(dst), "n", n, "iters", iters, "act", act, "rc", rc)
         T = Tn
     icp.close()
+# 4. non-finite inputs: the reference panics on a NaN residual (src/stats.rs:12) -> a status, never a fault;
+#    non-finite targets leave no grid -> the sweep serves, same indices as the oracle
+for seed in range(first, first + max(count // 8, 1)):
+    rng = np.random.default_rng(110_000 + seed)
+    dim = 2 if seed % 2 else 3
+    cls = I.Icp3d if dim == 3 else I.Icp2d
+    m, n = int(rng.choice([500, 3000, 9000, 20_000])), int(rng.choice([100, 3000, 20_000, 70_000]))
+    dst = rng.normal(size=(m, dim)) * 5
+    src = dst[rng.integers(0, m, size=n)] + rng.normal(size=(n, dim)) * 0.05
+    case = int(rng.integers(0, 3))
+    note("nonfinite seed", seed, "dim", dim, "n", n, "m", m, "case", case)
+    if case == 0:    # NaN in the source cloud
+        src[rng.integers(0, n, size=3), rng.integers(0, dim)] = np.nan
+    elif case == 1:  # +-inf targets
+        dst[rng.integers(0, m, size=2), 0] = np.inf
+        dst[rng.integers(0, m), 1] = -np.inf
+    else:            # NaN target
+        dst[rng.integers(0, m), dim - 1] = np.nan
+    icp = cls(dst)
+    try:
+        Tn, idx, inner = icp.estimate(src, I.Transform(), 2, return_info=True)
+        got = ("ok", Tn.as_array(), idx)
+    except I._lib.IcpError as e:
+        got = ("err", e.status, None)
+    icp.close()
+    b, t = I.reduce_geometry(n)
+    rc, oT, oidx, _ = O.icp_estimate(dim, dst, src, O.transform_identity(), 2, use_kdtree=False, sum_mode=1, reduce_blocks=b,
+                                     reduce_threads=t)
+    if rc == O.OK:
+        same = got[0] == "ok" and np.array_equal(got[1], oT.as_array()) and np.array_equal(got[2], oidx)
+    else:
+        same = got[0] == "err" and got[1] == rc
+    if not same:
+        bad += 1
+        print("NONFINITE MISMATCH seed", seed, "dim", dim, "n", n, "m", m, "case", case, "gpu", got[0], got[1] if got[0] == "err" else "",
+              "oracle rc", rc)
 print(f"extended fuzz: seeds {first}..{first + count - 1}, {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
