@@ -184,17 +184,41 @@ auto pair_step = [&](unsigned k) {
       const float pz = (DIM == 3) ? gz[k] : 0.f;
       float s[R];
       unsigned long long any = 0;  // per-r compares go straight to scalar masks, OR-ed on the SALU
+      if constexpr (R >= 2) {
+        // two queries per instruction (v_pk_add/mul/fma_f32: the packed rate is what the FP32 vector
+        // peak is quoted on) and fused multiply-adds.  The contract's "no FMA" is about the exact f64
+        // evaluation below; the screen only needs s <= |df|^2 (1 + 1e-6), and fewer roundings keep
+        // that with room to spare.
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float dx = hx[r] - px;
-        const float dy = hy[r] - py;
-        float v = dx * dx + dy * dy;
-        if (DIM == 3) {
-          const float dz = hz[r] - pz;
-          v = v + dz * dz;
+        for (int r = 0; r < R; r += 2) {
+          const f2 qx2 = {hx[r], hx[r + 1]}, qy2 = {hy[r], hy[r + 1]};
+          const f2 dx = qx2 - px2, dy = qy2 - py2;
+          f2 v = __builtin_elementwise_fma(dy, dy, dx * dx);
+          if (DIM == 3) {
+            const f2 qz2 = {hz[r], hz[r + 1]};
+            const f2 dz = qz2 - pz2;
+            v = __builtin_elementwise_fma(dz, dz, v);
+          }
+          s[r] = v.x;
+          s[r + 1] = v.y;
+          any |= __ballot(!(v.x > thr[r]));
+          any |= __ballot(!(v.y > thr[r + 1]));
         }
-        s[r] = v;
-        any |= __ballot(!(v > thr[r]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float dx = hx[r] - px;
+          const float dy = hy[r] - py;
+          float v = dx * dx + dy * dy;
+          if (DIM == 3) {
+            const float dz = hz[r] - pz;
+            v = v + dz * dz;
+          }
+          s[r] = v;
+          any |= __ballot(!(v > thr[r]));
+        }
       }
       if (any) {  // wave-uniform: some lane has a pair that could win or tie
         const double ex = sx[k], ey = sy[k];
