@@ -204,6 +204,7 @@ extern "C" void icp_reduce_geometry(size_t n, int *blocks, int *threads) { reduc
 
 // ---------------------------------------------------------------- handle ---------
 static icp_handle *pool_take(int device);
+static int resolved_nn_mode(const icp_handle *h);
 
 static int create_common(icp_handle **out, int dim, const double *dst, size_t m, int device, bool dst_on_device) {
   if (!out || (dim != 2 && dim != 3) || (m > 0 && !dst) || m >= 0xffffffffull) return ICP_BAD_ARGUMENT;
@@ -236,9 +237,14 @@ static int create_common(icp_handle **out, int dim, const double *dst, size_t m,
       h->owns_dst = true;
       if ((e = hipMemcpyAsync(h->d_dst_own, dst, m * dim * sizeof(double), hipMemcpyHostToDevice, h->stream)) != hipSuccess) { rc = map_hip(e); break; }
     }
-    if ((e = build_target_soa(h)) != hipSuccess) { rc = map_hip(e); break; }
     if ((e = build_grid(h)) != hipSuccess) { rc = map_hip(e); break; }
-    if ((e = build_target_screen(h)) != hipSuccess) { rc = map_hip(e); break; }
+    // the sweep's structures (SoA + f32 screen, 36 B per target) only where the sweep is the engine
+    // this cloud resolves to; otherwise launch_nn_brute builds them if it is ever asked
+    h->brute_valid = h->screen_valid = false;
+    if (resolved_nn_mode(h) == ICP_NN_BRUTE) {
+      if ((e = build_target_soa(h)) != hipSuccess) { rc = map_hip(e); break; }
+      if ((e = build_target_screen(h)) != hipSuccess) { rc = map_hip(e); break; }
+    }
     if ((e = ensure_workspace(h, 0, false)) != hipSuccess) { rc = map_hip(e); break; }
     // the host buffer may be freed by the caller as soon as we return
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) { rc = map_hip(e); break; }
