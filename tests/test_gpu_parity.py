@@ -473,3 +473,47 @@ def test_stage_calls_on_the_default_stream_are_ordered_and_shards_equal_the_whol
     assert inner1.tolist() == inner2
     ref = I.Icp3d(d_dst).estimate(d_src, I.Transform(), 4)
     assert np.array_equal(ref.as_array(), T.as_array())
+
+
+def test_distinct_handles_are_independent_across_host_threads():
+    """include/icp_mi355x.h: one in-flight call per handle, distinct handles are independent.  Four
+    host threads (ctypes releases the GIL during a call) register different clouds at the same time,
+    two of them creating and destroying their handles as they go (the handle pool is shared)."""
+    import threading
+
+    jobs = []
+    for k, (n, m, dim) in enumerate([(30_000, 25_000, 3), (646, 668, 2), (70_000, 40_000, 3), (5_000, 9_000, 2)]):
+        rng = np.random.default_rng(900 + k)
+        dst = rng.normal(size=(m, dim)) * 8
+        src = dst[rng.integers(0, m, size=n)] + rng.normal(size=(n, dim)) * 0.04
+        b, t = I.reduce_geometry(n)
+        rc, oT, oidx, oinner = O.icp_estimate(dim, dst, src, O.transform_identity(), 4, use_kdtree=True, sum_mode=1,
+                                              reduce_blocks=b, reduce_threads=t)
+        assert rc == O.OK
+        jobs.append((dim, dst, src, oT.as_array(), oidx, oinner))
+    errors = []
+
+    def work(k):
+        dim, dst, src, want_T, want_idx, want_inner = jobs[k]
+        cls = I.Icp3d if dim == 3 else I.Icp2d
+        try:
+            icp = cls(dst)
+            for rep in range(6):
+                if k % 2 and rep:  # handle turnover while the others are mid-call
+                    icp.close()
+                    icp = cls(dst)
+                T, idx, inner = icp.estimate(src, I.Transform(), 4, return_info=True)
+                if not (np.array_equal(T.as_array(), want_T) and np.array_equal(idx, want_idx)
+                        and np.array_equal(inner, want_inner)):
+                    errors.append((k, rep, "mismatch"))
+            icp.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not any(th.is_alive() for th in threads)
+    assert errors == []
