@@ -262,8 +262,14 @@ __device__ unsigned long long g_nn_hist[2][32];  // [0]: lanes by record chunks,
 // lane prunes with the distance of a real target of the SAME query (a valid bound, merely less
 // tight than the group's), every row is some lane's, and the lexicographic minimum over the lanes
 // is the minimum over all records visited: same result as L = 1.
+// One wave per workgroup.  The time of a wave is set by its slowest lane and varies several-fold;
+// four-wave workgroups held their registers and slots until the last of the four had finished, and
+// the evaluation kernels that run beside a speculative search had to wait for whole workgroups to
+// retire: 256 -> 128 -> 64 threads gave 4970 -> 5440 -> 5480 iterations/s on the 1M pair (A/B on one
+// box), the search alone 103.6 -> 97.2 -> 95.6 us.
+constexpr int kGridThreads = 64;
 template <int DIM, bool XFORM, bool COLD, int L>
-__global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
+__global__ __launch_bounds__(kGridThreads) void k_nn_grid(const double *__restrict__ src,
                                                  const uint32_t *__restrict__ perm, unsigned n, Pose T,
                                                  GridParams g, const uint32_t *__restrict__ start,
                                                  const GridPoint *__restrict__ pts,
@@ -274,8 +280,8 @@ __global__ __launch_bounds__(256) void k_nn_grid(const double *__restrict__ src,
   unsigned st[8] = {1, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
-  const unsigned k = (blockIdx.x * 256 + threadIdx.x) / L;
-  const unsigned sub = (blockIdx.x * 256 + threadIdx.x) % L;  // lane within the query's group (aligned: L divides 64)
+  const unsigned k = (blockIdx.x * kGridThreads + threadIdx.x) / L;
+  const unsigned sub = (blockIdx.x * kGridThreads + threadIdx.x) % L;  // lane within the query's group (aligned: L divides 64)
   if (k >= n) return;  // whole groups leave together
   // perm != null: src is the cell-sorted copy made by prepare_queries (neighbouring lanes
   // search neighbouring cells); results go back to the original positions
@@ -779,7 +785,7 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   // slower; ICP_NN_COOP_MAX_N: largest n that gets them, 0 = never)
   static const long coop_max = getenv("ICP_NN_COOP_MAX_N") ? atol(getenv("ICP_NN_COOP_MAX_N")) : 65536;
   const bool coop = (long)n <= coop_max;
-  const unsigned blocks = (unsigned)(((size_t)n * (coop ? 4 : 1) + 255) / 256);
+  const unsigned blocks = (unsigned)(((size_t)n * (coop ? 4 : 1) + kGridThreads - 1) / kGridThreads);
 #define GRID(DIM, XF)                       \
   do {                                      \
     if (q_prev) {                           \
@@ -797,7 +803,7 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
     }                                       \
   } while (0)
 #define GRID3(DIM, XF, CD, LN)                                                                          \
-  hipLaunchKernelGGL((k_nn_grid<DIM, XF, CD, LN>), dim3(blocks), dim3(256), 0, h->stream, q_src, q_perm, n, T, \
+  hipLaunchKernelGGL((k_nn_grid<DIM, XF, CD, LN>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, \
                      G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, q_prev, q_prev_out)
   if (h->dim == 3) {
     if (xform) { GRID(3, true); } else { GRID(3, false); }
