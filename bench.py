@@ -28,7 +28,30 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 MAX_ITER = 20                  # outer iterations per estimate() call (both reference examples pass 20)
 
 
-def cpu_baseline(src, dst, iters):
+def parity_vs_oracle(tree, src, gpu, n_iter, blocks, threads):
+    """Part of the CPU-baseline leg, outside every timed region: the registration the GPU just ran
+    (`n_iter` outer iterations from the identity pose), repeated by the oracle in the device's
+    documented summation order.  Pose, correspondence indices and inner-iteration counts must be
+    the same bits."""
+    import oracle_ffi as O
+
+    cores = os.cpu_count() or 1
+    O.set_threads(cores)
+    try:
+        rc, oT, oidx, oinner = tree.estimate(src, O.transform_identity(), n_iter, O.IcpOpts(1, 1, blocks, threads))
+    finally:
+        O.set_threads(1)
+    T, idx, inner = gpu
+    return {"checked": "estimate(src, identity, %d) on the benchmark pair vs the oracle in device summation order "
+                       "(%d x %d)" % (n_iter, blocks, threads),
+            "oracle_rc": int(rc),
+            "pose_bits_equal": bool(np.array_equal(T.as_array(), oT.as_array())),
+            "idx_equal": bool(np.array_equal(idx, oidx)),
+            "inner_iterations_equal": bool(np.array_equal(np.asarray(inner, dtype=np.uint32), oinner)),
+            "pose_max_abs_diff": float(np.max(np.abs(T.as_array() - oT.as_array())))}
+
+
+def cpu_baseline(src, dst, iters, parity_of=None):
     """The oracle (kd-tree exact NN + the reference-order inner loop), single thread, timed on
     this host: `iters` outer iterations of the same workload from the identity pose.  This is
     the only place bench.py touches oracle/ -- as the reported baseline, never as the thing
@@ -57,7 +80,9 @@ def cpu_baseline(src, dst, iters):
     per_iter, times = run(1)
     cores = os.cpu_count() or 1
     per_iter_all = run(cores)[0] if cores > 1 else per_iter
+    parity = parity_vs_oracle(tree, src, *parity_of) if parity_of is not None else None
     return {
+        "parity": parity,
         "value": 1.0 / per_iter,
         "unit": "iterations/s",
         "cores": 1,
@@ -220,7 +245,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(mode, steps, warmup):
+    def measure(mode, steps, warmup, want_parity=False):
         """K timed outer iterations = one Icp3d::estimate(src, T, K) call on resident data."""
         icp = I.Icp3d(d_dst, device=local_rank, nn_mode=mode)
         T = I.Transform()
@@ -234,10 +259,11 @@ def main():
             driver.stages.prepare(d_src, T)
             for _ in range(warmup):
                 T, _ = driver.step(d_src, T)
-        # HIP events around every 3rd search launch (every launch on short runs): an event pair costs a
-        # few us of stream time.  3 is coprime with the 20-step cycle, so the cold first search of each
-        # estimate call is sampled at its true share.
-        icp.profile_enable(3 if steps >= 20 else 1)
+        # HIP events around every search launch of a short run (<= 40 steps: the cold first search of
+        # each 20-step estimate call then weighs exactly its 1-in-20 share, as in a rocprofv3 trace of
+        # the same command); on longer runs around every 3rd launch (an event pair costs a few us of
+        # stream time; 3 is coprime with the 20-step cycle, so cold searches are sampled at their share)
+        icp.profile_enable(1 if steps <= 40 else 3)
         icp.profile_read()
         barrier()
         t0 = time.perf_counter()
@@ -285,9 +311,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         engine = {I.NN_BRUTE: "brute", I.NN_GRID: "grid"}[I.lib().icp_get_nn_mode(icp._h)]
+        checked = None
+        if world == 1 and want_parity:
+            # outside the timed region: the same call once more with the index buffer handed back, for the
+            # comparison with the oracle in the cpu_baseline leg
+            k_last = min(MAX_ITER, steps)
+            checked = (icp.estimate(d_src, I.Transform(), k_last, return_info=True), k_last)
         icp.close()
         return dict(elapsed=elapsed, steps=steps, inner=inner, nn_ms=nn_ms, nn_launches=nn_launches, T=T,
-                    engine=engine, alone_ms=alone_ms)
+                    engine=engine, alone_ms=alone_ms, checked=checked)
 
     def nn_roofline(r, n_shard):
         """Roofline of the dominant kernel (the NN search) from the live HIP-event timing."""
@@ -311,13 +343,17 @@ def main():
         # `traffic`: fabric-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected in
         # separate passes and committed under profiles/ (a PMC pass cannot run inside this process); only
         # valid for the full-size single-GPU workload it was measured on
-        traffic = None
-        tf_path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+        traffic, tf_name = None, None
+        for tf_name in ("r02_traffic_pmc.json", "r01_traffic_pmc.json"):
+            tf_path = os.path.join(ROOT, "profiles", tf_name)
+            if os.path.exists(tf_path):
+                break
         if os.path.exists(tf_path) and world == 1 and n == 1_000_000 and m == 1_000_000:
             traffic = json.load(open(tf_path))["k_nn_grid"]["traffic_bytes_per_launch"]
         return {"kernel": "k_nn_grid", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/r01_traffic_pmc.json (separate rocprofv3 --pmc passes)",
+                "traffic_source": f"profiles/{tf_name} (separate rocprofv3 --pmc passes of this command; a PMC pass "
+                                  "cannot run inside the timed process)",
                 "avg_launch_ms": 1e3 * avg_s,
                 "launches": int(r["nn_launches"]), "algorithmic_bytes_per_launch": nn_bytes,
                 # in the timed region the kernel shares the CUs with the Gauss-Newton evaluation that decides
@@ -326,7 +362,7 @@ def main():
                     "avg_launch_ms": r["alone_ms"], "achieved": nn_bytes / (1e-3 * r["alone_ms"]) / 1e9,
                     "frac": nn_bytes / (1e-3 * r["alone_ms"]) / 1e9 / HBM_PEAK_GBS}}
 
-    res = measure(nn_mode, args.steps, args.warmup)
+    res = measure(nn_mode, args.steps, args.warmup, want_parity=args.cpu_iters > 0)
     brute = None
     if args.brute_steps > 0 and res["engine"] != "brute":
         brute = measure(I.NN_BRUTE, args.brute_steps, 1)
@@ -379,7 +415,12 @@ def main():
         if world == 1 and args.gn_points > 0:
             out["gn_large"] = gn_large(args.gn_points)
         if world == 1 and args.cpu_iters > 0:
-            out["cpu_baseline"] = cpu_baseline(src_np, dst_np, args.cpu_iters)
+            par = None
+            if res["checked"] is not None:
+                blocks, threads = I.reduce_geometry(n)
+                par = (res["checked"][0], res["checked"][1], blocks, threads)
+            out["cpu_baseline"] = cpu_baseline(src_np, dst_np, args.cpu_iters, parity_of=par)
+            out["parity"] = out["cpu_baseline"].pop("parity")
             # (the CPU side of these is the oracle too: part of the same baseline leg)
             out["cpu_baseline"]["reference_sized"] = reference_sized()
         else:

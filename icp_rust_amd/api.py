@@ -36,6 +36,31 @@ def _ptr(a):
     return C.c_void_p(a.ctypes.data if a.size else None)
 
 
+def _dev_points(t, dim, device, what="points"):
+    """A device-tensor argument of the C ABI: contiguous float64 (n, dim) on the handle's GPU.  Anything
+    else (float32, a strided slice such as pts[:, :3], a 2-column tensor for Icp3d, another GPU) would be
+    read out of bounds or misread by the kernels, so it is refused here."""
+    if not _is_device_tensor(t):
+        raise ValueError(f"{what}: expected a CUDA tensor")
+    if t.dim() != 2 or t.shape[1] != dim or str(t.dtype) != "torch.float64" or not t.is_contiguous():
+        raise ValueError(f"{what}: expected a contiguous (n, {dim}) float64 CUDA tensor, got "
+                         f"{tuple(t.shape)} {t.dtype} contiguous={t.is_contiguous()}")
+    if device is not None and t.device.index != device:
+        raise ValueError(f"{what}: tensor lives on cuda:{t.device.index}, the handle on cuda:{device}")
+    return t
+
+
+def _dev_index(t, n, device, what="idx"):
+    """A device index buffer: contiguous 4-byte integers, at least n of them, on the handle's GPU."""
+    if not _is_device_tensor(t):
+        raise ValueError(f"{what}: expected a CUDA tensor")
+    if t.dim() != 1 or t.element_size() != 4 or t.dtype.is_floating_point or not t.is_contiguous() or t.shape[0] < n:
+        raise ValueError(f"{what}: expected a contiguous int32/uint32 CUDA tensor of length >= {n}")
+    if device is not None and t.device.index != device:
+        raise ValueError(f"{what}: tensor lives on cuda:{t.device.index}, the handle on cuda:{device}")
+    return t
+
+
 def _vec(v, n):
     a = np.ascontiguousarray(v, dtype=np.float64).reshape(-1)
     if a.size != n:
@@ -263,13 +288,15 @@ class _Icp:
         """Icp2d::new / Icp3d::new (src/lib.rs:97-102, 139-144)."""
         self._h = C.c_void_p()
         self._keep = None
+        self._device = None      # GPU index, known once a device tensor has been seen
+        self._own_stream = True  # the handle runs on its private streams (icp_set_stream not called)
         if _is_device_tensor(dst):
-            if dst.dim() != 2 or dst.shape[1] != self.DIM or str(dst.dtype) != "torch.float64" \
-                    or not dst.is_contiguous():
-                raise ValueError(f"expected a contiguous (m, {self.DIM}) float64 CUDA tensor")
-            self._keep = dst  # borrowed for the handle's lifetime, like `&'a [Vector]`
-            self.m = dst.shape[0]
             dev = dst.device.index if device < 0 else device
+            _dev_points(dst, self.DIM, dev, "dst")
+            self._keep = dst  # borrowed for the handle's lifetime, like `&'a [Vector]`
+            self._device = dev
+            self.m = dst.shape[0]
+            self._after_producer(dst)
             check(lib().icp_create_device(C.byref(self._h), self.DIM, C.c_void_p(dst.data_ptr()),
                                           self.m, dev), "icp_create_device")
         else:
@@ -278,6 +305,30 @@ class _Icp:
             check(lib().icp_create(C.byref(self._h), self.DIM, _ptr(d), self.m, device), "icp_create")
         if nn_mode != _lib.NN_AUTO:
             check(lib().icp_set_nn_mode(self._h, nn_mode), "icp_set_nn_mode")
+
+    def _after_producer(self, t):
+        """The handle's private streams are not ordered against the torch stream that produced a device
+        tensor (include/icp_mi355x.h: "device inputs must be complete when the call is made"): wait for
+        torch's current stream on that device.  Not needed -- and not done -- once icp_set_stream has put
+        the handle on the caller's stream, where everything is ordered."""
+        if self._own_stream:
+            import torch
+
+            torch.cuda.current_stream(t.device).synchronize()
+
+    def _dev(self, t, what):
+        if self._device is None:
+            self._device = t.device.index
+        _dev_points(t, self.DIM, self._device, what)
+        self._after_producer(t)
+        return t
+
+    def _dev_pairs(self, t, what):
+        if self._device is None:
+            self._device = t.device.index
+        _dev_points(t, 2, self._device, what)
+        self._after_producer(t)
+        return t
 
     # -- the reference's method ------------------------------------------------------
     def estimate(self, src, initial_transform, max_iter, return_info=False):
@@ -289,6 +340,7 @@ class _Icp:
         if _is_device_tensor(src):
             import torch
 
+            self._dev(src, "src")
             n = src.shape[0]
             want_idx = return_info is True
             idx = torch.empty(max(n, 1), dtype=torch.int32, device=src.device) if want_idx else None
@@ -314,8 +366,19 @@ class _Icp:
     # -- stage-level access (device tensors), used by the sharded driver and the bench --
     def set_stream(self, stream_ptr):
         check(lib().icp_set_stream(self._h, C.c_void_p(stream_ptr)), "icp_set_stream")
+        self._own_stream = False
+
+    def use_own_stream(self):
+        check(lib().icp_use_own_stream(self._h), "icp_use_own_stream")
+        self._own_stream = True
 
     def correspond_device(self, d_src, transform, d_a, d_b, d_idx=None):
+        n = self._dev(d_src, "d_src").shape[0]
+        for t, what in ((d_a, "d_a"), (d_b, "d_b")):
+            if t is not None and self._dev_pairs(t, what).shape[0] < n:
+                raise ValueError(f"{what}: needs {n} rows")
+        if d_idx is not None:
+            _dev_index(d_idx, n, self._device, "d_idx")
         check(lib().icp_correspond_device(self._h, C.c_void_p(d_src.data_ptr()), d_src.shape[0],
                                           C.byref(transform.pose),
                                           C.c_void_p(d_a.data_ptr()) if d_a is not None else None,
@@ -324,16 +387,24 @@ class _Icp:
               "icp_correspond_device")
 
     def materialize_pairs_device(self, d_src, transform, d_idx, d_a, d_b):
+        n = self._dev(d_src, "d_src").shape[0]
+        _dev_index(d_idx, n, self._device, "d_idx")
+        for t, what in ((d_a, "d_a"), (d_b, "d_b")):
+            if self._dev_pairs(t, what).shape[0] < n:
+                raise ValueError(f"{what}: needs {n} rows")
         check(lib().icp_materialize_pairs_device(self._h, C.c_void_p(d_src.data_ptr()), d_src.shape[0],
                                                  C.byref(transform.pose), C.c_void_p(d_idx.data_ptr()),
                                                  C.c_void_p(d_a.data_ptr()), C.c_void_p(d_b.data_ptr())),
               "icp_materialize_pairs_device")
 
     def prepare_source_device(self, d_src, transform):
+        self._dev(d_src, "d_src")
         check(lib().icp_prepare_source_device(self._h, C.c_void_p(d_src.data_ptr()), d_src.shape[0],
                                               C.byref(transform.pose)), "icp_prepare_source_device")
 
     def estimate_transform_device(self, d_a, d_b):
+        if self._dev_pairs(d_a, "d_a").shape[0] != self._dev_pairs(d_b, "d_b").shape[0]:
+            raise ValueError("d_a and d_b differ in length")  # debug_assert_eq!, src/lib.rs:223
         o = Transform()
         inner = C.c_uint32(0)
         check(lib().icp_estimate_transform_device(self._h, C.c_void_p(d_a.data_ptr()),
@@ -343,6 +414,7 @@ class _Icp:
         return o, inner.value
 
     def nn_search_device(self, d_q, d_idx):
+        _dev_index(d_idx, self._dev(d_q, "d_q").shape[0], self._device, "d_idx")
         check(lib().icp_nn_search_device(self._h, C.c_void_p(d_q.data_ptr()), d_q.shape[0],
                                          C.c_void_p(d_idx.data_ptr())), "icp_nn_search_device")
 
@@ -363,9 +435,7 @@ class _Icp:
         Icp*::new on the concatenated cloud (include/icp_mi355x.h section 6)."""
         tp = C.byref(transform.pose) if transform is not None else None
         if _is_device_tensor(points):
-            if points.dim() != 2 or points.shape[1] != self.DIM or str(points.dtype) != "torch.float64" \
-                    or not points.is_contiguous():
-                raise ValueError(f"expected a contiguous (k, {self.DIM}) float64 CUDA tensor")
+            self._dev(points, "points")
             check(lib().icp_append_targets_device(self._h, C.c_void_p(points.data_ptr()), points.shape[0], tp),
                   "icp_append_targets_device")
         else:

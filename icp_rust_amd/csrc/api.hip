@@ -4,6 +4,7 @@
 // gn.hip.  Nothing here falls back to a CPU computation: without a HIP device every
 // compute entry point fails with ICP_NO_DEVICE.
 #include <cfloat>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -205,6 +206,7 @@ extern "C" void icp_reduce_geometry(size_t n, int *blocks, int *threads) { reduc
 // ---------------------------------------------------------------- handle ---------
 static icp_handle *pool_take(int device);
 static int resolved_nn_mode(const icp_handle *h);
+static void destroy_failed(icp_handle *h);
 
 static int create_common(icp_handle **out, int dim, const double *dst, size_t m, int device, bool dst_on_device) {
   if (!out || (dim != 2 && dim != 3) || (m > 0 && !dst) || m >= 0xffffffffull) return ICP_BAD_ARGUMENT;
@@ -250,7 +252,8 @@ static int create_common(icp_handle **out, int dim, const double *dst, size_t m,
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) { rc = map_hip(e); break; }
   } while (0);
   if (rc != ICP_OK) {
-    icp_destroy(h);
+    // a half-built handle must not reach the pool (its scratch may be partly allocated): release it
+    destroy_failed(h);
     return rc;
   }
   *out = h;
@@ -295,6 +298,13 @@ std::mutex g_pool_mu;
 std::vector<icp_handle *> g_pool;
 
 }  // namespace
+
+static void destroy_failed(icp_handle *h) {
+  (void)hipSetDevice(h->device);
+  if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  if (h->ws.spec_stream) (void)hipStreamSynchronize(h->ws.spec_stream);
+  free_handle(h);
+}
 
 static icp_handle *pool_take(int device) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -471,15 +481,31 @@ extern "C" int icp_nn_search_device(icp_handle *h, const double *d_q, size_t n, 
 
 // Wait for the fast pipeline's result: poll the sequence number its last workgroup releases
 // into pinned memory (a few us earlier than the stream's completion signal, three times per
-// outer iteration); after ~2 ms of polling fall back to a blocking stream wait.
+// outer iteration).  The poll is bounded in TIME, not in spins: an evaluation at the sizes this
+// path serves lasts 30-60 us from its launch, so after 250 us something larger is running (a 64M-pair
+// evaluation, a cold search ahead of it) and the host thread blocks in hipStreamSynchronize instead
+// of burning a core.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __asm__ __volatile__("pause" ::: "memory");
+#elif defined(__aarch64__) || defined(__arm__)
+  __asm__ __volatile__("yield" ::: "memory");
+#else
+  __asm__ __volatile__("" ::: "memory");
+#endif
+}
 static hipError_t wait_result(icp_handle *h) {
   static const bool no_poll = getenv("ICP_NO_POLL") != nullptr;
   const unsigned want = h->ws.seq;
   volatile unsigned *seq = &h->ws.h_res->seq;
   if (!no_poll) {
-    for (unsigned spins = 0; spins < 2000000u; ++spins) {
-      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) return hipSuccess;
-      __builtin_ia32_pause();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      for (int spins = 0; spins < 256; ++spins) {
+        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) return hipSuccess;
+        cpu_relax();
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(250)) break;
     }
   }
   return hipStreamSynchronize(h->stream);
@@ -694,6 +720,18 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   if (!h || !init || !out || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(ensure_workspace(h, n, false));
+  // Whatever way this call ends, nothing of it may still be in flight afterwards: a speculative
+  // search or a pre-launched evaluation reads the caller's d_src and writes its d_last_idx, and the
+  // cell-sorted snapshot is keyed on (pointer, n) of a buffer the caller may now rewrite.
+  struct Quiesce {
+    icp_handle *h;
+    ~Quiesce() {
+      (void)hipStreamSynchronize(h->stream);
+      if (h->ws.spec_stream) (void)hipStreamSynchronize(h->ws.spec_stream);
+      h->qsort.valid = false;
+      h->qsort.have_prev = false;
+    }
+  } quiesce_on_exit{h};
   static const bool no_spec = getenv("ICP_NO_SPECULATION") != nullptr;
   static const bool one_stream_env = getenv("ICP_SPEC_SAME_STREAM") != nullptr;
   static const bool nn_first = getenv("ICP_SPEC_NN_LAST") == nullptr;
@@ -774,9 +812,8 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (two_streams) HIP_TRY(hipStreamSynchronize(w.spec_stream));
-  h->qsort.valid = false;  // the caller may reuse or rewrite the source buffer
   *out = T;
-  return ICP_OK;
+  return ICP_OK;  // (quiesce_on_exit invalidates the snapshot: the caller may reuse or rewrite the source buffer)
 }
 
 extern "C" int icp_estimate(icp_handle *h, const double *src, size_t n, const icp_pose *init, size_t max_iter,
@@ -1013,18 +1050,26 @@ int append_common(icp_handle *h, const double *pts, size_t k, const icp_pose *T,
   else
     hipLaunchKernelGGL(k_append_targets<2>, dim3(blocks), dim3(256), 0, h->stream, d_pts, (unsigned)k, P, T != nullptr, tail);
   HIP_TRY(hipGetLastError());
+  const size_t m_before = h->m;
   h->m += k;
-  // the grid is what a map-sized cloud is searched with; the sweep's structures (SoA + f32 screen,
-  // 36 B per target) are rebuilt right away only where the sweep is the engine in use
-  HIP_TRY(build_grid(h));
-  h->brute_valid = h->screen_valid = false;
-  if (resolved_nn_mode(h) == ICP_NN_BRUTE) {
-    HIP_TRY(build_target_soa(h));
-    HIP_TRY(build_target_screen(h));
-  }
   h->qsort.valid = false;  // snapshots and previous matches refer to the old grid
   h->qsort.have_prev = false;
-  HIP_TRY(hipStreamSynchronize(h->stream));  // host `pts` may be freed; later calls may use another stream
+  h->brute_valid = h->screen_valid = false;
+  // the grid is what a map-sized cloud is searched with; the sweep's structures (SoA + f32 screen,
+  // 36 B per target) are rebuilt right away only where the sweep is the engine in use
+  hipError_t e = build_grid(h);
+  if (e == hipSuccess && resolved_nn_mode(h) == ICP_NN_BRUTE) {
+    if ((e = build_target_soa(h)) == hipSuccess) e = build_target_screen(h);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // host `pts` may be freed; later calls may use another stream
+  if (e != hipSuccess) {
+    // back to the cloud as it was: the old points are untouched, the search structures are rebuilt
+    // for them (if even that fails the handle has no grid and the sweep rebuilds its copies on demand)
+    h->m = m_before;
+    (void)build_grid(h);
+    (void)hipStreamSynchronize(h->stream);
+    return map_hip(e);
+  }
   return ICP_OK;
 }
 

@@ -197,12 +197,23 @@ hipError_t build_grid(icp_handle *h) {
   // without adding rows (dense surfaces put ~10 targets into a cubic cell of the average
   // occupancy; the search radius there is a fraction of the cell).
   static const double fx = getenv("ICP_GRID_FX") ? fmax(1., atof(getenv("ICP_GRID_FX"))) : 4.;
+  // The cell size grows until the cells fit BOTH the 2^24 total and the per-axis limits (16384 along
+  // x, 4096 along y / z): an elongated cloud (a corridor map: 20000 x 50 x 5 m) must not collapse
+  // everything beyond the capped axis into its last cell -- results would stay exact (edge cells are
+  // unbounded) but queries there would scan tens of thousands of records.
+  // Only the offending axis gets coarser cells (every pruning bound uses the per-axis cell size).
   for (;;) {
     double cells = 1.;
     for (int d = 0; d < 3; ++d) {
       g.h[d] = d == 0 ? hh / fx : hh;
-      const double nd = (d < h->dim && ext[d] > 1e-9 * emax) ? floor(ext[d] / g.h[d]) + 1. : 1.;
-      g.n[d] = (int)fmin(nd, d == 0 ? 16384. : 4096.);
+      const bool flat = !(d < h->dim && ext[d] > 1e-9 * emax);
+      const double cap = d == 0 ? 16384. : 4096.;
+      double nd = flat ? 1. : floor(ext[d] / g.h[d]) + 1.;
+      if (nd > cap) {
+        g.h[d] = ext[d] / (cap - 1.5);
+        nd = fmin(floor(ext[d] / g.h[d]) + 1., cap);
+      }
+      g.n[d] = (int)nd;
       cells *= g.n[d];
     }
     if (cells <= 16777216.) break;

@@ -17,7 +17,12 @@
  *    panics (empty dst: src/lib.rs:122,165; NaN residual: src/stats.rs:12) are
  *    ICP_EMPTY_DST / ICP_NAN_INPUT;
  *  - one in-flight call per handle (it owns scratch + a HIP stream); handles are
- *    independent.  All compute runs on the GPU: without a usable HIP device every
+ *    independent.  Entry points that take DEVICE pointers run on the handle's private,
+ *    non-blocking streams unless icp_set_stream was called: the buffers they read must be
+ *    complete when the call is made (synchronise the stream that produced them, or put the
+ *    handle on that stream with icp_set_stream -- then everything is ordered there).  When a
+ *    call returns, whatever its status, none of its work is still in flight on the caller's
+ *    buffers.  All compute runs on the GPU: without a usable HIP device every
  *    compute entry point returns ICP_NO_DEVICE -- there is no CPU fallback.
  */
 #ifndef ICP_MI355X_H

@@ -193,8 +193,20 @@ int orc_inverse3x3(const double m[9], double out[9]) {
 
 /* --------------------------------------------------------------------- stats ---- */
 
-/* select_nth_unstable_by (stats.rs:19,23,24) returns an exact order statistic; which
- * selection algorithm finds it cannot change the value.  Quickselect, median-of-3. */
+/* select_nth_unstable_by (stats.rs:19,23,24) places an exact order statistic at its index; which
+ * selection algorithm finds it cannot change THAT value.  Quickselect, median-of-3.
+ *
+ * What the oracle (and therefore the GPU contract) pins for even n is the mathematically exact
+ * median: the mean of the lower and the upper middle order statistic.  The reference reads
+ * input[n/2 - 1] AFTER a second select_nth_unstable_by(n/2) on the whole vector (stats.rs:23-26);
+ * that second call only guarantees index n/2 and is free to permute the lower half, so whether
+ * input[n/2 - 1] still holds the lower middle order statistic depends on the std implementation of
+ * the toolchain the crate is built with.  For the slice lengths std finishes by insertion sort
+ * (all 24 reference tests: n <= 19) it provably does; beyond that this is PARITY UNPINNED until an
+ * even-n known answer (n > 50) from the real crate is available -- no Rust toolchain exists here.
+ * This restatement selects both ranks exactly (the second select below leaves v[n/2 - 1] the
+ * maximum of the lower half only because the first one already partitioned around it; see
+ * orc_median). */
 static void select_nth(double *v, size_t n, size_t kk) {
   ptrdiff_t lo = 0, hi = (ptrdiff_t)n - 1, k = (ptrdiff_t)kk;
   while (lo < hi) {
@@ -228,8 +240,10 @@ int orc_median(double *v, size_t n, double *out) {
     *out = v[n / 2];
     return ORC_OK;
   }
-  select_nth(v, n, n / 2 - 1);
+  /* upper middle first, then the lower middle INSIDE the lower half: v[n/2 - 1] is then the exact
+   * lower middle order statistic whatever the partitioning scheme does (see the note above) */
   select_nth(v, n, n / 2);
+  select_nth(v, n / 2, n / 2 - 1);
   double b = v[n / 2 - 1];
   double c = v[n / 2];
   *out = (b + c) / 2.;
@@ -502,8 +516,11 @@ static inline double dist2(const double *p, const double *q, int dim) {
   return d;
 }
 
+static int g_threads; /* orc_set_threads, below: splits independent queries over host cores */
+
 int orc_nn_brute(const double *dst, size_t m, int dim, const double *q, size_t n, uint32_t *idx) {
   if (m == 0) return ORC_EMPTY_DST;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads) if (g_threads > 1)
   for (size_t i = 0; i < n; ++i) {
     const double *qi = q + (size_t)dim * i;
     double best = dist2(dst, qi, dim);

@@ -1,5 +1,5 @@
 """Generates tests/golden/self_golden.json: poses the CPU oracle (reference summation order,
-kd-tree NN) produces for (a) the scan2d frame loop over the committed scans 001..005 and
+kd-tree NN) produces for (a) the scan2d frame loop over the committed scans 001..040 and
 (b) the reference's own 21-point "L" cases (src/lib.rs:509-595).  SELF-golden: there is no Rust
 toolchain here to produce them with the reference binary; they freeze the oracle so that any
 later change to it (or to libm) shows up as a diff.  Run from the repo root:
@@ -24,7 +24,7 @@ def main():
     src = load_scan2d(os.path.join(HERE, "scans2d", "001.txt"))
     T = O.transform_identity()
     frames = []
-    for k in (2, 3, 4, 5):  # examples/scan2d.rs:62-90: warm start from the previous frame
+    for k in range(2, 41):  # examples/scan2d.rs:62-90: warm start from the previous frame
         dst = load_scan2d(os.path.join(HERE, "scans2d", f"{k:03d}.txt"))
         rc, T, idx, inner = O.icp_estimate(2, dst, src, T, 20, use_kdtree=True)
         assert rc == O.OK

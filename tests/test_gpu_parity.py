@@ -517,3 +517,71 @@ def test_distinct_handles_are_independent_across_host_threads():
         th.join(timeout=300)
     assert not any(th.is_alive() for th in threads)
     assert errors == []
+
+
+def test_device_tensor_arguments_are_validated():
+    """a float32 tensor, a strided slice, the wrong column count or a short index buffer
+    must be refused by the host mirror, not read out of bounds by a kernel."""
+    import torch
+
+    src, dst = synth.synthetic_pair(5000, 9000)
+    d_dst, d_src = torch.from_numpy(dst).cuda(), torch.from_numpy(src).cuda()
+    icp = I.Icp3d(d_dst)
+    T = I.Transform()
+    wide = torch.zeros((5000, 4), dtype=torch.float64, device="cuda")
+    bad = [d_src.float(), wide[:, :3], d_src[:, :2].contiguous(), d_src.reshape(-1)]
+    for t in bad:
+        with pytest.raises(ValueError):
+            icp.estimate(t, T, 1)
+        with pytest.raises(ValueError):
+            icp.prepare_source_device(t, T)
+    with pytest.raises(ValueError):
+        I.Icp3d(d_dst.float())
+    with pytest.raises(ValueError):
+        I.Icp2d(d_dst)
+    idx_short = torch.empty(10, dtype=torch.int32, device="cuda")
+    idx_wide = torch.empty(5000, dtype=torch.int64, device="cuda")
+    for ix in (idx_short, idx_wide):
+        with pytest.raises(ValueError):
+            icp.nn_search_device(d_src, ix)
+    a = torch.empty((5000, 2), dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):
+        icp.correspond_device(d_src, T, a[:100], a)
+    with pytest.raises(ValueError):
+        icp.estimate_transform_device(a, a[:4000])
+    # and the well-formed call still works
+    assert icp.estimate(d_src, T, 2) is not None
+
+
+def test_grid_on_an_elongated_cloud_keeps_its_cells_small():
+    """a corridor-shaped cloud (20000 x 50 x 5) used to cap the x axis at 16384 cells of the
+    isotropic size and pile everything beyond into the last cell of each row.  Results were exact
+    either way; what is pinned here is that they still are and that the far end is searched as fast
+    as the near end."""
+    import time
+
+    import torch
+
+    rng = np.random.default_rng(77)
+    m = 2_000_000
+    dst = np.ascontiguousarray(rng.uniform(size=(m, 3)) * np.array([20000.0, 50.0, 5.0]))
+    icp = I.Icp3d(dst, nn_mode=I.NN_GRID)
+    tree = O.KdTree(dst)
+    times = []
+    for x0 in (100.0, 19000.0):
+        q = np.ascontiguousarray(rng.uniform(size=(200_000, 3)) * np.array([900.0, 50.0, 5.0]) + np.array([x0, 0.0, 0.0]))
+        d_q = torch.from_numpy(q).cuda()
+        idx = torch.empty(len(q), dtype=torch.int32, device="cuda")
+        icp.nn_search_device(d_q, idx)
+        icp.synchronize()
+        t0 = time.perf_counter()
+        icp.nn_search_device(d_q, idx)
+        icp.synchronize()
+        times.append(time.perf_counter() - t0)
+        O.set_threads(16)
+        try:
+            rc, want = tree.search(q[:20_000])
+        finally:
+            O.set_threads(1)
+        assert rc == O.OK and np.array_equal(idx[:20_000].cpu().numpy().view(np.uint32), want)
+    assert times[1] < 5 * times[0] + 1e-3, times

@@ -69,14 +69,44 @@ def test_invalid_value_filter():  # examples/scan3d.rs:63-69
     assert np.array_equal(synth.remove_invalid_values(p), p[2:])
 
 
+class CountingIcp2d:
+    """Icp2d factory that keeps what the GPU handles report: inner-iteration counts per outer iteration
+    and the speculative-search counters (confirmed, discarded) of every frame."""
+
+    def __init__(self):
+        self.inner, self.spec = [], [0, 0]
+
+    def __call__(self, dst):
+        self.icp = I.Icp2d(dst)
+        return self
+
+    def estimate(self, src, transform, max_iter):
+        T, _, inner = self.icp.estimate(src, transform, max_iter, return_info=True)
+        self.inner.append([int(x) for x in inner])
+        c = I.gn_path_counters(self.icp)
+        self.spec[0] += c[4]
+        self.spec[1] += c[5]
+        self.icp.close()
+        return T
+
+
 @pytest.mark.gpu
 def test_scan2d_trajectory_on_gpu_matches_oracle_bit_for_bit():
-    Ts, _, path = harness.run_scan2d(GOLDEN, max_iter=20)
+    """examples/scan2d.rs:62-90 over the reference's scans 001 .. 040 (39 frames, 780 outer iterations,
+    ~7 600 inner Gauss-Newton iterations with loops of up to 77): the whole trajectory bit-equal to the
+    oracle in the device's summation order."""
+    fac = CountingIcp2d()
+    Ts, _, path = harness.run_scan2d(GOLDEN, max_iter=20, icp_factory=fac)
     Os, _, opath = harness.run_scan2d(GOLDEN, max_iter=20, icp_factory=OracleIcp(2, tree_order=True))
-    assert len(Ts) == len(Os) == 4
+    assert len(Ts) == len(Os) == 39
     for a, b in zip(Ts, Os):
         assert np.array_equal(a.as_array(), b.as_array())
     assert np.array_equal(path, opath)
+    # the run really exercised long inner loops and wrong speculative bets (a bet on "one update, then
+    # the loop ends" that the loop did not honour: the search is discarded and repeated)
+    assert max(max(f) for f in fac.inner) >= 30
+    assert sum(sum(f) for f in fac.inner) > 5000
+    assert fac.spec[0] >= 1 and fac.spec[1] >= 1, fac.spec
     # and within the north_star tolerance of the reference-order oracle
     Rs, _, _ = harness.run_scan2d(GOLDEN, max_iter=20, icp_factory=OracleIcp(2))
     for a, b in zip(Ts, Rs):
@@ -98,7 +128,7 @@ def test_cli_prints_the_trajectories(capsys):
     assert harness.main(["scan2d", GOLDEN, "--max-iter", "5"]) == 0
     out = [ln for ln in capsys.readouterr().out.splitlines() if ln and not ln.startswith("#")]
     Ts, _, path = harness.run_scan2d(GOLDEN, max_iter=5)
-    assert len(out) == len(path) == 4
+    assert len(out) == len(path) == 39
     assert [float(v) for v in out[-1].split()[1:]] == pytest.approx(list(path[-1]), abs=1e-9)
     assert harness.main(["scan2map", "--frames", "2", "--max-iter", "3"]) == 0
     out = capsys.readouterr().out.splitlines()

@@ -33,13 +33,20 @@ def test_oracle_reproduces_the_frozen_scan2d_trajectory():
 def test_gpu_matches_the_frozen_scan2d_trajectory():
     src = load_scan2d(os.path.join(GOLDEN, "scans2d", "001.txt"))
     T = I.Transform()
+    oT = O.transform_identity()
     for fr in G["scan2d"]:
         dst = load_scan2d(os.path.join(GOLDEN, "scans2d", f"{fr['frame']:03d}.txt"))
         T, idx, inner = I.Icp2d(dst).estimate(src, T, 20, return_info=True)
         want = np.array([float(x) for x in fr["pose"]])
         assert np.max(np.abs(T.as_array() - want)) <= 1e-5 * max(1.0, np.max(np.abs(want)))  # north_star
-        # indices: equal up to identical-coordinate duplicates (the scans hold repeated (0, 0) returns)
         assert [int(x) for x in inner] == fr["inner_iters"]
+        # indices: the oracle's (whose checksum is the frozen one) up to identical-coordinate duplicates --
+        # the scans hold repeated (0, 0) returns, which tie only with each other
+        rc, oT, oidx, _ = O.icp_estimate(2, dst, src, oT, 20, use_kdtree=True)
+        assert rc == O.OK and _checksum(oidx) == fr["idx_checksum"]
+        diff = np.nonzero(idx != oidx)[0]
+        assert len(diff) <= 8
+        assert all(np.array_equal(dst[idx[i]], dst[oidx[i]]) for i in diff)
 
 
 @pytest.mark.gpu
