@@ -29,7 +29,7 @@ class Pose(C.Structure):
 def build(force=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "icp_mi355x.h"))
+    srcs += [os.path.join(os.path.dirname(_HERE), "include", f) for f in ("icp_mi355x.h", "icp_trig.h")]
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -61,6 +61,9 @@ SIGNATURES = {
     "icp_so2_log": (C.c_double, [_dp]),
     "icp_norm": (C.c_double, [_dp, _sz, _sz]),
     "icp_inverse3x3": (C.c_int, [_dp, _dp]),
+    "icp_f64_sin": (C.c_double, [C.c_double]),
+    "icp_f64_cos": (C.c_double, [C.c_double]),
+    "icp_transform_new_device": (C.c_int, [_vp, _sz, _vp, C.c_int]),
     "icp_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _sz, C.c_int]),
     "icp_create_device": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _sz, C.c_int]),
     "icp_destroy": (None, [_vp]),

@@ -202,6 +202,48 @@ extern "C" int icp_inverse3x3(const double m[9], double out[9]) {
   return inverse3x3(m, out) ? ICP_OK : ICP_NONE;
 }
 extern "C" void icp_reduce_geometry(size_t n, int *blocks, int *threads) { reduce_geometry(n, blocks, threads); }
+extern "C" double icp_f64_sin(double x) { return ref_sin(x); }
+extern "C" double icp_f64_cos(double x) { return ref_cos(x); }
+
+// Transform::new on the device (observability: host and device must agree to the bit)
+__global__ void k_transform_new(const double *__restrict__ params, unsigned n, icp_pose *__restrict__ out,
+                                int *__restrict__ out_of_range) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double p[3] = {params[3 * (size_t)i], params[3 * (size_t)i + 1], params[3 * (size_t)i + 2]};
+  bool ok;
+  out[i] = transform_new_in_range(p, &ok);
+  if (!ok) atomicOr(out_of_range, 1);
+}
+
+extern "C" int icp_transform_new_device(const double *params, size_t n, icp_pose *out, int device) {
+  if ((n > 0 && (!params || !out)) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ICP_NO_DEVICE;
+  if (n == 0) return ICP_OK;
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  double *d_p = nullptr;
+  icp_pose *d_o = nullptr;
+  int *d_f = nullptr;
+  int rc = ICP_OK, flag = 0;
+  do {
+    hipError_t e;
+    if ((e = hipMalloc(&d_p, n * 3 * sizeof(double))) != hipSuccess) { rc = map_hip(e); break; }
+    if ((e = hipMalloc(&d_o, n * sizeof(icp_pose))) != hipSuccess) { rc = map_hip(e); break; }
+    if ((e = hipMalloc(&d_f, sizeof(int))) != hipSuccess) { rc = map_hip(e); break; }
+    if ((e = hipMemcpy(d_p, params, n * 3 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) { rc = map_hip(e); break; }
+    if ((e = hipMemset(d_f, 0, sizeof(int))) != hipSuccess) { rc = map_hip(e); break; }
+    hipLaunchKernelGGL(k_transform_new, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d_p, (unsigned)n, d_o, d_f);
+    if ((e = hipGetLastError()) != hipSuccess) { rc = map_hip(e); break; }
+    if ((e = hipMemcpy(out, d_o, n * sizeof(icp_pose), hipMemcpyDeviceToHost)) != hipSuccess) { rc = map_hip(e); break; }
+    if ((e = hipMemcpy(&flag, d_f, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) { rc = map_hip(e); break; }
+  } while (0);
+  (void)hipFree(d_p);
+  (void)hipFree(d_o);
+  (void)hipFree(d_f);
+  if (rc != ICP_OK) return rc;
+  return flag ? ICP_BAD_ARGUMENT : ICP_OK;  // a theta beyond the restated range of sin / cos: host only
+}
 
 // ---------------------------------------------------------------- handle ---------
 static icp_handle *pool_take(int device);

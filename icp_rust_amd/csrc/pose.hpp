@@ -9,35 +9,41 @@
 #include <cstddef>
 
 #include "../../include/icp_mi355x.h"
+#include "../../include/icp_trig.h"
+
+#if defined(__HIPCC__)
+#define ICP_HD __host__ __device__
+#else
+#define ICP_HD
+#endif
 
 namespace icp {
 
 using Pose = icp_pose;
 
-// so2::exp / so2::new_rotation2 (src/so2.rs:8-31); column-major 2x2
-inline void so2_exp(double theta, double m[4]) {
-  const double c = std::cos(theta), s = std::sin(theta);
-  m[0] = c;
-  m[1] = s;
-  m[2] = -s;
-  m[3] = c;
+// f64::sin / f64::cos as the reference's no_std build evaluates them (num-traits -> libm crate, a
+// port of musl's kernels: include/icp_trig.h); the same definition runs on the device and in the
+// oracle.  Beyond 2^20 pi/2 (Payne-Hanek, not restated) the C library serves.
+inline double ref_sin(double x) {
+  int ok;
+  const double v = icp_sin(x, &ok);
+  return ok ? v : std::sin(x);
+}
+inline double ref_cos(double x) {
+  int ok;
+  const double v = icp_cos(x, &ok);
+  return ok ? v : std::cos(x);
 }
 
-// so2::log (src/so2.rs:19-21)
-inline double so2_log(const double m[4]) { return std::atan2(m[1], m[0]); }
-
-// se2::calc_rt (src/se2.rs:21-41) == Transform::new (src/transform.rs:13-16)
-inline Pose transform_new(const double p[3]) {
+// se2::calc_rt (src/se2.rs:21-41) from given cos / sin of theta -- the part host and device share
+ICP_HD inline icp_pose calc_rt_cs(const double p[3], double c, double s) {
   const double theta = p[2];
-  double r[4];
-  so2_exp(theta, r);
-  const double c = std::cos(theta), s = std::sin(theta);
   const double vx = p[0], vy = p[1];
-  Pose o;
-  o.r00 = r[0];
-  o.r10 = r[1];
-  o.r01 = r[2];
-  o.r11 = r[3];
+  icp_pose o;
+  o.r00 = c;
+  o.r10 = s;
+  o.r01 = -s;
+  o.r11 = c;
   if (theta == 0.) {
     o.tx = vx;
     o.ty = vy;
@@ -48,18 +54,42 @@ inline Pose transform_new(const double p[3]) {
   return o;
 }
 
+// Transform::new where only the restated range of sin / cos is available (device code): *ok = false
+// when |theta| >= 2^20 pi/2 -- the caller hands the update to the host
+ICP_HD inline icp_pose transform_new_in_range(const double p[3], bool *ok) {
+  int ok_s, ok_c;
+  const double s = icp_sin(p[2], &ok_s), c = icp_cos(p[2], &ok_c);
+  *ok = ok_s && ok_c;
+  return calc_rt_cs(p, c, s);
+}
+
+// so2::exp / so2::new_rotation2 (src/so2.rs:8-31); column-major 2x2
+inline void so2_exp(double theta, double m[4]) {
+  const double c = ref_cos(theta), s = ref_sin(theta);
+  m[0] = c;
+  m[1] = s;
+  m[2] = -s;
+  m[3] = c;
+}
+
+// so2::log (src/so2.rs:19-21)
+inline double so2_log(const double m[4]) { return std::atan2(m[1], m[0]); }
+
+// se2::calc_rt (src/se2.rs:21-41) == Transform::new (src/transform.rs:13-16)
+inline Pose transform_new(const double p[3]) { return calc_rt_cs(p, ref_cos(p[2]), ref_sin(p[2])); }
+
 // Transform::identity (src/transform.rs:34-39)
-inline Pose transform_identity() { return Pose{1., 0., 0., 1., 0., 0.}; }
+ICP_HD inline Pose transform_identity() { return Pose{1., 0., 0., 1., 0., 0.}; }
 
 // Transform::transform (src/transform.rs:22-24): rot * p + t
-inline void transform_apply(const Pose &T, const double p[2], double out[2]) {
+ICP_HD inline void transform_apply(const Pose &T, const double p[2], double out[2]) {
   const double x = p[0], y = p[1];
   out[0] = (T.r00 * x + T.r01 * y) + T.tx;
   out[1] = (T.r10 * x + T.r11 * y) + T.ty;
 }
 
 // Transform::inverse (src/transform.rs:26-32)
-inline Pose transform_inverse(const Pose &T) {
+ICP_HD inline Pose transform_inverse(const Pose &T) {
   Pose o;
   o.r00 = T.r00;
   o.r01 = T.r10;
@@ -73,7 +103,7 @@ inline Pose transform_inverse(const Pose &T) {
 }
 
 // impl Mul for Transform (src/transform.rs:42-51)
-inline Pose transform_mul(const Pose &l, const Pose &r) {
+ICP_HD inline Pose transform_mul(const Pose &l, const Pose &r) {
   Pose o;
   o.r00 = l.r00 * r.r00 + l.r01 * r.r10;
   o.r10 = l.r10 * r.r00 + l.r11 * r.r10;
@@ -112,7 +142,7 @@ inline void se2_log(const double m[9], double p[3]) {
   } else if (theta == M_PI) {
     v00 = 0.; v01 = 0.5 * theta; v10 = -0.5 * theta; v11 = 0.;
   } else {
-    const double k = std::sin(theta) / (1. - std::cos(theta));
+    const double k = ref_sin(theta) / (1. - ref_cos(theta));
     const double h = 0.5 * theta;
     v00 = h * k; v01 = h * 1.; v10 = h * -1.; v11 = h * k;
   }
@@ -122,7 +152,7 @@ inline void se2_log(const double m[9], double p[3]) {
 }
 
 // linalg::inverse3x3 (src/linalg.rs:3-29); row-major; false iff det == 0
-inline bool inverse3x3(const double m[9], double out[9]) {
+ICP_HD inline bool inverse3x3(const double m[9], double out[9]) {
   const double m00 = m[0], m01 = m[1], m02 = m[2];
   const double m10 = m[3], m11 = m[4], m12 = m[5];
   const double m20 = m[6], m21 = m[7], m22 = m[8];
@@ -139,7 +169,7 @@ inline bool inverse3x3(const double m[9], double out[9]) {
 }
 
 // `-jtj_inv * jtr` (src/lib.rs:212-215, 257-260); false where the reference returns None
-inline bool solve_update(const double jtj[9], const double jtr[3], double delta[3]) {
+ICP_HD inline bool solve_update(const double jtj[9], const double jtr[3], double delta[3]) {
   double inv[9];
   if (!inverse3x3(jtj, inv)) return false;
   for (int i = 0; i < 3; ++i)

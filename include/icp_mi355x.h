@@ -90,6 +90,15 @@ void icp_so2_exp(double theta, double m2_colmajor[4]);             /* so2::exp /
 double icp_so2_log(const double m2_colmajor[4]);                   /* so2::log, so2.rs:19-21 */
 double icp_norm(const double *m_colmajor, size_t nrows, size_t ncols); /* icp::norm, norm.rs:19-21 */
 int icp_inverse3x3(const double m_rowmajor[9], double out_rowmajor[9]); /* linalg::inverse3x3, linalg.rs:3-29 (ICP_NONE iff det == 0) */
+/* f64::sin / f64::cos as the reference's no_std build evaluates them (num-traits `libm` feature,
+ * Cargo.toml:17-20 -> the libm crate, a port of musl's kernels; restated in icp_trig.h).  Host and
+ * device share the definition: the inner loop's pose updates (Transform::new, src/lib.rs:81) run
+ * on the GPU and must give the bits the host API gives. */
+double icp_f64_sin(double x);
+double icp_f64_cos(double x);
+/* Transform::new on the DEVICE for n parameter vectors (host buffers in and out; test / observability
+ * entry: proves that device and host evaluate se2::calc_rt to the same bits) */
+int icp_transform_new_device(const double *params_xyz, size_t n, icp_pose *out, int device);
 
 /* ================================================================================
  * 2. The registration handle: Icp2d / Icp3d

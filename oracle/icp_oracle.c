@@ -16,11 +16,31 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* f64::sin / f64::cos of the reference's no_std build: num-traits' `libm` feature (Cargo.toml:17-20)
+ * -> the Rust libm crate, a port of musl's kernels.  The crate is not under /root/reference; its
+ * published algorithm is restated ONCE, in include/icp_trig.h, and shared with the library's host and
+ * device code so that all three agree to the bit (tests/test_trig.py pins it against the C library:
+ * <= 1 ulp).  Outside the restated range (|x| >= 2^20 pi/2) the C library serves. */
+#include "../include/icp_trig.h"
+static double ref_sin(double x) {
+  int ok;
+  double v = icp_sin(x, &ok);
+  return ok ? v : sin(x);
+}
+static double ref_cos(double x) {
+  int ok;
+  double v = icp_cos(x, &ok);
+  return ok ? v : cos(x);
+}
+
 /* ------------------------------------------------------------------ so2 / se2 ---- */
+
+double orc_sin(double x) { return ref_sin(x); }
+double orc_cos(double x) { return ref_cos(x); }
 
 /* so2.rs:23-31 `exp`; so2.rs:8-17 `new_rotation2` builds the same matrix. */
 void orc_so2_exp(double theta, double m[4]) {
-  double c = cos(theta), s = sin(theta);
+  double c = ref_cos(theta), s = ref_sin(theta);
   m[0] = c;  /* (0,0) */
   m[1] = s;  /* (1,0) */
   m[2] = -s; /* (0,1) */
@@ -35,7 +55,7 @@ void orc_se2_calc_rt(const double param[3], orc_pose *out) {
   double theta = param[2];
   double rot[4];
   orc_so2_exp(theta, rot); /* so2::new_rotation2(theta) */
-  double c = cos(theta), s = sin(theta);
+  double c = ref_cos(theta), s = ref_sin(theta);
   double vx = param[0], vy = param[1];
   out->r00 = rot[0];
   out->r10 = rot[1];
@@ -79,7 +99,7 @@ void orc_se2_log(const double m[9], double param[3]) {
   } else if (theta == M_PI) {
     v00 = 0.; v01 = 0.5 * theta; v10 = -0.5 * theta; v11 = 0.;
   } else {
-    double k = sin(theta) / (1. - cos(theta));
+    double k = ref_sin(theta) / (1. - ref_cos(theta));
     double h = 0.5 * theta; /* `0.5 * theta * m`: (0.5*theta) then scalar * matrix */
     v00 = h * k; v01 = h * 1.; v10 = h * -1.; v11 = h * k;
   }

@@ -43,6 +43,9 @@ typedef struct { double r00, r10, r01, r11, tx, ty; } orc_pose;
 #define ORC_PPF34 1.482602218505602
 
 /* --- so2 / se2 / Transform (src/so2.rs, src/se2.rs, src/transform.rs) ------------- */
+/* f64::sin / f64::cos as the reference's no_std build evaluates them (include/icp_trig.h) */
+double orc_sin(double x);
+double orc_cos(double x);
 void orc_so2_exp(double theta, double m_colmajor[4]);                /* so2.rs:23-31 */
 double orc_so2_log(const double m_colmajor[4]);                      /* so2.rs:19-21 */
 void orc_se2_calc_rt(const double param[3], orc_pose *out);          /* se2.rs:21-41 */

@@ -37,6 +37,7 @@ OK, NONE, EMPTY_DST, NAN = 0, 1, 2, 3
 
 def build_oracle():
     src = [os.path.join(_ORACLE_DIR, f) for f in ("icp_oracle.c", "icp_oracle.h", "Makefile")]
+    src.append(os.path.join(_ROOT, "include", "icp_trig.h"))
     if (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])
     return _SO
@@ -60,6 +61,8 @@ def lib():
         f.restype = res
         f.argtypes = list(args)
 
+    sig("orc_sin", C.c_double, C.c_double)
+    sig("orc_cos", C.c_double, C.c_double)
     sig("orc_so2_exp", None, C.c_double, dp)
     sig("orc_so2_log", C.c_double, dp)
     sig("orc_se2_calc_rt", None, dp, pp)
