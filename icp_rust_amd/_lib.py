@@ -95,6 +95,10 @@ SIGNATURES = {
     "icp_reserve_targets": (C.c_int, [_vp, _sz]),
     "icp_target_count": (_sz, [_vp]),
     "icp_read_targets": (C.c_int, [_vp, _sz, _sz, _vp]),
+    "icp_compute_target_normals": (C.c_int, [_vp, C.c_int]),
+    "icp_read_target_normals": (C.c_int, [_vp, _sz, _sz, _vp]),
+    "icp_estimate_point_to_plane": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
+    "icp_estimate_point_to_plane_device": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
 }
 
 _lib = None

@@ -458,6 +458,42 @@ class _Icp:
         check(lib().icp_read_targets(self._h, first, count, C.c_void_p(out.ctypes.data)), "icp_read_targets")
         return out
 
+    # -- EXTENSION (not in the reference): point-to-plane residuals, include/icp_mi355x.h section 7 --
+    def compute_normals(self, k=10):
+        """Unit normals of the target points from their k nearest targets (3-D handles)."""
+        check(lib().icp_compute_target_normals(self._h, int(k)), "icp_compute_target_normals")
+
+    def read_normals(self, first=0, count=None):
+        count = self.target_count - first if count is None else count
+        out = np.empty((count, 3), dtype=np.float64)
+        check(lib().icp_read_target_normals(self._h, first, count, C.c_void_p(out.ctypes.data)),
+              "icp_read_target_normals")
+        return out
+
+    def estimate_point_to_plane(self, src, initial_transform, max_iter, return_info=False):
+        """Icp3d::estimate with the residual n_q . (T p - q) (extension; needs compute_normals())."""
+        o = Transform()
+        inner = np.zeros(max(max_iter, 1), dtype=np.uint32)
+        if _is_device_tensor(src):
+            import torch
+
+            self._dev(src, "src")
+            n = src.shape[0]
+            idx = torch.empty(max(n, 1), dtype=torch.int32, device=src.device) if return_info else None
+            check(lib().icp_estimate_point_to_plane_device(self._h, C.c_void_p(src.data_ptr()), n,
+                                                           C.byref(initial_transform.pose), max_iter, C.byref(o.pose),
+                                                           C.c_void_p(idx.data_ptr()) if return_info else None,
+                                                           C.c_void_p(inner.ctypes.data)),
+                  "icp_estimate_point_to_plane_device")
+            return (o, idx[:n].cpu().numpy().view(np.uint32), inner[:max_iter]) if return_info else o
+        s = _host(src, self.DIM)
+        n = s.shape[0]
+        idx = np.zeros(max(n, 1), dtype=np.uint32)
+        check(lib().icp_estimate_point_to_plane(self._h, _ptr(s), n, C.byref(initial_transform.pose), max_iter,
+                                                C.byref(o.pose), C.c_void_p(idx.ctypes.data),
+                                                C.c_void_p(inner.ctypes.data)), "icp_estimate_point_to_plane")
+        return (o, idx[:n], inner[:max_iter]) if return_info else o
+
     def profile_enable(self, every=1):
         """Time every `every`-th NN search launch with HIP events (0 / False: off)."""
         check(lib().icp_profile_enable(self._h, int(every)), "icp_profile_enable")

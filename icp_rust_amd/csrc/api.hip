@@ -331,6 +331,10 @@ void free_handle(icp_handle *h) {  // really release everything
   (void)hipFree(h->qsort.d_perm);
   (void)hipFree(h->qsort.d_sorted);
   (void)hipFree(h->qsort.d_prev);
+  (void)hipFree(h->d_normals);
+  (void)hipFree(h->d_plane_pairs);
+  (void)hipFree(h->d_plane_fa);
+  (void)hipFree(h->d_plane_fb);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -391,6 +395,8 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->grid.built = false;
     h->qsort.valid = false;
     h->qsort.have_prev = false;
+    h->normals_m = 0;
+    h->normals_k = 0;
     w.win_valid = w.win_wide = false;
     w.win_kind[0] = w.win_kind[1] = Workspace::WinPred();
     w.win_tried = w.win_missed = w.short_evals = w.radix_evals = 0;
@@ -1094,6 +1100,7 @@ int append_common(icp_handle *h, const double *pts, size_t k, const icp_pose *T,
   HIP_TRY(hipGetLastError());
   const size_t m_before = h->m;
   h->m += k;
+  h->normals_m = 0;  // (extension) normals describe the cloud before the append
   h->qsort.valid = false;  // snapshots and previous matches refer to the old grid
   h->qsort.have_prev = false;
   h->brute_valid = h->screen_valid = false;
@@ -1138,4 +1145,114 @@ extern "C" int icp_read_targets(icp_handle *h, size_t first, size_t k, double *o
   HIP_TRY(hipMemcpyAsync(out, h->d_dst + first * h->dim, k * h->dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return ICP_OK;
+}
+
+// ------------------------------------------- EXTENSION: point-to-plane residuals -----
+// Not in the reference (no normals anywhere in src/); definition and CPU restatement: p2plane.hip,
+// the CPU checker under tests (tests/test_p2plane.py).  Everything around the residual is the reference's: exact 3-D
+// nearest neighbour, SE(2) pose on xy, Huber / MAD Gauss-Newton, the inner loop's break tests.
+extern "C" int icp_compute_target_normals(icp_handle *h, int k) {
+  if (!h || h->dim != 3 || k < 3 || k > 16) return ICP_BAD_ARGUMENT;
+  if (h->m == 0) return ICP_EMPTY_DST;
+  if (!h->grid.built) return ICP_BAD_ARGUMENT;  // non-finite targets: no grid to search neighbourhoods with
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(reserve(h->d_normals, h->cap_normals, h->m * 3));
+  HIP_TRY(launch_target_normals(h, k, h->d_normals));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->normals_m = h->m;
+  h->normals_k = k;
+  return ICP_OK;
+}
+
+extern "C" int icp_read_target_normals(icp_handle *h, size_t first, size_t count, double *out) {
+  if (!h || h->normals_m != h->m || h->m == 0 || first > h->m || count > h->m - first || (count > 0 && !out))
+    return ICP_BAD_ARGUMENT;
+  if (count == 0) return ICP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(out, h->d_normals + first * 3, count * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ICP_OK;
+}
+
+extern "C" int icp_estimate_point_to_plane_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *init,
+                                                  size_t max_iter, icp_pose *out, uint32_t *d_last_idx,
+                                                  uint32_t *inner_iters) {
+  if (!h || h->dim != 3 || !init || !out || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  if (h->normals_m != h->m || h->m == 0) return h->m == 0 && n > 0 && max_iter > 0 ? ICP_EMPTY_DST : (h->m == 0 ? ICP_OK : ICP_BAD_ARGUMENT);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(ensure_workspace(h, n, false));
+  if (n > h->cap_plane) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipFree(h->d_plane_pairs);
+    (void)hipFree(h->d_plane_fa);
+    (void)hipFree(h->d_plane_fb);
+    h->d_plane_pairs = nullptr;
+    h->d_plane_fa = h->d_plane_fb = nullptr;
+    h->cap_plane = 0;
+    HIP_TRY(hipMalloc(&h->d_plane_pairs, n * p2pl_pair_bytes()));
+    HIP_TRY(hipMalloc(&h->d_plane_fa, n * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->d_plane_fb, n * 2 * sizeof(double)));
+    h->cap_plane = n;
+  }
+  Workspace &w = h->ws;
+  Pose T = *init;
+  if (max_iter > 0) {
+    const int prc = icp_prepare_source_device(h, d_src, n, init);
+    if (prc != ICP_OK) return prc;
+  }
+  struct Quiesce {
+    icp_handle *h;
+    ~Quiesce() {
+      (void)hipStreamSynchronize(h->stream);
+      h->qsort.valid = false;
+      h->qsort.have_prev = false;
+    }
+  } quiesce_on_exit{h};
+  for (size_t it = 0; it < max_iter; ++it) {
+    uint32_t *idx = (it + 1 == max_iter && d_last_idx) ? d_last_idx : w.d_idx;
+    int rc = icp_correspond_device(h, d_src, n, &T, nullptr, nullptr, idx);  // exact 3-D NN, src/lib.rs:161-167
+    if (rc != ICP_OK) return rc;
+    HIP_TRY(launch_p2pl_gather(h, d_src, n, T, idx, h->d_normals, h->d_plane_pairs));
+    // the reference's inner loop (src/lib.rs:59-84) around the plane residual
+    Pose Ti = transform_identity();
+    uint32_t applied = 0;
+    if (n >= 2) {
+      double prev_error = DBL_MAX;
+      for (int k = 0; k < ICP_INNER_MAX_ITER; ++k) {
+        HIP_TRY(launch_p2pl_eval(h, h->d_plane_pairs, n, Ti, h->d_plane_fa, h->d_plane_fb));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const GnResult &r = *w.h_res;
+        if (r.nan_flag) return ICP_NAN_INPUT;
+        double delta[3];
+        if (!solve_update(r.acc, r.acc + 9, delta)) break;
+        if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD) break;
+        if (r.acc[12] > prev_error) break;
+        prev_error = r.acc[12];
+        Ti = transform_mul(transform_new(delta), Ti);
+        ++applied;
+      }
+    }
+    if (inner_iters) inner_iters[it] = applied;
+    T = transform_mul(Ti, T);
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *out = T;
+  return ICP_OK;
+}
+
+extern "C" int icp_estimate_point_to_plane(icp_handle *h, const double *src, size_t n, const icp_pose *init,
+                                           size_t max_iter, icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters) {
+  if (!h || h->dim != 3 || !init || !out || (n > 0 && !src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(ensure_workspace(h, n, true));
+  if (n > 0)
+    HIP_TRY(hipMemcpyAsync(h->ws.d_src, src, n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  uint32_t *d_li = nullptr;
+  if (last_idx && n > 0) HIP_TRY(hipMalloc(&d_li, n * sizeof(uint32_t)));
+  int rc = icp_estimate_point_to_plane_device(h, h->ws.d_src, n, init, max_iter, out, d_li, inner_iters);
+  if (rc == ICP_OK && d_li && max_iter > 0) {
+    if (hipMemcpy(last_idx, d_li, n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = ICP_HIP_ERROR;
+  }
+  (void)hipFree(d_li);
+  return rc;
 }

@@ -175,6 +175,8 @@ struct GridParams {
   int n[3];
   int fx;        // x cells per y/z cell size: the cold search grows its block by fx cells along x per ring
   double scale;  // coordinate magnitude used for the rounding margin of the pruning bounds
+  float ext;     // largest extent of the bounding box + one cell: magnitude of every grid-relative coordinate
+  int f32_ok;    // the grid-relative geometry is representable in f32 with room to spare (k_nn_grid_warm)
 };
 
 struct GridPoint {  // one target, cell-sorted: a 16-B pre-filter record = one load per candidate
@@ -187,13 +189,15 @@ struct Grid {
   GridParams p;
   uint32_t ncell = 0;
   uint32_t *d_start = nullptr;  // ncell + 1 cell offsets into d_pts
-  GridPoint *d_pts = nullptr;   // m targets sorted by cell
+  GridPoint *d_pts = nullptr;   // m targets sorted by cell, then kGridPad sentinel records (+inf: never pass a screen)
   // capacities (elements) and build temporaries: kept, so that a pooled handle rebuilds without allocating
   size_t cap_start = 0, cap_pts = 0;
   uint32_t *t_cell_of = nullptr, *t_cnt = nullptr, *t_btot = nullptr;
   size_t cap_tcell = 0, cap_tcnt = 0, cap_tbtot = 0;
   double *t_part = nullptr;     // bounding-box partials
 };
+
+constexpr unsigned kGridPad = 8;  // records past the last target that a quad-aligned read may touch
 
 struct PrevMatch {  // a query's previous nearest neighbour, stored per sorted slot (coalesced)
   double x, y, z;
@@ -233,6 +237,13 @@ struct icp_handle {
   icp::Workspace ws;
   icp::Grid grid;
   icp::QuerySort qsort;
+  // EXTENSION (p2plane.hip): unit normals of the target points (m x 3), valid while normals_m == m
+  double *d_normals = nullptr;
+  size_t cap_normals = 0, normals_m = 0;
+  int normals_k = 0;
+  void *d_plane_pairs = nullptr;  // per-pair constants of a point-to-plane inner loop
+  double *d_plane_fa = nullptr, *d_plane_fb = nullptr;
+  size_t cap_plane = 0;
   // live kernel timing (icp_profile_*): event pairs around the NN search kernel
   int profile = 0;         // 0: off; k: event pairs around every k-th search launch
   unsigned prof_seen = 0;
@@ -298,6 +309,12 @@ hipError_t launch_win_first_pass(icp_handle *h, const double *d_a, const double 
                                  const WinParams &P1);  // + copy of the histograms into h->ws.h_whist
 bool refine_window(const uint32_t *hist, size_t n, const WinParams &P1, WinParams *P2);
 hipError_t launch_win_second_pass(icp_handle *h, const double *d_a, size_t n, const Pose &T, const WinParams &P2);
+// EXTENSION: point-to-plane residuals (p2plane.hip)
+hipError_t launch_target_normals(icp_handle *h, int k, double *d_normals);
+hipError_t launch_p2pl_gather(icp_handle *h, const double *d_src, size_t n, const Pose &T, const uint32_t *d_idx,
+                              const double *d_normals, void *d_pairs);
+hipError_t launch_p2pl_eval(icp_handle *h, const void *d_pairs, size_t n, const Pose &T, double *d_fa, double *d_fb);
+size_t p2pl_pair_bytes();
 // unweighted accumulation (gauss_newton_update / error / huber_error)
 hipError_t launch_plain_gn(icp_handle *h, const double *d_a, const double *d_b, size_t n,
                            const Pose &T);

@@ -135,7 +135,11 @@ __global__ void k_grid_scatter(const double *__restrict__ dst, unsigned m, int d
                                const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ start,
                                uint32_t *__restrict__ cursor, GridParams g, GridPoint *__restrict__ pts) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
+  if (i >= m) {
+    // sentinels behind the last record: the warm search reads records in aligned quads (64-byte lines)
+    if (i < m + kGridPad) pts[i] = GridPoint{__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf(), 0u};
+    return;
+  }
   const uint32_t cell = cell_of[i];
   const uint32_t pos = start[cell] + atomicAdd(&cursor[cell], 1u);
   GridPoint p;
@@ -222,6 +226,13 @@ hipError_t build_grid(icp_handle *h) {
   for (int d = 0; d < 3; ++d) g.inv_h[d] = 1. / g.h[d];
   g.fx = (int)fmin(fmax(floor(fx + 0.5), 1.), 64.);
   g.scale = scale + hh;
+  g.ext = (float)(emax + hh);
+  // k_nn_grid_warm evaluates every pruning bound in f32, relative to the grid origin, with explicit
+  // margins; it needs cell sizes and extents that f32 represents as normal numbers with headroom
+  g.f32_ok = 1;
+  for (int d = 0; d < 3; ++d)
+    if (!(g.h[d] > 1e-10 && g.h[d] < 1e10)) g.f32_ok = 0;
+  if (!(emax + hh < 1e10)) g.f32_ok = 0;
   G.p = g;
   G.ncell = (uint32_t)g.n[0] * g.n[1] * g.n[2];
   // 3. counting sort of the targets by cell
@@ -232,7 +243,7 @@ hipError_t build_grid(icp_handle *h) {
     if ((e = reserve(G.t_cnt, G.cap_tcnt, (size_t)nscan)) != hipSuccess) break;
     if ((e = reserve(G.t_btot, G.cap_tbtot, (size_t)nb + 1)) != hipSuccess) break;
     if ((e = reserve(G.d_start, G.cap_start, (size_t)nscan)) != hipSuccess) break;
-    if ((e = reserve(G.d_pts, G.cap_pts, (size_t)m)) != hipSuccess) break;
+    if ((e = reserve(G.d_pts, G.cap_pts, (size_t)m + kGridPad)) != hipSuccess) break;
     uint32_t *cell_of = G.t_cell_of, *cnt = G.t_cnt, *btot = G.t_btot;
     if ((e = hipMemsetAsync(cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) break;
     hipLaunchKernelGGL(k_grid_count, dim3((m + 255) / 256), dim3(256), 0, s, h->d_dst, m, h->dim, g, cell_of, cnt);
@@ -240,7 +251,7 @@ hipError_t build_grid(icp_handle *h) {
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, btot, nb, btot + nb);
     hipLaunchKernelGGL(k_scan_add, dim3((nscan + 255) / 256), dim3(256), 0, s, G.d_start, nscan, btot);
     if ((e = hipMemsetAsync(cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) break;
-    hipLaunchKernelGGL(k_grid_scatter, dim3((m + 255) / 256), dim3(256), 0, s, h->d_dst, m, h->dim, cell_of,
+    hipLaunchKernelGGL(k_grid_scatter, dim3((m + kGridPad + 255) / 256), dim3(256), 0, s, h->d_dst, m, h->dim, cell_of,
                        G.d_start, cnt, g, G.d_pts);
     e = hipGetLastError();  // stream order is all the later kernels need; create_common synchronises once at the end
   } while (0);
@@ -684,6 +695,241 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid(const double *__restri
   if (b) b[i] = make_double2(bx, by);
 }
 
+// ---------------------------------------------------------------- warm search ----
+// The search of the second and later outer iterations of one estimate call, one lane per query
+// (clouds beyond ICP_NN_COOP_MAX_N points), rewritten in round 2 after the counters showed what the
+// kernel above is bound by: NOT memory latency but vector-instruction issue -- 2 600 VALU
+// instructions per wave, ~80 % of the SIMDs' issue slots (profiles/r02_nn_grid_sq_pmc.txt); f64
+// square roots (a 20-instruction sequence each: radius, per-row clip, every improvement), f64 floor /
+// clamp chains for every cell coordinate, a 12-instruction select chain per record to flatten the
+// runs of a row group.  Same search, same result -- the winner is still decided by the contract's
+// exact f64 distance and (d^2, index) order, so the indices are bit-identical to the sweep's -- with
+// everything that only PRUNES evaluated in f32 relative to the grid origin:
+//   * every bound is conservative by construction: radii are rounded up, distances to cell slabs
+//     down, by margins `mgf` / `em` that dominate the f32 rounding of the quantities involved
+//     (derivations at the definitions); a bound can therefore only cause extra visits;
+//   * the records of a row are read in ALIGNED QUADS (one 64-byte line): a run [s, e) becomes the
+//     quads [s / 4, (e + 3) / 4), so the flattening arithmetic is paid per quad, not per record.  The
+//     extra records a quad drags in are real targets of the neighbouring cells (or the +inf sentinels
+//     behind the last record): screening them can add candidates, never remove one.
+// Lanes whose geometry does not fit f32 (|q - lo| or the radius beyond 1e18) walk the whole grid
+// unpruned: correct, and never seen outside adversarial tests.
+template <int DIM>
+__global__ __launch_bounds__(kGridThreads) void k_nn_grid_warm(const double *__restrict__ src,
+                                                               const uint32_t *__restrict__ perm, unsigned n, Pose T,
+                                                               GridParams g, const uint32_t *__restrict__ start,
+                                                               const GridPoint *__restrict__ pts,
+                                                               const double *__restrict__ dst, uint32_t *__restrict__ idx,
+                                                               double2 *__restrict__ a, double2 *__restrict__ b,
+                                                               PrevMatch *prev) {
+  const unsigned k = blockIdx.x * kGridThreads + threadIdx.x;
+  if (k >= n) return;
+  const unsigned i = perm[k];
+  double q[3];
+  q[0] = src[(size_t)k * DIM + 0];
+  q[1] = src[(size_t)k * DIM + 1];
+  q[2] = DIM == 3 ? src[(size_t)k * DIM + 2] : 0.;
+  {  // Transform::transform, src/transform.rs:22-24
+    const double nx = (T.r00 * q[0] + T.r01 * q[1]) + T.tx;
+    const double ny = (T.r10 * q[0] + T.r11 * q[1]) + T.ty;
+    q[0] = nx;
+    q[1] = ny;
+  }
+  const PrevMatch pm = prev[k];
+  if (pm.idx == 0xffffffffu) {  // no finite distance was ever found (NaN query): index 0, as a scan from 0 would
+    if (idx) idx[i] = 0;
+    if (a) a[i] = make_double2(q[0], q[1]);
+    if (b) b[i] = make_double2(dst[0], dst[1]);
+    return;
+  }
+  // the contract's exact distance: d^2 = ((dx*dx + dy*dy) + dz*dz), no FMA
+  auto dist2 = [&](double tx, double ty, double tz) -> double {
+    const double ddx = q[0] - tx, ddy = q[1] - ty;
+    double dd = ddx * ddx + ddy * ddy;
+    if (DIM == 3) {
+      const double ddz = q[2] - tz;
+      dd = dd + ddz * ddz;
+    }
+    return dd;
+  };
+  double best = dist2(pm.x, pm.y, pm.z);
+  uint32_t bi = pm.idx;
+  double bx = pm.x, by = pm.y, bz = pm.z;
+
+  // ---- f32 geometry relative to the grid origin ----
+  float qf[3], amax = 0.f;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    qf[d] = d < DIM ? (float)(q[d] - g.lo[d]) : 0.f;  // |error| <= 2^-24 |q - lo|
+    amax = fmaxf(amax, fabsf(qf[d]));
+  }
+  // mgf: absolute margin of every f32 length below.  A grid-relative coordinate (|.| <= amax), a cell
+  // edge i * hf (|.| <= g.ext) and a handful of additions / multiplications of them are each within
+  // 2^-24 relative of the exact value: 4e-7 (amax + ext) covers six such roundings.
+  const float mgf = 4e-7f * (amax + g.ext);
+  // ecf: the screen's bound on |(qf - pf) - (q - p)| (three f32 roundings per component, sqrt(3) for
+  // the norm): 2^-23 (ext + |q - lo|) sqrt(3) = 2.07e-7 (...)
+  const float ecf = 2.1e-7f * (amax + g.ext);
+  float bf, rf, thr32;  // bf >= best; rf >= sqrt(best) + mgf; thr32: records with s32 > thr32 cannot win or tie
+  auto set_radius = [&]() {
+    bf = fmaxf((float)best * 1.0000003f, 1e-37f);      // (float) rounds to nearest: the factor restores >=
+    const float rs = __builtin_amdgcn_sqrtf(bf) * 1.0000003f;  // >= sqrt(best) (v_sqrt_f32: 1 ulp)
+    rf = rs + mgf;
+    // a target within sqrt(best) has |qf - pf| <= sqrt(best) + ecf, and its f32-evaluated square is
+    // at most 1.1e-6 above the exact one (nn_grid.hip, top of k_nn_grid)
+    thr32 = (rs + ecf) * (rs + ecf) * 1.000005f;
+  };
+  set_radius();
+  const bool wide = !(amax + rf < 1e18f);  // (also NaN): no f32 geometry for this lane
+  if (wide) {
+    bf = __builtin_huge_valf();
+    thr32 = __builtin_huge_valf();
+  }
+  const float hf[3] = {(float)g.h[0], (float)g.h[1], (float)g.h[2]};
+  const float ihf[3] = {(float)g.inv_h[0], (float)g.inv_h[1], (float)g.inv_h[2]};
+  // cell of a grid-relative coordinate, rounded towards `dir` by more than the f32 error of the
+  // product: |t - exact| <= 3e-7 (|v| inv_h); targets were binned in f64 (k_grid_count), whose own
+  // rounding (1e-12 cells) hides in the constant
+  auto cell_lo = [&](float v, float em, int d) -> int {
+    const float t = fminf(fmaxf(__builtin_floorf(v * ihf[d] - em), 0.f), (float)(g.n[d] - 1));
+    return (int)t;
+  };
+  auto cell_hi = [&](float v, float em, int d) -> int {
+    const float t = fminf(fmaxf(__builtin_floorf(v * ihf[d] + em), 0.f), (float)(g.n[d] - 1));
+    return (int)t;
+  };
+  int lo_c[3] = {0, 0, 0}, hi_c[3] = {0, 0, 0};
+  float em[3];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    em[d] = (fabsf(qf[d]) + rf) * ihf[d] * 4e-7f + 1e-3f;
+    lo_c[d] = wide ? 0 : cell_lo(qf[d] - rf, em[d], d);
+    hi_c[d] = wide ? g.n[d] - 1 : cell_hi(qf[d] + rf, em[d], d);
+  }
+  // squared distance from q to the slab of cells [c, c] on axis d, rounded DOWN (0 inside; the
+  // outermost cells extend to infinity: targets are clamped into them)
+  auto slab2 = [&](int d, int c) -> float {
+    const float e0 = (float)c * hf[d];
+    const float below = c <= 0 ? -__builtin_huge_valf() : e0 - qf[d];
+    const float above = c >= g.n[d] - 1 ? -__builtin_huge_valf() : qf[d] - (e0 + hf[d]);
+    const float v = fmaxf(fmaxf(below, above) - mgf, 0.f);
+    return v * v * 0.9999997f;
+  };
+  auto consider = [&](uint32_t ti) {
+    const double tx = dst[(size_t)ti * DIM + 0], ty = dst[(size_t)ti * DIM + 1];
+    const double tz = DIM == 3 ? dst[(size_t)ti * DIM + 2] : 0.;
+    const double dd = dist2(tx, ty, tz);
+    if (dd < best || (dd == best && ti < bi)) {
+      best = dd;
+      bi = ti;
+      bx = tx;
+      by = ty;
+      bz = tz;
+      if (!wide) set_radius();
+    }
+  };
+
+  int iz = lo_c[2], iy = lo_c[1];
+  float dz2 = (DIM == 3 && !wide) ? slab2(2, iz) : 0.f;
+  for (;;) {
+    // up to four unpruned rows: first / one-past-last QUAD of their (clipped) runs' cells
+    uint32_t ra0 = 0, ra1 = 0, ra2 = 0, ra3 = 0, rz0 = 0, rz1 = 0, rz2 = 0, rz3 = 0;
+    int nr = 0;
+    while (nr < 4 && iz <= hi_c[2]) {
+      if (iy > hi_c[1]) {
+        iy = lo_c[1];
+        ++iz;
+        if (DIM == 3 && !wide && iz <= hi_c[2]) dz2 = slab2(2, iz);
+        continue;
+      }
+      const int cy = iy++;
+      int xl = lo_c[0], xh = hi_c[0];
+      if (!wide) {
+        const float dyz = slab2(1, cy) + dz2;
+        if (dyz > bf) continue;  // every target of the row is strictly farther than the best so far
+        // a target of this row that can still win or tie has |x - qx| <= sqrt(best - dy^2 - dz^2)
+        // (v_sqrt_f32 returns 0 for a denormal argument: sqrt of it is < 1.1e-19 <= mgf, build_grid's f32_ok)
+        const float hw = __builtin_amdgcn_sqrtf(bf - dyz) * 1.000001f + mgf;
+        xl = max(xl, cell_lo(qf[0] - hw, em[0], 0));
+        xh = min(xh, cell_hi(qf[0] + hw, em[0], 0));
+        if (xl > xh) continue;
+      }
+      const uint32_t rb = ((uint32_t)iz * g.n[1] + cy) * g.n[0];
+      const uint32_t ra = rb + xl, rz = rb + xh + 1;
+      if (nr == 0) ra0 = ra, rz0 = rz;
+      else if (nr == 1) ra1 = ra, rz1 = rz;
+      else if (nr == 2) ra2 = ra, rz2 = rz;
+      else ra3 = ra, rz3 = rz;
+      ++nr;
+    }
+    if (nr == 0) break;
+    if (nr < 2) ra1 = ra0, rz1 = rz0;  // unused slots repeat row 0 (a cached address)
+    if (nr < 3) ra2 = ra0, rz2 = rz0;
+    if (nr < 4) ra3 = ra0, rz3 = rz0;
+    const uint32_t s0 = start[ra0], e0 = start[rz0];
+    const uint32_t s1 = start[ra1], e1 = start[rz1];
+    const uint32_t s2 = start[ra2], e2 = start[rz2];
+    const uint32_t s3 = start[ra3], e3 = start[rz3];
+    // runs -> aligned quads; an empty run has no quads
+    const uint32_t q0 = s0 >> 2, n0 = e0 > s0 ? ((e0 + 3) >> 2) - q0 : 0u;
+    const uint32_t q1 = s1 >> 2, n1 = (nr > 1 && e1 > s1) ? ((e1 + 3) >> 2) - q1 : 0u;
+    const uint32_t q2 = s2 >> 2, n2 = (nr > 2 && e2 > s2) ? ((e2 + 3) >> 2) - q2 : 0u;
+    const uint32_t q3 = s3 >> 2, n3 = (nr > 3 && e3 > s3) ? ((e3 + 3) >> 2) - q3 : 0u;
+    const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, Q = o3 + n3;
+    // quad j of the flattened sequence lives at quad index j + dk of the record array
+    const uint32_t d0 = q0, d1 = q1 - o1, d2 = q2 - o2, d3 = q3 - o3;
+    for (uint32_t base = 0; base < Q; base += 2) {
+      GridPoint t[8];
+      const uint4 *line[2];
+#pragma unroll
+      for (uint32_t h2 = 0; h2 < 2; ++h2) {
+        const uint32_t j = min(base + h2, Q - 1);  // the tail re-reads the last quad
+        uint32_t dq = d0;
+        if (j >= o1) dq = d1;
+        if (j >= o2) dq = d2;
+        if (j >= o3) dq = d3;
+        line[h2] = reinterpret_cast<const uint4 *>(pts) + (size_t)(j + dq) * 4;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 8; ++u) {  // all eight loads in flight before the first use
+        const uint4 w = line[u >> 2][u & 3];
+        t[u].x = __uint_as_float(w.x);
+        t[u].y = __uint_as_float(w.y);
+        t[u].z = __uint_as_float(w.z);
+        t[u].idx = w.w;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      float sc[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8; ++u) {
+        const float fx = qf[0] - t[u].x, fy = qf[1] - t[u].y;
+        float s2 = __builtin_fmaf(fy, fy, fx * fx);
+        if (DIM == 3) {
+          const float fz = qf[2] - t[u].z;
+          s2 = __builtin_fmaf(fz, fz, s2);
+        }
+        sc[u] = s2;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 8; ++u)
+        if (!(sc[u] > thr32) && t[u].idx != bi) consider(t[u].idx);
+    }
+  }
+  // a slot whose match did not change already holds this record
+  if (bi != pm.idx) {
+    PrevMatch out;
+    out.x = bx;
+    out.y = by;
+    out.z = bz;
+    out.idx = bi;
+    out.pad = 0;
+    prev[k] = out;
+  }
+  if (idx) idx[i] = bi;
+  if (a) a[i] = make_double2(q[0], q[1]);
+  if (b) b[i] = make_double2(bx, by);
+}
+
 // ------------------------------------------------ query locality (optional) -------
 // Counting-sort the source cloud by the target-grid cell of T*src.  The sorted copy keeps
 // the ORIGINAL coordinates (the search kernel applies the current pose with the same
@@ -797,6 +1043,23 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   static const long coop_max = getenv("ICP_NN_COOP_MAX_N") ? atol(getenv("ICP_NN_COOP_MAX_N")) : 65536;
   const bool coop = (long)n <= coop_max;
   const unsigned blocks = (unsigned)(((size_t)n * (coop ? 4 : 1) + kGridThreads - 1) / kGridThreads);
+  // the warm search beyond the four-lanes-per-query sizes: the f32-geometry kernel (ICP_NN_OLD_WARM: the
+  // round-1 kernel, for A/B runs; both return the same indices)
+  static const bool old_warm = getenv("ICP_NN_OLD_WARM") != nullptr;
+  if (q_prev && !coop && xform && G.p.f32_ok && !old_warm) {
+    if (h->dim == 3)
+      hipLaunchKernelGGL(k_nn_grid_warm<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
+                         G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev);
+    else
+      hipLaunchKernelGGL(k_nn_grid_warm<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
+                         G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev);
+    hipError_t we = hipGetLastError();
+    if (ev0 && ev1) {
+      (void)hipEventRecord(ev1, h->stream);
+      h->prof_events.emplace_back(ev0, ev1);
+    }
+    return we;
+  }
 #define GRID(DIM, XF)                       \
   do {                                      \
     if (q_prev) {                           \

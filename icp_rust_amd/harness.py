@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 from .api import Icp2d, Icp3d, Transform
-from .scans import load_scan2d
+from .scans import PacketFile, load_scan2d, write_packets
 from .synth import PACKETS_PER_FRAME, remove_invalid_values
 
 
@@ -44,28 +44,68 @@ def run_scan2d(scan_dir, max_iter=20, icp_factory=None, max_frames=None):
     return transforms, inverses, np.array(path).reshape(-1, 2)
 
 
-def run_scan3d(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=None):
-    """examples/scan3d.rs:104-158 on an in-memory packet array (n_packets, 384, 3): the source
-    is packets [0, step) with invalid returns removed (:104-107, 63-69); every frame takes
-    dst = packets [index, index+step), filtered, THEN advances index (:113-121) -- so the first
-    frame registers the source against itself; Icp3d::new(&dst); estimate warm-started
-    (:130-131); path of transform.inverse().t (:133,144).
+class _ArrayPackets:
+    """`Scan` (examples/scan3d.rs:17-61) over an in-memory packet array (n_packets, 384, 3)."""
+
+    def __init__(self, packets):
+        self.p = np.asarray(packets, dtype=np.float64)
+
+    def size(self):
+        return self.p.shape[0]
+
+    def get_range(self, start, end):
+        return self.p[start:end].reshape(-1, 3)
+
+
+def _packet_source(packets):
+    return packets if hasattr(packets, "get_range") and hasattr(packets, "size") else _ArrayPackets(packets)
+
+
+def run_scan3d(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=None, pipeline=True, timings=None):
+    """examples/scan3d.rs:104-158 on a packet stream -- an in-memory array (n_packets, 384, 3) or a
+    `scans.PacketFile` (the reference's `Scan` over scans.hdf5): the source is packets [0, step) with
+    invalid returns removed (:104-107, 63-69); every frame takes dst = packets [index, index+step),
+    filtered, THEN advances index (:113-121) -- so the first frame registers the source against itself;
+    Icp3d::new(&dst); estimate warm-started (:130-131); path of transform.inverse().t (:133,144).
+
+    `pipeline`: frame k+1's packets are read and filtered, uploaded and its
+    search structure built (`Icp3d::new`) by a second host thread on that handle's own stream WHILE frame
+    k estimates -- a ring of two handles; the registration itself is untouched, so the trajectory is the
+    same bit for bit.  `timings` (optional list) receives the wall time of every frame in seconds.
     Returns (transforms, inverse_transforms, path_xy)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
     icp_factory = icp_factory or Icp3d
-    packets = np.asarray(packets, dtype=np.float64)
-    src = remove_invalid_values(packets[0:step])
+    scan = _packet_source(packets)
+    src = remove_invalid_values(scan.get_range(0, step))
     transform = Transform.identity()
     transforms, inverses, path = [], [], []
+
+    def make(index):  # what the frame loop does before estimate: Scan::get_range + filter + Icp3d::new
+        return icp_factory(remove_invalid_values(scan.get_range(index, index + step)))
+
     index = 0
-    while index + step <= packets.shape[0]:
-        dst = remove_invalid_values(packets[index:index + step])
-        index += step
-        icp = icp_factory(dst)
-        transform = icp.estimate(src, transform, max_iter)
-        inv = transform.inverse()
-        transforms.append(transform)
-        inverses.append(inv)
-        path.append(inv.t.copy())
+    pool = ThreadPoolExecutor(max_workers=1) if pipeline else None
+    ahead = pool.submit(make, index) if pool and index + step <= scan.size() else None
+    try:
+        while index + step <= scan.size():
+            t0 = time.perf_counter()
+            icp = ahead.result() if ahead is not None else make(index)
+            index += step
+            ahead = pool.submit(make, index) if pool and index + step <= scan.size() else None
+            transform = icp.estimate(src, transform, max_iter)
+            if hasattr(icp, "close"):
+                icp.close()  # back to the handle pool: the NEXT make() reuses its buffers and streams
+            inv = transform.inverse()
+            transforms.append(transform)
+            inverses.append(inv)
+            path.append(inv.t.copy())
+            if timings is not None:
+                timings.append(time.perf_counter() - t0)
+    finally:
+        if pool:
+            pool.shutdown(wait=True)
     return transforms, inverses, np.array(path).reshape(-1, 2)
 
 
@@ -104,8 +144,9 @@ def main(argv=None):
     from . import synth
 
     ap = argparse.ArgumentParser(prog="python -m icp_rust_amd.harness", description=main.__doc__)
-    ap.add_argument("loop", choices=["scan2d", "scan3d", "scan2map"])
-    ap.add_argument("scan_dir", nargs="?", help="scan2d: directory with 001.txt, 002.txt, ...")
+    ap.add_argument("loop", choices=["scan2d", "scan3d", "scan2map", "write-synth"])
+    ap.add_argument("scan_dir", nargs="?", help="scan2d: directory with 001.txt, 002.txt, ...; scan3d / scan2map / "
+                                                "write-synth: packet container file")
     ap.add_argument("--frames", type=int, default=8, help="scan3d / scan2map: synthetic frames")
     ap.add_argument("--max-iter", type=int, default=20)
     args = ap.parse_args(argv)
@@ -113,11 +154,19 @@ def main(argv=None):
         if not args.scan_dir:
             ap.error("scan2d needs the scan directory")
         _, _, path = run_scan2d(args.scan_dir, max_iter=args.max_iter)
+    elif args.loop == "write-synth":
+        if not args.scan_dir:
+            ap.error("write-synth needs the output file")
+        write_packets(args.scan_dir, synth.synthetic_scan3d_packets(PACKETS_PER_FRAME * args.frames))
+        print(f"# wrote {PACKETS_PER_FRAME * args.frames} packets to {args.scan_dir}")
+        return 0
     elif args.loop == "scan3d":
-        _, _, path = run_scan3d(synth.synthetic_scan3d_packets(PACKETS_PER_FRAME * args.frames), max_iter=args.max_iter)
+        stream = PacketFile(args.scan_dir) if args.scan_dir else synth.synthetic_scan3d_packets(PACKETS_PER_FRAME * args.frames)
+        _, _, path = run_scan3d(stream, max_iter=args.max_iter)
     else:
-        _, path, world = run_scan_to_map(synth.synthetic_scan3d_packets(PACKETS_PER_FRAME * (args.frames + 1)),
-                                         max_iter=args.max_iter)
+        stream = PacketFile(args.scan_dir).as_array() if args.scan_dir else \
+            synth.synthetic_scan3d_packets(PACKETS_PER_FRAME * (args.frames + 1))
+        _, path, world = run_scan_to_map(stream, max_iter=args.max_iter)
         print(f"# map: {world.target_count} points")
     for k, (x, y) in enumerate(path):
         print(f"{k:4d} {x:+.9f} {y:+.9f}")

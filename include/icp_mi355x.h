@@ -225,7 +225,7 @@ void icp_trim_pool(void);
  * be extended; after an append every result is, bit for bit, that of a fresh icp_create on the
  * concatenated cloud (target indices = position in the concatenation).  Point-to-plane
  * residuals, also named by configs[4], have no definition in the reference (no normals
- * anywhere in src/) and are not built.
+ * anywhere in src/): section 7 builds them as a second labelled extension.
  *
  * icp_append_targets[_device]: append k points (AoS, the handle's dim) to the target cloud;
  * with T != NULL the points are first moved by T exactly as Transform::transform does
@@ -240,6 +240,28 @@ int icp_reserve_targets(icp_handle *h, size_t capacity);
 size_t icp_target_count(const icp_handle *h);
 /* copy target points [first, first + k) back to the host (AoS), e.g. to save the map */
 int icp_read_targets(icp_handle *h, size_t first, size_t k, double *out);
+
+/* ================================================================================
+ * 7. EXTENSION (not in the reference): point-to-plane residuals
+ * ==============================================================================
+ * The second thing BASELINE.json configs[4] names.  tier4/icp_rust is point-to-point only (no normal
+ * anywhere in src/; src/lib.rs:218-261), so there is no reference behaviour to match and no parity
+ * claim: the definition lives in icp_rust_amd/csrc/p2plane.hip, its CPU restatement (the checker of
+ * tests/test_p2plane.py) in oracle/icp_oracle.c (orc_p2pl_*).  Kept from the reference: the exact 3-D
+ * nearest neighbour, the SE(2) pose on xy with z carried through, the Huber / MAD Gauss-Newton loop
+ * with its constants and break tests, the 3x3 solve, Transform::new.  3-D handles only.
+ *
+ * icp_compute_target_normals: unit normal of every target = smallest-eigenvalue eigenvector of the
+ * covariance of its k nearest targets (3 <= k <= 16, itself included), searched through the handle's
+ * grid; must be called again after an append.  icp_estimate_point_to_plane*: Icp3d::estimate with the
+ * scalar residual n_q . (T p - q) in place of the two-row point-to-point residual. */
+int icp_compute_target_normals(icp_handle *h, int k);
+int icp_read_target_normals(icp_handle *h, size_t first, size_t count, double *out_xyz);
+int icp_estimate_point_to_plane(icp_handle *h, const double *src, size_t n, const icp_pose *init,
+                                size_t max_iter, icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters);
+int icp_estimate_point_to_plane_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *init,
+                                       size_t max_iter, icp_pose *out, uint32_t *d_last_idx,
+                                       uint32_t *inner_iters);
 
 #ifdef __cplusplus
 }

@@ -747,3 +747,188 @@ int orc_icp_estimate(int dim, const double *dst, size_t m, const double *src, si
   orc_kdtree_free(t);
   return rc;
 }
+
+/* ======================================================================================
+ * EXTENSION CHECKER (no reference counterpart): point-to-plane residuals.
+ * tier4/icp_rust has no normals and no plane residual anywhere in src/, so there is nothing to
+ * restate from the reference here and NO parity claim is attached to these functions: they are an
+ * independent CPU statement of the definition the library documents (include/icp_mi355x.h section
+ * 7, icp_rust_amd/csrc/p2plane.hip) -- brute-force k nearest neighbours instead of the device's grid
+ * walk, the reference's own left-fold sums instead of the device's tree -- used by
+ * tests/test_p2plane.py for self-consistency.  Everything around the residual follows the cited
+ * reference lines (inner loop lib.rs:59-84, weights :236-255, huber.rs, stats.rs, linalg.rs).
+ * ==================================================================================== */
+
+static void p2pl_jacobi3(double a[3][3], double v[3][3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) v[i][j] = i == j ? 1. : 0.;
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    double off = (a[0][1] * a[0][1] + a[0][2] * a[0][2]) + a[1][2] * a[1][2];
+    if (off == 0.) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p][q] == 0.) continue;
+        double theta = (a[q][q] - a[p][p]) / (2. * a[p][q]);
+        double t = (theta >= 0. ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+        double c = 1. / sqrt(t * t + 1.), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          double akp = a[k][p], akq = a[k][q];
+          a[k][p] = c * akp - s * akq;
+          a[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double apk = a[p][k], aqk = a[q][k];
+          a[p][k] = c * apk - s * aqk;
+          a[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double vkp = v[k][p], vkq = v[k][q];
+          v[k][p] = c * vkp - s * vkq;
+          v[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+}
+
+/* unit normals (m x 3) from the k nearest targets (itself included; ties by lowest index) */
+int orc_p2pl_normals(const double *dst, size_t m, int k_, double *normals) {
+  if (k_ < 3 || k_ > 16) return -1;
+  int k = (size_t)k_ < m ? k_ : (int)m;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(g_threads) if (g_threads > 1)
+  for (size_t i = 0; i < m; ++i) {
+    double bd[16];
+    uint32_t bi[16];
+    int cnt = 0;
+    const double *p = dst + 3 * i;
+    for (size_t j = 0; j < m; ++j) {
+      double dd = dist2(dst + 3 * j, p, 3);
+      uint32_t tj = (uint32_t)j;
+      if (cnt == k && !(dd < bd[k - 1] || (dd == bd[k - 1] && tj < bi[k - 1]))) continue;
+      int pos = cnt < k ? cnt : k - 1;
+      while (pos > 0 && (dd < bd[pos - 1] || (dd == bd[pos - 1] && tj < bi[pos - 1]))) {
+        bd[pos] = bd[pos - 1];
+        bi[pos] = bi[pos - 1];
+        --pos;
+      }
+      bd[pos] = dd;
+      bi[pos] = tj;
+      if (cnt < k) ++cnt;
+    }
+    double nrm[3] = {0., 0., 0.};
+    if (cnt >= 3) {
+      double mean[3] = {0., 0., 0.};
+      for (int j = 0; j < cnt; ++j)
+        for (int d = 0; d < 3; ++d) mean[d] = mean[d] + dst[3 * (size_t)bi[j] + d];
+      for (int d = 0; d < 3; ++d) mean[d] = mean[d] / (double)cnt;
+      double a[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}}, v[3][3];
+      for (int j = 0; j < cnt; ++j) {
+        double e[3];
+        for (int d = 0; d < 3; ++d) e[d] = dst[3 * (size_t)bi[j] + d] - mean[d];
+        for (int r = 0; r < 3; ++r)
+          for (int s = 0; s < 3; ++s) a[r][s] = a[r][s] + e[r] * e[s];
+      }
+      p2pl_jacobi3(a, v);
+      int col = 0;
+      if (a[1][1] < a[col][col]) col = 1;
+      if (a[2][2] < a[col][col]) col = 2;
+      double n0 = v[0][col], n1 = v[1][col], n2 = v[2][col];
+      double len = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
+      if (len > 0.) {
+        n0 = n0 / len;
+        n1 = n1 / len;
+        n2 = n2 / len;
+        double lead = n2 != 0. ? n2 : (n1 != 0. ? n1 : n0);
+        if (lead < 0.) {
+          n0 = -n0;
+          n1 = -n1;
+          n2 = -n2;
+        }
+        nrm[0] = n0;
+        nrm[1] = n1;
+        nrm[2] = n2;
+      }
+    }
+    normals[3 * i] = nrm[0];
+    normals[3 * i + 1] = nrm[1];
+    normals[3 * i + 2] = nrm[2];
+  }
+  return ORC_OK;
+}
+
+/* Icp3d::estimate (lib.rs:148-173) with the scalar residual n_q . (T p - q); sums as left folds */
+int orc_p2pl_estimate(const orc_kdtree *tree, const double *dst, size_t m, const double *normals,
+                      const double *src, size_t n, const orc_pose *init, size_t max_iter, orc_pose *out,
+                      uint32_t *last_idx, uint32_t *inner_iters) {
+  if (!tree || tree->dim != 3) return -1;
+  orc_pose T = *init;
+  size_t nn = n ? n : 1;
+  double *st = (double *)malloc(nn * 3 * sizeof(double));
+  double *r = (double *)malloc(nn * sizeof(double));
+  uint32_t *idx = (uint32_t *)malloc(nn * sizeof(uint32_t));
+  int rc = ORC_OK;
+  for (size_t it = 0; it < max_iter && rc == ORC_OK; ++it) {
+    for (size_t i = 0; i < n; ++i) orc_transform_xy(&T, src + 3 * i, st + 3 * i);
+    if (n > 0) {
+      if (m == 0) { rc = ORC_EMPTY_DST; break; }
+      rc = orc_kdtree_search(tree, st, n, idx);
+      if (rc != ORC_OK) break;
+    }
+    orc_pose Ti;
+    orc_transform_identity(&Ti);
+    int applied = 0;
+    double prev_error = 1.7976931348623157e308;
+    for (int k = 0; k < ORC_INNER_MAX_ITER && n >= 2; ++k) {
+      for (size_t i = 0; i < n; ++i) {
+        const double *q = dst + 3 * (size_t)idx[i], *nq = normals + 3 * (size_t)idx[i];
+        double a[2] = {st[3 * i], st[3 * i + 1]}, ta[2];
+        orc_transform_apply(&Ti, a, ta);
+        r[i] = (nq[0] * (ta[0] - q[0]) + nq[1] * (ta[1] - q[1])) + nq[2] * (st[3 * i + 2] - q[2]);
+      }
+      double sigma;
+      {
+        double *tmp = (double *)malloc(nn * sizeof(double));
+        memcpy(tmp, r, n * sizeof(double));
+        int src_ = orc_standard_deviation(tmp, n, &sigma);
+        free(tmp);
+        if (src_ == ORC_NAN) { rc = ORC_NAN; break; }
+      }
+      double jtr[3] = {0., 0., 0.}, jtj[9] = {0.}, err = 0.;
+      for (size_t i = 0; i < n; ++i) {
+        const double *nq = normals + 3 * (size_t)idx[i];
+        double e = r[i] * r[i];
+        if (sigma != 0.) {
+          double s2[2] = {st[3 * i], st[3 * i + 1]}, J2[2][3];
+          jacobian(&Ti, s2, J2);
+          double J[3];
+          for (int c = 0; c < 3; ++c) J[c] = nq[0] * J2[0][c] + nq[1] * J2[1][c];
+          double wg = orc_huber_drho(e, ORC_HUBER_K) * (1. / sigma);
+          for (int c = 0; c < 3; ++c) jtr[c] = jtr[c] + (wg * J[c]) * r[i];
+          for (int p = 0; p < 3; ++p)
+            for (int q2 = 0; q2 < 3; ++q2) jtj[3 * p + q2] = jtj[3 * p + q2] + (wg * J[p]) * J[q2];
+        }
+        err = err + orc_huber_rho(e, ORC_HUBER_K);
+      }
+      double delta[3];
+      if (solve_update(jtj, jtr, delta) != ORC_OK) break;
+      if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ORC_DELTA_NORM_THRESHOLD) break;
+      if (err > prev_error) break;
+      prev_error = err;
+      orc_pose D, Tn;
+      orc_transform_new(delta, &D);
+      orc_transform_mul(&D, &Ti, &Tn);
+      Ti = Tn;
+      ++applied;
+    }
+    if (rc != ORC_OK) break;
+    if (inner_iters) inner_iters[it] = (uint32_t)applied;
+    orc_pose Tn;
+    orc_transform_mul(&Ti, &T, &Tn);
+    T = Tn;
+  }
+  if (last_idx && rc == ORC_OK && max_iter > 0) memcpy(last_idx, idx, n * sizeof(uint32_t));
+  *out = T;
+  free(st);
+  free(r);
+  free(idx);
+  return rc;
+}

@@ -118,6 +118,13 @@ int orc_icp_estimate_tree(const orc_kdtree *t, const double *dst, size_t m, cons
                           const orc_icp_opts *opts, orc_pose *out, uint32_t *last_idx,
                           uint32_t *inner_iters);
 
+/* EXTENSION CHECKER (no reference counterpart, no parity claim): point-to-plane residuals as
+ * include/icp_mi355x.h section 7 defines them; see the block comment in icp_oracle.c */
+int orc_p2pl_normals(const double *dst, size_t m, int k, double *normals_out);
+int orc_p2pl_estimate(const orc_kdtree *tree, const double *dst, size_t m, const double *normals,
+                      const double *src, size_t n, const orc_pose *init, size_t max_iter, orc_pose *out,
+                      uint32_t *last_idx, uint32_t *inner_iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,8 @@ def lib():
         u32p)
     sig("orc_icp_estimate_tree", C.c_int, C.c_void_p, dp, sz, dp, sz, pp, sz, C.POINTER(IcpOpts), pp,
         u32p, u32p)
+    sig("orc_p2pl_normals", C.c_int, dp, sz, C.c_int, dp)
+    sig("orc_p2pl_estimate", C.c_int, C.c_void_p, dp, sz, dp, dp, sz, pp, sz, pp, u32p, u32p)
     _lib = L
     return L
 
@@ -312,4 +314,25 @@ def icp_estimate(dim, dst, src, init, max_iter, use_kdtree=False, sum_mode=0, re
     opts = IcpOpts(int(use_kdtree), sum_mode, reduce_blocks, reduce_threads)
     rc = lib().orc_icp_estimate(dim, dp_, dst.shape[0], sp, n, C.byref(init), max_iter,
                                 C.byref(opts), C.byref(o), ip, inp)
+    return rc, o, idx[:n], inner[:max_iter]
+
+
+# ---- EXTENSION checker (no reference counterpart): point-to-plane residuals -------------------
+def p2pl_normals(dst, k):
+    dst, dp_ = _d(dst)
+    out = np.zeros((dst.shape[0], 3))
+    rc = lib().orc_p2pl_normals(dp_, dst.shape[0], int(k), out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == OK
+    return out
+
+
+def p2pl_estimate(tree, normals, src, init, max_iter):
+    src, sp = _d(src)
+    normals, np_ = _d(normals)
+    _, dp_ = _d(tree.dst)
+    n = src.shape[0]
+    idx, ip = _u32(n)
+    inner, inp = _u32(max_iter)
+    o = Pose()
+    rc = lib().orc_p2pl_estimate(tree.h, dp_, tree.dst.shape[0], np_, sp, n, C.byref(init), max_iter, C.byref(o), ip, inp)
     return rc, o, idx[:n], inner[:max_iter]

@@ -133,3 +133,75 @@ def test_cli_prints_the_trajectories(capsys):
     assert harness.main(["scan2map", "--frames", "2", "--max-iter", "3"]) == 0
     out = capsys.readouterr().out.splitlines()
     assert out[0].startswith("# map:") and len(out) == 3
+
+
+# ---------------------------------------------------------------- on-disk formats (8(f) rank 4) --
+def test_packet_container_round_trip(tmp_path):
+    """the scans.hdf5 stand-in: one rank-3 f64 dataset of 24 x 16 x 3 values per packet
+    (examples/scan3d.rs:9,21-23,45-49), written and read back bit for bit"""
+    from icp_rust_amd import scans
+
+    pk = synth.synthetic_scan3d_packets(20)
+    f = tmp_path / "scans.icppkt"
+    scans.write_packets(str(f), pk)
+    assert os.path.getsize(f) == scans.file_size_for(20)
+    assert scans.is_packet_file(str(f)) and not scans.is_packet_file(os.path.join(GOLDEN, "001.txt"))
+    s = scans.PacketFile(str(f))
+    assert s.size() == 20 and s.dims == (24, 16, 3) and s.names[3] == "000003"
+    assert np.array_equal(s.get(7).view(np.uint64), pk[7].view(np.uint64))
+    assert np.array_equal(s.get_range(5, 9), pk[5:9].reshape(-1, 3))
+    assert s.get_range(4, 4).shape == (0, 3)
+    assert np.array_equal(s.as_array(), pk)
+    # packets handed over in the reference's 24 x 16 x 3 shape are the same bytes
+    g = tmp_path / "b.icppkt"
+    scans.write_packets(str(g), pk.reshape(20, 24, 16, 3), names=[f"packet_{k:04d}" for k in range(20)])
+    assert np.array_equal(scans.PacketFile(str(g)).as_array(), pk)
+    # malformed files are refused, not misread
+    bad = tmp_path / "bad.icppkt"
+    bad.write_bytes(open(f, "rb").read()[:5000])
+    with pytest.raises(ValueError):
+        scans.PacketFile(str(bad))
+    with pytest.raises(ValueError):
+        scans.PacketFile(os.path.join(GOLDEN, "001.txt"))
+    with pytest.raises(ValueError):
+        scans.write_packets(str(bad), pk[:, :100])
+
+
+def test_scan2d_text_round_trip(tmp_path):
+    from icp_rust_amd import scans
+
+    p = load_scan2d(os.path.join(GOLDEN, "017.txt"))
+    scans.save_scan2d(str(tmp_path / "a.txt"), p)
+    assert np.array_equal(load_scan2d(str(tmp_path / "a.txt")).view(np.uint64), p.view(np.uint64))
+
+
+def test_scan3d_from_a_packet_file_equals_the_in_memory_stream_with_and_without_pipelining(tmp_path):
+    from icp_rust_amd import scans
+
+    pk = synth.synthetic_scan3d_packets(32)
+    f = tmp_path / "s.icppkt"
+    scans.write_packets(str(f), pk)
+    a, _, pa = harness.run_scan3d(pk, step=8, max_iter=2, icp_factory=OracleIcp(3), pipeline=False)
+    t = []
+    b, _, pb = harness.run_scan3d(scans.PacketFile(str(f)), step=8, max_iter=2, icp_factory=lambda d: OracleIcp(3)(d),
+                                  pipeline=True, timings=t)
+    assert len(a) == len(b) == len(t) == 4
+    for x, y in zip(a, b):
+        assert np.array_equal(x.as_array(), y.as_array())
+    assert np.array_equal(pa, pb)
+
+
+@pytest.mark.gpu
+def test_pipelined_scan3d_loop_on_gpu_equals_the_serial_loop_bit_for_bit(tmp_path):
+    from icp_rust_amd import scans
+
+    pk = synth.synthetic_scan3d_packets(6 * 75)
+    f = tmp_path / "s.icppkt"
+    scans.write_packets(str(f), pk)
+    serial, _, _ = harness.run_scan3d(pk, max_iter=20, pipeline=False)
+    piped, _, _ = harness.run_scan3d(scans.PacketFile(str(f)), max_iter=20, pipeline=True)
+    assert len(serial) == len(piped) == 6
+    for a, b in zip(serial, piped):
+        assert np.array_equal(a.as_array(), b.as_array())
+    assert harness.main(["write-synth", str(tmp_path / "w.icppkt"), "--frames", "3"]) == 0
+    assert harness.main(["scan3d", str(tmp_path / "w.icppkt"), "--max-iter", "3"]) == 0

@@ -1,0 +1,142 @@
+"""EXTENSION beyond the reference (BASELINE.json configs[4], include/icp_mi355x.h section 7):
+point-to-plane residuals.  tier4/icp_rust has no normals and no plane residual, so there is NO
+reference behaviour and NO parity claim here.  The checker is an independent CPU statement of the
+documented definition (oracle/icp_oracle.c: orc_p2pl_*: brute-force k nearest neighbours, left-fold
+sums), plus properties any point-to-plane ICP must have."""
+import numpy as np
+import pytest
+
+import icp_rust_amd as I
+import oracle_ffi as O
+from icp_rust_amd import _lib
+
+
+def room(rng, m):
+    """points on the floor and two walls of a room, with a little noise off the planes"""
+    k = m // 3
+    fl = np.stack([rng.uniform(-3, 3, k), rng.uniform(-3, 3, k), rng.normal(0, 2e-3, k)], axis=1)
+    w1 = np.stack([rng.normal(3, 2e-3, k), rng.uniform(-3, 3, k), rng.uniform(0, 2, k)], axis=1)
+    w2 = np.stack([rng.uniform(-3, 3, m - 2 * k), rng.normal(-3, 2e-3, m - 2 * k), rng.uniform(0, 2, m - 2 * k)], axis=1)
+    return np.ascontiguousarray(np.concatenate([fl, w1, w2]))
+
+
+def moved(p, T):
+    q = p.copy()
+    r00, r10, r01, r11, tx, ty = T.pose.as_tuple()
+    q[:, 0] = (r00 * p[:, 0] + r01 * p[:, 1]) + tx
+    q[:, 1] = (r10 * p[:, 0] + r11 * p[:, 1]) + ty
+    return q
+
+
+def test_cpu_checker_normals_of_a_plane_and_its_sign_convention():
+    rng = np.random.default_rng(1)
+    p = np.stack([rng.uniform(-1, 1, 400), rng.uniform(-1, 1, 400), np.zeros(400)], axis=1)
+    n = O.p2pl_normals(p, 8)
+    assert np.allclose(n, [0, 0, 1], atol=1e-12)
+    # a tilted plane: normal parallel to (1, 1, 1) / sqrt(3), leading component positive
+    q = p.copy()
+    q[:, 2] = -(q[:, 0] + q[:, 1])
+    n = O.p2pl_normals(q, 10)
+    assert np.allclose(n, np.ones(3) / np.sqrt(3), atol=1e-9)
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-12)
+
+
+def test_cpu_checker_point_to_plane_recovers_a_pose_and_ignores_sliding():
+    rng = np.random.default_rng(2)
+    dst = room(rng, 3000)
+    normals = O.p2pl_normals(dst, 10)
+    tree = O.KdTree(dst)
+    Tt = O.transform_new(np.array([0.04, -0.03, 0.02]))
+    inv = O.transform_inverse(Tt)
+    src = dst[rng.integers(0, len(dst), 1500)].copy()
+    src[:, :2] = O.transform_apply_many(inv, src[:, :2])
+    rc, T, _, inner = O.p2pl_estimate(tree, normals, src, O.transform_identity(), 10)
+    assert rc == O.OK and inner.sum() > 0
+    assert np.allclose(T.as_array(), Tt.as_array(), atol=5e-3)
+
+
+gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize("m,k", [(5000, 10), (20000, 6), (9000, 16), (300, 3)])
+def test_device_normals_equal_the_cpu_statement(m, k):
+    rng = np.random.default_rng(10 * m + k)
+    dst = room(rng, m)
+    icp = I.Icp3d(dst, nn_mode=I.NN_GRID) if m >= 8192 else I.Icp3d(dst)
+    icp.compute_normals(k)
+    got = icp.read_normals()
+    O.set_threads(16)
+    try:
+        want = O.p2pl_normals(dst, k)
+    finally:
+        O.set_threads(1)
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-12)
+    # same neighbours (exact k-NN by (d^2, index)), same Jacobi sequence: equal to rounding
+    assert np.max(np.abs(got - want)) < 1e-9
+
+
+@gpu
+def test_device_point_to_plane_registration_tracks_the_cpu_statement():
+    rng = np.random.default_rng(77)
+    dst = room(rng, 30000)
+    src = dst[rng.integers(0, len(dst), 12000)] + rng.normal(0, 1e-3, (12000, 3))
+    Tt = I.Transform([0.05, -0.04, 0.015])
+    src = moved(src, Tt.inverse())
+    icp = I.Icp3d(dst)
+    with pytest.raises(I.IcpError):  # normals first
+        icp.estimate_point_to_plane(src, I.Transform(), 3)
+    icp.compute_normals(10)
+    T, idx, inner = icp.estimate_point_to_plane(src, I.Transform(), 8, return_info=True)
+    normals = icp.read_normals()
+    tree = O.KdTree(dst)
+    O.set_threads(16)
+    try:
+        rc, oT, oidx, oinner = O.p2pl_estimate(tree, normals, src, O.transform_identity(), 8)
+    finally:
+        O.set_threads(1)
+    assert rc == O.OK
+    assert np.array_equal(idx, oidx)          # correspondences are the reference's exact 3-D NN either way
+    assert np.array_equal(inner, oinner)
+    assert np.max(np.abs(T.as_array() - oT.as_array())) < 1e-9  # tree sums vs left folds
+    assert np.allclose(T.as_array(), Tt.as_array(), atol=3e-3)
+    # device-resident source: same bits as the host-buffer call
+    import torch
+
+    T2 = icp.estimate_point_to_plane(torch.from_numpy(src).cuda(), I.Transform(), 8)
+    assert np.array_equal(T.as_array(), T2.as_array())
+
+
+@gpu
+def test_point_to_plane_ignores_motion_inside_the_plane_where_point_to_point_does_not():
+    """a single wall x = 3: translating the scan ALONG the wall (in y) leaves every plane residual
+    unchanged, so point-to-plane must not 'correct' it, while point-to-point pulls the points back"""
+    rng = np.random.default_rng(5)
+    m = 20000
+    wall = np.ascontiguousarray(np.stack([np.full(m, 3.0), rng.uniform(-3, 3, m), rng.uniform(0, 2, m)], axis=1))
+    src = wall[rng.integers(0, m, 6000)].copy()
+    src[:, 1] += 0.05   # slide along the wall
+    src[:, 0] -= 0.02   # and move off it
+    icp = I.Icp3d(wall)
+    icp.compute_normals(8)
+    Tp = icp.estimate_point_to_plane(src, I.Transform(), 5)
+    assert abs(Tp.pose.tx - 0.02) < 1e-3 and abs(Tp.pose.ty) < 1e-3 and abs(Tp.pose.r10) < 1e-3
+    Tq = icp.estimate(src, I.Transform(), 5)
+    assert abs(Tq.pose.tx - 0.02) < 2e-3 and Tq.pose.ty < -0.01
+
+
+@gpu
+def test_normals_must_be_recomputed_after_an_append_and_3d_only():
+    rng = np.random.default_rng(9)
+    dst = room(rng, 9000)
+    icp = I.Icp3d(dst)
+    icp.compute_normals(8)
+    icp.append(room(rng, 600))
+    with pytest.raises(I.IcpError) as e:
+        icp.estimate_point_to_plane(dst[:100], I.Transform(), 1)
+    assert e.value.status == _lib.BAD_ARGUMENT
+    icp.compute_normals(8)
+    assert icp.read_normals().shape == (9600, 3)
+    assert icp.estimate_point_to_plane(dst[:100], I.Transform(), 1) is not None
+    with pytest.raises(I.IcpError):
+        I.Icp2d(dst[:, :2]).compute_normals(8)
