@@ -39,9 +39,27 @@ for _ in range(3): rc, oT, _, oin = tree3.estimate(s3, O.transform_identity(), 2
 print(f"   CPU oracle estimate(20 it) {1e3*(time.perf_counter()-t0)/3:.3f} ms (+ kd build {tb*1e3:.2f} ms), inner {oin.tolist()}")
 # the reference's frame loop itself (examples/scan3d.rs:104-158): a new Icp3d per frame, warm-started
 # estimate(src, T, 20); handle turnover comes out of the pool after the first frame
-pk = synth.synthetic_scan3d_packets(75 * 9)
+pk = synth.synthetic_scan3d_packets(75 * 12)
 harness.run_scan3d(pk[:75 * 3])
-t0 = time.perf_counter()
-Ts, inv, path = harness.run_scan3d(pk)
-nf = len(Ts)
-print(f"scan3d frame loop ({nf} frames of ~28k points): {1e3*(time.perf_counter()-t0)/nf:.3f} ms per frame (Icp3d::new + estimate(20) + drop)")
+for piped in (False, True):
+    tm = []
+    t0 = time.perf_counter()
+    Ts, inv, path = harness.run_scan3d(pk, pipeline=piped, timings=tm)
+    nf = len(Ts)
+    print(f"scan3d frame loop ({nf} frames of ~28k points, {'frame k+1 created while frame k estimates' if piped else 'serial'}): "
+          f"{1e3*(time.perf_counter()-t0)/nf:.3f} ms per frame (Icp3d::new + estimate(20) + drop); "
+          f"per-frame ms {[round(1e3*x, 2) for x in tm]}")
+    if not piped:
+        ref = [t.as_array() for t in Ts]
+    else:
+        assert all(np.array_equal(a, t.as_array()) for a, t in zip(ref, Ts)), "pipelining changed the trajectory"
+# the same stream from a packet container on disk (scans.hdf5 stand-in), pipelined
+import tempfile
+from icp_rust_amd import scans
+with tempfile.TemporaryDirectory() as d:
+    f = os.path.join(d, "scans.icppkt")
+    scans.write_packets(f, pk)
+    t0 = time.perf_counter()
+    Tf, _, _ = harness.run_scan3d(scans.PacketFile(f))
+    print(f"scan3d frame loop from a packet file: {1e3*(time.perf_counter()-t0)/len(Tf):.3f} ms per frame")
+    assert all(np.array_equal(a, t.as_array()) for a, t in zip(ref, Tf))

@@ -13,7 +13,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 # ICP_MI355X_LIB: load another build of the same library (e.g. the diagnostic one with counters)
 LIB_PATH = os.environ.get("ICP_MI355X_LIB") or os.path.join(_HERE, "lib", "libicp_mi355x.so")
 
-OK, NONE, EMPTY_DST, NAN_INPUT, BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, OUT_OF_MEMORY = range(8)
+OK, NONE, EMPTY_DST, NAN_INPUT, BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, OUT_OF_MEMORY, RETRY_REPLICATED = range(9)
 NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
 
 
@@ -84,6 +84,18 @@ SIGNATURES = {
     "icp_prepare_source_device": (C.c_int, [_vp, _vp, _sz, _pp]),
     "icp_estimate_transform_device": (C.c_int, [_vp, _vp, _vp, _sz, _pp, _vp]),
     "icp_nn_search_device": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "icp_weighted_gn_step_device": (C.c_int, [_vp, _vp, _vp, _sz, _pp, C.c_int, _dp, _dp]),
+    "icp_shard_geometry": (C.c_int, [_sz, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.POINTER(_sz)]),
+    "icp_shard_histogram_words": (_sz, []),
+    "icp_shard_candidates_bytes": (_sz, []),
+    "icp_shard_partials_bytes": (_sz, [C.c_int]),
+    "icp_shard_take_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _sz]),
+    "icp_shard_put_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _sz]),
+    "icp_shard_eval_hist_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _pp, C.c_int, C.POINTER(_vp)]),
+    "icp_shard_eval_compact_device": (C.c_int, [_vp, _vp]),
+    "icp_shard_eval_accumulate_device": (C.c_int, [_vp, _vp, _vp]),
+    "icp_shard_eval_finish_device": (C.c_int, [_vp, _vp, _dp, _dp]),
     "icp_synchronize": (C.c_int, [_vp]),
     "icp_profile_enable": (C.c_int, [_vp, C.c_int]),
     "icp_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_uint64)]),

@@ -164,6 +164,7 @@ extern "C" const char *icp_status_string(int s) {
     case ICP_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
     case ICP_HIP_ERROR: return "HIP error";
     case ICP_OUT_OF_MEMORY: return "out of device memory";
+    case ICP_RETRY_REPLICATED: return "sharded evaluation: evaluate this one on the gathered pairs";
     default: return "unknown status";
   }
 }
@@ -331,6 +332,7 @@ void free_handle(icp_handle *h) {  // really release everything
   (void)hipFree(h->qsort.d_perm);
   (void)hipFree(h->qsort.d_sorted);
   (void)hipFree(h->qsort.d_prev);
+  (void)hipFree(h->shard.d_ordered);
   (void)hipFree(h->d_normals);
   (void)hipFree(h->d_plane_pairs);
   (void)hipFree(h->d_plane_fa);
@@ -562,6 +564,22 @@ static hipError_t wait_result(icp_handle *h) {
 // check_input_size, src/lib.rs:186-189
 static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
 
+// what the next evaluation's window is centred on: this evaluation's exact median and sigma, kept per
+// kind of evaluation (common.hpp, Workspace::win_kind) and as "the most recent one"
+static void record_statistics(Workspace &w, int kind, bool has_median, const GnResult &r) {
+  w.win_valid = has_median;
+  if (kind >= 0 && kind < 2) w.win_kind[kind].valid = has_median;
+  if (has_median)
+    for (int d = 0; d < 2; ++d) {
+      w.win_med[d] = r.median[d];
+      w.win_sigma[d] = r.sigma[d];
+      if (kind >= 0 && kind < 2) {
+        w.win_kind[kind].med[d] = r.median[d];
+        w.win_kind[kind].sigma[d] = r.sigma[d];
+      }
+    }
+}
+
 // weighted_gauss_newton_update on device pairs (src/lib.rs:218-261); also yields the
 // Huber error of the same T (src/lib.rs:75), which shares the pass.
 // `after_launch` (optional) runs once, right after the first attempt's kernels have been enqueued
@@ -657,17 +675,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
     w.gn_dirty = true;
   }
   const GnResult &r = *w.h_res;
-  w.win_valid = has_median;
-  if (kind >= 0 && kind < 2) w.win_kind[kind].valid = has_median;
-  if (has_median)
-    for (int d = 0; d < 2; ++d) {
-      w.win_med[d] = r.median[d];
-      w.win_sigma[d] = r.sigma[d];
-      if (kind >= 0 && kind < 2) {
-        w.win_kind[kind].med[d] = r.median[d];
-        w.win_kind[kind].sigma[d] = r.sigma[d];
-      }
-    }
+  record_statistics(w, kind, has_median, r);
   if (r.nan_flag) {
     w.gn_dirty = true;
     return ICP_NAN_INPUT;
@@ -1178,7 +1186,12 @@ extern "C" int icp_estimate_point_to_plane_device(icp_handle *h, const double *d
                                                   size_t max_iter, icp_pose *out, uint32_t *d_last_idx,
                                                   uint32_t *inner_iters) {
   if (!h || h->dim != 3 || !init || !out || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
-  if (h->normals_m != h->m || h->m == 0) return h->m == 0 && n > 0 && max_iter > 0 ? ICP_EMPTY_DST : (h->m == 0 ? ICP_OK : ICP_BAD_ARGUMENT);
+  if (h->m == 0) {  // index.unwrap() on an empty tree, src/lib.rs:165 -- only when a search would run
+    if (n > 0 && max_iter > 0) return ICP_EMPTY_DST;
+    *out = *init;
+    return ICP_OK;
+  }
+  if (h->normals_m != h->m) return ICP_BAD_ARGUMENT;  // icp_compute_target_normals first (again after an append)
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(ensure_workspace(h, n, false));
   if (n > h->cap_plane) {
@@ -1255,4 +1268,129 @@ extern "C" int icp_estimate_point_to_plane(icp_handle *h, const double *src, siz
   }
   (void)hipFree(d_li);
   return rc;
+}
+
+// ------------------------------------------------ sharded evaluation (stage calls) -----
+// shard.hip has the design.  One evaluation = hist -> [sum the histograms over ranks] -> compact ->
+// [gather the candidates] -> accumulate -> [gather the block sums] -> finish.  ICP_RETRY_REPLICATED
+// from hist (no prediction yet) or finish (the window missed) means: gather the pairs of all ranks in
+// global order and call icp_weighted_gn_step_device on them -- same bits, and it seeds the prediction.
+extern "C" int icp_shard_geometry(size_t n_total, int rank, int world, int *b0, int *b1, int *blocks, size_t *n_local) {
+  if (world < 1 || rank < 0 || rank >= world || !b0 || !b1 || !n_local || n_total >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  shard_geometry(n_total, rank, world, b0, b1, blocks, n_local);
+  return ICP_OK;
+}
+extern "C" size_t icp_shard_histogram_words(void) { return (size_t)2 * kWinBins; }
+extern "C" size_t icp_shard_candidates_bytes(void) { return shard_cand_bytes(); }
+extern "C" size_t icp_shard_partials_bytes(int world) { return world >= 1 ? shard_part_bytes(world) : 0; }
+
+static int shard_copy(icp_handle *h, const void *src, void *dst, size_t n_total, int rank, int world, size_t elem_bytes,
+                      bool take) {
+  if (!h || world < 1 || rank < 0 || rank >= world || elem_bytes == 0 || elem_bytes % 4 || n_total >= 0xffffffffull ||
+      (n_total > 0 && (!src || !dst)))
+    return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(launch_shard_copy(h, src, dst, n_total, rank, world, (unsigned)(elem_bytes / 4), take));
+  return ICP_OK;
+}
+extern "C" int icp_shard_take_device(icp_handle *h, const void *d_full, void *d_local, size_t n_total, int rank, int world,
+                                     size_t elem_bytes) {
+  return shard_copy(h, d_full, d_local, n_total, rank, world, elem_bytes, true);
+}
+extern "C" int icp_shard_put_device(icp_handle *h, const void *d_local, void *d_full, size_t n_total, int rank, int world,
+                                    size_t elem_bytes) {
+  return shard_copy(h, d_local, d_full, n_total, rank, world, elem_bytes, false);
+}
+
+extern "C" int icp_shard_eval_hist_device(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, int rank,
+                                          int world, const icp_pose *T, int kind, uint32_t **d_hist) {
+  if (!h || !T || !d_hist || world < 1 || rank < 0 || rank >= world || n_total >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  icp_handle::ShardEval &S = h->shard;
+  S.active = false;
+  if (!input_size_ok(n_total)) return ICP_NONE;  // check_input_size, src/lib.rs:225-228
+  shard_geometry(n_total, rank, world, &S.b0, &S.b1, &S.blocks, &S.n_local);
+  if (S.blocks < world || (S.n_local > 0 && (!d_a || !d_b))) return S.blocks < world ? ICP_RETRY_REPLICATED : ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(ensure_workspace(h, S.n_local, false));
+  Workspace &w = h->ws;
+  if (!window_usable(h, n_total, &S.P, kind)) return ICP_RETRY_REPLICATED;
+  if (!S.d_ordered) HIP_TRY(hipMalloc(&S.d_ordered, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double)));
+  if (w.gn_dirty) {
+    HIP_TRY(launch_sel_init(h, S.n_local));
+    w.gn_dirty = false;
+  }
+  S.kind = kind;
+  S.rank = rank;
+  S.world = world;
+  S.n_total = n_total;
+  S.d_a = d_a;
+  S.T = *T;
+  ++w.win_tried;
+  HIP_TRY(shard_launch_hist(h, d_a, d_b, S.n_local, S.T, S.P));
+  *d_hist = w.d_whist;
+  S.active = true;
+  return ICP_OK;
+}
+
+extern "C" int icp_shard_eval_compact_device(icp_handle *h, void *d_candidates_out) {
+  if (!h || !h->shard.active || !d_candidates_out) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(shard_launch_compact(h, h->shard.n_local, h->shard.n_total, h->shard.P, d_candidates_out));
+  return ICP_OK;
+}
+
+extern "C" int icp_shard_eval_accumulate_device(icp_handle *h, const void *d_candidates_all, void *d_partials_out) {
+  if (!h || !h->shard.active || !d_candidates_all || !d_partials_out) return ICP_BAD_ARGUMENT;
+  const icp_handle::ShardEval &S = h->shard;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(shard_launch_accumulate(h, S.d_a, S.n_local, S.n_total, S.T, d_candidates_all, S.world, S.b1 - S.b0,
+                                  d_partials_out));
+  return ICP_OK;
+}
+
+extern "C" int icp_shard_eval_finish_device(icp_handle *h, const void *d_partials_all, double delta[3], double *huber_err) {
+  if (!h || !h->shard.active || !d_partials_all || !delta) return ICP_BAD_ARGUMENT;
+  icp_handle::ShardEval &S = h->shard;
+  Workspace &w = h->ws;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(shard_launch_fold(h, d_partials_all, S.world, S.blocks, S.d_ordered));
+  HIP_TRY(wait_result(h));
+  S.active = false;
+  const GnResult &r = *w.h_res;
+  const int kind = S.kind;
+  const bool own = kind >= 0 && kind < 2 && w.win_kind[kind].valid;
+  bool &wide = own ? w.win_kind[kind].wide : w.win_wide;
+  if (r.nan_flag) {
+    w.gn_dirty = true;
+    return ICP_NAN_INPUT;
+  }
+  if (r.overflow) {  // the window missed: wider next time, and this evaluation again on the gathered pairs
+    ++w.win_missed;
+    wide = true;
+    return ICP_RETRY_REPLICATED;
+  }
+  if (wide) {
+    double shift = 0.;
+    for (int d = 0; d < 2; ++d) {
+      const double pm = own ? w.win_kind[kind].med[d] : w.win_med[d], ps = own ? w.win_kind[kind].sigma[d] : w.win_sigma[d];
+      shift = fmax(shift, (fabs(r.median[d] - pm) + fabs(r.sigma[d] - ps)) / ps);
+    }
+    if (shift < 0.01) wide = false;
+  }
+  record_statistics(w, kind, true, r);
+  if (huber_err) *huber_err = r.acc[12];
+  return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
+}
+
+// One evaluation of weighted_gauss_newton_update (+ the Huber error of the same pose) on device pairs,
+// through whichever pipeline serves it -- what the inner loop of icp_estimate_transform_device calls per
+// iteration, exposed for hosts that drive that loop themselves (the sharded driver's replicated fallback).
+// kind: 0 first evaluation on new correspondences, 1 the one after the first update, 2 later ones.
+extern "C" int icp_weighted_gn_step_device(icp_handle *h, const double *d_a, const double *d_b, size_t n,
+                                           const icp_pose *T, int kind, double delta[3], double *huber_err) {
+  if (!h || !T || !delta || (n > 0 && (!d_a || !d_b)) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  if (!input_size_ok(n)) return ICP_NONE;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(ensure_workspace(h, n, false));
+  return wgn_step(h, d_a, d_b, n, *T, delta, huber_err, false, kind);
 }

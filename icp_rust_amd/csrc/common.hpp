@@ -237,6 +237,16 @@ struct icp_handle {
   icp::Workspace ws;
   icp::Grid grid;
   icp::QuerySort qsort;
+  // sharded evaluation in flight (shard.hip): what eval_hist decided, for the stages that follow
+  struct ShardEval {
+    icp::WinParams P;
+    int kind = 2, rank = 0, world = 1, b0 = 0, b1 = 0, blocks = 0;
+    size_t n_local = 0, n_total = 0;
+    const double *d_a = nullptr;
+    icp::Pose T;
+    double *d_ordered = nullptr;  // kReduceMaxBlocks x (kNAcc + 1): the block sums of all ranks in block order
+    bool active = false;
+  } shard;
   // EXTENSION (p2plane.hip): unit normals of the target points (m x 3), valid while normals_m == m
   double *d_normals = nullptr;
   size_t cap_normals = 0, normals_m = 0;
@@ -309,6 +319,19 @@ hipError_t launch_win_first_pass(icp_handle *h, const double *d_a, const double 
                                  const WinParams &P1);  // + copy of the histograms into h->ws.h_whist
 bool refine_window(const uint32_t *hist, size_t n, const WinParams &P1, WinParams *P2);
 hipError_t launch_win_second_pass(icp_handle *h, const double *d_a, size_t n, const Pose &T, const WinParams &P2);
+// sharded evaluation (shard.hip)
+void shard_geometry(size_t n_total, int rank, int world, int *b0, int *b1, int *blocks, size_t *n_local);
+hipError_t launch_shard_copy(icp_handle *h, const void *src, void *dst, size_t n_total, int rank, int world,
+                             unsigned words, bool take);
+size_t shard_cand_bytes();
+int shard_part_rows(int world);
+size_t shard_part_bytes(int world);
+hipError_t shard_launch_hist(icp_handle *h, const double *d_a, const double *d_b, size_t n_local, const Pose &T,
+                             const WinParams &P);
+hipError_t shard_launch_compact(icp_handle *h, size_t n_local, size_t n_total, const WinParams &P, void *d_out);
+hipError_t shard_launch_accumulate(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
+                                   const void *d_cand_all, int world, int blocks_local, void *d_out);
+hipError_t shard_launch_fold(icp_handle *h, const void *d_part_all, int world, int blocks_total, double *d_ordered);
 // EXTENSION: point-to-plane residuals (p2plane.hip)
 hipError_t launch_target_normals(icp_handle *h, int k, double *d_normals);
 hipError_t launch_p2pl_gather(icp_handle *h, const double *d_src, size_t n, const Pose &T, const uint32_t *d_idx,

@@ -180,11 +180,12 @@ __device__ __forceinline__ void accumulate_points(const double2 *__restrict__ a,
 // result to the host, which polls `seq` in pinned memory.
 __device__ __forceinline__ void publish_result(const double *partials, GnResult *res, unsigned seq,
                                                const double (&sig)[2], const double (&med)[2], int nan_flag,
-                                               int overflow) {
+                                               int overflow, int blocks_override = 0) {
   double tot[kNAcc + 1];
 #pragma unroll
   for (int k = 0; k < kNAcc + 1; ++k) tot[k] = 0.;
-  const int blocks = gridDim.x;
+  // (a sharded evaluation folds the block sums of ALL ranks from a one-workgroup launch)
+  const int blocks = blocks_override > 0 ? blocks_override : (int)gridDim.x;
   for (int i = threadIdx.x; i < blocks; i += kReduceThreads) {
     double v[kNAcc];
 #pragma unroll

@@ -366,11 +366,15 @@ __device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, co
 // k_win_rehist made of the points inside the three fine windows (llen[d] entries, at most lcap) --
 // every median or MAD candidate is among them once the bins resolved below are checked to lie inside
 // those windows -- so the compaction streams a few hundred thousand values instead of n.
+// n_local: the residuals THIS launch streams; n: the points the histogram counts.  They differ only in a
+// sharded evaluation (api.hip, "sharded evaluation"), where whist holds the sum over all ranks and every
+// rank resolves the same bins but appends only its own candidates.
 template <bool LISTS>
 __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__restrict__ rx,
-                                                             const double *__restrict__ ry, unsigned n,
-                                                             WinParams P, const uint32_t *__restrict__ whist,
-                                                             WinState *st, double *wmed, double *wring,
+                                                             const double *__restrict__ ry, unsigned n_local,
+                                                             unsigned n, WinParams P,
+                                                             const uint32_t *__restrict__ whist, WinState *st,
+                                                             double *wmed, double *wring,
                                                              const unsigned *__restrict__ llen, unsigned lcap) {
   __shared__ uint32_t cum[2 * kWinBins];  // points in lower bins
   __shared__ unsigned s_wtot[2][16];
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
     i1[d] = (unsigned)s_rng[d][5];
   }
   const unsigned G = gridDim.x * kWinThreads;
-  const unsigned lim[2] = {LISTS ? llen[0] : n, LISTS ? llen[1] : n};
+  const unsigned lim[2] = {LISTS ? llen[0] : n_local, LISTS ? llen[1] : n_local};
   const unsigned nmax = lim[0] > lim[1] ? lim[0] : lim[1];
   for (unsigned base = blockIdx.x * kWinThreads + tid; base < nmax; base += G * kWinBatch) {
     double v[2][kWinBatch];
@@ -749,11 +753,16 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_select(unsigned n, WinSt
 // INLINE_SELECT: every workgroup derives the order statistics itself (lowest latency: the
 // evaluation the host is waiting for).  Otherwise k_win_select has left them in `scal`, and this
 // kernel needs few enough registers (68) to be placed beside three search waves per SIMD.
-template <bool INLINE_SELECT>
+// n_total: the points of the whole evaluation (ranks of the order statistics); n: the points THIS launch
+// accumulates.  PUBLISH = false (sharded evaluation): the block sums are all this rank contributes -- no
+// ticket, no second stage; the statistics it selected go to `scal` for the kernel that folds every rank's
+// block sums (k_shard_fold).
+template <bool INLINE_SELECT, bool PUBLISH = true>
 __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
-    const double2 *__restrict__ a, const double *__restrict__ rx, const double *__restrict__ ry, unsigned n, Pose T,
-    const WinState *__restrict__ st, const double *__restrict__ wmed, const double *__restrict__ wring,
-    GnScalars *scal, double *partials, uint32_t *whist, SelCtl *ctl, GnResult *res, unsigned seq) {
+    const double2 *__restrict__ a, const double *__restrict__ rx, const double *__restrict__ ry, unsigned n,
+    unsigned n_total, Pose T, const WinState *__restrict__ st, const double *__restrict__ wmed,
+    const double *__restrict__ wring, GnScalars *scal, double *partials, uint32_t *whist, SelCtl *ctl, GnResult *res,
+    unsigned seq) {
   if (!INLINE_SELECT) {
     const bool failed = st->fail != 0;
     const double med0[2] = {scal->median[0], scal->median[1]};
@@ -802,7 +811,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
     printf("[A] fail: st %u got %u %u %u %u want %u %u %u %u\n", st->fail, got[0], got[1], got[2], got[3], em[0], em[1], er[0], er[1]);
 #endif
   STAMP();
-  const unsigned klo = (n - 1) / 2, khi = n / 2;
+  const unsigned klo = (n_total - 1) / 2, khi = n_total / 2;
   double med[2] = {0., 0.}, sig[2] = {0., 0.};
   if (!fail) {
     unsigned long long key[2][2];
@@ -813,7 +822,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
     if (!fail) {
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        med[d] = middle_of(n, key[d][0], key[d][1]);
+        med[d] = middle_of(n_total, key[d][0], key[d][1]);
 #pragma unroll
         for (int u = 0; u < PR; ++u) vr[d][u] = fabs(vr[d][u] - med[d]);  // src/stats.rs:35
       }
@@ -822,8 +831,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
       select_n<2, PR>(vr, er, r_lo, r_hi, dlo, dhi, key, fail);
       STAMP();
       if (!fail) {
-        sig[0] = ICP_PPF34 * middle_of(n, key[0][0], key[0][1]);  // src/stats.rs:42-46
-        sig[1] = ICP_PPF34 * middle_of(n, key[1][0], key[1][1]);
+        sig[0] = ICP_PPF34 * middle_of(n_total, key[0][0], key[0][1]);  // src/stats.rs:42-46
+        sig[1] = ICP_PPF34 * middle_of(n_total, key[1][0], key[1][1]);
       }
     }
   }
@@ -847,9 +856,29 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
            stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4]);
 #endif
 
+  if (!PUBLISH) {
+    if (blockIdx.x == 0 && tid == 0) {  // every rank selects the same statistics from the same candidates
+      scal->median[0] = med[0];
+      scal->median[1] = med[1];
+      scal->sigma[0] = sig[0];
+      scal->sigma[1] = sig[1];
+      scal->overflow = fail ? 2 : 0;
+    }
+    return;
+  }
   if (!last_block_arrives(&ctl->t[2])) return;
   publish_result(partials, res, seq, sig, med, scal->nan_flag, fail ? 2 : 0);
 }
+
+// the sharded evaluation (shard.hip) launches this variant from another translation unit
+template __global__ void k_win_accumulate<true, false>(const double2 *__restrict__, const double *__restrict__,
+                                                       const double *__restrict__, unsigned, unsigned, Pose,
+                                                       const WinState *__restrict__, const double *__restrict__,
+                                                       const double *__restrict__, GnScalars *, double *, uint32_t *,
+                                                       SelCtl *, GnResult *, unsigned);
+template __global__ void k_win_compact<false>(const double *__restrict__, const double *__restrict__, unsigned, unsigned,
+                                              WinParams, const uint32_t *__restrict__, WinState *, double *, double *,
+                                              const unsigned *__restrict__, unsigned);
 
 // ---- host ---------------------------------------------------------------------------
 bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind) {
@@ -907,7 +936,7 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
   hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(kWinThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
                      w.d_wstate, w.d_scal);
   hipLaunchKernelGGL(k_win_compact<false>, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
-                     (const double *)w.d_ry, n, P, (const uint32_t *)w.d_whist, w.d_wstate, w.d_wmed,
+                     (const double *)w.d_ry, n, n, P, (const uint32_t *)w.d_whist, w.d_wstate, w.d_wmed,
                      w.d_wring, (const unsigned *)nullptr, 0u);
   int blocks, threads;
   reduce_geometry(n_, &blocks, &threads);
@@ -915,11 +944,11 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
     hipLaunchKernelGGL(k_win_select, dim3(2), dim3(kReduceThreads), 0, s, n, w.d_wstate, (const double *)w.d_wmed,
                        (const double *)w.d_wring, w.d_scal);
     hipLaunchKernelGGL(k_win_accumulate<false>, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
-                       (const double *)w.d_ry, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
+                       (const double *)w.d_ry, n, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
                        (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, ++w.seq);
   } else {
     hipLaunchKernelGGL(k_win_accumulate<true>, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
-                       (const double *)w.d_ry, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
+                       (const double *)w.d_ry, n, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
                        (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, ++w.seq);
   }
   return hipGetLastError();
@@ -1055,13 +1084,13 @@ hipError_t launch_win_second_pass(icp_handle *h, const double *d_a, size_t n_, c
   hipLaunchKernelGGL(k_win_rehist, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx, (const double *)w.d_ry, n,
                      P2, w.d_whist, w.d_wstate, lx, ly, (unsigned)kRefineListCap, w.d_rlist_len);
   const unsigned cb = hb < (unsigned)kWinBlocks ? hb : (unsigned)kWinBlocks;  // a few hundred thousand values: one workgroup per CU
-  hipLaunchKernelGGL(k_win_compact<true>, dim3(cb), dim3(kWinThreads), 0, s, (const double *)lx, (const double *)ly, n,
+  hipLaunchKernelGGL(k_win_compact<true>, dim3(cb), dim3(kWinThreads), 0, s, (const double *)lx, (const double *)ly, n, n,
                      P2, (const uint32_t *)w.d_whist, w.d_wstate, w.d_wmed, w.d_wring, (const unsigned *)w.d_rlist_len,
                      (unsigned)kRefineListCap);
   int blocks, threads;
   reduce_geometry(n_, &blocks, &threads);
   hipLaunchKernelGGL(k_win_accumulate<true>, dim3(blocks), dim3(threads), 0, s, (const double2 *)d_a,
-                     (const double *)w.d_rx, (const double *)w.d_ry, n, T, (const WinState *)w.d_wstate,
+                     (const double *)w.d_rx, (const double *)w.d_ry, n, n, T, (const WinState *)w.d_wstate,
                      (const double *)w.d_wmed, (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl,
                      w.h_res, ++w.seq);
   return hipGetLastError();

@@ -1,0 +1,261 @@
+// Sharded evaluation of the robust Gauss-Newton step (src/lib.rs:218-261 + :45-50) across ranks --
+// GPUs of one node, or "virtual ranks" on one GPU in tests -- with results that are, bit for bit, those
+// of one GPU.  SURVEY.md 8(e) options 2/3; VERDICT r1 item 2.
+//
+// The N-term sums are folded in a fixed tree (DESIGN.md "GN reduction order"): global thread g of
+// `blocks x 512` folds points g, g + G, g + 2G, ...; a block folds its threads; a second stage folds
+// the block sums in block order.  Rank r OWNS the blocks [B r / W, B (r + 1) / W): it holds exactly the
+// points those blocks fold (`n_local` of them, compacted in fold order: chunk `it` of the local arrays
+// is the global range [it G + b0 512, it G + b1 512)), searches their nearest neighbours and produces
+// their block sums with the SAME kernels the one-GPU path runs -- launched over its own blocks, on its
+// local arrays, every per-thread and per-block sum is the one the global launch would have produced.
+// What crosses ranks is small and exact:
+//   1. the window histograms (2 x 2048 u32): integer sums, order-free;
+//   2. the candidate lists around the median and the MAD ring (a few hundred doubles per rank): order
+//      statistics do not depend on the order of the list;
+//   3. the block sums (14 doubles per block), placed in block order -- the second stage then folds the
+//      same numbers in the same order as on one GPU.
+// The exchange itself is the caller's (RCCL through torch.distributed in icp_rust_amd/dist.py, peer
+// copies inside icp_create_multi); these are the stage-level calls between the exchanges.
+#include "common.hpp"
+#include "gn_device.hpp"
+
+namespace icp {
+
+hipError_t launch_sel_init(icp_handle *h, size_t n);
+__global__ void k_win_hist(const double2 *__restrict__ a, const double2 *__restrict__ b, Pose T, double *__restrict__ rx,
+                           double *__restrict__ ry, unsigned n, WinParams P, uint32_t *whist, WinState *st,
+                           GnScalars *scal);
+template <bool LISTS>
+__global__ void k_win_compact(const double *__restrict__ rx, const double *__restrict__ ry, unsigned n_local, unsigned n,
+                              WinParams P, const uint32_t *__restrict__ whist, WinState *st, double *wmed, double *wring,
+                              const unsigned *__restrict__ llen, unsigned lcap);
+template <bool INLINE_SELECT, bool PUBLISH>
+__global__ void k_win_accumulate(const double2 *__restrict__ a, const double *__restrict__ rx,
+                                 const double *__restrict__ ry, unsigned n, unsigned n_total, Pose T,
+                                 const WinState *__restrict__ st, const double *__restrict__ wmed,
+                                 const double *__restrict__ wring, GnScalars *scal, double *partials, uint32_t *whist,
+                                 SelCtl *ctl, GnResult *res, unsigned seq);
+
+void shard_geometry(size_t n_total, int rank, int world, int *b0, int *b1, int *blocks, size_t *n_local) {
+  int B, threads;
+  reduce_geometry(n_total, &B, &threads);
+  const int lo = (int)((long long)B * rank / world), hi = (int)((long long)B * (rank + 1) / world);
+  const size_t G = (size_t)B * kReduceThreads, c0 = (size_t)lo * kReduceThreads, c1 = (size_t)hi * kReduceThreads;
+  size_t cnt = 0;
+  for (size_t base = 0; base < n_total; base += G) {
+    const size_t s = base + c0, e = base + c1 < n_total ? base + c1 : n_total;
+    if (e > s) cnt += e - s;
+  }
+  *b0 = lo;
+  *b1 = hi;
+  if (blocks) *blocks = B;
+  *n_local = cnt;
+}
+
+// local slot l of rank (b0, b1) <-> global point index (fold order: see the header comment)
+__device__ __forceinline__ size_t shard_global_index(size_t l, unsigned b0, unsigned b1, unsigned B) {
+  const size_t row = (size_t)(b1 - b0) * kReduceThreads;
+  const size_t it = l / row, off = l % row;
+  return it * ((size_t)B * kReduceThreads) + (size_t)b0 * kReduceThreads + off;
+}
+
+// words = 4-byte words per element (6 for a 3-D point, 4 for a 2-D point, 1 for an index)
+__global__ void k_shard_take(const uint32_t *__restrict__ full, uint32_t *__restrict__ local, size_t n_local,
+                             unsigned b0, unsigned b1, unsigned B, unsigned words) {
+  const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_local) return;
+  const size_t i = shard_global_index(l, b0, b1, B);
+  for (unsigned k = 0; k < words; ++k) local[l * words + k] = full[i * words + k];
+}
+__global__ void k_shard_put(const uint32_t *__restrict__ local, uint32_t *__restrict__ full, size_t n_local,
+                            unsigned b0, unsigned b1, unsigned B, unsigned words) {
+  const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_local) return;
+  const size_t i = shard_global_index(l, b0, b1, B);
+  for (unsigned k = 0; k < words; ++k) full[i * words + k] = local[l * words + k];
+}
+
+hipError_t launch_shard_copy(icp_handle *h, const void *src, void *dst, size_t n_total, int rank, int world,
+                             unsigned words, bool take) {
+  int b0, b1, B;
+  size_t n_local;
+  shard_geometry(n_total, rank, world, &b0, &b1, &B, &n_local);
+  if (n_local == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n_local + 255) / 256);
+  if (take)
+    hipLaunchKernelGGL(k_shard_take, dim3(blocks), dim3(256), 0, h->stream, (const uint32_t *)src, (uint32_t *)dst, n_local,
+                       (unsigned)b0, (unsigned)b1, (unsigned)B, words);
+  else
+    hipLaunchKernelGGL(k_shard_put, dim3(blocks), dim3(256), 0, h->stream, (const uint32_t *)src, (uint32_t *)dst, n_local,
+                       (unsigned)b0, (unsigned)b1, (unsigned)B, words);
+  return hipGetLastError();
+}
+
+// ---- what a rank hands to the others ---------------------------------------------------
+// candidates: [ShardCandHeader][med x: kWinCapMed][med y][ring x: kWinCapRing][ring y] doubles
+struct ShardCandHeader {
+  unsigned cnt[4];  // appended {med x, med y, ring x, ring y}
+  unsigned fail;    // this rank's compaction missed (identical on every rank: same histogram)
+  unsigned pad[11];
+};
+size_t shard_cand_bytes() { return sizeof(ShardCandHeader) + (size_t)(2 * kWinCapMed + 2 * kWinCapRing) * sizeof(double); }
+// block sums: rows of (kNAcc + 1) doubles, `shard_part_rows(world)` rows per rank: its blocks first (unused
+// rows zero), the last row = {nan flag, overflow, median x, median y, sigma x, sigma y}
+int shard_part_rows(int world) { return (kReduceMaxBlocks + world - 1) / world + 1; }
+size_t shard_part_bytes(int world) { return (size_t)shard_part_rows(world) * (kNAcc + 1) * sizeof(double); }
+
+__global__ void k_shard_pack_candidates(const WinState *__restrict__ st, const double *__restrict__ wmed,
+                                        const double *__restrict__ wring, unsigned char *__restrict__ out) {
+  ShardCandHeader *hd = reinterpret_cast<ShardCandHeader *>(out);
+  double *body = reinterpret_cast<double *>(out + sizeof(ShardCandHeader));
+  const unsigned cm[2] = {min(st->list_cnt[0][0], (unsigned)kWinCapMed), min(st->list_cnt[1][0], (unsigned)kWinCapMed)};
+  const unsigned cr[2] = {min(st->list_cnt[2][0], (unsigned)kWinCapRing), min(st->list_cnt[3][0], (unsigned)kWinCapRing)};
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hd->cnt[0] = st->list_cnt[0][0];
+    hd->cnt[1] = st->list_cnt[1][0];
+    hd->cnt[2] = st->list_cnt[2][0];
+    hd->cnt[3] = st->list_cnt[3][0];
+    hd->fail = st->fail;
+  }
+  const unsigned G = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int d = 0; d < 2; ++d) {
+    for (unsigned e = t; e < cm[d]; e += G) body[(size_t)d * kWinCapMed + e] = wmed[(size_t)d * kWinCapMed + e];
+    for (unsigned e = t; e < cr[d]; e += G)
+      body[(size_t)2 * kWinCapMed + (size_t)d * kWinCapRing + e] = wring[(size_t)d * kWinCapRing + e];
+  }
+}
+
+// the candidates of every rank, concatenated in rank order into this rank's dense lists (any order would do)
+__global__ void k_shard_merge_candidates(const unsigned char *__restrict__ all, size_t stride, int world, WinState *st,
+                                         double *__restrict__ wmed, double *__restrict__ wring) {
+  __shared__ unsigned s_base[4];
+  __shared__ unsigned s_fail;
+  const int r = blockIdx.x;  // one workgroup per source rank
+  if (threadIdx.x == 0) {
+    unsigned base[4] = {0, 0, 0, 0}, fail = 0;
+    for (int q = 0; q < world; ++q) {
+      const ShardCandHeader *hq = reinterpret_cast<const ShardCandHeader *>(all + (size_t)q * stride);
+      fail |= hq->fail;
+      if (q < r)
+        for (int k = 0; k < 4; ++k) base[k] += hq->cnt[k];
+    }
+    for (int k = 0; k < 4; ++k) s_base[k] = base[k];
+    s_fail = fail;
+    if (r == world - 1) {  // totals: what k_win_accumulate cross-checks against the histogram's counts
+      const ShardCandHeader *hl = reinterpret_cast<const ShardCandHeader *>(all + (size_t)r * stride);
+      for (int k = 0; k < 4; ++k) st->list_cnt[k][0] = base[k] + hl->cnt[k];
+      st->fail = fail ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  if (s_fail) return;
+  const ShardCandHeader *hd = reinterpret_cast<const ShardCandHeader *>(all + (size_t)r * stride);
+  const double *body = reinterpret_cast<const double *>(all + (size_t)r * stride + sizeof(ShardCandHeader));
+  for (int d = 0; d < 2; ++d) {
+    for (unsigned e = threadIdx.x; e < hd->cnt[d]; e += blockDim.x)
+      if (s_base[d] + e < (unsigned)kWinCapMed) wmed[(size_t)d * kWinCapMed + s_base[d] + e] = body[(size_t)d * kWinCapMed + e];
+    for (unsigned e = threadIdx.x; e < hd->cnt[2 + d]; e += blockDim.x)
+      if (s_base[2 + d] + e < (unsigned)kWinCapRing)
+        wring[(size_t)d * kWinCapRing + s_base[2 + d] + e] = body[(size_t)2 * kWinCapMed + (size_t)d * kWinCapRing + e];
+  }
+}
+
+__global__ void k_shard_pack_partials(const double *__restrict__ partials, int blocks_local, int rows,
+                                      const GnScalars *__restrict__ scal, double *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = kNAcc + 1;
+  if (t >= rows * W) return;
+  const int row = t / W, k = t % W;
+  double v = 0.;
+  if (row < blocks_local) v = k < kNAcc ? partials[(size_t)row * W + k] : 0.;
+  else if (row == rows - 1) {
+    if (k == 0) v = (double)scal->nan_flag;
+    else if (k == 1) v = (double)scal->overflow;
+    else if (k == 2) v = scal->median[0];
+    else if (k == 3) v = scal->median[1];
+    else if (k == 4) v = scal->sigma[0];
+    else if (k == 5) v = scal->sigma[1];
+  }
+  out[t] = v;
+}
+
+// second stage of the tree over the block sums of every rank, in block order; one workgroup
+__global__ __launch_bounds__(kReduceThreads) void k_shard_fold(const double *__restrict__ all, int rows, int world,
+                                                               int blocks_total, double *__restrict__ ordered,
+                                                               GnResult *res, unsigned seq) {
+  const int W = kNAcc + 1;
+  // gather the rows into block order (rank r owns blocks [B r / world, B (r + 1) / world))
+  for (int b = threadIdx.x; b < blocks_total; b += kReduceThreads) {
+    int r = (int)(((long long)(b + 1) * world - 1) / blocks_total);  // the rank whose range holds b
+    while ((long long)blocks_total * r / world > b) --r;
+    while ((long long)blocks_total * (r + 1) / world <= b) ++r;
+    const int b0 = (int)((long long)blocks_total * r / world);
+    for (int k = 0; k < W; ++k) ordered[(size_t)b * W + k] = all[((size_t)r * rows + (b - b0)) * W + k];
+  }
+  int nan_flag = 0, overflow = 0;
+  for (int r = 0; r < world; ++r) {
+    const double *fl = all + ((size_t)r * rows + (rows - 1)) * W;
+    nan_flag |= fl[0] != 0.;
+    overflow |= (int)fl[1];
+  }
+  const double *f0 = all + (size_t)(rows - 1) * W;  // every rank selected the same statistics
+  const double med[2] = {f0[2], f0[3]}, sig[2] = {f0[4], f0[5]};
+  __syncthreads();
+  __threadfence();
+  publish_result(ordered, res, seq, sig, med, nan_flag, overflow, blocks_total);
+}
+
+// ---- stage launchers (api.hip drives them; each enqueues on h->stream) ---------------------------
+hipError_t shard_launch_hist(icp_handle *h, const double *d_a, const double *d_b, size_t n_local, const Pose &T,
+                             const WinParams &P) {
+  Workspace &w = h->ws;
+  const unsigned n = (unsigned)n_local;
+  const unsigned per = 512 * 4;
+  unsigned hb = (n + per - 1) / per;
+  if (hb > (unsigned)kWinBlocks) hb = kWinBlocks;
+  if (hb < 1) hb = 1;
+  hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(512), 0, h->stream, (const double2 *)d_a, (const double2 *)d_b, T, w.d_rx,
+                     w.d_ry, n, P, w.d_whist, w.d_wstate, w.d_scal);
+  return hipGetLastError();
+}
+
+hipError_t shard_launch_compact(icp_handle *h, size_t n_local, size_t n_total, const WinParams &P, void *d_out) {
+  Workspace &w = h->ws;
+  const unsigned n = (unsigned)n_local;
+  const unsigned per = 512 * 4;
+  unsigned hb = (n + per - 1) / per;
+  if (hb > (unsigned)kWinBlocks) hb = kWinBlocks;
+  if (hb < 1) hb = 1;
+  hipLaunchKernelGGL(k_win_compact<false>, dim3(hb), dim3(512), 0, h->stream, (const double *)w.d_rx,
+                     (const double *)w.d_ry, n, (unsigned)n_total, P, (const uint32_t *)w.d_whist, w.d_wstate, w.d_wmed,
+                     w.d_wring, (const unsigned *)nullptr, 0u);
+  hipLaunchKernelGGL(k_shard_pack_candidates, dim3(8), dim3(256), 0, h->stream, (const WinState *)w.d_wstate,
+                     (const double *)w.d_wmed, (const double *)w.d_wring, (unsigned char *)d_out);
+  return hipGetLastError();
+}
+
+hipError_t shard_launch_accumulate(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
+                                   const void *d_cand_all, int world, int blocks_local, void *d_out) {
+  Workspace &w = h->ws;
+  hipLaunchKernelGGL(k_shard_merge_candidates, dim3(world), dim3(256), 0, h->stream, (const unsigned char *)d_cand_all,
+                     shard_cand_bytes(), world, w.d_wstate, w.d_wmed, w.d_wring);
+  if (blocks_local > 0)
+    hipLaunchKernelGGL((k_win_accumulate<true, false>), dim3(blocks_local), dim3(kReduceThreads), 0, h->stream,
+                       (const double2 *)d_a, (const double *)w.d_rx, (const double *)w.d_ry, (unsigned)n_local,
+                       (unsigned)n_total, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
+                       (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, 0u);
+  const int rows = shard_part_rows(world);
+  hipLaunchKernelGGL(k_shard_pack_partials, dim3((rows * (kNAcc + 1) + 255) / 256), dim3(256), 0, h->stream,
+                     (const double *)w.d_partials, blocks_local, rows, (const GnScalars *)w.d_scal, (double *)d_out);
+  return hipGetLastError();
+}
+
+hipError_t shard_launch_fold(icp_handle *h, const void *d_part_all, int world, int blocks_total, double *d_ordered) {
+  Workspace &w = h->ws;
+  hipLaunchKernelGGL(k_shard_fold, dim3(1), dim3(kReduceThreads), 0, h->stream, (const double *)d_part_all,
+                     shard_part_rows(world), world, blocks_total, d_ordered, w.h_res, ++w.seq);
+  return hipGetLastError();
+}
+
+}  // namespace icp

@@ -1,36 +1,112 @@
-"""Multi-GPU driver: the source cloud shards across ranks, the target cloud is replicated.
+"""Multi-GPU driver: one ICP registration across the GPUs of a node, bit-identical to one GPU.
 
-One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  Per outer ICP
-iteration (src/lib.rs:155-171):
+SURVEY.md 8(e); include/icp_mi355x.h section 5; icp_rust_amd/csrc/shard.hip.  The target cloud is
+replicated; the SOURCE cloud is sharded by REDUCTION-TREE BLOCK: the N-term sums of the inner loop are
+folded in a fixed tree of `blocks x 512` threads (icp_reduce_geometry), and rank r owns the blocks
+[blocks r / W, blocks (r + 1) / W) -- i.e. the source points those blocks fold.  It searches THEIR
+nearest neighbours and evaluates THEIR residuals, histogram counts and block sums; per evaluation three
+small exchanges cross the ranks (integer histograms summed; order-statistic candidates gathered; block
+sums gathered in block order), after which every rank holds the totals one GPU would have computed, to
+the bit, and takes the same decisions (3x3 solve, break tests, pose update) on its own.  No pair or
+index all-gather remains on the steady-state path; the first evaluation of a kind, and an evaluation
+whose predicted window missed, fall back to gathering the pairs and evaluating them replicated.
 
-  1. every rank transforms + nearest-neighbour-matches ITS contiguous range of the source
-     cloud (no communication: source points are independent);
-  2. one all-gather gives every rank all N matched pairs in the global point order: of the
-     4-byte correspondence indices when the host hands every rank the whole source cloud
-     (`src_full`; 24 MB at 1M points, replicated once) -- each rank then rebuilds the pairs
-     locally with the same arithmetic -- or else of the 32-byte pairs themselves;
-  3. every rank runs the identical, deterministic inner Gauss-Newton loop on all N pairs
-     (exact medians are not all-reducible sums; replicating the loop costs < 1 % of step 1
-     and needs no further collective), so all ranks hold bit-identical poses and the
-     N-GPU result equals the 1-GPU result bit for bit.
-
-The compute is delegated to a `stages` object so that the orchestration (ranges, gather,
-replication) is testable on CPU with the gloo backend; production uses HipStages.
+The orchestration is written over a list of LOCAL ranks and a `comm`:
+  * one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; gloo in the CPU tests):
+    one local rank, `TorchComm`;
+  * N "virtual ranks" in one process (N handles, possibly on one GPU -- the 1-GPU test of the N-rank
+    path): all ranks local, `LocalComm`.
+The compute is delegated to `stages` objects: `HipStages` (the C ABI) in production; the CPU tests
+inject an oracle-backed stand-in.
 """
+import ctypes as C
+
 import numpy as np
 
+from . import _lib
+from ._lib import lib
 from .api import Transform
+
+INNER_MAX_ITER = 200          # src/lib.rs:61
+DELTA_NORM_THRESHOLD = 1e-6   # src/lib.rs:60
 
 
 def shard_range(n, rank, world):
-    """contiguous range [lo, hi) of rank `rank`: sizes differ by at most one."""
+    """contiguous range [lo, hi) of rank `rank`: sizes differ by at most one (round-1 sharding; still
+    what the brute-force engine's bench uses)."""
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def block_shard(n_total, rank, world):
+    """(first block, end block, blocks, n_local) of rank `rank` (icp_shard_geometry)."""
+    b0, b1, bl, nl = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+    _lib.check(lib().icp_shard_geometry(n_total, rank, world, C.byref(b0), C.byref(b1), C.byref(bl), C.byref(nl)),
+               "icp_shard_geometry")
+    return b0.value, b1.value, bl.value, nl.value
+
+
+def local_indices(n_total, rank, world, threads=512):
+    """global indices of rank `rank`'s points, in its local (fold) order: chunk `it` of the local arrays
+    is the part of the tree's row `it` that its blocks cover."""
+    b0, b1, blocks, n_local = block_shard(n_total, rank, world)
+    G = blocks * threads
+    parts = [np.arange(base + b0 * threads, min(n_total, base + b1 * threads), dtype=np.int64)
+             for base in range(0, max(n_total, 1), G) if min(n_total, base + b1 * threads) > base + b0 * threads]
+    out = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+    assert len(out) == n_local
+    return out
+
+
+# ------------------------------------------------------------------------------------ comms ----
+class TorchComm:
+    """One local rank per process; collectives through torch.distributed (nccl = RCCL, or gloo)."""
+
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.local_ranks = [rank]
+
+    def sum_(self, bufs):
+        import torch.distributed as dist
+
+        if self.world > 1:
+            dist.all_reduce(bufs[0], op=dist.ReduceOp.SUM, group=self.group)
+
+    def gather(self, sends, recvs):
+        """recvs[0] (world x len) <- every rank's sends[0] (len), rank order"""
+        import torch.distributed as dist
+
+        if self.world > 1:
+            dist.all_gather_into_tensor(recvs[0].view(-1), sends[0].view(-1), group=self.group)
+        else:
+            recvs[0].view(-1).copy_(sends[0].view(-1))
+
+
+class LocalComm:
+    """All ranks live in this process (virtual ranks): the exchanges are plain copies."""
+
+    def __init__(self, world):
+        self.world = world
+        self.local_ranks = list(range(world))
+
+    def sum_(self, bufs):
+        total = bufs[0].clone()
+        for b in bufs[1:]:
+            total += b.to(total.device)
+        for b in bufs:
+            b.copy_(total)
+
+    def gather(self, sends, recvs):
+        for rv in recvs:
+            flat = rv.view(self.world, -1)
+            for r, s in enumerate(sends):
+                flat[r].copy_(s.view(-1))
+
+
+# ----------------------------------------------------------------------------------- stages ----
 class HipStages:
-    """The two device stages of the C ABI on torch CUDA tensors (include/icp_mi355x.h, section 4)."""
+    """The device stages of the C ABI on torch CUDA tensors (include/icp_mi355x.h, sections 4 and 5)."""
 
     def __init__(self, icp):
         import torch
@@ -38,12 +114,27 @@ class HipStages:
         self.icp = icp
         self.torch = torch
         icp.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.hist_words = int(lib().icp_shard_histogram_words())
+        self.cand_bytes = int(lib().icp_shard_candidates_bytes())
 
+    def part_bytes(self, world):
+        return int(lib().icp_shard_partials_bytes(world))
+
+    def empty(self, nbytes, like):
+        return self.torch.empty(nbytes, dtype=self.torch.uint8, device=like.device)
+
+    def empty_points(self, n, cols, like):
+        return self.torch.empty((n, cols), dtype=self.torch.float64, device=like.device)
+
+    def empty_index(self, n, like):
+        return self.torch.empty(n, dtype=self.torch.int32, device=like.device)
+
+    # -- round-1 stage calls (replicated inner loop) --
     def prepare(self, src_shard, T):
         self.icp.prepare_source_device(src_shard, T)
 
-    def correspond(self, src_shard, T, a_out, b_out):
-        self.icp.correspond_device(src_shard, T, a_out, b_out)
+    def correspond(self, src_shard, T, a_out, b_out, idx_out=None):
+        self.icp.correspond_device(src_shard, T, a_out, b_out, idx_out)
 
     def correspond_idx(self, src_shard, T, idx_out):
         self.icp.correspond_device(src_shard, T, None, None, idx_out)
@@ -54,8 +145,212 @@ class HipStages:
     def estimate_transform(self, a_full, b_full):
         return self.icp.estimate_transform_device(a_full, b_full)
 
+    # -- block-sharded evaluation --
+    def take(self, full, local, n_total, rank, world):
+        _lib.check(lib().icp_shard_take_device(self.icp._h, C.c_void_p(full.data_ptr()), C.c_void_p(local.data_ptr()),
+                                               n_total, rank, world, full.element_size() * (full.shape[1] if full.dim() > 1 else 1)),
+                   "icp_shard_take_device")
 
+    def put(self, local, full, n_total, rank, world):
+        _lib.check(lib().icp_shard_put_device(self.icp._h, C.c_void_p(local.data_ptr()), C.c_void_p(full.data_ptr()),
+                                              n_total, rank, world, full.element_size() * (full.shape[1] if full.dim() > 1 else 1)),
+                   "icp_shard_put_device")
+
+    def eval_hist(self, a, b, n_total, rank, world, T, kind):
+        ptr = C.c_void_p()
+        rc = lib().icp_shard_eval_hist_device(self.icp._h, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), n_total,
+                                              rank, world, C.byref(T.pose), kind, C.byref(ptr))
+        if rc != _lib.OK:
+            return rc, None
+        # a tensor view of the handle's histogram buffer, for the collective (no copy)
+        hist = self._wrap(ptr.value, self.hist_words, a.device)
+        return rc, hist
+
+    def _wrap(self, ptr, words, device):
+        key = (ptr, words)
+        cache = self.__dict__.setdefault("_views", {})
+        if key not in cache:
+            torch = self.torch
+
+            class _Raw:  # __cuda_array_interface__ of a foreign device allocation
+                pass
+
+            raw = _Raw()
+            raw.__cuda_array_interface__ = {"shape": (words,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+            cache[key] = torch.as_tensor(raw, device=device)
+        return cache[key]
+
+    def eval_compact(self, cand_out):
+        return lib().icp_shard_eval_compact_device(self.icp._h, C.c_void_p(cand_out.data_ptr()))
+
+    def eval_accumulate(self, cand_all, part_out):
+        return lib().icp_shard_eval_accumulate_device(self.icp._h, C.c_void_p(cand_all.data_ptr()),
+                                                      C.c_void_p(part_out.data_ptr()))
+
+    def eval_finish(self, part_all):
+        delta = np.zeros(3)
+        err = C.c_double(0.0)
+        rc = lib().icp_shard_eval_finish_device(self.icp._h, C.c_void_p(part_all.data_ptr()),
+                                                delta.ctypes.data_as(C.POINTER(C.c_double)), C.byref(err))
+        return rc, delta, err.value
+
+    def gn_step(self, a_full, b_full, T, kind):
+        delta = np.zeros(3)
+        err = C.c_double(0.0)
+        rc = lib().icp_weighted_gn_step_device(self.icp._h, C.c_void_p(a_full.data_ptr()), C.c_void_p(b_full.data_ptr()),
+                                               a_full.shape[0], C.byref(T.pose), kind,
+                                               delta.ctypes.data_as(C.POINTER(C.c_double)), C.byref(err))
+        return rc, delta, err.value
+
+
+# ------------------------------------------------------------------------ block-sharded driver ----
+class _Rank:
+    def __init__(self, rank, stages):
+        self.rank, self.stages = rank, stages
+        self.bufs = None
+
+
+class BlockShardedIcp:
+    """Icp{2,3}d::estimate (src/lib.rs:105-130, 148-173) with the source cloud sharded by reduction-tree
+    block.  `stages_by_rank`: {rank: stages} for the ranks that live in this process (one for
+    torch.distributed; all of them for virtual ranks); `comm`: TorchComm or LocalComm."""
+
+    def __init__(self, stages_by_rank, n_total, world, comm, mul=None):
+        self.n, self.world, self.comm = n_total, world, comm
+        self.ranks = [_Rank(r, stages_by_rank[r]) for r in comm.local_ranks]
+        self._mul = mul or (lambda a, b: a * b)
+        self._new = lambda d: Transform(d)
+        self.geom = {r: block_shard(n_total, r, world) for r in range(world)}
+        self.n_local_max = max(g[3] for g in self.geom.values())
+        self.counters = {"sharded": 0, "replicated": 0}
+
+    def set_pose_algebra(self, new, mul):
+        """(tests) Transform::new / Mul implementations; default: the C ABI's"""
+        self._new, self._mul = new, mul
+
+    def take_source(self, src_full_by_rank):
+        """compact each local rank's points out of a full source cloud -> {rank: local cloud}"""
+        out = {}
+        for rk in self.ranks:
+            full = src_full_by_rank[rk.rank] if isinstance(src_full_by_rank, dict) else src_full_by_rank
+            loc = rk.stages.empty_points(self.geom[rk.rank][3], full.shape[1], full)
+            rk.stages.take(full, loc, self.n, rk.rank, self.world)
+            out[rk.rank] = loc
+        return out
+
+    def _buffers(self, rk, like):
+        if rk.bufs is None:
+            st, W = rk.stages, self.world
+            nl = max(self.geom[rk.rank][3], 1)
+            rk.bufs = dict(
+                a=st.empty_points(nl, 2, like), b=st.empty_points(nl, 2, like), idx=st.empty_index(nl, like),
+                cand=st.empty(st.cand_bytes, like), cand_all=st.empty(W * st.cand_bytes, like),
+                part=st.empty(st.part_bytes(W), like), part_all=st.empty(W * st.part_bytes(W), like),
+                # replicated fallback: every rank's pairs, padded to the largest shard, and the full arrays
+                pair_send=st.empty_points(self.n_local_max, 4, like),
+                pair_recv=st.empty_points(W * self.n_local_max, 4, like),
+                a_full=st.empty_points(max(self.n, 1), 2, like), b_full=st.empty_points(max(self.n, 1), 2, like),
+                have_full=False)
+        return rk.bufs
+
+    # one evaluation of weighted_gauss_newton_update at inner pose T, on every local rank
+    def _evaluate(self, T, kind):
+        rks = self.ranks
+        res = [rk.stages.eval_hist(rk.bufs["a"][:self.geom[rk.rank][3]], rk.bufs["b"][:self.geom[rk.rank][3]], self.n,
+                                   rk.rank, self.world, T, kind) for rk in rks]
+        rcs = {rc for rc, _ in res}
+        if rcs == {_lib.OK}:
+            self.comm.sum_([h for _, h in res])
+            for rk in rks:
+                _lib.check(rk.stages.eval_compact(rk.bufs["cand"]), "icp_shard_eval_compact_device")
+            self.comm.gather([rk.bufs["cand"] for rk in rks], [rk.bufs["cand_all"] for rk in rks])
+            for rk in rks:
+                _lib.check(rk.stages.eval_accumulate(rk.bufs["cand_all"], rk.bufs["part"]),
+                           "icp_shard_eval_accumulate_device")
+            self.comm.gather([rk.bufs["part"] for rk in rks], [rk.bufs["part_all"] for rk in rks])
+            outs = [rk.stages.eval_finish(rk.bufs["part_all"]) for rk in rks]
+            rc = outs[0][0]
+            assert all(o[0] == rc for o in outs)  # every rank folds the same numbers
+            if rc != _lib.RETRY_REPLICATED:
+                self.counters["sharded"] += 1
+                return outs[0]
+        elif rcs == {_lib.NONE}:
+            return _lib.NONE, None, 0.0
+        elif rcs != {_lib.RETRY_REPLICATED}:
+            _lib.check(max(rcs), "icp_shard_eval_hist_device")
+        # replicated: gather the pairs of all ranks into global order, evaluate them on every rank
+        self.counters["replicated"] += 1
+        if not rks[0].bufs["have_full"]:
+            for rk in rks:
+                nl = self.geom[rk.rank][3]
+                rk.bufs["pair_send"][:nl, 0:2] = rk.bufs["a"][:nl]
+                rk.bufs["pair_send"][:nl, 2:4] = rk.bufs["b"][:nl]
+            self.comm.gather([rk.bufs["pair_send"] for rk in rks], [rk.bufs["pair_recv"] for rk in rks])
+            for rk in rks:
+                recv = rk.bufs["pair_recv"].view(self.world, self.n_local_max, 4)
+                for q in range(self.world):
+                    nq = self.geom[q][3]
+                    if nq:
+                        rk.stages.put(recv[q, :nq, 0:2].contiguous(), rk.bufs["a_full"], self.n, q, self.world)
+                        rk.stages.put(recv[q, :nq, 2:4].contiguous(), rk.bufs["b_full"], self.n, q, self.world)
+                rk.bufs["have_full"] = True
+        outs = [rk.stages.gn_step(rk.bufs["a_full"][:self.n], rk.bufs["b_full"][:self.n], T, kind) for rk in rks]
+        assert all(o[0] == outs[0][0] for o in outs)
+        return outs[0]
+
+    def step(self, src_local, T):
+        """one outer iteration (src/lib.rs:113-127 / 156-170); src_local: {rank: local cloud}.
+        Returns (dT * T, inner iterations applied)."""
+        for rk in self.ranks:
+            s = src_local[rk.rank]
+            bf = self._buffers(rk, s)
+            nl = self.geom[rk.rank][3]
+            bf["have_full"] = False
+            if nl:
+                rk.stages.correspond(s, T, bf["a"][:nl], bf["b"][:nl], bf["idx"][:nl])
+        # estimate_transform, src/lib.rs:59-84
+        Ti = Transform()
+        applied = 0
+        if self.n >= 2:
+            prev_error = float(np.finfo(np.float64).max)
+            for it in range(INNER_MAX_ITER):
+                rc, delta, err = self._evaluate(Ti, min(it, 2))
+                if rc == _lib.NONE:
+                    break
+                _lib.check(rc, "sharded evaluation")
+                if (delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < DELTA_NORM_THRESHOLD:
+                    break
+                if err > prev_error:
+                    break
+                prev_error = err
+                Ti = self._mul(self._new(delta), Ti)
+                applied += 1
+        return self._mul(Ti, T), applied
+
+    def estimate(self, src_local, initial_transform, max_iter):
+        T = initial_transform
+        inner = []
+        if max_iter > 0:
+            for rk in self.ranks:
+                if hasattr(rk.stages, "prepare") and self.geom[rk.rank][3]:
+                    rk.stages.prepare(src_local[rk.rank], T)
+        for _ in range(max_iter):
+            T, k = self.step(src_local, T)
+            inner.append(k)
+        return T, np.array(inner, dtype=np.uint32)
+
+    def last_indices(self):
+        """{rank: correspondence indices of its local points in the last outer iteration}"""
+        return {rk.rank: rk.bufs["idx"][:self.geom[rk.rank][3]] for rk in self.ranks}
+
+
+# ------------------------------------------------- round-1 driver: replicated inner loop ----------
 class ShardedIcp:
+    """Contiguous source shards, pairs (or indices) all-gathered once per outer iteration, the whole
+    inner loop replicated on every rank.  Kept for the brute-force engine, whose search is 99.8 % of the
+    step (the search is all that needs to shard there), and as the reference the block-sharded driver is
+    compared with."""
+
     def __init__(self, stages, n_total, rank=0, world=1, group=None, mul=None, src_full=None):
         self.stages = stages
         self.n = n_total
@@ -107,7 +402,6 @@ class ShardedIcp:
 
     def step(self, src_shard, T):
         """one outer iteration; returns (dT * T, inner_iters)."""
-        import torch
         import torch.distributed as dist
 
         if self.world > 1 and self.src_full is not None and hasattr(self.stages, "materialize"):

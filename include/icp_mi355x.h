@@ -45,7 +45,8 @@ typedef enum icp_status {
   ICP_BAD_ARGUMENT = 4,
   ICP_NO_DEVICE = 5,   /* HIP runtime/device unavailable -- no CPU fallback exists    */
   ICP_HIP_ERROR = 6,
-  ICP_OUT_OF_MEMORY = 7
+  ICP_OUT_OF_MEMORY = 7,
+  ICP_RETRY_REPLICATED = 8 /* sharded evaluation (section 5): evaluate this one on the gathered pairs */
 } icp_status;
 
 /* Transform (src/transform.rs:6-10) */
@@ -186,6 +187,52 @@ int icp_estimate_transform_device(icp_handle *h, const double *d_a_xy, const dou
 /* brute-force / grid NN alone (parity tests): d_q n x dim AoS -> d_idx[n] */
 int icp_nn_search_device(icp_handle *h, const double *d_q, size_t n, uint32_t *d_idx);
 int icp_synchronize(icp_handle *h);
+
+/* One evaluation of weighted_gauss_newton_update (src/lib.rs:218-261) plus the Huber error of the same
+ * pose (:75) on device pairs -- the body of one inner iteration of icp_estimate_transform_device, for
+ * hosts that drive the inner loop themselves.  kind: 0 = first evaluation on new correspondences,
+ * 1 = the evaluation after the first update, 2 = later ones (only selects which earlier evaluation
+ * predicts this one's statistics; results never depend on it).  ICP_NONE where the reference returns
+ * None. */
+int icp_weighted_gn_step_device(icp_handle *h, const double *d_a_xy, const double *d_b_xy, size_t n,
+                                const icp_pose *T, int kind, double delta[3], double *huber_err);
+
+/* ================================================================================
+ * 5. Sharded evaluation: the inner loop's sums across the GPUs of a node, bit-identical to one GPU
+ * ==============================================================================
+ * SURVEY.md 8(e).  The N-term sums are folded in a fixed tree of `blocks x 512` threads
+ * (icp_reduce_geometry).  Rank r of `world` owns the blocks [blocks r / world, blocks (r+1) / world):
+ * the points those blocks fold (icp_shard_geometry: n_local of them; icp_shard_take_device compacts
+ * them out of a full array in fold order, icp_shard_put_device is the inverse).  It searches their
+ * nearest neighbours (icp_correspond_device on its compact source cloud) and evaluates them with
+ *   icp_shard_eval_hist_device        residuals + window histograms of its points   -> *d_hist
+ *      [host: SUM the icp_shard_histogram_words() u32 at *d_hist over all ranks, in place]
+ *   icp_shard_eval_compact_device     its candidates around the median / the MAD    -> d_candidates_out
+ *      [host: ALL-GATHER icp_shard_candidates_bytes() bytes per rank, rank order]
+ *   icp_shard_eval_accumulate_device  exact statistics + the sums of its blocks     -> d_partials_out
+ *      [host: ALL-GATHER icp_shard_partials_bytes(world) bytes per rank, rank order]
+ *   icp_shard_eval_finish_device      second stage over all block sums, 3x3 solve   -> delta, Huber error
+ * What crosses ranks is integer counts, order statistics candidates and per-block sums placed in block
+ * order, so every rank ends with the bits one GPU computes.  The exchange is the host's: RCCL
+ * (icp_rust_amd/dist.py drives these calls through torch.distributed), or the peer copies of
+ * icp_multi_* below.  ICP_RETRY_REPLICATED (from hist: no prediction of this evaluation's statistics
+ * yet / fewer blocks than ranks; from finish: the predicted window missed) means: gather the pairs of
+ * all ranks in global order and call icp_weighted_gn_step_device on them instead -- same result, and
+ * it provides the prediction.  All calls are asynchronous on the handle's stream except finish. */
+int icp_shard_geometry(size_t n_total, int rank, int world, int *block_first, int *block_end, int *blocks,
+                       size_t *n_local);
+size_t icp_shard_histogram_words(void);
+size_t icp_shard_candidates_bytes(void);
+size_t icp_shard_partials_bytes(int world);
+int icp_shard_take_device(icp_handle *h, const void *d_full, void *d_local, size_t n_total, int rank, int world,
+                          size_t elem_bytes);
+int icp_shard_put_device(icp_handle *h, const void *d_local, void *d_full, size_t n_total, int rank, int world,
+                         size_t elem_bytes);
+int icp_shard_eval_hist_device(icp_handle *h, const double *d_a_xy_local, const double *d_b_xy_local, size_t n_total,
+                               int rank, int world, const icp_pose *T, int kind, uint32_t **d_hist);
+int icp_shard_eval_compact_device(icp_handle *h, void *d_candidates_out);
+int icp_shard_eval_accumulate_device(icp_handle *h, const void *d_candidates_all, void *d_partials_out);
+int icp_shard_eval_finish_device(icp_handle *h, const void *d_partials_all, double delta[3], double *huber_err);
 
 /* Live kernel timing for the benchmark: with enable = k > 0, HIP events bracket every
  * k-th launch of the nearest-neighbour search kernel on the handle's stream (an event pair

@@ -484,6 +484,50 @@ int orc_weighted_gauss_newton_update_tree(const orc_pose *T, const double *a, co
   return solve_update(total, total + 9, delta);
 }
 
+/* The two halves of orc_weighted_gauss_newton_update_tree, for checking a SHARDED evaluation
+ * (tests/test_dist_gloo.py): a rank that owns `blocks_local` of the tree's blocks holds exactly the
+ * points they fold, compacted in fold order (chunk `it` of the local arrays is the part of global row
+ * `it` its blocks cover), so running stage 1 over the local arrays with G = blocks_local * threads
+ * reproduces those blocks' sums; stage 2 folds the block sums of all ranks in block order. */
+int orc_wgn_tree_partials(const orc_pose *T, const double *a, const double *b, size_t n_local, int blocks_local,
+                          int threads, const double stddevs[2], double *out /* blocks_local x 13 */) {
+  if (threads % 64 != 0 || blocks_local < 0) return -1;
+  size_t G = (size_t)blocks_local * (size_t)threads;
+  double(*thr)[NACC] = (double(*)[NACC])malloc((size_t)threads * sizeof(*thr));
+  for (int blk = 0; blk < blocks_local; ++blk) {
+    for (int t = 0; t < threads; ++t) {
+      double acc[NACC];
+      for (int k = 0; k < NACC; ++k) acc[k] = 0.;
+      for (size_t i = (size_t)blk * threads + t; i < n_local; i += G) {
+        double r[2];
+        orc_residual(T, a + 2 * i, b + 2 * i, r);
+        wgn_accumulate_point(T, a + 2 * i, r, stddevs, acc + 9, acc);
+        acc[12] = acc[12] + orc_huber_rho(r[0] * r[0] + r[1] * r[1], ORC_HUBER_K);
+      }
+      memcpy(thr[t], acc, sizeof(acc));
+    }
+    tree_block_reduce(thr, threads, out + (size_t)blk * NACC);
+  }
+  free(thr);
+  return ORC_OK;
+}
+
+int orc_wgn_tree_fold(const double *partials /* blocks x 13, block order */, int blocks, int threads, double delta[3],
+                      double *huber_err) {
+  if (threads % 64 != 0 || blocks < 1) return -1;
+  double(*thr)[NACC] = (double(*)[NACC])malloc((size_t)threads * sizeof(*thr));
+  double total[NACC];
+  for (int t = 0; t < threads; ++t) {
+    for (int k = 0; k < NACC; ++k) thr[t][k] = 0.;
+    for (int i = t; i < blocks; i += threads)
+      for (int k = 0; k < NACC; ++k) thr[t][k] = thr[t][k] + partials[(size_t)i * NACC + k];
+  }
+  tree_block_reduce(thr, threads, total);
+  free(thr);
+  if (huber_err) *huber_err = total[12];
+  return solve_update(total, total + 9, delta);
+}
+
 /* lib.rs:59-84, generic over the summation order */
 static int estimate_transform_impl(const double *a, const double *b, size_t n,
                                    const orc_icp_opts *opts, orc_pose *out) {

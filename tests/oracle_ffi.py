@@ -100,6 +100,8 @@ def lib():
         u32p)
     sig("orc_icp_estimate_tree", C.c_int, C.c_void_p, dp, sz, dp, sz, pp, sz, C.POINTER(IcpOpts), pp,
         u32p, u32p)
+    sig("orc_wgn_tree_partials", C.c_int, pp, dp, dp, sz, C.c_int, C.c_int, dp, dp)
+    sig("orc_wgn_tree_fold", C.c_int, dp, C.c_int, C.c_int, dp, dp)
     sig("orc_p2pl_normals", C.c_int, dp, sz, C.c_int, dp)
     sig("orc_p2pl_estimate", C.c_int, C.c_void_p, dp, sz, dp, dp, sz, pp, sz, pp, u32p, u32p)
     _lib = L
@@ -336,3 +338,23 @@ def p2pl_estimate(tree, normals, src, init, max_iter):
     o = Pose()
     rc = lib().orc_p2pl_estimate(tree.h, dp_, tree.dst.shape[0], np_, sp, n, C.byref(init), max_iter, C.byref(o), ip, inp)
     return rc, o, idx[:n], inner[:max_iter]
+
+
+# ---- halves of the tree-order evaluation (checking sharded evaluations) -------------------------
+def wgn_tree_partials(T, a, b, blocks_local, threads, stddevs):
+    a, ap = _d(a)
+    b, bp = _d(b)
+    sd, sp = _d(stddevs)
+    out = np.zeros((max(blocks_local, 1), 13))
+    rc = lib().orc_wgn_tree_partials(C.byref(T), ap, bp, a.size // 2, blocks_local, threads, sp,
+                                     out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == OK
+    return out[:blocks_local]
+
+
+def wgn_tree_fold(partials, threads):
+    p, pp_ = _d(partials)
+    delta = np.zeros(3)
+    err = C.c_double(0.0)
+    rc = lib().orc_wgn_tree_fold(pp_, p.shape[0], threads, delta.ctypes.data_as(C.POINTER(C.c_double)), C.byref(err))
+    return rc, delta, err.value

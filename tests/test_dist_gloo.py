@@ -120,3 +120,204 @@ def test_synthetic_shards_concatenate_to_the_full_cloud():
     parts = [synth.synthetic_pair(1000, 10, src_first=lo, src_count=hi - lo)[0]
              for lo, hi in (shard_range(1000, k, 3) for k in range(3))]
     assert np.array_equal(np.concatenate(parts), full)
+
+
+# =========================================================================================
+# Block-sharded driver (round 2): source sharded by reduction-tree block, three small exchanges per
+# evaluation, bit-identical to one rank.  CPU stand-in for the device stages below; the real
+# HipStages run the same orchestration in tests/test_gpu_shard.py (virtual ranks on one GPU).
+# =========================================================================================
+from icp_rust_amd import _lib  # noqa: E402
+from icp_rust_amd.dist import BlockShardedIcp, LocalComm, TorchComm, block_shard, local_indices  # noqa: E402
+
+
+def _opose(T):
+    return O.Pose(*T.pose.as_tuple())
+
+
+class OracleBlockStages:
+    """The block-sharded stage interface on CPU tensors.  What is under test is the ORCHESTRATION
+    (ownership, the three exchanges, the replicated fallback, lockstep decisions), so the stand-in keeps
+    the protocol's shape but not the device's selection kernels: its "histogram" is one counter, its
+    "candidates" are all of its residuals; statistics and sums come from the oracle (exact medians,
+    tree-order block sums)."""
+
+    hist_words = 16
+
+    def __init__(self, dst, n_total, world, miss_every=0):
+        self.dst, self.tree = dst, O.KdTree(dst)
+        self.n_total, self.world = n_total, world
+        self.nl_max = max(block_shard(n_total, r, world)[3] for r in range(world))
+        self.cand_bytes = 8 * (1 + 2 * self.nl_max)
+        self.seen_kind = set()
+        self.evals = 0
+        self.miss_every = miss_every
+        self.prepared = 0
+
+    def part_bytes(self, world):
+        return 8 * 13 * (256 // world + 2)
+
+    def empty(self, nbytes, like):
+        return torch.zeros(nbytes, dtype=torch.uint8)
+
+    def empty_points(self, n, cols, like):
+        return torch.zeros((n, cols), dtype=torch.float64)
+
+    def empty_index(self, n, like):
+        return torch.zeros(n, dtype=torch.int32)
+
+    def prepare(self, src_local, T):
+        self.prepared += 1
+
+    def take(self, full, local, n_total, rank, world):
+        local.copy_(full[torch.from_numpy(local_indices(n_total, rank, world))])
+
+    def put(self, local, full, n_total, rank, world):
+        full[torch.from_numpy(local_indices(n_total, rank, world))] = local
+
+    def correspond(self, src_local, T, a_out, b_out, idx_out=None):
+        p = T.pose
+        s = src_local.numpy()
+        st = s.copy()
+        st[:, 0] = (p.r00 * s[:, 0] + p.r01 * s[:, 1]) + p.tx
+        st[:, 1] = (p.r10 * s[:, 0] + p.r11 * s[:, 1]) + p.ty
+        rc, idx = self.tree.search(st)
+        assert rc == O.OK
+        a_out.copy_(torch.from_numpy(np.ascontiguousarray(st[:, :2])))
+        b_out.copy_(torch.from_numpy(np.ascontiguousarray(self.dst[idx][:, :2])))
+        if idx_out is not None:
+            idx_out.copy_(torch.from_numpy(idx.astype(np.int32)))
+
+    def eval_hist(self, a, b, n_total, rank, world, T, kind):
+        if n_total < 2:
+            return _lib.NONE, None
+        if kind not in self.seen_kind:  # no prediction for this kind of evaluation yet
+            return _lib.RETRY_REPLICATED, None
+        self.cur = (a.numpy(), b.numpy(), rank, world, T)
+        p = T.pose
+        an = self.cur[0]
+        self.res = np.stack([((p.r00 * an[:, 0] + p.r01 * an[:, 1]) + p.tx) - self.cur[1][:, 0],
+                             ((p.r10 * an[:, 0] + p.r11 * an[:, 1]) + p.ty) - self.cur[1][:, 1]], axis=1)
+        h = torch.zeros(self.hist_words, dtype=torch.int32)
+        h[0] = len(an)
+        self.hist = h
+        return _lib.OK, h
+
+    def eval_compact(self, cand_out):
+        assert int(self.hist[0]) == self.n_total  # the histogram now holds the sum over ranks
+        v = cand_out.view(torch.float64)
+        v[0] = float(len(self.res))
+        v[1:1 + 2 * len(self.res)] = torch.from_numpy(self.res.reshape(-1).copy())
+        return _lib.OK
+
+    def eval_accumulate(self, cand_all, part_out):
+        a, b, rank, world, T = self.cur
+        allv = cand_all.view(torch.float64).numpy().reshape(world, -1)
+        res = np.concatenate([allv[q, 1:1 + 2 * int(allv[q, 0])].reshape(-1, 2) for q in range(world)])
+        assert len(res) == self.n_total
+        rc, sd = O.calc_stddevs(res)
+        assert rc == O.OK
+        b0, b1, blocks, nl = block_shard(self.n_total, rank, world)
+        parts = O.wgn_tree_partials(_opose(T), a, b, b1 - b0, 512, sd)
+        out = part_out.view(torch.float64)
+        out.zero_()
+        out[0] = float(b1 - b0)
+        out[1:1 + parts.size] = torch.from_numpy(parts.reshape(-1).copy())
+        return _lib.OK
+
+    def eval_finish(self, part_all):
+        world = self.cur[3]
+        allv = part_all.view(torch.float64).numpy().reshape(world, -1)
+        parts = np.concatenate([allv[q, 1:1 + 13 * int(allv[q, 0])].reshape(-1, 13) for q in range(world)])
+        self.evals += 1
+        if self.miss_every and self.evals % self.miss_every == 0:  # "the predicted window missed"
+            return _lib.RETRY_REPLICATED, None, 0.0
+        rc, delta, err = O.wgn_tree_fold(parts, 512)
+        return (_lib.OK if rc == O.OK else _lib.NONE), delta, err
+
+    def gn_step(self, a_full, b_full, T, kind):
+        self.seen_kind.add(kind)
+        blocks, threads = I.reduce_geometry(a_full.shape[0])
+        rc, delta, err = O.weighted_gauss_newton_update_tree(_opose(T), a_full.numpy(), b_full.numpy(), blocks, threads)
+        return (_lib.OK if rc == O.OK else _lib.NONE), delta, err
+
+
+def test_block_shard_geometry_partitions_the_fold_order():
+    for n in (2, 511, 512, 513, 4096, 70_001, 131_072, 131_073, 1_000_000):
+        blocks, threads = I.reduce_geometry(n)
+        G = blocks * threads
+        for w in (1, 2, 3, 8):
+            seen = []
+            for r in range(w):
+                b0, b1, bl, nl = block_shard(n, r, w)
+                assert bl == blocks and b0 == blocks * r // w and b1 == blocks * (r + 1) // w
+                idx = local_indices(n, r, w)
+                assert len(idx) == nl
+                # exactly the points whose fold thread lives in the rank's blocks, in fold order per thread
+                assert np.all(((idx % G) // threads >= b0) & ((idx % G) // threads < b1))
+                assert np.all(np.diff(idx) > 0)
+                seen.append(idx)
+            assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(n))
+
+
+def _reference(n, m, max_iter):
+    src, dst = synth.synthetic_pair(n, m)
+    blocks, threads = I.reduce_geometry(n)
+    rc, T, idx, inner = O.icp_estimate(3, dst, src, O.transform_identity(), max_iter, use_kdtree=True, sum_mode=1,
+                                       reduce_blocks=blocks, reduce_threads=threads)
+    assert rc == O.OK
+    return src, dst, T, idx, inner
+
+
+@pytest.mark.parametrize("world,n,miss_every", [(1, 5000, 0), (2, 5000, 0), (3, 9001, 0), (8, 6000, 0), (4, 70_001, 3)])
+def test_block_sharded_driver_with_virtual_ranks_equals_one_rank(world, n, miss_every):
+    """all ranks in one process (LocalComm): the lockstep path the 1-GPU test of the N-rank code uses"""
+    m, max_iter = 3000, 4
+    src, dst, want_T, want_idx, want_inner = _reference(n, m, max_iter)
+    stages = {r: OracleBlockStages(dst, n, world, miss_every) for r in range(world)}
+    drv = BlockShardedIcp(stages, n, world, LocalComm(world))
+    full = torch.from_numpy(src)
+    T, inner = drv.estimate(drv.take_source(full), I.Transform(), max_iter)
+    assert np.array_equal(T.as_array(), want_T.as_array())
+    assert np.array_equal(inner, want_inner)
+    assert drv.counters["sharded"] > 0 and drv.counters["replicated"] >= 2
+    got_idx = np.zeros(n, dtype=np.uint32)
+    for r, ix in drv.last_indices().items():
+        got_idx[local_indices(n, r, world)] = ix.numpy().astype(np.uint32)
+    assert np.array_equal(got_idx, want_idx)
+    assert all(s.prepared == 1 for s in stages.values())
+
+
+def _block_worker(rank, world, port, n, m, max_iter, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        src, dst = synth.synthetic_pair(n, m)
+        stages = {rank: OracleBlockStages(dst, n, world, miss_every=4)}
+        drv = BlockShardedIcp(stages, n, world, TorchComm(rank, world))
+        local = drv.take_source(torch.from_numpy(src))
+        assert local[rank].shape[0] == block_shard(n, rank, world)[3]
+        T, inner = drv.estimate(local, I.Transform(), max_iter)
+        t = torch.from_numpy(T.as_array().copy())
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        for g in gathered:
+            assert torch.equal(g, gathered[0])
+        if rank == 0:
+            np.save(out, np.concatenate([T.as_array(), inner.astype(np.float64),
+                                         [drv.counters["sharded"], drv.counters["replicated"]]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 6000), (3, 9001)])
+def test_block_sharded_driver_over_gloo_equals_one_rank(tmp_path, world, n):
+    m, max_iter = 3000, 4
+    out = str(tmp_path / "pose.npy")
+    mp.spawn(_block_worker, args=(world, _free_port(), n, m, max_iter, out), nprocs=world, join=True)
+    got = np.load(out)
+    _, _, want_T, _, want_inner = _reference(n, m, max_iter)
+    assert np.array_equal(got[:6], want_T.as_array())
+    assert np.array_equal(got[6:6 + max_iter], want_inner.astype(np.float64))
+    assert got[-2] > 0 and got[-1] > 0

@@ -1,0 +1,80 @@
+"""The N-rank path on ONE GPU: N "virtual ranks" (N handles on cuda:0) run the block-sharded driver
+(icp_rust_amd/dist.py: BlockShardedIcp + HipStages, include/icp_mi355x.h section 5) in lockstep and must
+reproduce the one-handle registration bit for bit -- pose, inner-iteration counts, correspondence
+indices.  (8 real GPUs are the driver's to launch; tests/test_dist_gloo.py covers the same
+orchestration over gloo with a CPU stand-in for the stages.)"""
+import numpy as np
+import pytest
+
+import icp_rust_amd as I
+import oracle_ffi as O
+from icp_rust_amd import synth
+from icp_rust_amd.dist import BlockShardedIcp, HipStages, LocalComm, block_shard, local_indices
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(world, n, m, max_iter, dim=3):
+    import torch
+
+    src, dst = synth.synthetic_pair(n, m)
+    if dim == 2:
+        src, dst = np.ascontiguousarray(src[:, :2]), np.ascontiguousarray(dst[:, :2])
+    cls = I.Icp3d if dim == 3 else I.Icp2d
+    d_src, d_dst = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+    one = cls(d_dst)
+    T1, idx1, inner1 = one.estimate(d_src, I.Transform(), max_iter, return_info=True)
+    handles = [cls(d_dst) for _ in range(world)]
+    stages = {r: HipStages(handles[r]) for r in range(world)}
+    drv = BlockShardedIcp(stages, n, world, LocalComm(world))
+    local = drv.take_source(d_src)
+    for r in range(world):
+        assert np.array_equal(local[r].cpu().numpy(), src[local_indices(n, r, world)])
+    T, inner = drv.estimate(local, I.Transform(), max_iter)
+    torch.cuda.synchronize()
+    idx = np.zeros(n, dtype=np.uint32)
+    for r, ix in drv.last_indices().items():
+        idx[local_indices(n, r, world)] = ix.cpu().numpy().view(np.uint32)
+    return (T1, idx1, inner1), (T, idx, inner), drv, (src, dst)
+
+
+@pytest.mark.parametrize("world,n,m", [(2, 150_000, 120_000), (3, 70_001, 50_000), (8, 150_000, 120_000), (4, 20_000, 9_000)])
+def test_virtual_ranks_reproduce_one_rank_bit_for_bit(world, n, m):
+    (T1, idx1, inner1), (T, idx, inner), drv, _ = _run(world, n, m, 6)
+    assert np.array_equal(T.as_array(), T1.as_array())
+    assert np.array_equal(inner, inner1)
+    assert np.array_equal(idx, idx1)
+    # the steady state really ran sharded (three small exchanges), not on gathered pairs
+    assert drv.counters["sharded"] >= 4, drv.counters
+    assert drv.counters["replicated"] >= 2  # the first evaluation of each kind has no prediction yet
+
+
+def test_virtual_ranks_2d_and_against_the_oracle():
+    (T1, idx1, inner1), (T, idx, inner), drv, (src, dst) = _run(4, 60_000, 40_000, 4, dim=2)
+    assert np.array_equal(T.as_array(), T1.as_array()) and np.array_equal(idx, idx1) and np.array_equal(inner, inner1)
+    b, t = I.reduce_geometry(len(src))
+    rc, oT, oidx, oinner = O.icp_estimate(2, dst, src, O.transform_identity(), 4, use_kdtree=True, sum_mode=1,
+                                          reduce_blocks=b, reduce_threads=t)
+    assert rc == O.OK
+    assert np.array_equal(T.as_array(), oT.as_array()) and np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
+
+
+def test_eight_virtual_ranks_at_the_full_size():
+    """BASELINE configs[3] (1M x 1M over 8 ranks), as far as one GPU can rehearse it"""
+    (T1, idx1, inner1), (T, idx, inner), drv, _ = _run(8, 1_000_000, 1_000_000, 5)
+    assert np.array_equal(T.as_array(), T1.as_array())
+    assert np.array_equal(inner, inner1) and np.array_equal(idx, idx1)
+    assert drv.counters["sharded"] >= 6
+
+
+def test_stage_calls_refuse_what_they_cannot_serve():
+    import torch
+
+    src, dst = synth.synthetic_pair(3000, 9000)  # 6 blocks: fewer than 8 ranks
+    h = I.Icp3d(torch.from_numpy(dst).cuda())
+    st = HipStages(h)
+    a = torch.zeros((3000, 2), dtype=torch.float64, device="cuda")
+    rc, _ = st.eval_hist(a, a, 3000, 0, 8, I.Transform(), 0)
+    assert rc == I._lib.RETRY_REPLICATED
+    assert block_shard(3000, 7, 8)[3] + block_shard(3000, 0, 8)[3] <= 3000
+    assert I.lib().icp_shard_eval_compact_device(h._h, None) == I._lib.BAD_ARGUMENT

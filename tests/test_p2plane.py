@@ -117,6 +117,9 @@ def test_point_to_plane_ignores_motion_inside_the_plane_where_point_to_point_doe
     src = wall[rng.integers(0, m, 6000)].copy()
     src[:, 1] += 0.05   # slide along the wall
     src[:, 0] -= 0.02   # and move off it
+    # (range noise: with identical residuals the MAD is 0 and -- as in the reference, src/lib.rs:243-245 and
+    # test_weighted_gauss_newton_update_zero_x_diff -- no update is produced at all)
+    src[:, 0] += rng.normal(0, 2e-3, len(src))
     icp = I.Icp3d(wall)
     icp.compute_normals(8)
     Tp = icp.estimate_point_to_plane(src, I.Transform(), 5)
