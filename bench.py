@@ -195,6 +195,8 @@ def main():
                          "at this size); all engines return bit-identical correspondences")
     ap.add_argument("--brute-steps", type=int, default=3,
                     help="outer iterations of the brute-force sweep measured alongside (0 = skip)")
+    ap.add_argument("--weak-steps", type=int, default=40,
+                    help="N > 1: outer iterations of the weak-scaling line (N x n-src source points; 0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=10,
                     help="outer iterations of the CPU baseline: ~7 s on one core + ~3 s with all cores (0 = skip)")
     ap.add_argument("--gn-points", type=int, default=64 * 1024 * 1024,
@@ -206,7 +208,7 @@ def main():
 
     import icp_rust_amd as I
     from icp_rust_amd import synth
-    from icp_rust_amd.dist import HipStages, ShardedIcp, shard_range
+    from icp_rust_amd.dist import BlockShardedIcp, HipStages, ShardedIcp, TorchComm, block_shard, shard_range
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -232,28 +234,45 @@ def main():
     lo, hi = shard_range(n, rank, world)
     src_np, dst_np = synth.synthetic_pair(n, m, src_first=lo, src_count=hi - lo)
     d_dst = torch.from_numpy(dst_np).cuda()
-    d_src = torch.from_numpy(src_np).cuda()
+    d_src = torch.from_numpy(src_np).cuda()  # contiguous shard: what the sweep engine's driver takes
     d_src_full = None
     if world > 1:
-        # the source cloud is replicated (24 MB) so that ranks exchange 4-byte indices, not 32-byte pairs
+        # every rank regenerates the whole source cloud (counter-based generator: no communication) and
+        # keeps the points of its reduction-tree blocks (dist.BlockShardedIcp.take_source)
         full_np, _ = synth.synthetic_pair(n, 1)
         d_src_full = torch.from_numpy(full_np).cuda()
     nn_mode = {"auto": I.NN_AUTO, "brute": I.NN_BRUTE, "grid": I.NN_GRID}[args.nn]
+    comm = TorchComm(rank, world) if world > 1 else None
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(mode, steps, warmup, want_parity=False):
-        """K timed outer iterations = one Icp3d::estimate(src, T, K) call on resident data."""
+    def measure(mode, steps, warmup, want_parity=False, weak=False):
+        """K timed outer iterations = one Icp3d::estimate(src, T, K) call on resident data.
+        N ranks: the grid engine runs block-sharded (dist.BlockShardedIcp: every rank searches and
+        evaluates the points of its reduction-tree blocks, three small exchanges per evaluation, same
+        bits as one GPU); the sweep, whose search is 99.8 % of the step, keeps contiguous shards and a
+        replicated inner loop (dist.ShardedIcp).  weak: N x n source points instead of n."""
         icp = I.Icp3d(d_dst, device=local_rank, nn_mode=mode)
         T = I.Transform()
+        n_run = n * world if weak else n
+        block = world > 1 and mode != I.NN_BRUTE
         if world == 1:
             # one rank: the handle keeps its own streams (the library overlaps the next search with the
             # evaluation that decides it); nothing else is enqueued on them
             if warmup > 0:
                 icp.estimate(d_src, T, warmup)
+        elif block:
+            full = d_src_full
+            if weak:
+                full = torch.from_numpy(synth.synthetic_pair(n_run, 1)[0]).cuda()
+            driver = BlockShardedIcp({rank: HipStages(icp)}, n_run, world, comm)
+            local = driver.take_source(full)
+            torch.cuda.synchronize()
+            del full
+            T, _ = driver.estimate(local, T, max(warmup, 2))  # (also seeds the window predictions)
         else:
             driver = ShardedIcp(HipStages(icp), n, rank, world, src_full=d_src_full)
             driver.stages.prepare(d_src, T)
@@ -278,8 +297,15 @@ def main():
                 T, k = icp.estimate(d_src, I.Transform(), k_iters, return_info="inner")
                 inner.extend(int(x) for x in k[:k_iters])
                 done += k_iters
+        elif block:
+            done = 0
+            while done < steps:
+                k_iters = min(MAX_ITER, steps - done)
+                T, k = driver.estimate(local, I.Transform(), k_iters)
+                inner.extend(int(x) for x in k[:k_iters])
+                done += k_iters
         else:
-            # N ranks: the same iteration as stage calls around one collective (icp_rust_amd/dist.py)
+            # N ranks, sweep engine: stage calls around one index all-gather per iteration
             for k_step in range(steps):
                 if k_step % MAX_ITER == 0:
                     T = I.Transform()
@@ -317,9 +343,10 @@ def main():
             # comparison with the oracle in the cpu_baseline leg
             k_last = min(MAX_ITER, steps)
             checked = (icp.estimate(d_src, I.Transform(), k_last, return_info=True), k_last)
+        counters = dict(driver.counters) if block else None
         icp.close()
         return dict(elapsed=elapsed, steps=steps, inner=inner, nn_ms=nn_ms, nn_launches=nn_launches, T=T,
-                    engine=engine, alone_ms=alone_ms, checked=checked)
+                    engine=engine, alone_ms=alone_ms, checked=checked, counters=counters, n_run=n_run)
 
     def nn_roofline(r, n_shard):
         """Roofline of the dominant kernel (the NN search) from the live HIP-event timing."""
@@ -366,11 +393,14 @@ def main():
     brute = None
     if args.brute_steps > 0 and res["engine"] != "brute":
         brute = measure(I.NN_BRUTE, args.brute_steps, 1)
+    weak = None
+    if world > 1 and res["engine"] == "grid" and args.weak_steps > 0:
+        weak = measure(nn_mode, args.weak_steps, 2, weak=True)
     elapsed, inner, T = res["elapsed"], res["inner"], res["T"]
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        n_shard = hi - lo
+        n_shard = block_shard(n, rank, world)[3] if (world > 1 and res["engine"] == "grid") else hi - lo
         truth = I.Transform(synth.TRUTH_PARAM).as_array()
         evals = [k + 1 for k in inner]  # GN evaluations per step: the applied updates + the terminating one
         # whole-step algorithmic HBM bytes: 28 N + 24 M + k * 96 N
@@ -394,8 +424,13 @@ def main():
                             "NN engine = " + res["engine"] + " (bit-identical correspondences to the "
                             "brute-force sweep, which is timed alongside under `brute_force`)",
                 "n_src": n, "n_dst": m, "nn": res["engine"], "outer_iterations_per_estimate_call": MAX_ITER,
-                "parallelism": f"NN over the source cloud sharded x{world} (index all-gather), target replicated, "
-                               "inner loop replicated",
+                "parallelism": ("one GPU" if world == 1 else
+                                f"source cloud sharded x{world} by reduction-tree block (every rank searches and evaluates "
+                                "its blocks' points; per evaluation: integer histograms all-reduced, candidate lists and "
+                                "block sums all-gathered over RCCL), target replicated; bit-identical to one GPU"
+                                if res["engine"] == "grid" else
+                                f"NN over contiguous source shards x{world} (index all-gather), target replicated, inner "
+                                "loop replicated"),
                 "seed": hex(synth.SEED),
             },
             "roofline": nn_roofline(res, n_shard),
@@ -407,10 +442,23 @@ def main():
             "pose": T.as_array().tolist(),
             "pose_abs_err_vs_truth": float(np.max(np.abs(T.as_array() - truth))),
         }
+        if res.get("counters"):
+            out["sharded_evaluations"] = res["counters"]
         if brute is not None:
             out["brute_force"] = {
                 "value": brute["steps"] / brute["elapsed"], "unit": "iterations/s", "steps": brute["steps"],
-                "ms_per_step": 1e3 * brute["elapsed"] / brute["steps"], "roofline": nn_roofline(brute, n_shard),
+                "ms_per_step": 1e3 * brute["elapsed"] / brute["steps"], "roofline": nn_roofline(brute, hi - lo),
+                "scaling": "strong", "n_gpus": world,
+            }
+        if weak is not None:
+            wv = weak["steps"] / weak["elapsed"]
+            out["weak_scaling"] = {
+                "workload": f"{weak['n_run']} source points ({world} x {n}) against the {m}-point target, grid engine, "
+                            "block-sharded", "n_gpus": world, "scaling": "weak",
+                "value": wv, "unit": "iterations/s", "steps": weak["steps"], "ms_per_step": 1e3 / wv,
+                "source_points_per_second": wv * weak["n_run"],
+                "inner_iterations_per_step": weak["inner"], "sharded_evaluations": weak["counters"],
+                "note": "compare source_points_per_second with n_src x value of the 1-GPU line",
             }
         if world == 1 and args.gn_points > 0:
             out["gn_large"] = gn_large(args.gn_points)

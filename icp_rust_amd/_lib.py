@@ -96,6 +96,10 @@ SIGNATURES = {
     "icp_shard_eval_compact_device": (C.c_int, [_vp, _vp]),
     "icp_shard_eval_accumulate_device": (C.c_int, [_vp, _vp, _vp]),
     "icp_shard_eval_finish_device": (C.c_int, [_vp, _vp, _dp, _dp]),
+    "icp_create_multi": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _sz, C.POINTER(C.c_int), C.c_int]),
+    "icp_multi_estimate": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
+    "icp_multi_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "icp_destroy_multi": (None, [_vp]),
     "icp_synchronize": (C.c_int, [_vp]),
     "icp_profile_enable": (C.c_int, [_vp, C.c_int]),
     "icp_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_uint64)]),

@@ -529,3 +529,42 @@ class Icp3d(_Icp):
     """`icp::Icp3d` (src/lib.rs:133-174): 3-D nearest neighbours, SE(2) pose on the xy-plane."""
 
     DIM = 3
+
+
+class IcpMulti:
+    """Icp{2,3}d over several GPUs from one process (icp_create_multi): same result as one GPU, bit for
+    bit.  `device_ids` may repeat a device (virtual ranks)."""
+
+    def __init__(self, dst, device_ids, dim=3):
+        self.dim = dim
+        d = _host(dst, dim)
+        ids = (C.c_int * len(device_ids))(*[int(x) for x in device_ids])
+        self._h = C.c_void_p()
+        check(lib().icp_create_multi(C.byref(self._h), dim, _ptr(d), d.shape[0], ids, len(device_ids)),
+              "icp_create_multi")
+
+    def estimate(self, src, initial_transform, max_iter, return_info=False):
+        s = _host(src, self.dim)
+        n = s.shape[0]
+        o = Transform()
+        idx = np.zeros(max(n, 1), dtype=np.uint32)
+        inner = np.zeros(max(max_iter, 1), dtype=np.uint32)
+        check(lib().icp_multi_estimate(self._h, _ptr(s), n, C.byref(initial_transform.pose), max_iter, C.byref(o.pose),
+                                       C.c_void_p(idx.ctypes.data), C.c_void_p(inner.ctypes.data)), "icp_multi_estimate")
+        return (o, idx[:n], inner[:max_iter]) if return_info else o
+
+    def counters(self):
+        out = (C.c_uint64 * 2)()
+        check(lib().icp_multi_counters(self._h, out), "icp_multi_counters")
+        return int(out[0]), int(out[1])
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().icp_destroy_multi(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

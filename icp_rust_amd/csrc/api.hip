@@ -1348,12 +1348,10 @@ extern "C" int icp_shard_eval_accumulate_device(icp_handle *h, const void *d_can
   return ICP_OK;
 }
 
-extern "C" int icp_shard_eval_finish_device(icp_handle *h, const void *d_partials_all, double delta[3], double *huber_err) {
-  if (!h || !h->shard.active || !d_partials_all || !delta) return ICP_BAD_ARGUMENT;
+// the host half of `finish`: wait for the folded result, keep the prediction state, solve
+static int shard_finish_common(icp_handle *h, double delta[3], double *huber_err) {
   icp_handle::ShardEval &S = h->shard;
   Workspace &w = h->ws;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(shard_launch_fold(h, d_partials_all, S.world, S.blocks, S.d_ordered));
   HIP_TRY(wait_result(h));
   S.active = false;
   const GnResult &r = *w.h_res;
@@ -1380,6 +1378,21 @@ extern "C" int icp_shard_eval_finish_device(icp_handle *h, const void *d_partial
   record_statistics(w, kind, true, r);
   if (huber_err) *huber_err = r.acc[12];
   return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
+}
+
+extern "C" int icp_shard_eval_finish_device(icp_handle *h, const void *d_partials_all, double delta[3], double *huber_err) {
+  if (!h || !h->shard.active || !d_partials_all || !delta) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(shard_launch_fold(h, d_partials_all, h->shard.world, h->shard.blocks, h->shard.d_ordered));
+  return shard_finish_common(h, delta, huber_err);
+}
+
+// (multi.hip) the same with the block sums of every rank read where they lie: one pointer per rank
+int icp_shard_eval_finish_ptrs(icp_handle *h, const void *const *part_ptrs, double delta[3], double *huber_err) {
+  if (!h || !h->shard.active || !part_ptrs || !delta) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(shard_launch_fold_ptrs(h, part_ptrs, h->shard.world, h->shard.blocks, h->shard.d_ordered));
+  return shard_finish_common(h, delta, huber_err);
 }
 
 // One evaluation of weighted_gauss_newton_update (+ the Huber error of the same pose) on device pairs,

@@ -197,6 +197,7 @@ struct Grid {
   double *t_part = nullptr;     // bounding-box partials
 };
 
+constexpr int kShardMaxWorld = 16;  // ranks of one sharded evaluation (a node has 8 GPUs)
 constexpr unsigned kGridPad = 8;  // records past the last target that a quad-aligned read may touch
 
 struct PrevMatch {  // a query's previous nearest neighbour, stored per sorted slot (coalesced)
@@ -332,6 +333,19 @@ hipError_t shard_launch_compact(icp_handle *h, size_t n_local, size_t n_total, c
 hipError_t shard_launch_accumulate(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
                                    const void *d_cand_all, int world, int blocks_local, void *d_out);
 hipError_t shard_launch_fold(icp_handle *h, const void *d_part_all, int world, int blocks_total, double *d_ordered);
+// ... the same from one pointer per rank (peer memory read in place), and the flag exchange of icp_create_multi
+hipError_t shard_launch_accumulate_ptrs(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
+                                        const void *const *cand_ptrs, int world, int blocks_local, void *d_out);
+hipError_t shard_launch_fold_ptrs(icp_handle *h, const void *const *part_ptrs, int world, int blocks_total,
+                                  double *d_ordered);
+}  // namespace icp
+int icp_shard_eval_finish_ptrs(icp_handle *h, const void *const *part_ptrs, double delta[3], double *huber_err);
+namespace icp {
+hipError_t multi_signal(hipStream_t s, unsigned *flag, unsigned value);
+hipError_t multi_wait(hipStream_t s, const unsigned *const *flags, int world, unsigned value, unsigned *err);
+hipError_t multi_sum_hist(hipStream_t s, const void *const *hists, int world, uint32_t *out);
+hipError_t multi_put_pairs(hipStream_t s, const double *a_loc, const double *b_loc, size_t n_total, int rank, int world,
+                           double *a_full, double *b_full);
 // EXTENSION: point-to-plane residuals (p2plane.hip)
 hipError_t launch_target_normals(icp_handle *h, int k, double *d_normals);
 hipError_t launch_p2pl_gather(icp_handle *h, const double *d_src, size_t n, const Pose &T, const uint32_t *d_idx,

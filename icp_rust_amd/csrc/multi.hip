@@ -1,0 +1,387 @@
+// icp_create_multi / icp_multi_estimate: ONE host process driving the GPUs of a node (SURVEY.md 8(b)
+// sketch `icp_create(..., device_ids, n_devices)`, 8(e) options 2 and 3).
+//
+// Rank r = a handle on device_ids[r]; the source cloud is sharded by reduction-tree block and every
+// evaluation is the sharded evaluation of shard.hip, so the pose equals the one-GPU pose bit for bit.
+// The three exchanges per evaluation need no collective library: a rank EXPORTS a stage's bytes
+// (histogram / candidates / block sums) into a buffer its peers have mapped (hipDeviceEnablePeerAccess:
+// xGMI), bumps a flag behind them, and the consumers -- after a bounded wait on every peer's flag --
+// read the peers' exports IN PLACE: the histograms are summed, the candidate lists merged, the block
+// sums folded straight out of peer memory (a few KB each).  One host thread enqueues everything; it
+// waits once per evaluation, for the folded result, exactly as the one-GPU loop does.
+//
+// Ranks may share a device ("virtual ranks": device_ids = {0, 0, 0, 0}) -- that is how the N-rank path
+// is tested on a one-GPU box.  Ranks on one device share ONE stream and are enqueued stage by stage,
+// so every wait is already satisfied when the queue reaches it (two spinning kernels on one hardware
+// queue could otherwise wait for each other).  STATUS: the peer-memory path itself (distinct devices)
+// has not run on hardware -- no multi-GPU box is available to this build; its flags are bounded spins,
+// so a visibility problem would surface as ICP_HIP_ERROR, not as a hang.
+#include <cfloat>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace icp;
+
+struct icp_multi {
+  int world = 0, dim = 0;
+  size_t m = 0;
+  bool one_device = true;
+  struct Rank {
+    icp_handle *h = nullptr;
+    int device = 0;
+    size_t cap_n = 0;       // local points the buffers below hold
+    size_t cap_full = 0;
+    double *d_src = nullptr;            // local source cloud
+    double *d_a = nullptr, *d_b = nullptr;
+    uint32_t *d_idx = nullptr;
+    double *d_a_full = nullptr, *d_b_full = nullptr;  // replicated fallback
+    // exports (peer-visible) and this rank's flag words {hist, candidates, partials, pairs}
+    unsigned char *x_hist = nullptr, *x_cand = nullptr, *x_part = nullptr;
+    unsigned *x_flags = nullptr;
+    unsigned *d_err = nullptr;
+  };
+  std::vector<Rank> r;
+  unsigned seq = 0;  // generation of the exchanges
+  uint64_t sharded = 0, replicated = 0;
+};
+
+namespace {
+
+int map_hip(hipError_t e) {
+  switch (e) {
+    case hipSuccess: return ICP_OK;
+    case hipErrorOutOfMemory: return ICP_OUT_OF_MEMORY;
+    case hipErrorNoDevice:
+    case hipErrorInvalidDevice: return ICP_NO_DEVICE;
+    default: return ICP_HIP_ERROR;
+  }
+}
+#define HIP_TRY(expr)                           \
+  do {                                          \
+    hipError_t e__ = (expr);                    \
+    if (e__ != hipSuccess) return map_hip(e__); \
+  } while (0)
+#define ICP_TRY(expr)              \
+  do {                             \
+    const int rc__ = (expr);       \
+    if (rc__ != ICP_OK) return rc__; \
+  } while (0)
+
+// memory a peer device reads while the owner's kernels are still running must be fine-grained
+hipError_t alloc_export(void **p, size_t bytes, bool peers) {
+  if (peers) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+  return hipMalloc(p, bytes);
+}
+
+int ensure_rank_buffers(icp_multi *M, icp_multi::Rank &R, size_t n_local, size_t n_total) {
+  HIP_TRY(hipSetDevice(R.device));
+  if (n_local > R.cap_n) {
+    (void)hipFree(R.d_src);
+    (void)hipFree(R.d_a);
+    (void)hipFree(R.d_b);
+    (void)hipFree(R.d_idx);
+    R.d_src = R.d_a = R.d_b = nullptr;
+    R.d_idx = nullptr;
+    R.cap_n = 0;
+    const size_t cap = n_local + n_local / 8 + 1;
+    // the pairs are read by peers (replicated fallback): exported too
+    HIP_TRY(hipMalloc(&R.d_src, cap * 3 * sizeof(double)));
+    HIP_TRY(alloc_export((void **)&R.d_a, cap * 2 * sizeof(double), !M->one_device));
+    HIP_TRY(alloc_export((void **)&R.d_b, cap * 2 * sizeof(double), !M->one_device));
+    HIP_TRY(hipMalloc(&R.d_idx, cap * sizeof(uint32_t)));
+    R.cap_n = cap;
+  }
+  if (n_total > R.cap_full) {
+    (void)hipFree(R.d_a_full);
+    (void)hipFree(R.d_b_full);
+    R.d_a_full = R.d_b_full = nullptr;
+    R.cap_full = 0;
+    HIP_TRY(hipMalloc(&R.d_a_full, (n_total + 1) * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc(&R.d_b_full, (n_total + 1) * 2 * sizeof(double)));
+    R.cap_full = n_total + 1;
+  }
+  return ICP_OK;
+}
+
+enum { kFlagHist = 0, kFlagCand = 1, kFlagPart = 2, kFlagPairs = 3 };
+
+// every rank bumps flag `which` to `value` behind what it has enqueued so far
+int signal_all(icp_multi *M, int which, unsigned value) {
+  for (auto &R : M->r) {
+    HIP_TRY(hipSetDevice(R.device));
+    HIP_TRY(multi_signal(R.h->stream, R.x_flags + 32 * which, value));
+  }
+  return ICP_OK;
+}
+int wait_all(icp_multi *M, icp_multi::Rank &R, int which, unsigned value) {
+  const unsigned *flags[kShardMaxWorld];
+  for (int q = 0; q < M->world; ++q) flags[q] = M->r[q].x_flags + 32 * which;
+  HIP_TRY(multi_wait(R.h->stream, flags, M->world, value, R.d_err));
+  return ICP_OK;
+}
+
+// weighted_gauss_newton_update at inner pose T on every rank; all ranks return the same status / delta
+int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta[3], double *err) {
+  const int W = M->world;
+  uint32_t *hist[kShardMaxWorld];
+  int rc0 = ICP_OK;
+  for (int q = 0; q < W; ++q) {
+    auto &R = M->r[q];
+    const int rc = icp_shard_eval_hist_device(R.h, R.d_a, R.d_b, n_total, q, W, &T, kind, &hist[q]);
+    if (q == 0) rc0 = rc;
+    else if (rc != rc0) return ICP_HIP_ERROR;  // the ranks' prediction state diverged: cannot happen
+  }
+  if (rc0 == ICP_OK) {
+    const unsigned gen = ++M->seq;
+    // 1. histograms: export, signal, (wait) sum over peers in place
+    for (int q = 0; q < W; ++q) {
+      auto &R = M->r[q];
+      HIP_TRY(hipSetDevice(R.device));
+      HIP_TRY(hipMemcpyAsync(R.x_hist, hist[q], icp_shard_histogram_words() * 4, hipMemcpyDeviceToDevice, R.h->stream));
+    }
+    ICP_TRY(signal_all(M, kFlagHist, gen));
+    const void *ptrs[kShardMaxWorld];
+    for (int q = 0; q < W; ++q) {
+      auto &R = M->r[q];
+      HIP_TRY(hipSetDevice(R.device));
+      ICP_TRY(wait_all(M, R, kFlagHist, gen));
+      for (int p = 0; p < W; ++p) ptrs[p] = M->r[p].x_hist;
+      HIP_TRY(multi_sum_hist(R.h->stream, ptrs, W, hist[q]));
+      // 2. candidates
+      ICP_TRY(icp_shard_eval_compact_device(R.h, R.x_cand));
+    }
+    ICP_TRY(signal_all(M, kFlagCand, gen));
+    for (int q = 0; q < W; ++q) {
+      auto &R = M->r[q];
+      HIP_TRY(hipSetDevice(R.device));
+      ICP_TRY(wait_all(M, R, kFlagCand, gen));
+      for (int p = 0; p < W; ++p) ptrs[p] = M->r[p].x_cand;
+      const icp_handle::ShardEval &S = R.h->shard;
+      HIP_TRY(shard_launch_accumulate_ptrs(R.h, S.d_a, S.n_local, S.n_total, S.T, ptrs, W, S.b1 - S.b0, R.x_part));
+    }
+    // 3. block sums
+    ICP_TRY(signal_all(M, kFlagPart, gen));
+    for (int q = 0; q < W; ++q) {
+      auto &R = M->r[q];
+      HIP_TRY(hipSetDevice(R.device));
+      ICP_TRY(wait_all(M, R, kFlagPart, gen));
+    }
+    int rcf = ICP_OK;
+    for (int q = 0; q < W; ++q) {
+      auto &R = M->r[q];
+      double dq[3], eq = 0.;
+      // (finish = fold from the peers' exports + wait + bookkeeping; the contiguous-buffer entry point
+      // of the ABI is not used here: the block sums are read in place)
+      for (int p = 0; p < W; ++p) ptrs[p] = M->r[p].x_part;
+      const int rc = icp_shard_eval_finish_ptrs(R.h, ptrs, dq, &eq);
+      if (q == 0) {
+        rcf = rc;
+        for (int k = 0; k < 3; ++k) delta[k] = dq[k];
+        if (err) *err = eq;
+      } else if (rc != rcf) {
+        return ICP_HIP_ERROR;
+      }
+    }
+    for (auto &R : M->r)  // a peer that never arrived?
+      if (__atomic_load_n(R.d_err, __ATOMIC_ACQUIRE)) return ICP_HIP_ERROR;
+    if (rcf != ICP_RETRY_REPLICATED) {
+      ++M->sharded;
+      return rcf;
+    }
+  } else if (rc0 != ICP_RETRY_REPLICATED) {
+    return rc0;
+  }
+  // replicated: every rank assembles the pairs of all ranks in global order and evaluates them
+  ++M->replicated;
+  const unsigned gen = ++M->seq;
+  ICP_TRY(signal_all(M, kFlagPairs, gen));
+  int rcr = ICP_OK;
+  for (int q = 0; q < W; ++q) {
+    auto &R = M->r[q];
+    HIP_TRY(hipSetDevice(R.device));
+    ICP_TRY(wait_all(M, R, kFlagPairs, gen));
+    for (int p = 0; p < W; ++p)
+      HIP_TRY(multi_put_pairs(R.h->stream, M->r[p].d_a, M->r[p].d_b, n_total, p, W, R.d_a_full, R.d_b_full));
+  }
+  for (int q = 0; q < W; ++q) {
+    auto &R = M->r[q];
+    double dq[3], eq = 0.;
+    const int rc = icp_weighted_gn_step_device(R.h, R.d_a_full, R.d_b_full, n_total, &T, kind, dq, &eq);
+    if (q == 0) {
+      rcr = rc;
+      for (int k = 0; k < 3; ++k) delta[k] = dq[k];
+      if (err) *err = eq;
+    } else if (rc != rcr) {
+      return ICP_HIP_ERROR;
+    }
+  }
+  return rcr;
+}
+
+}  // namespace
+
+extern "C" void icp_destroy_multi(icp_multi *M) {
+  if (!M) return;
+  for (auto &R : M->r) {
+    (void)hipSetDevice(R.device);
+    if (R.h) icp_destroy(R.h);
+    (void)hipFree(R.d_src);
+    (void)hipFree(R.d_a);
+    (void)hipFree(R.d_b);
+    (void)hipFree(R.d_idx);
+    (void)hipFree(R.d_a_full);
+    (void)hipFree(R.d_b_full);
+    (void)hipFree(R.x_hist);
+    (void)hipFree(R.x_cand);
+    (void)hipFree(R.x_part);
+    (void)hipFree(R.x_flags);
+    if (R.d_err) (void)hipHostFree(R.d_err);
+  }
+  delete M;
+}
+
+extern "C" int icp_create_multi(icp_multi **out, int dim, const double *dst, size_t m, const int *device_ids,
+                                int n_devices) {
+  if (!out || (dim != 2 && dim != 3) || (m > 0 && !dst) || !device_ids || n_devices < 1 || n_devices > kShardMaxWorld)
+    return ICP_BAD_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ICP_NO_DEVICE;
+  for (int q = 0; q < n_devices; ++q)
+    if (device_ids[q] < 0 || device_ids[q] >= count) return ICP_BAD_ARGUMENT;
+  icp_multi *M = new (std::nothrow) icp_multi();
+  if (!M) return ICP_OUT_OF_MEMORY;
+  M->world = n_devices;
+  M->dim = dim;
+  M->m = m;
+  M->r.resize(n_devices);
+  M->one_device = true;
+  for (int q = 1; q < n_devices; ++q) M->one_device = M->one_device && device_ids[q] == device_ids[0];
+  int rc = ICP_OK;
+  for (int q = 0; q < n_devices && rc == ICP_OK; ++q) {
+    auto &R = M->r[q];
+    R.device = device_ids[q];
+    hipError_t e = hipSetDevice(R.device);
+    if (e != hipSuccess) { rc = map_hip(e); break; }
+    if (!M->one_device)
+      for (int p = 0; p < n_devices; ++p)
+        if (device_ids[p] != R.device) {
+          e = hipDeviceEnablePeerAccess(device_ids[p], 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { rc = map_hip(e); break; }
+          (void)hipGetLastError();
+        }
+    if (rc != ICP_OK) break;
+    rc = icp_create(&R.h, dim, dst, m, R.device);  // the target cloud is replicated
+    if (rc != ICP_OK) break;
+    const bool peers = !M->one_device;
+    if ((e = alloc_export((void **)&R.x_hist, icp_shard_histogram_words() * 4, peers)) != hipSuccess ||
+        (e = alloc_export((void **)&R.x_cand, icp_shard_candidates_bytes(), peers)) != hipSuccess ||
+        (e = alloc_export((void **)&R.x_part, icp_shard_partials_bytes(n_devices), peers)) != hipSuccess ||
+        (e = alloc_export((void **)&R.x_flags, 4 * 32 * sizeof(unsigned), peers)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&R.d_err, sizeof(unsigned), hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipMemset(R.x_flags, 0, 4 * 32 * sizeof(unsigned))) != hipSuccess) {
+      rc = map_hip(e);
+      break;
+    }
+    *R.d_err = 0;  // (pinned, device-visible: a wait kernel that gives up raises it, the host reads it directly)
+  }
+  if (rc == ICP_OK && M->one_device)  // ranks on one device share one stream: lockstep order, no waiting
+    for (int q = 1; q < n_devices; ++q) rc = rc == ICP_OK ? icp_set_stream(M->r[q].h, M->r[0].h->stream) : rc;
+  if (rc != ICP_OK) {
+    icp_destroy_multi(M);
+    return rc;
+  }
+  *out = M;
+  return ICP_OK;
+}
+
+extern "C" int icp_multi_counters(const icp_multi *M, uint64_t out[2]) {
+  if (!M || !out) return ICP_BAD_ARGUMENT;
+  out[0] = M->sharded;
+  out[1] = M->replicated;
+  return ICP_OK;
+}
+
+// Icp{2,3}d::estimate (src/lib.rs:105-130, 148-173) over all the devices of `M`; host buffers
+extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, const icp_pose *init, size_t max_iter,
+                                  icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters) {
+  if (!M || !init || !out || (n > 0 && !src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  const int W = M->world, dim = M->dim;
+  Pose T = *init;
+  if (n > 0 && max_iter > 0 && M->m == 0) return ICP_EMPTY_DST;  // index.unwrap(), src/lib.rs:122,165
+  // every rank's share of the source cloud, compacted in fold order on the host (the reference hands
+  // over a host slice; device-resident sources shard with icp_shard_take_device)
+  std::vector<size_t> n_local(W);
+  std::vector<double> stage;
+  for (int q = 0; q < W; ++q) {
+    int b0, b1, B;
+    shard_geometry(n, q, W, &b0, &b1, &B, &n_local[q]);
+    auto &R = M->r[q];
+    ICP_TRY(ensure_rank_buffers(M, R, n_local[q], n));
+    if (n_local[q] == 0) continue;
+    stage.resize(n_local[q] * dim);
+    const size_t G = (size_t)B * kReduceThreads, c0 = (size_t)b0 * kReduceThreads, c1 = (size_t)b1 * kReduceThreads;
+    size_t l = 0;
+    for (size_t base = 0; base < n; base += G) {
+      const size_t s = base + c0, e = base + c1 < n ? base + c1 : n;
+      if (e > s) {
+        memcpy(stage.data() + l * dim, src + s * dim, (e - s) * dim * sizeof(double));
+        l += e - s;
+      }
+    }
+    HIP_TRY(hipSetDevice(R.device));
+    HIP_TRY(hipMemcpyAsync(R.d_src, stage.data(), n_local[q] * dim * sizeof(double), hipMemcpyHostToDevice, R.h->stream));
+    HIP_TRY(hipStreamSynchronize(R.h->stream));  // `stage` is reused for the next rank
+    if (max_iter > 0) ICP_TRY(icp_prepare_source_device(R.h, R.d_src, n_local[q], init));
+  }
+  for (size_t it = 0; it < max_iter; ++it) {
+    for (int q = 0; q < W; ++q) {
+      auto &R = M->r[q];
+      if (n_local[q]) ICP_TRY(icp_correspond_device(R.h, R.d_src, n_local[q], &T, R.d_a, R.d_b, R.d_idx));
+    }
+    // estimate_transform, src/lib.rs:59-84
+    Pose Ti = transform_identity();
+    uint32_t applied = 0;
+    if (n >= 2) {
+      double prev_error = DBL_MAX;
+      for (int k = 0; k < ICP_INNER_MAX_ITER; ++k) {
+        double delta[3], err = 0.;
+        const int rc = evaluate(M, n, Ti, k < 2 ? k : 2, delta, &err);
+        if (rc == ICP_NONE) break;
+        if (rc != ICP_OK) return rc;
+        if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD) break;
+        if (err > prev_error) break;
+        prev_error = err;
+        Ti = transform_mul(transform_new(delta), Ti);
+        ++applied;
+      }
+    }
+    if (inner_iters) inner_iters[it] = applied;
+    T = transform_mul(Ti, T);
+  }
+  for (int q = 0; q < W; ++q) {
+    auto &R = M->r[q];
+    HIP_TRY(hipSetDevice(R.device));
+    HIP_TRY(hipStreamSynchronize(R.h->stream));
+    R.h->qsort.valid = false;
+    R.h->qsort.have_prev = false;
+    if (last_idx && max_iter > 0 && n_local[q]) {  // back to the caller's point order
+      std::vector<uint32_t> li(n_local[q]);
+      HIP_TRY(hipMemcpy(li.data(), R.d_idx, n_local[q] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      int b0, b1, B;
+      size_t nl;
+      shard_geometry(n, q, W, &b0, &b1, &B, &nl);
+      const size_t G = (size_t)B * kReduceThreads, c0 = (size_t)b0 * kReduceThreads, c1 = (size_t)b1 * kReduceThreads;
+      size_t l = 0;
+      for (size_t base = 0; base < n; base += G) {
+        const size_t s = base + c0, e = base + c1 < n ? base + c1 : n;
+        for (size_t i = s; i < e; ++i) last_idx[i] = li[l++];
+      }
+    }
+  }
+  *out = T;
+  return ICP_OK;
+}

@@ -127,15 +127,20 @@ __global__ void k_shard_pack_candidates(const WinState *__restrict__ st, const d
 }
 
 // the candidates of every rank, concatenated in rank order into this rank's dense lists (any order would do)
-__global__ void k_shard_merge_candidates(const unsigned char *__restrict__ all, size_t stride, int world, WinState *st,
-                                         double *__restrict__ wmed, double *__restrict__ wring) {
+// (`srcs`: one pointer per rank -- slices of an all-gathered buffer, or the ranks' own export buffers
+// read in place over xGMI, icp_create_multi)
+struct ShardPtrs {
+  const unsigned char *p[kShardMaxWorld];
+};
+__global__ void k_shard_merge_candidates(ShardPtrs srcs, int world, WinState *st, double *__restrict__ wmed,
+                                         double *__restrict__ wring) {
   __shared__ unsigned s_base[4];
   __shared__ unsigned s_fail;
   const int r = blockIdx.x;  // one workgroup per source rank
   if (threadIdx.x == 0) {
     unsigned base[4] = {0, 0, 0, 0}, fail = 0;
     for (int q = 0; q < world; ++q) {
-      const ShardCandHeader *hq = reinterpret_cast<const ShardCandHeader *>(all + (size_t)q * stride);
+      const ShardCandHeader *hq = reinterpret_cast<const ShardCandHeader *>(srcs.p[q]);
       fail |= hq->fail;
       if (q < r)
         for (int k = 0; k < 4; ++k) base[k] += hq->cnt[k];
@@ -143,15 +148,15 @@ __global__ void k_shard_merge_candidates(const unsigned char *__restrict__ all, 
     for (int k = 0; k < 4; ++k) s_base[k] = base[k];
     s_fail = fail;
     if (r == world - 1) {  // totals: what k_win_accumulate cross-checks against the histogram's counts
-      const ShardCandHeader *hl = reinterpret_cast<const ShardCandHeader *>(all + (size_t)r * stride);
+      const ShardCandHeader *hl = reinterpret_cast<const ShardCandHeader *>(srcs.p[r]);
       for (int k = 0; k < 4; ++k) st->list_cnt[k][0] = base[k] + hl->cnt[k];
       st->fail = fail ? 1u : 0u;
     }
   }
   __syncthreads();
   if (s_fail) return;
-  const ShardCandHeader *hd = reinterpret_cast<const ShardCandHeader *>(all + (size_t)r * stride);
-  const double *body = reinterpret_cast<const double *>(all + (size_t)r * stride + sizeof(ShardCandHeader));
+  const ShardCandHeader *hd = reinterpret_cast<const ShardCandHeader *>(srcs.p[r]);
+  const double *body = reinterpret_cast<const double *>(srcs.p[r] + sizeof(ShardCandHeader));
   for (int d = 0; d < 2; ++d) {
     for (unsigned e = threadIdx.x; e < hd->cnt[d]; e += blockDim.x)
       if (s_base[d] + e < (unsigned)kWinCapMed) wmed[(size_t)d * kWinCapMed + s_base[d] + e] = body[(size_t)d * kWinCapMed + e];
@@ -181,7 +186,7 @@ __global__ void k_shard_pack_partials(const double *__restrict__ partials, int b
 }
 
 // second stage of the tree over the block sums of every rank, in block order; one workgroup
-__global__ __launch_bounds__(kReduceThreads) void k_shard_fold(const double *__restrict__ all, int rows, int world,
+__global__ __launch_bounds__(kReduceThreads) void k_shard_fold(ShardPtrs srcs, int rows, int world,
                                                                int blocks_total, double *__restrict__ ordered,
                                                                GnResult *res, unsigned seq) {
   const int W = kNAcc + 1;
@@ -191,15 +196,16 @@ __global__ __launch_bounds__(kReduceThreads) void k_shard_fold(const double *__r
     while ((long long)blocks_total * r / world > b) --r;
     while ((long long)blocks_total * (r + 1) / world <= b) ++r;
     const int b0 = (int)((long long)blocks_total * r / world);
-    for (int k = 0; k < W; ++k) ordered[(size_t)b * W + k] = all[((size_t)r * rows + (b - b0)) * W + k];
+    const double *pr = reinterpret_cast<const double *>(srcs.p[r]);
+    for (int k = 0; k < W; ++k) ordered[(size_t)b * W + k] = pr[(size_t)(b - b0) * W + k];
   }
   int nan_flag = 0, overflow = 0;
   for (int r = 0; r < world; ++r) {
-    const double *fl = all + ((size_t)r * rows + (rows - 1)) * W;
+    const double *fl = reinterpret_cast<const double *>(srcs.p[r]) + (size_t)(rows - 1) * W;
     nan_flag |= fl[0] != 0.;
     overflow |= (int)fl[1];
   }
-  const double *f0 = all + (size_t)(rows - 1) * W;  // every rank selected the same statistics
+  const double *f0 = reinterpret_cast<const double *>(srcs.p[0]) + (size_t)(rows - 1) * W;  // every rank selected the same statistics
   const double med[2] = {f0[2], f0[3]}, sig[2] = {f0[4], f0[5]};
   __syncthreads();
   __threadfence();
@@ -235,11 +241,22 @@ hipError_t shard_launch_compact(icp_handle *h, size_t n_local, size_t n_total, c
   return hipGetLastError();
 }
 
-hipError_t shard_launch_accumulate(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
-                                   const void *d_cand_all, int world, int blocks_local, void *d_out) {
+static ShardPtrs slices(const void *base, size_t stride, int world) {
+  ShardPtrs t;
+  for (int q = 0; q < kShardMaxWorld; ++q) t.p[q] = (const unsigned char *)base + (size_t)(q < world ? q : 0) * stride;
+  return t;
+}
+static ShardPtrs table(const void *const *ptrs, int world) {
+  ShardPtrs t;
+  for (int q = 0; q < kShardMaxWorld; ++q) t.p[q] = (const unsigned char *)ptrs[q < world ? q : 0];
+  return t;
+}
+
+static hipError_t accumulate_from(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
+                                  const ShardPtrs &cands, int world, int blocks_local, void *d_out) {
   Workspace &w = h->ws;
-  hipLaunchKernelGGL(k_shard_merge_candidates, dim3(world), dim3(256), 0, h->stream, (const unsigned char *)d_cand_all,
-                     shard_cand_bytes(), world, w.d_wstate, w.d_wmed, w.d_wring);
+  hipLaunchKernelGGL(k_shard_merge_candidates, dim3(world), dim3(256), 0, h->stream, cands, world, w.d_wstate, w.d_wmed,
+                     w.d_wring);
   if (blocks_local > 0)
     hipLaunchKernelGGL((k_win_accumulate<true, false>), dim3(blocks_local), dim3(kReduceThreads), 0, h->stream,
                        (const double2 *)d_a, (const double *)w.d_rx, (const double *)w.d_ry, (unsigned)n_local,
@@ -250,11 +267,100 @@ hipError_t shard_launch_accumulate(icp_handle *h, const double *d_a, size_t n_lo
                      (const double *)w.d_partials, blocks_local, rows, (const GnScalars *)w.d_scal, (double *)d_out);
   return hipGetLastError();
 }
+hipError_t shard_launch_accumulate(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
+                                   const void *d_cand_all, int world, int blocks_local, void *d_out) {
+  return accumulate_from(h, d_a, n_local, n_total, T, slices(d_cand_all, shard_cand_bytes(), world), world, blocks_local,
+                         d_out);
+}
+hipError_t shard_launch_accumulate_ptrs(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
+                                        const void *const *cand_ptrs, int world, int blocks_local, void *d_out) {
+  return accumulate_from(h, d_a, n_local, n_total, T, table(cand_ptrs, world), world, blocks_local, d_out);
+}
 
 hipError_t shard_launch_fold(icp_handle *h, const void *d_part_all, int world, int blocks_total, double *d_ordered) {
   Workspace &w = h->ws;
-  hipLaunchKernelGGL(k_shard_fold, dim3(1), dim3(kReduceThreads), 0, h->stream, (const double *)d_part_all,
+  hipLaunchKernelGGL(k_shard_fold, dim3(1), dim3(kReduceThreads), 0, h->stream,
+                     slices(d_part_all, shard_part_bytes(world), world), shard_part_rows(world), world, blocks_total,
+                     d_ordered, w.h_res, ++w.seq);
+  return hipGetLastError();
+}
+hipError_t shard_launch_fold_ptrs(icp_handle *h, const void *const *part_ptrs, int world, int blocks_total,
+                                  double *d_ordered) {
+  Workspace &w = h->ws;
+  hipLaunchKernelGGL(k_shard_fold, dim3(1), dim3(kReduceThreads), 0, h->stream, table(part_ptrs, world),
                      shard_part_rows(world), world, blocks_total, d_ordered, w.h_res, ++w.seq);
+  return hipGetLastError();
+}
+
+// ---- in-library exchange of icp_create_multi: flags + peer reads ---------------------------------
+// A rank publishes a stage by bumping its own flag (system scope) behind the kernels that wrote the
+// exported bytes; a consumer first runs k_multi_wait, one lane per peer, BOUNDED (a peer that never
+// arrives raises the error word instead of hanging the queue).  Ranks that share a device run on ONE
+// stream in lockstep order, so their waits are already satisfied when they are reached.
+__global__ void k_multi_signal(unsigned *flag, unsigned value) {
+  __threadfence_system();
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct FlagPtrs {
+  const unsigned *p[kShardMaxWorld];
+};
+__global__ void k_multi_wait(FlagPtrs flags, int world, unsigned value, unsigned *err) {
+  const int q = threadIdx.x;
+  if (q < world) {
+    bool ok = false;
+    for (unsigned spin = 0; spin < 4000000u; ++spin) {
+      if ((int)(__hip_atomic_load(flags.p[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) >= 0) {
+        ok = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok) atomicOr(err, 1u);
+  }
+  __threadfence_system();
+}
+__global__ void k_multi_sum_hist(ShardPtrs srcs, int world, uint32_t *__restrict__ out, unsigned words) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= words) return;
+  uint32_t s = 0;
+  for (int q = 0; q < world; ++q) s += reinterpret_cast<const uint32_t *>(srcs.p[q])[i];
+  out[i] = s;
+}
+// pairs of rank q (its local a | b, n_q each) into this rank's full arrays, global order
+__global__ void k_multi_put_pairs(const double2 *__restrict__ a_loc, const double2 *__restrict__ b_loc, size_t n_q,
+                                  unsigned b0, unsigned b1, unsigned B, double2 *__restrict__ a_full,
+                                  double2 *__restrict__ b_full) {
+  const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_q) return;
+  const size_t i = shard_global_index(l, b0, b1, B);
+  a_full[i] = a_loc[l];
+  b_full[i] = b_loc[l];
+}
+
+hipError_t multi_signal(hipStream_t s, unsigned *flag, unsigned value) {
+  hipLaunchKernelGGL(k_multi_signal, dim3(1), dim3(1), 0, s, flag, value);
+  return hipGetLastError();
+}
+hipError_t multi_wait(hipStream_t s, const unsigned *const *flags, int world, unsigned value, unsigned *err) {
+  FlagPtrs f;
+  for (int q = 0; q < kShardMaxWorld; ++q) f.p[q] = flags[q < world ? q : 0];
+  hipLaunchKernelGGL(k_multi_wait, dim3(1), dim3(64), 0, s, f, world, value, err);
+  return hipGetLastError();
+}
+hipError_t multi_sum_hist(hipStream_t s, const void *const *hists, int world, uint32_t *out) {
+  const unsigned words = 2 * kWinBins;
+  hipLaunchKernelGGL(k_multi_sum_hist, dim3((words + 255) / 256), dim3(256), 0, s, table(hists, world), world, out, words);
+  return hipGetLastError();
+}
+hipError_t multi_put_pairs(hipStream_t s, const double *a_loc, const double *b_loc, size_t n_total, int rank, int world,
+                           double *a_full, double *b_full) {
+  int b0, b1, B;
+  size_t nq;
+  shard_geometry(n_total, rank, world, &b0, &b1, &B, &nq);
+  if (!nq) return hipSuccess;
+  hipLaunchKernelGGL(k_multi_put_pairs, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (const double2 *)a_loc,
+                     (const double2 *)b_loc, nq, (unsigned)b0, (unsigned)b1, (unsigned)B, (double2 *)a_full,
+                     (double2 *)b_full);
   return hipGetLastError();
 }
 

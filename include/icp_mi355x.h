@@ -234,6 +234,20 @@ int icp_shard_eval_compact_device(icp_handle *h, void *d_candidates_out);
 int icp_shard_eval_accumulate_device(icp_handle *h, const void *d_candidates_all, void *d_partials_out);
 int icp_shard_eval_finish_device(icp_handle *h, const void *d_partials_all, double delta[3], double *huber_err);
 
+/* The same from ONE host process over the GPUs of a node (SURVEY.md 8(b) sketch: device_ids /
+ * n_devices): rank r is a handle on device_ids[r], the target cloud is replicated, the source cloud
+ * sharded by reduction-tree block, and the three exchanges are peer reads over xGMI behind flags (no
+ * collective library: there is no ICP_RCCL_ERROR).  The result equals icp_estimate's on one GPU bit
+ * for bit.  device_ids may repeat a device ("virtual ranks": how the N-rank path is tested on a
+ * one-GPU box; ranks on one device share a stream).  icp_multi_counters: out[0] evaluations that ran
+ * sharded, out[1] evaluations that fell back to gathered pairs. */
+typedef struct icp_multi icp_multi;
+int icp_create_multi(icp_multi **out, int dim, const double *dst, size_t m, const int *device_ids, int n_devices);
+int icp_multi_estimate(icp_multi *M, const double *src, size_t n, const icp_pose *init, size_t max_iter,
+                       icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters);
+int icp_multi_counters(const icp_multi *M, uint64_t out[2]);
+void icp_destroy_multi(icp_multi *M);
+
 /* Live kernel timing for the benchmark: with enable = k > 0, HIP events bracket every
  * k-th launch of the nearest-neighbour search kernel on the handle's stream (an event pair
  * costs a few us of stream time, so the benchmark samples instead of timing every launch);

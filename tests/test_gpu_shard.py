@@ -46,7 +46,7 @@ def test_virtual_ranks_reproduce_one_rank_bit_for_bit(world, n, m):
     assert np.array_equal(idx, idx1)
     # the steady state really ran sharded (three small exchanges), not on gathered pairs
     assert drv.counters["sharded"] >= 4, drv.counters
-    assert drv.counters["replicated"] >= 2  # the first evaluation of each kind has no prediction yet
+    assert drv.counters["replicated"] >= 1  # the very first evaluation has no prediction of its statistics yet
 
 
 def test_virtual_ranks_2d_and_against_the_oracle():
@@ -78,3 +78,41 @@ def test_stage_calls_refuse_what_they_cannot_serve():
     assert rc == I._lib.RETRY_REPLICATED
     assert block_shard(3000, 7, 8)[3] + block_shard(3000, 0, 8)[3] <= 3000
     assert I.lib().icp_shard_eval_compact_device(h._h, None) == I._lib.BAD_ARGUMENT
+
+
+@pytest.mark.parametrize("world,n,m,dim", [(2, 150_000, 120_000, 3), (8, 150_000, 120_000, 3), (3, 70_001, 50_000, 2),
+                                            (4, 3_000, 9_000, 3), (4, 1, 5000, 3), (2, 0, 5000, 3)])
+def test_icp_create_multi_with_virtual_ranks_equals_one_handle(world, n, m, dim):
+    """icp_create_multi (one process, in-library exchange) with every rank on cuda:0: pose, indices
+    and inner-iteration counts of icp_estimate on one handle, bit for bit.  3 000 points: fewer tree
+    blocks than ranks -> every evaluation falls back to gathered pairs (still the same bits)."""
+    src, dst = synth.synthetic_pair(max(n, 1), m)
+    src = src[:n]
+    if dim == 2:
+        src, dst = np.ascontiguousarray(src[:, :2]), np.ascontiguousarray(dst[:, :2])
+    one = (I.Icp3d if dim == 3 else I.Icp2d)(dst)
+    init = I.Transform([0.01, -0.02, 0.001])
+    T1, idx1, inner1 = one.estimate(src, init, 5, return_info=True)
+    multi = I.IcpMulti(dst, [0] * world, dim=dim)
+    T, idx, inner = multi.estimate(src, init, 5, return_info=True)
+    assert np.array_equal(T.as_array(), T1.as_array())
+    assert np.array_equal(inner, inner1) and np.array_equal(idx, idx1)
+    sharded, replicated = multi.counters()
+    if n >= 20_000:
+        assert sharded >= 4 and replicated >= 1
+    # a second call on the same object (buffers, flags and generations carry over)
+    T2 = multi.estimate(src, init, 5)
+    assert np.array_equal(T2.as_array(), T1.as_array())
+    multi.close()
+
+
+def test_icp_create_multi_argument_checks():
+    _, dst = synth.synthetic_pair(1, 5000)
+    with pytest.raises(I.IcpError):
+        I.IcpMulti(dst, [0, 99])
+    with pytest.raises(I.IcpError):
+        I.IcpMulti(dst, [])
+    e = I.IcpMulti(np.zeros((0, 3)), [0, 0])
+    with pytest.raises(I.IcpError) as ex:
+        e.estimate(dst[:10], I.Transform(), 1)
+    assert ex.value.status == I._lib.EMPTY_DST
