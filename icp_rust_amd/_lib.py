@@ -13,7 +13,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 # ICP_MI355X_LIB: load another build of the same library (e.g. the diagnostic one with counters)
 LIB_PATH = os.environ.get("ICP_MI355X_LIB") or os.path.join(_HERE, "lib", "libicp_mi355x.so")
 
-OK, NONE, EMPTY_DST, NAN_INPUT, BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, OUT_OF_MEMORY, RETRY_REPLICATED = range(9)
+OK, NONE, EMPTY_DST, NAN_INPUT, BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, OUT_OF_MEMORY, RETRY_REPLICATED, RETRY_SHARDED = range(10)
 NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
 
 
@@ -92,7 +92,8 @@ SIGNATURES = {
     "icp_shard_partials_bytes": (_sz, [C.c_int]),
     "icp_shard_take_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _sz]),
     "icp_shard_put_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _sz]),
-    "icp_shard_eval_hist_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _pp, C.c_int, C.POINTER(_vp)]),
+    "icp_shard_eval_hist_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _pp, C.c_int, C.c_int,
+                                             C.POINTER(_vp)]),
     "icp_shard_eval_compact_device": (C.c_int, [_vp, _vp]),
     "icp_shard_eval_accumulate_device": (C.c_int, [_vp, _vp, _vp]),
     "icp_shard_eval_finish_device": (C.c_int, [_vp, _vp, _dp, _dp]),

@@ -75,6 +75,7 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_sa);
   (void)hipFree(w.d_sb);
   if (w.h_whist) (void)hipHostFree(w.h_whist);
+  if (w.h_tiny) (void)hipHostFree(w.h_tiny);
   (void)hipFree(w.d_rlist);
   (void)hipFree(w.d_rlist_len);
   (void)hipFree(w.d_part_d);
@@ -165,6 +166,7 @@ extern "C" const char *icp_status_string(int s) {
     case ICP_HIP_ERROR: return "HIP error";
     case ICP_OUT_OF_MEMORY: return "out of device memory";
     case ICP_RETRY_REPLICATED: return "sharded evaluation: evaluate this one on the gathered pairs";
+    case ICP_RETRY_SHARDED: return "sharded evaluation: the window missed; again with the refined window";
     default: return "unknown status";
   }
 }
@@ -788,6 +790,16 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
       h->qsort.have_prev = false;
     }
   } quiesce_on_exit{h};
+  // the reference's own sizes (2-D scans of ~650 points): the whole call in one launch on one CU
+  if (n > 0 && max_iter > 0 && h->m > 0) {
+    int tiny_status = -1;
+    HIP_TRY(launch_tiny_estimate(h, d_src, n, *init, max_iter, out, d_last_idx, inner_iters, &tiny_status));
+    if (tiny_status == 0) {
+      ++h->ws.tiny_calls;
+      return ICP_OK;
+    }
+    if (tiny_status == 3) return ICP_NAN_INPUT;
+  }
   static const bool no_spec = getenv("ICP_NO_SPECULATION") != nullptr;
   static const bool one_stream_env = getenv("ICP_SPEC_SAME_STREAM") != nullptr;
   static const bool nn_first = getenv("ICP_SPEC_NN_LAST") == nullptr;
@@ -1303,18 +1315,31 @@ extern "C" int icp_shard_put_device(icp_handle *h, const void *d_local, void *d_
 }
 
 extern "C" int icp_shard_eval_hist_device(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, int rank,
-                                          int world, const icp_pose *T, int kind, uint32_t **d_hist) {
+                                          int world, const icp_pose *T, int kind, int refined, uint32_t **d_hist) {
   if (!h || !T || !d_hist || world < 1 || rank < 0 || rank >= world || n_total >= 0xffffffffull) return ICP_BAD_ARGUMENT;
   icp_handle::ShardEval &S = h->shard;
   S.active = false;
+  if (refined && !S.refined_ready) return ICP_BAD_ARGUMENT;  // only right after ICP_RETRY_SHARDED
   if (!input_size_ok(n_total)) return ICP_NONE;  // check_input_size, src/lib.rs:225-228
   shard_geometry(n_total, rank, world, &S.b0, &S.b1, &S.blocks, &S.n_local);
   if (S.blocks < world || (S.n_local > 0 && (!d_a || !d_b))) return S.blocks < world ? ICP_RETRY_REPLICATED : ICP_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(ensure_workspace(h, S.n_local, false));
   Workspace &w = h->ws;
-  if (!window_usable(h, n_total, &S.P, kind)) return ICP_RETRY_REPLICATED;
+  if (refined) {
+    S.P = S.P2;
+  } else if (!window_usable(h, n_total, &S.P, kind, true, n_total > 1000000 ? 0.2 : 0.)) {
+    // (beyond 1M points a window narrow enough for the candidate lists would have to be predicted to
+    // ~0.01 sigma: the first attempt is instead as WIDE as the layout allows -- it tolerates a
+    // prediction that is off by 0.2 sigma -- and serves as the counting pass whose exact, global
+    // counts place the narrow window of the second attempt: two sharded passes, like the one-GPU path
+    // beyond 4M points, instead of a gather of all pairs)
+    return ICP_RETRY_REPLICATED;
+  }
+  S.attempt_refined = refined != 0;
+  S.refined_ready = false;
   if (!S.d_ordered) HIP_TRY(hipMalloc(&S.d_ordered, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double)));
+  if (!w.h_whist) HIP_TRY(hipHostMalloc(&w.h_whist, (size_t)2 * kWinBins * sizeof(uint32_t), hipHostMallocDefault));
   if (w.gn_dirty) {
     HIP_TRY(launch_sel_init(h, S.n_local));
     w.gn_dirty = false;
@@ -1335,6 +1360,9 @@ extern "C" int icp_shard_eval_hist_device(icp_handle *h, const double *d_a, cons
 extern "C" int icp_shard_eval_compact_device(icp_handle *h, void *d_candidates_out) {
   if (!h || !h->shard.active || !d_candidates_out) return ICP_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
+  // the global counts also go to the host: if this window misses, they place the next attempt's
+  HIP_TRY(hipMemcpyAsync(h->ws.h_whist, h->ws.d_whist, (size_t)2 * kWinBins * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                         h->stream));
   HIP_TRY(shard_launch_compact(h, h->shard.n_local, h->shard.n_total, h->shard.P, d_candidates_out));
   return ICP_OK;
 }
@@ -1362,9 +1390,18 @@ static int shard_finish_common(icp_handle *h, double delta[3], double *huber_err
     w.gn_dirty = true;
     return ICP_NAN_INPUT;
   }
-  if (r.overflow) {  // the window missed: wider next time, and this evaluation again on the gathered pairs
+  if (r.overflow) {
+    // The window missed (an order statistic outside its fine bins, or more candidates than the lists
+    // hold).  Its counts are still exact counts of ALL ranks' residuals: they place the median and the
+    // MAD to within a bin, and windows as narrow as the lists require go around them (refine_window,
+    // the host half of the one-GPU path beyond 4M points) -- the next attempt, still sharded, then
+    // hits.  Only a refined attempt that misses too goes back to the gathered pairs.
     ++w.win_missed;
     wide = true;
+    if (!S.attempt_refined && refine_window(w.h_whist, S.n_total, S.P, &S.P2)) {
+      S.refined_ready = true;
+      return ICP_RETRY_SHARDED;
+    }
     return ICP_RETRY_REPLICATED;
   }
   if (wide) {

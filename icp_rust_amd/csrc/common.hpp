@@ -142,6 +142,8 @@ struct Workspace : GnCtx {
   // refined windows (n > 4M, gn_win.hip): a strided sample of the pairs and a host copy of the histograms
   double *d_sa = nullptr, *d_sb = nullptr;
   uint32_t *h_whist = nullptr;
+  void *h_tiny = nullptr;  // pinned result block of the one-launch registration of small clouds (gn_fast.hip)
+  unsigned long long tiny_calls = 0, tiny_evals = 0, tiny_sorted = 0;
   double *d_rlist = nullptr;        // 2 x kRefineListCap: the residuals inside the second pass' fine windows
   unsigned *d_rlist_len = nullptr;  // [2]
   unsigned long long refine_tried = 0, refine_missed = 0;
@@ -247,6 +249,8 @@ struct icp_handle {
     icp::Pose T;
     double *d_ordered = nullptr;  // kReduceMaxBlocks x (kNAcc + 1): the block sums of all ranks in block order
     bool active = false;
+    icp::WinParams P2;            // the window refined from a missed attempt's global counts
+    bool refined_ready = false, attempt_refined = false;
   } shard;
   // EXTENSION (p2plane.hip): unit normals of the target points (m x 3), valid while normals_m == m
   double *d_normals = nullptr;
@@ -305,8 +309,12 @@ hipError_t launch_weighted_gn_fast(icp_handle *h, const double *d_a, const doubl
                                    const Pose &T);
 hipError_t launch_weighted_gn_pull(icp_handle *h, const double *d_a, const double *d_b, size_t n,
                                    const Pose &T);
+// the whole Icp::estimate of a small cloud in one launch (gn_fast.hip); *status = -1: not served
+hipError_t launch_tiny_estimate(icp_handle *h, const double *d_src, size_t n, const Pose &T0, size_t max_iter,
+                                Pose *out, uint32_t *d_last_idx, uint32_t *inner_iters, int *status);
 // three launches around a predicted window (gn_win.hip); h_res->overflow == 2 when it missed
-bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind = 2);
+bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind = 2, bool any_n = false,
+                   double f_override = 0.);
 hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double *d_b, size_t n,
                                   const Pose &T, const WinParams &P);
 // n > 4M: the window is found in two passes (gn_win.hip, "refined windows"); the host part of the

@@ -100,6 +100,12 @@ __device__ __forceinline__ void mad_ranks(const unsigned long long *S, unsigned 
   if (less <= hi_rank && hi_rank < leq) out[1] = d;
 }
 
+// src/stats.rs:18-27 on two order-preserving keys
+__device__ __forceinline__ double middle_of_host(unsigned n, unsigned long long klo, unsigned long long khi) {
+  const double lo = k2f(klo), hi = k2f(khi);
+  return (n & 1) ? lo : (lo + hi) / 2.;
+}
+
 // fold `acc` over a group of 8 waves (512 threads) in the tree of block_reduce_store:
 // wave shuffle tree, then a left fold of the wave sums from the group's first wave
 template <int N>
@@ -243,6 +249,447 @@ __global__ __launch_bounds__(1024) void k_tiny_eval(const double2 *__restrict__ 
            tst[1] - tst[0], tst[2] - tst[1], tst[3] - tst[2], tst[4] - tst[3], tst[5] - tst[4], tst[6] - tst[5],
            tst[7] - tst[6], tst[8] - tst[7]);
 #endif
+}
+
+// =======================================================================================
+// The WHOLE registration of a small cloud in ONE workgroup and ONE launch (round 2).
+//
+// Icp{2,3}d::estimate (src/lib.rs:105-130, 148-173) on the reference's own data -- 2-D scans of ~650
+// points (scans/2d) -- used to be ~80 launches with a host round trip per inner iteration
+// (src/lib.rs:66-82): 2.15 ms per estimate(20), level with one CPU core.  For n <= 1024 source points
+// and m <= 2048 targets everything now stays on one CU: the targets live in LDS (exact f64 + an f32
+// copy for the screen), every thread owns one source point; per outer iteration an exact
+// nearest-neighbour sweep (warm-started from the previous match), then the inner loop -- residuals,
+// the four exact order statistics, the weighted normal equations in the tree of reduce_geometry(n),
+// and, on thread 0, the 3x3 solve, the two break tests and Transform::new * T (src/lib.rs:71-81) with
+// the sin / cos of include/icp_trig.h, which the host and the oracle share -- so the bits are those of
+// the host-driven path.
+//
+// Order statistics without a full sort (the bitonic sort of k_tiny_eval is 12 of its 29 us): 64
+// evenly strided sample keys are sorted by one wave (register shuffles); every key finds its bucket
+// among the 64 splitters; one wave scans the 65 counts, finds the bucket(s) of the two middle ranks; the
+// ~10 keys in them are ranked by counting.  Exact for any input; more than 128 keys in the middle
+// buckets (heavy duplicates) -> the sorting path below serves that evaluation.
+// =======================================================================================
+struct TinySel {
+  unsigned long long spl[2][64];
+  unsigned long long list[2][128];
+  unsigned long long out[2][2];
+  unsigned hist[2][68];
+  unsigned ctl[2][4];  // b_lo, b_hi, points below b_lo, points in [b_lo, b_hi]
+  unsigned nlist[2];
+  unsigned overflow;
+};
+
+// the two middle order statistics (ranks (n-1)/2 and n/2) of the keys k0 (dimension 0) and k1, one
+// key of each per thread (`has`); false: too many equal-ish keys, the caller sorts instead
+__device__ __forceinline__ bool tiny_select(unsigned long long k0, unsigned long long k1, bool has, unsigned n,
+                                            TinySel *S) {
+  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned lo_rank = (n - 1) / 2, hi_rank = n / 2;
+  const unsigned long long key[2] = {k0, k1};
+  if (tid < 2 * 68) (&S->hist[0][0])[tid] = 0;
+  if (tid < 2) S->nlist[tid] = 0;
+  if (tid == 0) S->overflow = 0;
+  if (tid < 128) (&S->spl[0][0])[tid] = ~0ull;  // fewer than 64 points: the missing samples sort last
+  __syncthreads();
+  // samples: sample j is the key of thread floor(j n / ns)
+  const unsigned ns = n < 64u ? n : 64u;
+  if (has) {
+    const unsigned j = (tid * ns + n - 1) / n;  // smallest j with floor(j n / ns) >= tid
+    if (j < ns && (j * n) / ns == tid) {
+      S->spl[0][j] = k0;
+      S->spl[1][j] = k1;
+    }
+  }
+  __syncthreads();
+  if (wave < 2) {  // one wave per dimension: bitonic sort of the 64 samples in registers
+    unsigned long long v = S->spl[wave][lane];
+    for (unsigned k = 2; k <= 64; k <<= 1)
+      for (unsigned j = k >> 1; j > 0; j >>= 1) {
+        const unsigned long long o = __shfl_xor(v, (int)j);
+        const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+        v = keep_min ? (v < o ? v : o) : (v > o ? v : o);
+      }
+    S->spl[wave][lane] = v;
+  }
+  __syncthreads();
+  unsigned bucket[2] = {0, 0};
+  if (has) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {  // bucket = number of splitters < key: monotone in the key
+      unsigned lo = 0, hi = 64;
+      while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (S->spl[d][mid] < key[d]) lo = mid + 1;
+        else hi = mid;
+      }
+      bucket[d] = lo;
+      atomicAdd(&S->hist[d][lo], 1u);
+    }
+  }
+  __syncthreads();
+  if (wave < 2) {
+    const int d = wave;
+    const unsigned c = S->hist[d][lane], c64 = S->hist[d][64];
+    unsigned inc = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned t = __shfl_up(inc, off);
+      if ((int)lane >= off) inc += t;
+    }
+    const unsigned excl = inc - c;
+    const unsigned long long m_lo = __ballot(inc > lo_rank), m_hi = __ballot(inc > hi_rank);
+    const unsigned b_lo = m_lo ? (unsigned)__ffsll((long long)m_lo) - 1u : 64u;
+    const unsigned b_hi = m_hi ? (unsigned)__ffsll((long long)m_hi) - 1u : 64u;
+    const unsigned tot63 = __shfl(inc, 63);
+    const unsigned below = b_lo < 64u ? __shfl(excl, (int)b_lo) : tot63;
+    const unsigned upto = b_hi < 64u ? __shfl(inc, (int)b_hi) : tot63 + c64;
+    if (lane == 0) {
+      S->ctl[d][0] = b_lo;
+      S->ctl[d][1] = b_hi;
+      S->ctl[d][2] = below;
+      S->ctl[d][3] = upto - below;
+    }
+  }
+  __syncthreads();
+  if (has) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+      if (bucket[d] >= S->ctl[d][0] && bucket[d] <= S->ctl[d][1]) {
+        const unsigned pos = atomicAdd(&S->nlist[d], 1u);
+        if (pos < 128u) S->list[d][pos] = key[d];
+      }
+  }
+  __syncthreads();
+  if (wave < 2) {
+    const int d = wave;
+    const unsigned cnt = S->nlist[d];
+    if (cnt > 128u || cnt != S->ctl[d][3]) {
+      if (lane == 0) S->overflow = 1;
+    } else {
+      const unsigned r_lo = lo_rank - S->ctl[d][2], r_hi = hi_rank - S->ctl[d][2];
+      for (unsigned e = lane; e < cnt; e += 64) {
+        const unsigned long long ke = S->list[d][e];
+        unsigned less = 0, eq = 0;
+        for (unsigned j = 0; j < cnt; ++j) {
+          const unsigned long long kj = S->list[d][j];
+          less += kj < ke;
+          eq += kj == ke;
+        }
+        if (less <= r_lo && r_lo < less + eq) S->out[d][0] = ke;
+        if (less <= r_hi && r_hi < less + eq) S->out[d][1] = ke;
+      }
+    }
+  }
+  __syncthreads();
+  return S->overflow == 0;
+}
+
+struct TinyResult {  // pinned host memory
+  Pose pose;
+  int status;       // 0 ok, 3 NaN residual (ICP_NAN_INPUT), -1 hand the call to the host-driven path
+  unsigned evals;   // Gauss-Newton evaluations run, in all
+  unsigned sorted;  // ... of which by the sorting path
+  unsigned pad;
+};
+constexpr unsigned kTinyMaxN = 1024, kTinyMaxM = 2048, kTinyMaxIter = 1024;
+
+template <int DIM>
+__global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict__ src, unsigned n,
+                                                        const double *__restrict__ dst, unsigned m, Pose T0,
+                                                        unsigned max_iter, double cx, double cy, double cz, double scale,
+                                                        TinyResult *res, uint32_t *inner_out, uint32_t *idx_out) {
+  extern __shared__ unsigned char lds_raw[];
+  // ---- LDS carve-up ----
+  const unsigned mp = (m + 63u) & ~63u;
+  double *tx = reinterpret_cast<double *>(lds_raw);
+  double *ty = tx + mp;
+  double *tz = ty + mp;  // (DIM == 2: unused, zero length below)
+  float *gx = reinterpret_cast<float *>(tz + (DIM == 3 ? mp : 0));
+  float *gy = gx + mp;
+  float *gz = gy + mp;
+  unsigned char *p = reinterpret_cast<unsigned char *>(gz + (DIM == 3 ? mp : 0));
+  p = reinterpret_cast<unsigned char *>((reinterpret_cast<size_t>(p) + 15) & ~size_t(15));
+  unsigned long long(*sbuf)[2][1024] = reinterpret_cast<unsigned long long(*)[2][1024]>(p);  // sorting path
+  p += sizeof(unsigned long long) * 2 * 2 * 1024;
+  TinySel *S = reinterpret_cast<TinySel *>(p);
+  p += (sizeof(TinySel) + 15) & ~size_t(15);
+  double(*sm)[kNAcc + 1] = reinterpret_cast<double(*)[kNAcc + 1]>(p);
+  p += sizeof(double) * 16 * (kNAcc + 1);
+  double(*part)[kNAcc + 1] = reinterpret_cast<double(*)[kNAcc + 1]>(p);
+  p += sizeof(double) * 2 * (kNAcc + 1);
+  struct Ctl {
+    Pose Ti, T;
+    double s_mad[2][2];
+    int done, nan, bail;
+    unsigned applied, evals, sorted;
+  };
+  Ctl *C = reinterpret_cast<Ctl *>(p);
+
+  const unsigned tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const bool has = tid < n;
+  for (unsigned k = tid; k < m; k += 1024) {
+    const double x = dst[(size_t)k * DIM], y = dst[(size_t)k * DIM + 1];
+    tx[k] = x;
+    ty[k] = y;
+    gx[k] = (float)(x - cx);
+    gy[k] = (float)(y - cy);
+    if (DIM == 3) {
+      const double z = dst[(size_t)k * DIM + 2];
+      tz[k] = z;
+      gz[k] = (float)(z - cz);
+    }
+  }
+  double px = 0., py = 0., pz = 0.;
+  if (has) {
+    px = src[(size_t)tid * DIM];
+    py = src[(size_t)tid * DIM + 1];
+    if (DIM == 3) pz = src[(size_t)tid * DIM + 2];
+  }
+  if (tid == 0) {
+    C->T = T0;
+    C->nan = C->bail = 0;
+    C->evals = C->sorted = 0;
+  }
+  __syncthreads();
+  const int blocks = n > 512u ? 2 : 1;  // reduce_geometry(n) for n <= 1024: 512-thread blocks
+  const unsigned lo_rank = (n - 1) / 2, hi_rank = n / 2;
+  unsigned bi = 0xffffffffu;
+  for (unsigned it = 0; it < max_iter; ++it) {
+    const Pose T = C->T;
+    // ---- transform + exact nearest neighbour (src/lib.rs:113-124 / 156-167) ----
+    double ax = 0., ay = 0., bx = 0., by = 0.;
+    if (has) {
+      const double qx = (T.r00 * px + T.r01 * py) + T.tx;  // Transform::transform, src/transform.rs:22-24
+      const double qy = (T.r10 * px + T.r11 * py) + T.ty;
+      const double qz = pz;
+      const double ox = qx - cx, oy = qy - cy, oz = DIM == 3 ? qz - cz : 0.;
+      const float hx = (float)ox, hy = (float)oy, hz = (float)oz;
+      const double ec = (fmax(fmax(fabs(ox), fabs(oy)), fabs(oz)) + 2. * scale) * 1.2e-7 * 1.7320508075688774;
+      double best = __builtin_huge_val();
+      float thr = __builtin_huge_valf();
+      unsigned nb = 0xffffffffu;
+      auto exact = [&](unsigned k) {
+        const double dx = qx - tx[k], dy = qy - ty[k];
+        double d = dx * dx + dy * dy;
+        if (DIM == 3) {
+          const double dz = qz - tz[k];
+          d = d + dz * dz;
+        }
+        if (d < best || (d == best && k < nb)) {
+          best = d;
+          nb = k;
+          const double rr = sqrt(d) + ec;
+          thr = (float)(rr * rr * 1.000004) * 1.000001f + 1e-37f;  // rounded up (nn_brute.hip)
+        }
+      };
+      if (bi != 0xffffffffu) exact(bi);  // warm start: the previous match bounds the sweep
+      for (unsigned k = 0; k < m; ++k) {
+        const float fx = hx - gx[k], fy = hy - gy[k];
+        float s2 = __builtin_fmaf(fy, fy, fx * fx);
+        if (DIM == 3) {
+          const float fz = hz - gz[k];
+          s2 = __builtin_fmaf(fz, fz, s2);
+        }
+        if (!(s2 > thr)) exact(k);
+      }
+      bi = nb;
+      const unsigned bb = nb == 0xffffffffu ? 0u : nb;  // no finite distance (NaN query): index 0, as a scan from 0 would
+      ax = qx;
+      ay = qy;
+      bx = tx[bb];
+      by = ty[bb];
+      if (idx_out && it + 1 == max_iter) idx_out[tid] = bb;
+    }
+    // ---- estimate_transform, src/lib.rs:59-84 ----
+    if (tid == 0) {
+      C->Ti = transform_identity();
+      C->done = n < 2u ? 1 : 0;  // check_input_size, src/lib.rs:186-189
+      C->applied = 0;
+    }
+    double prev_error = 1.7976931348623157e308;  // f64::MAX (thread 0 only)
+    __syncthreads();
+    for (int k = 0; k < ICP_INNER_MAX_ITER && !C->done; ++k) {
+      const Pose Ti = C->Ti;
+      double r0 = 0., r1 = 0.;
+      if (has) {  // residual(), src/lib.rs:34-36
+        r0 = ((Ti.r00 * ax + Ti.r01 * ay) + Ti.tx) - bx;
+        r1 = ((Ti.r10 * ax + Ti.r11 * ay) + Ti.ty) - by;
+        if ((r0 != r0) | (r1 != r1)) C->nan = 1;
+      }
+      double med[2], sig[2];
+      // medians, then MADs (src/stats.rs:11-47)
+      bool ok = tiny_select(has ? f2k(r0) : ~0ull, has ? f2k(r1) : ~0ull, has, n, S);
+      if (ok) {
+        med[0] = middle_of_host(n, S->out[0][0], S->out[0][1]);
+        med[1] = middle_of_host(n, S->out[1][0], S->out[1][1]);
+        __syncthreads();  // (S->out is rewritten by the next selection)
+        ok = tiny_select(has ? f2k(fabs(r0 - med[0])) : ~0ull, has ? f2k(fabs(r1 - med[1])) : ~0ull, has, n, S);
+        if (ok) {
+          sig[0] = ICP_PPF34 * middle_of_host(n, S->out[0][0], S->out[0][1]);
+          sig[1] = ICP_PPF34 * middle_of_host(n, S->out[1][0], S->out[1][1]);
+        }
+      }
+      if (!ok) {  // the sorting path of k_tiny_eval (uniform: S->overflow is shared)
+        unsigned long long ka = has ? f2k(r0) : ~0ull, kb = has ? f2k(r1) : ~0ull;
+        __syncthreads();
+        bitonic_sort2_1024(ka, kb, sbuf);
+        __syncthreads();
+        sbuf[0][0][tid] = ka;
+        sbuf[0][1][tid] = kb;
+        __syncthreads();
+        const double xl = k2f(sbuf[0][0][lo_rank]), xh = k2f(sbuf[0][0][hi_rank]);
+        const double yl = k2f(sbuf[0][1][lo_rank]), yh = k2f(sbuf[0][1][hi_rank]);
+        med[0] = (n & 1) ? xl : (xl + xh) / 2.;
+        med[1] = (n & 1) ? yl : (yl + yh) / 2.;
+        mad_ranks(sbuf[0][0], n, med[0], lo_rank, hi_rank, C->s_mad[0]);
+        mad_ranks(sbuf[0][1], n, med[1], lo_rank, hi_rank, C->s_mad[1]);
+        __syncthreads();
+        sig[0] = ICP_PPF34 * ((n & 1) ? C->s_mad[0][0] : (C->s_mad[0][0] + C->s_mad[0][1]) / 2.);
+        sig[1] = ICP_PPF34 * ((n & 1) ? C->s_mad[1][0] : (C->s_mad[1][0] + C->s_mad[1][1]) / 2.);
+        if (tid == 0) ++C->sorted;
+      }
+      // weighted normal equations + Huber error (src/lib.rs:238-255, 45-50), one point per thread
+      double acc[kNAcc + 1];
+#pragma unroll
+      for (int q = 0; q < kNAcc + 1; ++q) acc[q] = 0.;
+      if (has) {
+        const double g[2] = {1. / sig[0], 1. / sig[1]};
+        const double r[2] = {r0, r1};
+        const double a0 = -ay, a1 = ax;  // jacobian(), src/lib.rs:176-184
+        const double b0 = Ti.r00 * a0 + Ti.r01 * a1;
+        const double b1 = Ti.r10 * a0 + Ti.r11 * a1;
+        const double J[2][3] = {{Ti.r00, Ti.r01, b0}, {Ti.r10, Ti.r11, b1}};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (sig[j] == 0.) continue;
+          const double r_ij = r[j];
+          const double wg = huber_drho(r_ij * r_ij) * g[j];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc[9 + q] = acc[9 + q] + (wg * J[j][q]) * r_ij;
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[3 * pp + q] = acc[3 * pp + q] + (wg * J[j][pp]) * J[j][q];
+        }
+        acc[12] = acc[12] + huber_rho(r[0] * r[0] + r[1] * r[1]);
+      }
+      // the tree of reduce_geometry(n), exactly as k_tiny_eval folds it
+      if ((unsigned)wave * 64u < n) {
+        group_reduce<kNAcc + 1>(acc, sm, wave);
+      } else if ((tid & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < kNAcc + 1; ++q) sm[wave][q] = 0.;
+      }
+      __syncthreads();
+      if (tid < 2 * (kNAcc + 1)) {
+        const int vb = tid / (kNAcc + 1), q = tid % (kNAcc + 1);
+        double v = sm[8 * vb][q];
+        for (int w = 1; w < 8; ++w) v = v + sm[8 * vb + w][q];
+        part[vb][q] = v;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double tot[kNAcc];
+        for (int q = 0; q < kNAcc; ++q) {
+          const double p0 = (0. + part[0][q]) + 0.;
+          const double p1 = blocks > 1 ? (0. + part[1][q]) + 0. : 0.;
+          tot[q] = (p0 + p1) + 0.;
+        }
+        ++C->evals;
+        double delta[3];
+        if (C->nan) {
+          C->done = 1;
+        } else if (!solve_update(tot, tot + 9, delta)) {
+          C->done = 1;  // None, src/lib.rs:67-69
+        } else if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD) {
+          C->done = 1;  // src/lib.rs:71-73
+        } else if (tot[12] > prev_error) {
+          C->done = 1;  // src/lib.rs:75-78
+        } else {
+          prev_error = tot[12];
+          bool in_range;
+          const Pose D = transform_new_in_range(delta, &in_range);
+          if (!in_range) {
+            C->bail = 1;  // a rotation beyond the restated range of sin / cos: the host-driven path serves
+            C->done = 1;
+          } else {
+            C->Ti = transform_mul(D, Ti);  // src/lib.rs:81
+            ++C->applied;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      if (inner_out) inner_out[it] = C->applied;
+      C->T = transform_mul(C->Ti, T);  // src/lib.rs:127, 170
+    }
+    __syncthreads();
+    if (C->nan | C->bail) break;
+  }
+  if (tid == 0) {
+    res->pose = C->T;
+    res->evals = C->evals;
+    res->sorted = C->sorted;
+    res->status = C->nan ? 3 : (C->bail ? -1 : 0);
+  }
+}
+
+static size_t tiny_lds_bytes(int dim, unsigned m) {
+  const size_t mp = (m + 63u) & ~63u;
+  size_t b = mp * (size_t)dim * (sizeof(double) + sizeof(float)) + 16;
+  b += sizeof(unsigned long long) * 2 * 2 * 1024;
+  b += (sizeof(TinySel) + 15) & ~size_t(15);
+  b += sizeof(double) * 18 * (kNAcc + 1);
+  b += 512;  // Ctl
+  return b;
+}
+
+// Icp{2,3}d::estimate for a small cloud in one launch.  *status: 0 done, 3 NaN, -1 not served (too large,
+// no bounding box, disabled, or the kernel handed the call back): the caller runs the general path.
+hipError_t launch_tiny_estimate(icp_handle *h, const double *d_src, size_t n, const Pose &T0, size_t max_iter,
+                                Pose *out, uint32_t *d_last_idx, uint32_t *inner_iters, int *status) {
+  static const bool off = getenv("ICP_NO_TINY_ESTIMATE") != nullptr;
+  *status = -1;
+  if (off || n < 1 || n > kTinyMaxN || h->m < 1 || h->m > kTinyMaxM || max_iter < 1 || max_iter > kTinyMaxIter ||
+      !h->grid.built || h->nn_mode == ICP_NN_GRID)
+    return hipSuccess;
+  Workspace &w = h->ws;
+  hipError_t e;
+  if (!w.h_tiny) {
+    if ((e = hipHostMalloc(&w.h_tiny, sizeof(TinyResult) + kTinyMaxIter * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+      return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiny_estimate<2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess)
+      return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiny_estimate<3>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess)
+      return e;
+  }
+  TinyResult *res = reinterpret_cast<TinyResult *>(w.h_tiny);
+  uint32_t *inner = reinterpret_cast<uint32_t *>(res + 1);
+  const GridParams &g = h->grid.p;
+  const double cx = 0.5 * (g.lo[0] + g.hi[0]), cy = 0.5 * (g.lo[1] + g.hi[1]), cz = 0.5 * (g.lo[2] + g.hi[2]);
+  const size_t lds = tiny_lds_bytes(h->dim, (unsigned)h->m);
+  if (h->dim == 3)
+    hipLaunchKernelGGL(k_tiny_estimate<3>, dim3(1), dim3(1024), lds, h->stream, d_src, (unsigned)n, h->d_dst,
+                       (unsigned)h->m, T0, (unsigned)max_iter, cx, cy, cz, g.scale, res, inner, d_last_idx);
+  else
+    hipLaunchKernelGGL(k_tiny_estimate<2>, dim3(1), dim3(1024), lds, h->stream, d_src, (unsigned)n, h->d_dst,
+                       (unsigned)h->m, T0, (unsigned)max_iter, cx, cy, cz, g.scale, res, inner, d_last_idx);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
+  *status = res->status;
+  if (res->status == 0) {
+    *out = res->pose;
+    if (inner_iters)
+      for (size_t i = 0; i < max_iter; ++i) inner_iters[i] = inner[i];
+    w.tiny_evals += res->evals;
+    w.tiny_sorted += res->sorted;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_weighted_gn_fast(icp_handle *h, const double *d_a, const double *d_b, size_t n_, const Pose &T) {

@@ -881,12 +881,14 @@ template __global__ void k_win_compact<false>(const double *__restrict__, const 
                                               const unsigned *__restrict__, unsigned);
 
 // ---- host ---------------------------------------------------------------------------
-bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind) {
+bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind, bool any_n, double f_override) {
   static const bool off = getenv("ICP_GN_NO_WIN") != nullptr;
   // half-width of the fine windows in sigmas: the prediction may be off by about that much
   static const double hw_sigmas = getenv("ICP_WIN_HW") ? atof(getenv("ICP_WIN_HW")) : 0.05;
   const Workspace &w = h->ws;
-  if (off || n < kWinMinN || n > kWinMaxN) return false;
+  // (any_n: the sharded evaluation, which refines a window that missed from that attempt's own counts
+  // instead of giving up -- api.hip, shard_finish_common -- and so serves any number of points)
+  if (off || n < kWinMinN || (n > kWinMaxN && !any_n)) return false;
   // the evaluation's own kind first (common.hpp, Workspace::win_kind), else the most recent evaluation
   const bool own = kind >= 0 && kind < 2 && w.win_kind[kind].valid;
   if (!own && !w.win_valid) return false;
@@ -894,6 +896,7 @@ bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind) {
   const double *p_sigma = own ? w.win_kind[kind].sigma : w.win_sigma;
   double f = hw_sigmas * ((own ? w.win_kind[kind].wide : w.win_wide) ? 4. : 1.);
   if (n > 1000000) f *= 1e6 / (double)n;  // candidates per fine bin grow with n
+  if (f_override > 0.) f = f_override;
   if (f > 0.2) f = 0.2;                   // the windows must not overlap (MAD = 0.6745 sigma)
   return make_window(p_med, p_sigma, f, P);
 }

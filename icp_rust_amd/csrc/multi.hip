@@ -124,13 +124,13 @@ int wait_all(icp_multi *M, icp_multi::Rank &R, int which, unsigned value) {
 }
 
 // weighted_gauss_newton_update at inner pose T on every rank; all ranks return the same status / delta
-int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta[3], double *err) {
+int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta[3], double *err, int refined = 0) {
   const int W = M->world;
   uint32_t *hist[kShardMaxWorld];
   int rc0 = ICP_OK;
   for (int q = 0; q < W; ++q) {
     auto &R = M->r[q];
-    const int rc = icp_shard_eval_hist_device(R.h, R.d_a, R.d_b, n_total, q, W, &T, kind, &hist[q]);
+    const int rc = icp_shard_eval_hist_device(R.h, R.d_a, R.d_b, n_total, q, W, &T, kind, refined, &hist[q]);
     if (q == 0) rc0 = rc;
     else if (rc != rc0) return ICP_HIP_ERROR;  // the ranks' prediction state diverged: cannot happen
   }
@@ -187,6 +187,7 @@ int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta
     }
     for (auto &R : M->r)  // a peer that never arrived?
       if (__atomic_load_n(R.d_err, __ATOMIC_ACQUIRE)) return ICP_HIP_ERROR;
+    if (rcf == ICP_RETRY_SHARDED) return evaluate(M, n_total, T, kind, delta, err, 1);  // refined window
     if (rcf != ICP_RETRY_REPLICATED) {
       ++M->sharded;
       return rcf;

@@ -260,6 +260,163 @@ auto pair_step = [&](unsigned k) {
   }
 }
 
+// The sweep with the screen as a DOT PRODUCT (round 2).  The screen above spends 3 subtractions, a
+// multiplication and two FMAs on a pair; |q - p|^2 = |q|^2 + (|p|^2 - 2 q.p) needs three FMAs: the
+// bracket is accumulated from the target's precomputed |p|^2 with the query's precomputed -2q, and
+// |q|^2 moves into the threshold.  7 -> 4 vector operations per pair (the compare included), which is
+// what this kernel is bound by (10^12 pairs against 52 MB).  The price is
+// cancellation: the bracket is evaluated in f32 on magnitudes up to (|q| + |p|)^2, so it differs from
+// the exact |qf - pf|^2 - |qf|^2 by up to 6 * 2^-24 (|q| + |p|)^2 (three FMA roundings on partial sums
+// bounded by |p|^2 + 2|q||p|, the rounding of the stored |p|^2, of |q|^2 and of the threshold
+// arithmetic).  That bound -- `margin`, with coordinates taken relative to the CENTRE of the target
+// bounding box to keep it small -- is added to the threshold, so the screen lets more pairs through to
+// the exact f64 test (at 1M points in an 80 m box: pairs within ~0.15 m of a query instead of ~0.07 m),
+// never fewer: same indices, bit for bit.  A tile holds {x, y, z, |p|^2} per target: one 16-byte LDS
+// broadcast read per target.
+template <int DIM, int R, bool XFORM, bool FULL = true>
+__global__ __launch_bounds__(kNnThreads) void k_nn_brute_dot(
+    const double *__restrict__ src, unsigned n, const double *__restrict__ tx, const double *__restrict__ ty,
+    const double *__restrict__ tz, const float *__restrict__ fx, const float *__restrict__ fy,
+    const float *__restrict__ fz, unsigned m_pad, unsigned chunk, Pose T, double ox, double oy, double oz, double scale,
+    float pmax, double *__restrict__ part_d, uint32_t *__restrict__ part_i) {
+  static_assert(R >= 2 && R % 2 == 0, "queries are processed two per packed instruction");
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  __shared__ double sx[kNnTile];
+  __shared__ double sy[kNnTile];
+  __shared__ double sz[DIM == 3 ? kNnTile : 1];
+  __shared__ float4 g4[kNnTile];
+
+  const unsigned q0 = blockIdx.x * (kNnThreads * R) + threadIdx.x;
+  // Registers decide how many waves hide the LDS latency of the hot loop (the first version kept the
+  // queries' f64 coordinates resident: 174 VGPRs, two waves per SIMD, and every target step waited out
+  // its LDS read -- profiles/r02_brute_pmc.txt).  The exact coordinates are needed only in the rare
+  // exact test: they are re-read from `src` there (same loads, same arithmetic, same bits).
+  auto query = [&](int r, double &x, double &y, double &z) {
+    const unsigned q = q0 + r * kNnThreads;
+    x = y = z = 0.;
+    if (q < n) {
+      x = src[(size_t)q * DIM + 0];
+      y = src[(size_t)q * DIM + 1];
+      if (DIM == 3) z = src[(size_t)q * DIM + 2];
+    }
+    if (XFORM) {  // Transform::transform, src/transform.rs:22-24 (z untouched, lib.rs:52-57)
+      const double nx = (T.r00 * x + T.r01 * y) + T.tx;
+      const double ny = (T.r10 * x + T.r11 * y) + T.ty;
+      x = nx;
+      y = ny;
+    }
+  };
+  double best[R];
+  f2 mx[R / 2], my[R / 2], mz[R / 2];  // -2 (q - org), two queries per register pair
+  float thr[R], mq[R];                 // mq = margin - |q - org|^2
+  float ecf = 0.f;                     // (one bound for the lane's queries: the largest)
+  unsigned bi[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double x, y, z;
+    query(r, x, y, z);
+    const double ax = x - ox, ay = y - oy, az = DIM == 3 ? z - oz : 0.;
+    const float hx = (float)ax, hy = (float)ay, hz = (float)az;
+    if (r & 1) {
+      mx[r / 2].y = -2.f * hx;
+      my[r / 2].y = -2.f * hy;
+      mz[r / 2].y = -2.f * hz;
+    } else {
+      mx[r / 2].x = -2.f * hx;
+      my[r / 2].x = -2.f * hy;
+      mz[r / 2].x = -2.f * hz;
+    }
+    const float qq = (float)(((double)hx * hx + (double)hy * hy) + (double)hz * hz);  // exact in f64, rounded once
+    const float qn = __builtin_sqrtf(qq) * 1.000001f + pmax;
+    mq[r] = 5.5e-7f * qn * qn - qq;  // see the header comment
+    // rounded up: the bound on |(qf - pf) - (q - p)|, as in the screen above
+    ecf = fmaxf(ecf, (float)((fmax(fmax(fabs(ax), fabs(ay)), fabs(az)) + 2. * scale) * 1.2e-7 * 1.7320508075688774) * 1.000001f);
+    best[r] = __builtin_huge_val();
+    thr[r] = __builtin_huge_valf();
+    bi[r] = 0xffffffffu;
+  }
+
+  const unsigned t_begin = blockIdx.y * chunk;
+  const unsigned t_end = min(m_pad, t_begin + chunk);
+  for (unsigned t0 = t_begin; t0 < t_end; t0 += kNnTile) {
+    const unsigned len = FULL ? (unsigned)kNnTile : min((unsigned)kNnTile, t_end - t0);  // a multiple of 64
+    __syncthreads();
+    for (unsigned k = threadIdx.x; k < len; k += kNnThreads) {
+      sx[k] = tx[t0 + k];
+      sy[k] = ty[t0 + k];
+      const float px = fx[t0 + k], py = fy[t0 + k];
+      float pz = 0.f;
+      if (DIM == 3) {
+        sz[k] = tz[t0 + k];
+        pz = fz[t0 + k];
+      }
+      g4[k] = make_float4(px, py, pz, __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px)));
+    }
+    __syncthreads();
+    auto pair_step = [&](unsigned k, const float4 g) {
+      const f2 px2 = {g.x, g.x}, py2 = {g.y, g.y}, pz2 = {g.z, g.z}, pp2 = {g.w, g.w};
+      float s[R];
+      unsigned long long any = 0;
+#pragma unroll
+      for (int r = 0; r < R; r += 2) {
+        f2 v = __builtin_elementwise_fma(mx[r / 2], px2, pp2);
+        v = __builtin_elementwise_fma(my[r / 2], py2, v);
+        if (DIM == 3) v = __builtin_elementwise_fma(mz[r / 2], pz2, v);
+        s[r] = v.x;
+        s[r + 1] = v.y;
+        any |= __ballot(!(v.x > thr[r]));
+        any |= __ballot(!(v.y > thr[r + 1]));
+      }
+      if (any) {  // wave-uniform: some lane has a pair that could win or tie
+        const double ex = sx[k], ey = sy[k];
+        const double ez = (DIM == 3) ? sz[k] : 0.;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (s[r] > thr[r]) continue;
+          double x, y, z;
+          query(r, x, y, z);
+          const double dx = x - ex;
+          const double dy = y - ey;
+          double d = dx * dx + dy * dy;
+          if (DIM == 3) {
+            const double dz = z - ez;
+            d = d + dz * dz;
+          }
+          if (d < best[r]) {
+            best[r] = d;
+            bi[r] = t0 + k;
+            const double rr = sqrt(d) + (double)ecf;
+            const float tq = (float)(rr * rr * 1.000004) * 1.000001f + 1e-37f;  // rounded up, as in the screen above
+            thr[r] = tq + mq[r];
+          }
+        }
+      }
+    };
+    // the LDS read of the next target is issued before the current one is processed: with few waves per
+    // SIMD nothing else hides its latency
+    if (FULL) {
+      float4 nxt = g4[0];
+#pragma unroll 4
+      for (unsigned k = 0; k < (unsigned)kNnTile; ++k) {
+        const float4 g = nxt;
+        nxt = g4[(k + 1) & (kNnTile - 1)];
+        pair_step(k, g);
+      }
+    } else {
+      for (unsigned k = 0; k < len; ++k) pair_step(k, g4[k]);
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const unsigned q = q0 + r * kNnThreads;
+    if (q < n) {
+      part_i[(size_t)blockIdx.y * n + q] = bi[r];
+      if (gridDim.y > 1) part_d[(size_t)blockIdx.y * n + q] = best[r];
+    }
+  }
+}
+
 // Merge the per-chunk minima (ascending chunk order + strict `<` keeps the lowest
 // index on ties), then emit idx and the matched xy pairs a = xy(T.src), b = xy(dst[idx]).
 template <int DIM, bool XFORM>
@@ -409,8 +566,10 @@ hipError_t build_target_screen(icp_handle *h) {
   hipError_t e = reserve(h->d_dst_f32, h->cap_f32, 3 * h->m_pad);
   if (e != hipSuccess) return e;
   const GridParams &g = h->grid.p;
+  // relative to the CENTRE of the bounding box: halves the magnitudes the dot-product screen cancels on
   hipLaunchKernelGGL(k_build_soa_f32, dim3((unsigned)((h->m_pad + 255) / 256)), dim3(256), 0, h->stream, h->d_dst,
-                     (unsigned)h->m, (unsigned)h->m_pad, h->dim, g.lo[0], g.lo[1], g.lo[2], h->d_dst_f32);
+                     (unsigned)h->m, (unsigned)h->m_pad, h->dim, 0.5 * (g.lo[0] + g.hi[0]), 0.5 * (g.lo[1] + g.hi[1]),
+                     0.5 * (g.lo[2] + g.hi[2]), h->d_dst_f32);
   h->screen_valid = true;
   return hipGetLastError();
 }
@@ -446,13 +605,32 @@ static void launch_one(icp_handle *h, const double *d_src, unsigned n, const Pos
   if (h->screen_valid && !no_screen) {
     const float *fx = h->d_dst_f32, *fy = fx + h->m_pad, *fz = fy + h->m_pad;
     const GridParams &g = h->grid.p;
+    const double cx = 0.5 * (g.lo[0] + g.hi[0]), cy = 0.5 * (g.lo[1] + g.hi[1]), cz = 0.5 * (g.lo[2] + g.hi[2]);
+    // the dot-product screen (two queries per packed instruction) unless its cancellation margin would
+    // swamp the distances it has to tell apart; ICP_NN_OLD_SCREEN: the difference-based screen, for A/B
+    static const bool old_screen = getenv("ICP_NN_OLD_SCREEN") != nullptr;
+    const double ex = g.hi[0] - g.lo[0], ey = g.hi[1] - g.lo[1], ez = g.hi[2] - g.lo[2];
+    const double half_diag = 0.5 * sqrt((ex * ex + ey * ey) + ez * ez) * 1.000001;
+    if constexpr (R >= 2) {
+      if (!old_screen && half_diag < 1e15 && half_diag > 0.) {
+        if (full)
+          hipLaunchKernelGGL((k_nn_brute_dot<DIM, R, XFORM, true>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
+                             d_src, n, tx, ty, tz, fx, fy, fz, (unsigned)h->m_pad, chunk, T, cx, cy, cz, g.scale,
+                             (float)half_diag, h->ws.d_part_d, h->ws.d_part_i);
+        else
+          hipLaunchKernelGGL((k_nn_brute_dot<DIM, R, XFORM, false>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
+                             d_src, n, tx, ty, tz, fx, fy, fz, (unsigned)h->m_pad, chunk, T, cx, cy, cz, g.scale,
+                             (float)half_diag, h->ws.d_part_d, h->ws.d_part_i);
+        return;
+      }
+    }
     if (full)
       hipLaunchKernelGGL((k_nn_brute_scr<DIM, R, XFORM, true>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
-                         d_src, n, tx, ty, tz, fx, fy, fz, (unsigned)h->m_pad, chunk, T, g.lo[0], g.lo[1], g.lo[2],
+                         d_src, n, tx, ty, tz, fx, fy, fz, (unsigned)h->m_pad, chunk, T, cx, cy, cz,
                          g.scale, h->ws.d_part_d, h->ws.d_part_i);
     else
       hipLaunchKernelGGL((k_nn_brute_scr<DIM, R, XFORM, false>), dim3(qblocks, chunks), dim3(kNnThreads), 0, h->stream,
-                         d_src, n, tx, ty, tz, fx, fy, fz, (unsigned)h->m_pad, chunk, T, g.lo[0], g.lo[1], g.lo[2],
+                         d_src, n, tx, ty, tz, fx, fy, fz, (unsigned)h->m_pad, chunk, T, cx, cy, cz,
                          g.scale, h->ws.d_part_d, h->ws.d_part_i);
     return;
   }

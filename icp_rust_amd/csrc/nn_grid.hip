@@ -714,8 +714,16 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid(const double *__restri
 //     behind the last record): screening them can add candidates, never remove one.
 // Lanes whose geometry does not fit f32 (|q - lo| or the radius beyond 1e18) walk the whole grid
 // unpruned: correct, and never seen outside adversarial tests.
+#ifdef ICP_WARM_WAVES
+#define ICP_WARM_ATTR __attribute__((amdgpu_waves_per_eu(ICP_WARM_WAVES, ICP_WARM_WAVES)))
+#else
+#define ICP_WARM_ATTR
+#endif
+#ifndef ICP_WARM_QUADS
+#define ICP_WARM_QUADS 2  // aligned quads (of four records) in flight per lane
+#endif
 template <int DIM>
-__global__ __launch_bounds__(kGridThreads) void k_nn_grid_warm(const double *__restrict__ src,
+__global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(const double *__restrict__ src,
                                                                const uint32_t *__restrict__ perm, unsigned n, Pose T,
                                                                GridParams g, const uint32_t *__restrict__ start,
                                                                const GridPoint *__restrict__ pts,
@@ -849,10 +857,12 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_warm(const double *__r
         if (dyz > bf) continue;  // every target of the row is strictly farther than the best so far
         // a target of this row that can still win or tie has |x - qx| <= sqrt(best - dy^2 - dz^2)
         // (v_sqrt_f32 returns 0 for a denormal argument: sqrt of it is < 1.1e-19 <= mgf, build_grid's f32_ok)
+#ifndef ICP_WARM_NOCLIP
         const float hw = __builtin_amdgcn_sqrtf(bf - dyz) * 1.000001f + mgf;
         xl = max(xl, cell_lo(qf[0] - hw, em[0], 0));
         xh = min(xh, cell_hi(qf[0] + hw, em[0], 0));
         if (xl > xh) continue;
+#endif
       }
       const uint32_t rb = ((uint32_t)iz * g.n[1] + cy) * g.n[0];
       const uint32_t ra = rb + xl, rz = rb + xh + 1;
@@ -878,11 +888,12 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_warm(const double *__r
     const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, Q = o3 + n3;
     // quad j of the flattened sequence lives at quad index j + dk of the record array
     const uint32_t d0 = q0, d1 = q1 - o1, d2 = q2 - o2, d3 = q3 - o3;
-    for (uint32_t base = 0; base < Q; base += 2) {
-      GridPoint t[8];
-      const uint4 *line[2];
+    constexpr uint32_t kQ = ICP_WARM_QUADS, kR = 4 * kQ;
+    for (uint32_t base = 0; base < Q; base += kQ) {
+      GridPoint t[kR];
+      const uint4 *line[kQ];
 #pragma unroll
-      for (uint32_t h2 = 0; h2 < 2; ++h2) {
+      for (uint32_t h2 = 0; h2 < kQ; ++h2) {
         const uint32_t j = min(base + h2, Q - 1);  // the tail re-reads the last quad
         uint32_t dq = d0;
         if (j >= o1) dq = d1;
@@ -891,7 +902,7 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_warm(const double *__r
         line[h2] = reinterpret_cast<const uint4 *>(pts) + (size_t)(j + dq) * 4;
       }
 #pragma unroll
-      for (uint32_t u = 0; u < 8; ++u) {  // all eight loads in flight before the first use
+      for (uint32_t u = 0; u < kR; ++u) {  // all loads in flight before the first use
         const uint4 w = line[u >> 2][u & 3];
         t[u].x = __uint_as_float(w.x);
         t[u].y = __uint_as_float(w.y);
@@ -899,9 +910,9 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_warm(const double *__r
         t[u].idx = w.w;
       }
       __builtin_amdgcn_sched_barrier(0);
-      float sc[8];
+      float sc[kR];
 #pragma unroll
-      for (uint32_t u = 0; u < 8; ++u) {
+      for (uint32_t u = 0; u < kR; ++u) {
         const float fx = qf[0] - t[u].x, fy = qf[1] - t[u].y;
         float s2 = __builtin_fmaf(fy, fy, fx * fx);
         if (DIM == 3) {
@@ -910,9 +921,28 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_warm(const double *__r
         }
         sc[u] = s2;
       }
+#ifdef ICP_WARM_DEFER
+      // the best-screened survivor first (one gather round trip for the common single survivor); the
+      // tightened threshold then rejects most of the others
+      float smin = __builtin_huge_valf();
+      uint32_t imin = 0xffffffffu;
 #pragma unroll
-      for (uint32_t u = 0; u < 8; ++u)
+      for (uint32_t u = 0; u < kR; ++u) {
+        const bool pass = !(sc[u] > thr32) && t[u].idx != bi && sc[u] < smin;
+        smin = pass ? sc[u] : smin;
+        imin = pass ? t[u].idx : imin;
+      }
+      if (imin != 0xffffffffu) {
+        consider(imin);
+#pragma unroll
+        for (uint32_t u = 0; u < kR; ++u)
+          if (!(sc[u] > thr32) && t[u].idx != bi && t[u].idx != imin) consider(t[u].idx);
+      }
+#else
+#pragma unroll
+      for (uint32_t u = 0; u < kR; ++u)
         if (!(sc[u] > thr32) && t[u].idx != bi) consider(t[u].idx);
+#endif
     }
   }
   // a slot whose match did not change already holds this record

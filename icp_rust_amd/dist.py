@@ -156,10 +156,10 @@ class HipStages:
                                               n_total, rank, world, full.element_size() * (full.shape[1] if full.dim() > 1 else 1)),
                    "icp_shard_put_device")
 
-    def eval_hist(self, a, b, n_total, rank, world, T, kind):
+    def eval_hist(self, a, b, n_total, rank, world, T, kind, refined=False):
         ptr = C.c_void_p()
         rc = lib().icp_shard_eval_hist_device(self.icp._h, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), n_total,
-                                              rank, world, C.byref(T.pose), kind, C.byref(ptr))
+                                              rank, world, C.byref(T.pose), kind, int(refined), C.byref(ptr))
         if rc != _lib.OK:
             return rc, None
         # a tensor view of the handle's histogram buffer, for the collective (no copy)
@@ -254,10 +254,10 @@ class BlockShardedIcp:
         return rk.bufs
 
     # one evaluation of weighted_gauss_newton_update at inner pose T, on every local rank
-    def _evaluate(self, T, kind):
+    def _evaluate(self, T, kind, refined=False):
         rks = self.ranks
         res = [rk.stages.eval_hist(rk.bufs["a"][:self.geom[rk.rank][3]], rk.bufs["b"][:self.geom[rk.rank][3]], self.n,
-                                   rk.rank, self.world, T, kind) for rk in rks]
+                                   rk.rank, self.world, T, kind, refined) for rk in rks]
         rcs = {rc for rc, _ in res}
         if rcs == {_lib.OK}:
             self.comm.sum_([h for _, h in res])
@@ -271,6 +271,9 @@ class BlockShardedIcp:
             outs = [rk.stages.eval_finish(rk.bufs["part_all"]) for rk in rks]
             rc = outs[0][0]
             assert all(o[0] == rc for o in outs)  # every rank folds the same numbers
+            if rc == _lib.RETRY_SHARDED:  # the window missed; its counts place one that will not
+                self.counters["refined"] = self.counters.get("refined", 0) + 1
+                return self._evaluate(T, kind, refined=True)
             if rc != _lib.RETRY_REPLICATED:
                 self.counters["sharded"] += 1
                 return outs[0]

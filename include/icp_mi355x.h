@@ -46,7 +46,8 @@ typedef enum icp_status {
   ICP_NO_DEVICE = 5,   /* HIP runtime/device unavailable -- no CPU fallback exists    */
   ICP_HIP_ERROR = 6,
   ICP_OUT_OF_MEMORY = 7,
-  ICP_RETRY_REPLICATED = 8 /* sharded evaluation (section 5): evaluate this one on the gathered pairs */
+  ICP_RETRY_REPLICATED = 8, /* sharded evaluation (section 5): evaluate this one on the gathered pairs */
+  ICP_RETRY_SHARDED = 9     /* sharded evaluation: the window missed; hist again with refined = 1      */
 } icp_status;
 
 /* Transform (src/transform.rs:6-10) */
@@ -218,7 +219,9 @@ int icp_weighted_gn_step_device(icp_handle *h, const double *d_a_xy, const doubl
  * icp_multi_* below.  ICP_RETRY_REPLICATED (from hist: no prediction of this evaluation's statistics
  * yet / fewer blocks than ranks; from finish: the predicted window missed) means: gather the pairs of
  * all ranks in global order and call icp_weighted_gn_step_device on them instead -- same result, and
- * it provides the prediction.  All calls are asynchronous on the handle's stream except finish. */
+ * it provides the prediction.  ICP_RETRY_SHARDED from finish: the window missed, but its (exact,
+ * global) counts place a narrower one that will not -- run the four stages again with refined = 1.
+ * All calls are asynchronous on the handle's stream except finish. */
 int icp_shard_geometry(size_t n_total, int rank, int world, int *block_first, int *block_end, int *blocks,
                        size_t *n_local);
 size_t icp_shard_histogram_words(void);
@@ -229,7 +232,7 @@ int icp_shard_take_device(icp_handle *h, const void *d_full, void *d_local, size
 int icp_shard_put_device(icp_handle *h, const void *d_local, void *d_full, size_t n_total, int rank, int world,
                          size_t elem_bytes);
 int icp_shard_eval_hist_device(icp_handle *h, const double *d_a_xy_local, const double *d_b_xy_local, size_t n_total,
-                               int rank, int world, const icp_pose *T, int kind, uint32_t **d_hist);
+                               int rank, int world, const icp_pose *T, int kind, int refined, uint32_t **d_hist);
 int icp_shard_eval_compact_device(icp_handle *h, void *d_candidates_out);
 int icp_shard_eval_accumulate_device(icp_handle *h, const void *d_candidates_all, void *d_partials_out);
 int icp_shard_eval_finish_device(icp_handle *h, const void *d_partials_all, double delta[3], double *huber_err);

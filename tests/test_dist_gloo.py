@@ -188,11 +188,12 @@ class OracleBlockStages:
         if idx_out is not None:
             idx_out.copy_(torch.from_numpy(idx.astype(np.int32)))
 
-    def eval_hist(self, a, b, n_total, rank, world, T, kind):
+    def eval_hist(self, a, b, n_total, rank, world, T, kind, refined=False):
         if n_total < 2:
             return _lib.NONE, None
         if kind not in self.seen_kind:  # no prediction for this kind of evaluation yet
             return _lib.RETRY_REPLICATED, None
+        self.refined = refined
         self.cur = (a.numpy(), b.numpy(), rank, world, T)
         p = T.pose
         an = self.cur[0]
@@ -229,9 +230,13 @@ class OracleBlockStages:
         world = self.cur[3]
         allv = part_all.view(torch.float64).numpy().reshape(world, -1)
         parts = np.concatenate([allv[q, 1:1 + 13 * int(allv[q, 0])].reshape(-1, 13) for q in range(world)])
-        self.evals += 1
+        if not self.refined:
+            self.evals += 1
         if self.miss_every and self.evals % self.miss_every == 0:  # "the predicted window missed"
-            return _lib.RETRY_REPLICATED, None, 0.0
+            if not self.refined:
+                return _lib.RETRY_SHARDED, None, 0.0      # its counts place a refined window: again, sharded
+            if self.evals % (2 * self.miss_every) == 0:
+                return _lib.RETRY_REPLICATED, None, 0.0   # every other time the refined attempt misses too
         rc, delta, err = O.wgn_tree_fold(parts, 512)
         return (_lib.OK if rc == O.OK else _lib.NONE), delta, err
 

@@ -116,3 +116,13 @@ def test_icp_create_multi_argument_checks():
     with pytest.raises(I.IcpError) as ex:
         e.estimate(dst[:10], I.Transform(), 1)
     assert ex.value.status == I._lib.EMPTY_DST
+
+
+def test_virtual_ranks_beyond_4m_points_use_refined_windows_not_gathered_pairs():
+    """past 4M points the one-GPU path finds its windows in two passes; the sharded path instead refines
+    a window that missed from that attempt's own (global, exact) counts and stays sharded"""
+    (T1, idx1, inner1), (T, idx, inner), drv, _ = _run(2, 4_500_000, 400_000, 3)
+    assert np.array_equal(T.as_array(), T1.as_array())
+    assert np.array_equal(inner, inner1) and np.array_equal(idx, idx1)
+    assert drv.counters["sharded"] >= 3, drv.counters
+    assert drv.counters["replicated"] <= 2, drv.counters
