@@ -68,6 +68,8 @@ SIGNATURES = {
     "icp_create_device": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _sz, C.c_int]),
     "icp_destroy": (None, [_vp]),
     "icp_set_nn_mode": (C.c_int, [_vp, C.c_int]),
+    "icp_set_single_launch": (C.c_int, [_vp, C.c_int]),
+    "icp_single_launch_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_get_nn_mode": (C.c_int, [_vp]),
     "icp_set_stream": (C.c_int, [_vp, _vp]),
     "icp_use_own_stream": (C.c_int, [_vp]),

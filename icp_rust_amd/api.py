@@ -363,6 +363,15 @@ class _Icp:
             return o, idx[:n], inner[:max_iter]
         return o
 
+    def set_single_launch(self, enable=True):
+        """small clouds: whole estimate in one launch (default on); off = the general host-driven path"""
+        check(lib().icp_set_single_launch(self._h, int(bool(enable))), "icp_set_single_launch")
+
+    def single_launch_counters(self):
+        out = (C.c_uint64 * 3)()
+        check(lib().icp_single_launch_counters(self._h, out), "icp_single_launch_counters")
+        return tuple(int(x) for x in out)
+
     # -- stage-level access (device tensors), used by the sharded driver and the bench --
     def set_stream(self, stream_ptr):
         check(lib().icp_set_stream(self._h, C.c_void_p(stream_ptr)), "icp_set_stream")

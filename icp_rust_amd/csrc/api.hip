@@ -393,6 +393,7 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->d_dst = nullptr;
     h->owns_dst = false;
     h->nn_mode = ICP_NN_AUTO;
+    h->single_launch = true;
     h->stream = h->own_stream;
     h->profile = 0;
     h->prof_seen = 0;
@@ -405,6 +406,7 @@ extern "C" void icp_destroy(icp_handle *h) {
     w.win_kind[0] = w.win_kind[1] = Workspace::WinPred();
     w.win_tried = w.win_missed = w.short_evals = w.radix_evals = 0;
     w.spec_hits = w.spec_misses = w.pre_evals = 0;
+    w.tiny_calls = w.tiny_evals = w.tiny_sorted = 0;
     w.refine_tried = w.refine_missed = 0;
     w.last_inner = 0xffffffffu;
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -447,6 +449,18 @@ static hipError_t launch_nn(icp_handle *h, const double *d_src, size_t n, const 
   return launch_nn_brute(h, d_src, n, T, d_a, d_b, d_idx);
 }
 
+extern "C" int icp_set_single_launch(icp_handle *h, int enable) {
+  if (!h) return ICP_BAD_ARGUMENT;
+  h->single_launch = enable != 0;
+  return ICP_OK;
+}
+extern "C" int icp_single_launch_counters(icp_handle *h, uint64_t out[3]) {
+  if (!h || !out) return ICP_BAD_ARGUMENT;
+  out[0] = h->ws.tiny_calls;
+  out[1] = h->ws.tiny_evals;
+  out[2] = h->ws.tiny_sorted;
+  return ICP_OK;
+}
 extern "C" int icp_get_nn_mode(const icp_handle *h) {
   if (!h) return ICP_BAD_ARGUMENT;
   return resolved_nn_mode(h);

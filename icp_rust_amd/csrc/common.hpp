@@ -226,6 +226,7 @@ struct icp_handle {
   size_t m = 0;
   int device = 0;
   int nn_mode = ICP_NN_AUTO;
+  bool single_launch = true;  // small clouds: the whole estimate in one launch (icp_set_single_launch)
   bool owns_dst = false;
   const double *d_dst = nullptr; // AoS m x dim (the owned copy below, or borrowed)
   double *d_dst_own = nullptr;   // buffer for a host-supplied target cloud

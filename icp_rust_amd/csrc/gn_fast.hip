@@ -7,6 +7,8 @@
 //
 // (The first short pipeline, whose launches ended in a last-workgroup tail, lived here; the
 // "pull" variant replaced it: +8 % per step, same bits.  Its lessons are in DESIGN.md.)
+#include <cstdio>
+
 #include "common.hpp"
 #include "gn_device.hpp"
 
@@ -391,6 +393,7 @@ struct TinyResult {  // pinned host memory
   unsigned evals;   // Gauss-Newton evaluations run, in all
   unsigned sorted;  // ... of which by the sorting path
   unsigned pad;
+  unsigned long long t[6];  // ICP_TINY_PROFILE builds: shader cycles in {setup, search, selections, sums, step, all}
 };
 constexpr unsigned kTinyMaxN = 1024, kTinyMaxM = 2048, kTinyMaxIter = 1024;
 
@@ -400,16 +403,14 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
                                                         unsigned max_iter, double cx, double cy, double cz, double scale,
                                                         TinyResult *res, uint32_t *inner_out, uint32_t *idx_out) {
   extern __shared__ unsigned char lds_raw[];
-  // ---- LDS carve-up ----
+  // ---- LDS carve-up ----  (targets are kept SORTED BY x: position j below is not the target's index)
   const unsigned mp = (m + 63u) & ~63u;
   double *tx = reinterpret_cast<double *>(lds_raw);
   double *ty = tx + mp;
   double *tz = ty + mp;  // (DIM == 2: unused, zero length below)
-  float *gx = reinterpret_cast<float *>(tz + (DIM == 3 ? mp : 0));
-  float *gy = gx + mp;
-  float *gz = gy + mp;
-  unsigned char *p = reinterpret_cast<unsigned char *>(gz + (DIM == 3 ? mp : 0));
-  p = reinterpret_cast<unsigned char *>((reinterpret_cast<size_t>(p) + 15) & ~size_t(15));
+  unsigned char *p = reinterpret_cast<unsigned char *>(tz + (DIM == 3 ? mp : 0));
+  float4 *g4 = reinterpret_cast<float4 *>(p);  // {x, y, z relative to the box centre as f32, original index}
+  p += sizeof(float4) * (mp + 4);
   unsigned long long(*sbuf)[2][1024] = reinterpret_cast<unsigned long long(*)[2][1024]>(p);  // sorting path
   p += sizeof(unsigned long long) * 2 * 2 * 1024;
   TinySel *S = reinterpret_cast<TinySel *>(p);
@@ -429,17 +430,63 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
   const unsigned tid = threadIdx.x;
   const int wave = tid >> 6;
   const bool has = tid < n;
-  for (unsigned k = tid; k < m; k += 1024) {
-    const double x = dst[(size_t)k * DIM], y = dst[(size_t)k * DIM + 1];
-    tx[k] = x;
-    ty[k] = y;
-    gx[k] = (float)(x - cx);
-    gy[k] = (float)(y - cy);
-    if (DIM == 3) {
-      const double z = dst[(size_t)k * DIM + 2];
-      tz[k] = z;
-      gz[k] = (float)(z - cz);
+#ifdef ICP_TINY_PROFILE
+  unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = t_last;
+#define TINY_STAMP(slot)                                         \
+  do {                                                           \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    tp[slot] += now_ - t_last;                                   \
+    t_last = now_;                                               \
+  } while (0)
+#else
+#define TINY_STAMP(slot) ((void)0)
+#endif
+  // Targets sorted by x (once per call): keys = (order-preserving bits of fl32(x - cx), index), bitonic
+  // sort of the next power of two in LDS.  A sweep then visits only targets whose x lies within the
+  // current best distance of the query's -- a few of them instead of all m (sweep and prune; exact:
+  // a target with |dx| > sqrt(best) is strictly farther).
+  {
+    unsigned long long *keys = &sbuf[0][0][0];  // 4096 slots: room for 2048 keys
+    unsigned P = 64;
+    while (P < m) P <<= 1;
+    for (unsigned k = tid; k < P; k += 1024) {
+      unsigned long long key = ~0ull;
+      if (k < m) {
+        const unsigned u = __float_as_uint((float)(dst[(size_t)k * DIM] - cx));
+        const unsigned o = (u >> 31) ? ~u : (u | 0x80000000u);
+        key = ((unsigned long long)o << 32) | k;
+      }
+      keys[k] = key;
     }
+    __syncthreads();
+    for (unsigned kk = 2; kk <= P; kk <<= 1)
+      for (unsigned j = kk >> 1; j > 0; j >>= 1) {
+        for (unsigned t = tid; t < (P >> 1); t += 1024) {
+          const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+          const unsigned long long a = keys[i], c = keys[l];
+          const bool up = (i & kk) == 0;
+          if ((a > c) == up) {
+            keys[i] = c;
+            keys[l] = a;
+          }
+        }
+        __syncthreads();
+      }
+    for (unsigned j = tid; j < mp + 4; j += 1024) {
+      if (j < m) {
+        const unsigned k = (unsigned)(keys[j] & 0xffffffffull);
+        const double x = dst[(size_t)k * DIM], y = dst[(size_t)k * DIM + 1];
+        const double z = DIM == 3 ? dst[(size_t)k * DIM + 2] : 0.;
+        tx[j] = x;
+        ty[j] = y;
+        if (DIM == 3) tz[j] = z;
+        g4[j] = make_float4((float)(x - cx), (float)(y - cy), DIM == 3 ? (float)(z - cz) : 0.f, __uint_as_float(k));
+      } else {  // pads: beyond every bound
+        g4[j] = make_float4(__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf(), __uint_as_float(0xffffffffu));
+      }
+    }
+    __syncthreads();
   }
   double px = 0., py = 0., pz = 0.;
   if (has) {
@@ -452,10 +499,12 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
     C->nan = C->bail = 0;
     C->evals = C->sorted = 0;
   }
+
   __syncthreads();
   const int blocks = n > 512u ? 2 : 1;  // reduce_geometry(n) for n <= 1024: 512-thread blocks
   const unsigned lo_rank = (n - 1) / 2, hi_rank = n / 2;
   unsigned bi = 0xffffffffu;
+  TINY_STAMP(0);
   for (unsigned it = 0; it < max_iter; ++it) {
     const Pose T = C->T;
     // ---- transform + exact nearest neighbour (src/lib.rs:113-124 / 156-167) ----
@@ -469,38 +518,82 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
       const double ec = (fmax(fmax(fabs(ox), fabs(oy)), fabs(oz)) + 2. * scale) * 1.2e-7 * 1.7320508075688774;
       double best = __builtin_huge_val();
       float thr = __builtin_huge_valf();
-      unsigned nb = 0xffffffffu;
-      auto exact = [&](unsigned k) {
-        const double dx = qx - tx[k], dy = qy - ty[k];
+      unsigned nb = 0xffffffffu, nbo = 0xffffffffu;  // sorted position / original index of the best so far
+      auto exact = [&](unsigned j, unsigned orig) {
+        const double dx = qx - tx[j], dy = qy - ty[j];
         double d = dx * dx + dy * dy;
         if (DIM == 3) {
-          const double dz = qz - tz[k];
+          const double dz = qz - tz[j];
           d = d + dz * dz;
         }
-        if (d < best || (d == best && k < nb)) {
+        if (d < best || (d == best && orig < nbo)) {  // ties -> lowest ORIGINAL index
           best = d;
-          nb = k;
+          nb = j;
+          nbo = orig;
           const double rr = sqrt(d) + ec;
           thr = (float)(rr * rr * 1.000004) * 1.000001f + 1e-37f;  // rounded up (nn_brute.hip)
         }
       };
-      if (bi != 0xffffffffu) exact(bi);  // warm start: the previous match bounds the sweep
-      for (unsigned k = 0; k < m; ++k) {
-        const float fx = hx - gx[k], fy = hy - gy[k];
+      // start: the previous match (warm), else the first target at or right of the query's x
+      unsigned start;
+      if (bi != 0xffffffffu) {
+        start = bi;
+        exact(bi, __float_as_uint(g4[bi].w));
+      } else {
+        unsigned lo = 0, hi = m;
+        while (lo < hi) {
+          const unsigned mid = (lo + hi) >> 1;
+          if (g4[mid].x < hx) lo = mid + 1;
+          else hi = mid;
+        }
+        start = lo < m ? lo : m - 1;
+      }
+      // outwards in both directions while a target's x alone does not rule it out.  The f32 x
+      // difference is within ec of the true one, so (|dx| - ec)^2 > best is what rules out; thr already
+      // carries that margin: dx^2 > thr  =>  strictly farther.
+      auto visit = [&](const float4 g, unsigned j) {  // (beyond the x bound: s2 > thr as well)
+        const float fx = hx - g.x, fy = hy - g.y;
         float s2 = __builtin_fmaf(fy, fy, fx * fx);
         if (DIM == 3) {
-          const float fz = hz - gz[k];
+          const float fz = hz - g.z;
           s2 = __builtin_fmaf(fz, fz, s2);
         }
-        if (!(s2 > thr)) exact(k);
+        if (!(s2 > thr) && j < m) exact(j, __float_as_uint(g.w));
+      };
+      // four targets per step (their LDS reads in flight together: one CU has little else to hide the
+      // latency with, and a wave is as slow as its lane with the widest window)
+      for (unsigned j = start; j < m; j += 4) {  // (g4 carries four +inf pads past mp)
+        const float4 g0 = g4[j], g1 = g4[j + 1], g2 = g4[j + 2], g3 = g4[j + 3];
+        const float f0 = hx - g0.x;
+        if (f0 * f0 > thr) break;  // sorted by x: everything further right is farther still
+        visit(g0, j);
+        visit(g1, j + 1);
+        visit(g2, j + 2);
+        visit(g3, j + 3);
+      }
+      for (unsigned j = start; j > 0;) {
+        const unsigned j0 = j - 1, j1 = j > 1 ? j - 2 : 0, j2 = j > 2 ? j - 3 : 0, j3 = j > 3 ? j - 4 : 0;
+        const float4 g0 = g4[j0], g1 = g4[j1], g2 = g4[j2], g3 = g4[j3];  // (a repeated target is harmless)
+        const float f0 = hx - g0.x;
+        if (f0 * f0 > thr) break;
+        visit(g0, j0);
+        visit(g1, j1);
+        visit(g2, j2);
+        visit(g3, j3);
+        j = j3;
       }
       bi = nb;
-      const unsigned bb = nb == 0xffffffffu ? 0u : nb;  // no finite distance (NaN query): index 0, as a scan from 0 would
       ax = qx;
       ay = qy;
-      bx = tx[bb];
-      by = ty[bb];
-      if (idx_out && it + 1 == max_iter) idx_out[tid] = bb;
+      if (nb != 0xffffffffu) {
+        bx = tx[nb];
+        by = ty[nb];
+      } else {  // no finite distance (NaN query): index 0, as a scan from 0 would
+        bx = dst[0];
+        by = dst[1];
+        nbo = 0;
+      }
+      if (idx_out && it + 1 == max_iter) idx_out[tid] = nbo;
     }
     // ---- estimate_transform, src/lib.rs:59-84 ----
     if (tid == 0) {
@@ -510,6 +603,7 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
     }
     double prev_error = 1.7976931348623157e308;  // f64::MAX (thread 0 only)
     __syncthreads();
+    TINY_STAMP(1);
     for (int k = 0; k < ICP_INNER_MAX_ITER && !C->done; ++k) {
       const Pose Ti = C->Ti;
       double r0 = 0., r1 = 0.;
@@ -550,6 +644,7 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
         sig[1] = ICP_PPF34 * ((n & 1) ? C->s_mad[1][0] : (C->s_mad[1][0] + C->s_mad[1][1]) / 2.);
         if (tid == 0) ++C->sorted;
       }
+      TINY_STAMP(2);
       // weighted normal equations + Huber error (src/lib.rs:238-255, 45-50), one point per thread
       double acc[kNAcc + 1];
 #pragma unroll
@@ -590,6 +685,7 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
         part[vb][q] = v;
       }
       __syncthreads();
+      TINY_STAMP(3);
       if (tid == 0) {
         double tot[kNAcc];
         for (int q = 0; q < kNAcc; ++q) {
@@ -621,6 +717,7 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
         }
       }
       __syncthreads();
+      TINY_STAMP(4);
     }
     if (tid == 0) {
       if (inner_out) inner_out[it] = C->applied;
@@ -634,12 +731,16 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
     res->evals = C->evals;
     res->sorted = C->sorted;
     res->status = C->nan ? 3 : (C->bail ? -1 : 0);
+#ifdef ICP_TINY_PROFILE
+    tp[5] = __builtin_amdgcn_s_memtime() - t_begin;
+    for (int q = 0; q < 6; ++q) res->t[q] = tp[q];
+#endif
   }
 }
 
 static size_t tiny_lds_bytes(int dim, unsigned m) {
   const size_t mp = (m + 63u) & ~63u;
-  size_t b = mp * (size_t)dim * (sizeof(double) + sizeof(float)) + 16;
+  size_t b = mp * (size_t)dim * sizeof(double) + (mp + 4) * sizeof(float4) + 16;
   b += sizeof(unsigned long long) * 2 * 2 * 1024;
   b += (sizeof(TinySel) + 15) & ~size_t(15);
   b += sizeof(double) * 18 * (kNAcc + 1);
@@ -653,7 +754,7 @@ hipError_t launch_tiny_estimate(icp_handle *h, const double *d_src, size_t n, co
                                 Pose *out, uint32_t *d_last_idx, uint32_t *inner_iters, int *status) {
   static const bool off = getenv("ICP_NO_TINY_ESTIMATE") != nullptr;
   *status = -1;
-  if (off || n < 1 || n > kTinyMaxN || h->m < 1 || h->m > kTinyMaxM || max_iter < 1 || max_iter > kTinyMaxIter ||
+  if (off || !h->single_launch || n < 1 || n > kTinyMaxN || h->m < 1 || h->m > kTinyMaxM || max_iter < 1 || max_iter > kTinyMaxIter ||
       !h->grid.built || h->nn_mode == ICP_NN_GRID)
     return hipSuccess;
   Workspace &w = h->ws;
@@ -688,6 +789,11 @@ hipError_t launch_tiny_estimate(icp_handle *h, const double *d_src, size_t n, co
       for (size_t i = 0; i < max_iter; ++i) inner_iters[i] = inner[i];
     w.tiny_evals += res->evals;
     w.tiny_sorted += res->sorted;
+#ifdef ICP_TINY_PROFILE
+    if (getenv("ICP_TINY_PRINT"))
+      fprintf(stderr, "[tiny] evals %u sorted %u; cycles: setup %llu search %llu select %llu sums %llu step %llu all %llu\n",
+              res->evals, res->sorted, res->t[0], res->t[1], res->t[2], res->t[3], res->t[4], res->t[5]);
+#endif
   }
   return hipSuccess;
 }

@@ -117,6 +117,13 @@ int icp_create(icp_handle **out, int dim, const double *dst, size_t m, int devic
 int icp_create_device(icp_handle **out, int dim, const double *d_dst, size_t m, int device);
 void icp_destroy(icp_handle *h);
 
+/* Clouds of the reference's own size (scans/2d: ~650 points; here: up to 1024 source points against up
+ * to 2048 targets) are registered by icp_estimate[_device] in ONE launch of one workgroup -- search,
+ * inner loop, 3x3 solve, break tests and pose updates all on the device, same bits as the general
+ * path.  icp_set_single_launch(h, 0) switches that off for a handle (tests, A/B); the counters:
+ * out[0] calls served, out[1] Gauss-Newton evaluations in them, out[2] of which needed the sorting path. */
+int icp_set_single_launch(icp_handle *h, int enable);
+int icp_single_launch_counters(icp_handle *h, uint64_t out[3]);
 int icp_set_nn_mode(icp_handle *h, int mode);   /* icp_nn_mode; default ICP_NN_AUTO */
 int icp_get_nn_mode(const icp_handle *h);       /* the engine AUTO resolved to      */
 /* run the handle's kernels on a caller-chosen HIP stream (hipStream_t) instead of the handle's

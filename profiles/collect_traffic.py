@@ -56,7 +56,7 @@ def main():
     # (the benchmark's timed region holds one cold search per 20 launches; a short PMC run holds more)
     tot = {"f": 0.0, "w": 0.0, "nf": 0, "nw": 0}
     for k, e in kernels.items():
-        if not k.startswith("icp::k_nn_grid<3, true"):
+        if not (k.startswith("icp::k_nn_grid<3, true") or k.startswith("icp::k_nn_grid_warm<3")):
             continue
         tot["f"] += e.get("FETCH_SIZE_KB_avg_per_launch", 0.0) * e.get("launches_FETCH_SIZE", 0)
         tot["nf"] += e.get("launches_FETCH_SIZE", 0)
@@ -71,7 +71,7 @@ def main():
                 if k.startswith(prefix) and "FETCH_SIZE_KB_avg_per_launch" in e and "WRITE_SIZE_KB_avg_per_launch" in e:
                     return e
             return None
-        warm = pick("icp::k_nn_grid<3, true, false")
+        warm = pick("icp::k_nn_grid_warm<3") or pick("icp::k_nn_grid<3, true, false")
         if warm and "FETCH_SIZE_KB_avg_per_launch" in warm and "WRITE_SIZE_KB_avg_per_launch" in warm:
             wb_ = 1024 * (warm["FETCH_SIZE_KB_avg_per_launch"] + warm["WRITE_SIZE_KB_avg_per_launch"])
             doc["k_nn_grid"]["warm_only_bytes_per_launch"] = wb_

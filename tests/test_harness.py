@@ -73,11 +73,12 @@ class CountingIcp2d:
     """Icp2d factory that keeps what the GPU handles report: inner-iteration counts per outer iteration
     and the speculative-search counters (confirmed, discarded) of every frame."""
 
-    def __init__(self):
-        self.inner, self.spec = [], [0, 0]
+    def __init__(self, single_launch=True):
+        self.inner, self.spec, self.single, self.single_launch = [], [0, 0], [0, 0, 0], single_launch
 
     def __call__(self, dst):
         self.icp = I.Icp2d(dst)
+        self.icp.set_single_launch(self.single_launch)
         return self
 
     def estimate(self, src, transform, max_iter):
@@ -86,6 +87,8 @@ class CountingIcp2d:
         c = I.gn_path_counters(self.icp)
         self.spec[0] += c[4]
         self.spec[1] += c[5]
+        for k, v in enumerate(self.icp.single_launch_counters()):
+            self.single[k] += v
         self.icp.close()
         return T
 
@@ -95,18 +98,26 @@ def test_scan2d_trajectory_on_gpu_matches_oracle_bit_for_bit():
     """examples/scan2d.rs:62-90 over the reference's scans 001 .. 040 (39 frames, 780 outer iterations,
     ~7 600 inner Gauss-Newton iterations with loops of up to 77): the whole trajectory bit-equal to the
     oracle in the device's summation order."""
-    fac = CountingIcp2d()
-    Ts, _, path = harness.run_scan2d(GOLDEN, max_iter=20, icp_factory=fac)
     Os, _, opath = harness.run_scan2d(GOLDEN, max_iter=20, icp_factory=OracleIcp(2, tree_order=True))
-    assert len(Ts) == len(Os) == 39
-    for a, b in zip(Ts, Os):
-        assert np.array_equal(a.as_array(), b.as_array())
-    assert np.array_equal(path, opath)
-    # the run really exercised long inner loops and wrong speculative bets (a bet on "one update, then
-    # the loop ends" that the loop did not honour: the search is discarded and repeated)
-    assert max(max(f) for f in fac.inner) >= 30
-    assert sum(sum(f) for f in fac.inner) > 5000
-    assert fac.spec[0] >= 1 and fac.spec[1] >= 1, fac.spec
+    # twice: every frame registered in ONE launch (the default at this size), and by the general
+    # host-driven path (stage kernels, speculative searches)
+    for single in (True, False):
+        fac = CountingIcp2d(single_launch=single)
+        Ts, _, path = harness.run_scan2d(GOLDEN, max_iter=20, icp_factory=fac)
+        assert len(Ts) == len(Os) == 39
+        for a, b in zip(Ts, Os):
+            assert np.array_equal(a.as_array(), b.as_array())
+        assert np.array_equal(path, opath)
+        # the run really exercised long inner loops ...
+        assert max(max(f) for f in fac.inner) >= 30
+        assert sum(sum(f) for f in fac.inner) > 5000
+        if single:
+            assert fac.single[0] == 39 and fac.single[1] > 5000 + 39 * 20 - 1, fac.single
+        else:
+            # ... and wrong speculative bets (a bet on "one update, then the loop ends" that the loop did not
+            # honour: the search is discarded and repeated)
+            assert fac.single[0] == 0
+            assert fac.spec[0] >= 1 and fac.spec[1] >= 1, fac.spec
     # and within the north_star tolerance of the reference-order oracle
     Rs, _, _ = harness.run_scan2d(GOLDEN, max_iter=20, icp_factory=OracleIcp(2))
     for a, b in zip(Ts, Rs):
