@@ -77,7 +77,7 @@ def main():
         "metric": "scan-to-growing-map frames/s (EXTENSION: not a reference workload)",
         "value": 1e3 / frame_ms, "unit": "frames/s", "n_gpus": 1,
         "config": {"workload": "BASELINE.json configs[4] stand-in: synthetic frames registered against a growing map, "
-                               "point-to-point (the reference's estimator); point-to-plane is not built",
+                               "point-to-point (the reference's estimator; the point-to-plane extension: tests/test_p2plane.py)",
                    "map_points_start": m0, "map_points_end": world.target_count,
                    "frame_points": args.frame_points, "frames": args.frames, "max_iter": args.max_iter},
         "ms_per_frame": frame_ms,
