@@ -274,117 +274,166 @@ __global__ __launch_bounds__(1024) void k_tiny_eval(const double2 *__restrict__ 
 // buckets (heavy duplicates) -> the sorting path below serves that evaluation.
 // =======================================================================================
 struct TinySel {
-  unsigned long long spl[2][64];
+  unsigned spl[2][64];  // sorted splitters: the HIGH words of 64 sampled keys (monotone in the key, and 32-bit compares)
   unsigned long long list[2][128];
   unsigned long long out[2][2];
   unsigned hist[2][68];
-  unsigned ctl[2][4];  // b_lo, b_hi, points below b_lo, points in [b_lo, b_hi]
   unsigned nlist[2];
-  unsigned overflow;
 };
 
+// cross-lane sums without the LDS pipe (DPP): over aligned groups of 8 lanes, and the wave's inclusive scan
+#define ICP_DPP(v, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rows, 0xf, true)
+__device__ __forceinline__ unsigned dpp_sum8(unsigned v) {
+  v += ICP_DPP(v, 0xB1, 0xf);   // quad_perm [1,0,3,2]
+  v += ICP_DPP(v, 0x4E, 0xf);   // quad_perm [2,3,0,1]
+  v += ICP_DPP(v, 0x141, 0xf);  // row_half_mirror: lane i of an 8-group reads lane 7-i, in the other quad
+  return v;
+}
+__device__ __forceinline__ unsigned wave_scan_inclusive(unsigned v) {
+  v += ICP_DPP(v, 0x111, 0xf);  // row_shr:1 (zero fill at the row's start)
+  v += ICP_DPP(v, 0x112, 0xf);  // row_shr:2
+  v += ICP_DPP(v, 0x114, 0xf);  // row_shr:4
+  v += ICP_DPP(v, 0x118, 0xf);  // row_shr:8  -> inclusive within each row of 16
+  v += ICP_DPP(v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  v += ICP_DPP(v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+#ifdef ICP_TINY_PROFILE
+#define SEL_STAMP(slot)                                             \
+  do {                                                              \
+    if (sp) {                                                       \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+      sp[slot] += now_ - st_;                                       \
+      st_ = now_;                                                   \
+    }                                                               \
+  } while (0)
+#else
+#define SEL_STAMP(slot) ((void)0)
+#endif
+
 // the two middle order statistics (ranks (n-1)/2 and n/2) of the keys k0 (dimension 0) and k1, one
-// key of each per thread (`has`); false: too many equal-ish keys, the caller sorts instead
+// key of each per thread (~0 from the threads past n); false: too many equal-ish keys, the caller
+// sorts instead. B threads (a multiple of 64), five barriers, no single-wave phase: sample 64 keys per dimension
+// and rank the samples (every thread a few compares) -> bucket every key between the sorted
+// samples -> every wave scans the 65 bucket counts itself and the keys of the bucket(s) holding
+// the two ranks are listed -> the listed keys are ranked against each other, 8 lanes per key.
+// kbuf: 2 x 1024 keys of LDS (the sorting path's buffer).
+template <unsigned B>
 __device__ __forceinline__ bool tiny_select(unsigned long long k0, unsigned long long k1, bool has, unsigned n,
-                                            TinySel *S) {
-  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                            TinySel *S, unsigned long long (*kbuf)[1024],
+                                            unsigned long long *sp = nullptr) {
+#ifdef ICP_TINY_PROFILE
+  unsigned long long st_ = __builtin_amdgcn_s_memtime();
+#endif
+  // (opaque to the optimiser: everything below that depends on n alone -- the sample positions,
+  // for one -- would otherwise be hoisted out of the caller's loop and, at 128 registers, spilled)
+  asm volatile("" : "+s"(n));
+  const unsigned tid = threadIdx.x, lane = tid & 63;
   const unsigned lo_rank = (n - 1) / 2, hi_rank = n / 2;
   const unsigned long long key[2] = {k0, k1};
+  kbuf[0][tid] = k0;
+  kbuf[1][tid] = k1;
   if (tid < 2 * 68) (&S->hist[0][0])[tid] = 0;
   if (tid < 2) S->nlist[tid] = 0;
-  if (tid == 0) S->overflow = 0;
-  if (tid < 128) (&S->spl[0][0])[tid] = ~0ull;  // fewer than 64 points: the missing samples sort last
   __syncthreads();
-  // samples: sample j is the key of thread floor(j n / ns)
-  const unsigned ns = n < 64u ? n : 64u;
-  if (has) {
-    const unsigned j = (tid * ns + n - 1) / n;  // smallest j with floor(j n / ns) >= tid
-    if (j < ns && (j * n) / ns == tid) {
-      S->spl[0][j] = k0;
-      S->spl[1][j] = k1;
-    }
-  }
-  __syncthreads();
-  if (wave < 2) {  // one wave per dimension: bitonic sort of the 64 samples in registers
-    unsigned long long v = S->spl[wave][lane];
-    for (unsigned k = 2; k <= 64; k <<= 1)
-      for (unsigned j = k >> 1; j > 0; j >>= 1) {
-        const unsigned long long o = __shfl_xor(v, (int)j);
-        const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-        v = keep_min ? (v < o ? v : o) : (v > o ? v : o);
-      }
-    S->spl[wave][lane] = v;
-  }
-  __syncthreads();
-  unsigned bucket[2] = {0, 0};
-  if (has) {
+  SEL_STAMP(0);
+  // sample j is the key of thread floor(j n / ns); slot (d, i, c) compares sample i with samples 8c .. 8c+7
+  for (unsigned slot = tid; slot < 1024u; slot += B) {  // (whole 8-lane groups: B is a multiple of 64)
+    const unsigned d = slot >> 9, i = (slot >> 3) & 63, c = slot & 7;
+    const unsigned ns = n < 64u ? n : 64u;  // (the missing samples sort last)
+    const unsigned *kh = reinterpret_cast<const unsigned *>(kbuf[d]);
+    // floor(j n / ns) without a division: ns is 64, or n itself (24-bit products: j < 64, n <= 1024)
+    auto sample = [&](unsigned j) -> unsigned {
+      const unsigned t = n >= 64u ? __umul24(j, n) >> 6 : j;
+      return j < ns ? kh[2 * t + 1] : 0xffffffffu;
+    };
+    const unsigned si = sample(i);
+    unsigned part = 0;
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {  // bucket = number of splitters < key: monotone in the key
-      unsigned lo = 0, hi = 64;
-      while (lo < hi) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (S->spl[d][mid] < key[d]) lo = mid + 1;
-        else hi = mid;
-      }
-      bucket[d] = lo;
-      atomicAdd(&S->hist[d][lo], 1u);
+    for (unsigned u = 0; u < 8; ++u) {
+      const unsigned j = 8 * c + u;
+      const unsigned sj = sample(j);
+      part += (sj < si) | ((sj == si) & (j < i));
+    }
+    const unsigned rank = dpp_sum8(part);
+    if (c == 0) S->spl[d][rank] = si;
+  }
+  __syncthreads();
+  SEL_STAMP(1);
+  // bucket = number of splitters below the key's high word (monotone in the key): a branch-free
+  // lower bound over the 64 sorted splitters, the two dimensions' LDS reads in flight together
+  unsigned bucket[2] = {0, 0};
+  {
+    const unsigned kd0 = (unsigned)(k0 >> 32), kd1 = (unsigned)(k1 >> 32);
+#pragma unroll
+    for (unsigned step = 32; step > 0; step >>= 1) {
+      const unsigned s0 = S->spl[0][bucket[0] + step - 1], s1 = S->spl[1][bucket[1] + step - 1];
+      bucket[0] += s0 < kd0 ? step : 0u;
+      bucket[1] += s1 < kd1 ? step : 0u;
+    }
+    const unsigned s0 = S->spl[0][bucket[0]], s1 = S->spl[1][bucket[1]];  // (positions 0 .. 63)
+    bucket[0] += s0 < kd0;
+    bucket[1] += s1 < kd1;
+    if (has) {
+      atomicAdd(&S->hist[0][bucket[0]], 1u);
+      atomicAdd(&S->hist[1][bucket[1]], 1u);
     }
   }
   __syncthreads();
-  if (wave < 2) {
-    const int d = wave;
+  SEL_STAMP(2);
+  unsigned below[2], expect[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
     const unsigned c = S->hist[d][lane], c64 = S->hist[d][64];
-    unsigned inc = c;
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned t = __shfl_up(inc, off);
-      if ((int)lane >= off) inc += t;
-    }
-    const unsigned excl = inc - c;
+    const unsigned inc = wave_scan_inclusive(c);
     const unsigned long long m_lo = __ballot(inc > lo_rank), m_hi = __ballot(inc > hi_rank);
     const unsigned b_lo = m_lo ? (unsigned)__ffsll((long long)m_lo) - 1u : 64u;
     const unsigned b_hi = m_hi ? (unsigned)__ffsll((long long)m_hi) - 1u : 64u;
-    const unsigned tot63 = __shfl(inc, 63);
-    const unsigned below = b_lo < 64u ? __shfl(excl, (int)b_lo) : tot63;
-    const unsigned upto = b_hi < 64u ? __shfl(inc, (int)b_hi) : tot63 + c64;
-    if (lane == 0) {
-      S->ctl[d][0] = b_lo;
-      S->ctl[d][1] = b_hi;
-      S->ctl[d][2] = below;
-      S->ctl[d][3] = upto - below;
+    const unsigned tot63 = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+    below[d] = b_lo < 64u ? (unsigned)__builtin_amdgcn_readlane((int)(inc - c), (int)b_lo) : tot63;
+    const unsigned upto = b_hi < 64u ? (unsigned)__builtin_amdgcn_readlane((int)inc, (int)b_hi) : tot63 + c64;
+    expect[d] = upto - below[d];
+    if (has && bucket[d] >= b_lo && bucket[d] <= b_hi) {
+      const unsigned pos = atomicAdd(&S->nlist[d], 1u);
+      if (pos < 128u) S->list[d][pos] = key[d];
     }
   }
   __syncthreads();
-  if (has) {
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-      if (bucket[d] >= S->ctl[d][0] && bucket[d] <= S->ctl[d][1]) {
-        const unsigned pos = atomicAdd(&S->nlist[d], 1u);
-        if (pos < 128u) S->list[d][pos] = key[d];
+  SEL_STAMP(3);
+  const unsigned cnt0 = S->nlist[0], cnt1 = S->nlist[1];
+  const bool bad = cnt0 > 128u || cnt0 != expect[0] || cnt1 > 128u || cnt1 != expect[1];  // the same in every thread
+  if (!bad) {  // listed key e is ranked by the 8 lanes (e, 0..7), each against every 8th listed key
+    const unsigned cmax = cnt0 > cnt1 ? cnt0 : cnt1;
+    for (unsigned slot = tid; slot < 8u * cmax; slot += B) {  // (whole 8-lane groups)
+      const unsigned e = slot >> 3, c = slot & 7;
+      const bool in0 = e < cnt0, in1 = e < cnt1;
+      const unsigned long long ke0 = S->list[0][in0 ? e : 0], ke1 = S->list[1][in1 ? e : 0];
+      unsigned acc0 = 0, acc1 = 0;  // keys below in the low half, equal keys in the high half (at most 128 each)
+      for (unsigned j = c; j < cmax; j += 8) {
+        const unsigned long long kj0 = S->list[0][j < cnt0 ? j : 0], kj1 = S->list[1][j < cnt1 ? j : 0];
+        if (j < cnt0) acc0 += (unsigned)(kj0 < ke0) + ((unsigned)(kj0 == ke0) << 16);
+        if (j < cnt1) acc1 += (unsigned)(kj1 < ke1) + ((unsigned)(kj1 == ke1) << 16);
       }
-  }
-  __syncthreads();
-  if (wave < 2) {
-    const int d = wave;
-    const unsigned cnt = S->nlist[d];
-    if (cnt > 128u || cnt != S->ctl[d][3]) {
-      if (lane == 0) S->overflow = 1;
-    } else {
-      const unsigned r_lo = lo_rank - S->ctl[d][2], r_hi = hi_rank - S->ctl[d][2];
-      for (unsigned e = lane; e < cnt; e += 64) {
-        const unsigned long long ke = S->list[d][e];
-        unsigned less = 0, eq = 0;
-        for (unsigned j = 0; j < cnt; ++j) {
-          const unsigned long long kj = S->list[d][j];
-          less += kj < ke;
-          eq += kj == ke;
+      acc0 = dpp_sum8(acc0);
+      acc1 = dpp_sum8(acc1);
+      if (c == 0) {
+        if (in0) {
+          const unsigned less = acc0 & 0xffffu, eq = acc0 >> 16, r_lo = lo_rank - below[0], r_hi = hi_rank - below[0];
+          if (less <= r_lo && r_lo < less + eq) S->out[0][0] = ke0;
+          if (less <= r_hi && r_hi < less + eq) S->out[0][1] = ke0;
         }
-        if (less <= r_lo && r_lo < less + eq) S->out[d][0] = ke;
-        if (less <= r_hi && r_hi < less + eq) S->out[d][1] = ke;
+        if (in1) {
+          const unsigned less = acc1 & 0xffffu, eq = acc1 >> 16, r_lo = lo_rank - below[1], r_hi = hi_rank - below[1];
+          if (less <= r_lo && r_lo < less + eq) S->out[1][0] = ke1;
+          if (less <= r_hi && r_hi < less + eq) S->out[1][1] = ke1;
+        }
       }
     }
   }
   __syncthreads();
-  return S->overflow == 0;
+  SEL_STAMP(4);
+  return !bad;
 }
 
 struct TinyResult {  // pinned host memory
@@ -394,11 +443,12 @@ struct TinyResult {  // pinned host memory
   unsigned sorted;  // ... of which by the sorting path
   unsigned pad;
   unsigned long long t[6];  // ICP_TINY_PROFILE builds: shader cycles in {setup, search, selections, sums, step, all}
+  unsigned long long ts[8]; // ... and inside the selections, per phase
 };
 constexpr unsigned kTinyMaxN = 1024, kTinyMaxM = 2048, kTinyMaxIter = 1024;
 
-template <int DIM>
-__global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict__ src, unsigned n,
+template <int DIM, unsigned B>
+__global__ __launch_bounds__(B) void k_tiny_estimate(const double *__restrict__ src, unsigned n,
                                                         const double *__restrict__ dst, unsigned m, Pose T0,
                                                         unsigned max_iter, double cx, double cy, double cz, double scale,
                                                         TinyResult *res, uint32_t *inner_out, uint32_t *idx_out) {
@@ -432,6 +482,7 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
   const bool has = tid < n;
 #ifdef ICP_TINY_PROFILE
   unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+  unsigned long long tsel[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = t_last;
 #define TINY_STAMP(slot)                                         \
   do {                                                           \
@@ -450,7 +501,7 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
     unsigned long long *keys = &sbuf[0][0][0];  // 4096 slots: room for 2048 keys
     unsigned P = 64;
     while (P < m) P <<= 1;
-    for (unsigned k = tid; k < P; k += 1024) {
+    for (unsigned k = tid; k < P; k += B) {
       unsigned long long key = ~0ull;
       if (k < m) {
         const unsigned u = __float_as_uint((float)(dst[(size_t)k * DIM] - cx));
@@ -462,7 +513,7 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
     __syncthreads();
     for (unsigned kk = 2; kk <= P; kk <<= 1)
       for (unsigned j = kk >> 1; j > 0; j >>= 1) {
-        for (unsigned t = tid; t < (P >> 1); t += 1024) {
+        for (unsigned t = tid; t < (P >> 1); t += B) {
           const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
           const unsigned long long a = keys[i], c = keys[l];
           const bool up = (i & kk) == 0;
@@ -473,7 +524,7 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
         }
         __syncthreads();
       }
-    for (unsigned j = tid; j < mp + 4; j += 1024) {
+    for (unsigned j = tid; j < mp + 4; j += B) {
       if (j < m) {
         const unsigned k = (unsigned)(keys[j] & 0xffffffffull);
         const double x = dst[(size_t)k * DIM], y = dst[(size_t)k * DIM + 1];
@@ -498,6 +549,10 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
     C->T = T0;
     C->nan = C->bail = 0;
     C->evals = C->sorted = 0;
+  }
+  if (tid >= B / 64 && tid < 16) {  // the wave sums of the waves a smaller workgroup does not have
+#pragma unroll
+    for (int q = 0; q < kNAcc + 1; ++q) sm[tid][q] = 0.;
   }
 
   __syncthreads();
@@ -614,35 +669,46 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
       }
       double med[2], sig[2];
       // medians, then MADs (src/stats.rs:11-47)
-      bool ok = tiny_select(has ? f2k(r0) : ~0ull, has ? f2k(r1) : ~0ull, has, n, S);
+#ifdef ICP_TINY_PROFILE
+      unsigned long long *selp = tsel;
+#else
+      unsigned long long *selp = nullptr;
+#endif
+      bool ok = tiny_select<B>(has ? f2k(r0) : ~0ull, has ? f2k(r1) : ~0ull, has, n, S, sbuf[0], selp);
       if (ok) {
         med[0] = middle_of_host(n, S->out[0][0], S->out[0][1]);
         med[1] = middle_of_host(n, S->out[1][0], S->out[1][1]);
-        __syncthreads();  // (S->out is rewritten by the next selection)
-        ok = tiny_select(has ? f2k(fabs(r0 - med[0])) : ~0ull, has ? f2k(fabs(r1 - med[1])) : ~0ull, has, n, S);
+        // (S->out is next written four barriers into the next selection)
+        ok = tiny_select<B>(has ? f2k(fabs(r0 - med[0])) : ~0ull, has ? f2k(fabs(r1 - med[1])) : ~0ull, has, n, S, sbuf[0],
+                         selp);
         if (ok) {
           sig[0] = ICP_PPF34 * middle_of_host(n, S->out[0][0], S->out[0][1]);
           sig[1] = ICP_PPF34 * middle_of_host(n, S->out[1][0], S->out[1][1]);
         }
       }
-      if (!ok) {  // the sorting path of k_tiny_eval (uniform: S->overflow is shared)
-        unsigned long long ka = has ? f2k(r0) : ~0ull, kb = has ? f2k(r1) : ~0ull;
-        __syncthreads();
-        bitonic_sort2_1024(ka, kb, sbuf);
-        __syncthreads();
-        sbuf[0][0][tid] = ka;
-        sbuf[0][1][tid] = kb;
-        __syncthreads();
-        const double xl = k2f(sbuf[0][0][lo_rank]), xh = k2f(sbuf[0][0][hi_rank]);
-        const double yl = k2f(sbuf[0][1][lo_rank]), yh = k2f(sbuf[0][1][hi_rank]);
-        med[0] = (n & 1) ? xl : (xl + xh) / 2.;
-        med[1] = (n & 1) ? yl : (yl + yh) / 2.;
-        mad_ranks(sbuf[0][0], n, med[0], lo_rank, hi_rank, C->s_mad[0]);
-        mad_ranks(sbuf[0][1], n, med[1], lo_rank, hi_rank, C->s_mad[1]);
-        __syncthreads();
-        sig[0] = ICP_PPF34 * ((n & 1) ? C->s_mad[0][0] : (C->s_mad[0][0] + C->s_mad[0][1]) / 2.);
-        sig[1] = ICP_PPF34 * ((n & 1) ? C->s_mad[1][0] : (C->s_mad[1][0] + C->s_mad[1][1]) / 2.);
-        if (tid == 0) ++C->sorted;
+      if (!ok) {  // (uniform: every thread saw the same list counts)
+        if constexpr (B == 1024) {  // the sorting path of k_tiny_eval
+          unsigned long long ka = has ? f2k(r0) : ~0ull, kb = has ? f2k(r1) : ~0ull;
+          __syncthreads();
+          bitonic_sort2_1024(ka, kb, sbuf);
+          __syncthreads();
+          sbuf[0][0][tid] = ka;
+          sbuf[0][1][tid] = kb;
+          __syncthreads();
+          const double xl = k2f(sbuf[0][0][lo_rank]), xh = k2f(sbuf[0][0][hi_rank]);
+          const double yl = k2f(sbuf[0][1][lo_rank]), yh = k2f(sbuf[0][1][hi_rank]);
+          med[0] = (n & 1) ? xl : (xl + xh) / 2.;
+          med[1] = (n & 1) ? yl : (yl + yh) / 2.;
+          mad_ranks(sbuf[0][0], n, med[0], lo_rank, hi_rank, C->s_mad[0]);
+          mad_ranks(sbuf[0][1], n, med[1], lo_rank, hi_rank, C->s_mad[1]);
+          __syncthreads();
+          sig[0] = ICP_PPF34 * ((n & 1) ? C->s_mad[0][0] : (C->s_mad[0][0] + C->s_mad[0][1]) / 2.);
+          sig[1] = ICP_PPF34 * ((n & 1) ? C->s_mad[1][0] : (C->s_mad[1][0] + C->s_mad[1][1]) / 2.);
+          if (tid == 0) ++C->sorted;
+        } else {  // the sort is written for 1024 threads: hand the call back, the host-driven path serves
+          med[0] = med[1] = sig[0] = sig[1] = 0.;
+          if (tid == 0) C->bail = 1;
+        }
       }
       TINY_STAMP(2);
       // weighted normal equations + Huber error (src/lib.rs:238-255, 45-50), one point per thread
@@ -695,7 +761,7 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
         }
         ++C->evals;
         double delta[3];
-        if (C->nan) {
+        if (C->nan | C->bail) {
           C->done = 1;
         } else if (!solve_update(tot, tot + 9, delta)) {
           C->done = 1;  // None, src/lib.rs:67-69
@@ -734,6 +800,7 @@ __global__ __launch_bounds__(1024) void k_tiny_estimate(const double *__restrict
 #ifdef ICP_TINY_PROFILE
     tp[5] = __builtin_amdgcn_s_memtime() - t_begin;
     for (int q = 0; q < 6; ++q) res->t[q] = tp[q];
+    for (int q = 0; q < 8; ++q) res->ts[q] = tsel[q];
 #endif
   }
 }
@@ -762,24 +829,36 @@ hipError_t launch_tiny_estimate(icp_handle *h, const double *d_src, size_t n, co
   if (!w.h_tiny) {
     if ((e = hipHostMalloc(&w.h_tiny, sizeof(TinyResult) + kTinyMaxIter * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
       return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiny_estimate<2>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess)
-      return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tiny_estimate<3>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess)
-      return e;
+    const void *kernels[] = {
+        reinterpret_cast<const void *>(&k_tiny_estimate<2, 512>),  reinterpret_cast<const void *>(&k_tiny_estimate<2, 768>),
+        reinterpret_cast<const void *>(&k_tiny_estimate<2, 1024>), reinterpret_cast<const void *>(&k_tiny_estimate<3, 512>),
+        reinterpret_cast<const void *>(&k_tiny_estimate<3, 768>),  reinterpret_cast<const void *>(&k_tiny_estimate<3, 1024>)};
+    for (const void *k : kernels)
+      if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
   }
   TinyResult *res = reinterpret_cast<TinyResult *>(w.h_tiny);
   uint32_t *inner = reinterpret_cast<uint32_t *>(res + 1);
   const GridParams &g = h->grid.p;
   const double cx = 0.5 * (g.lo[0] + g.hi[0]), cy = 0.5 * (g.lo[1] + g.hi[1]), cz = 0.5 * (g.lo[2] + g.hi[2]);
   const size_t lds = tiny_lds_bytes(h->dim, (unsigned)h->m);
-  if (h->dim == 3)
-    hipLaunchKernelGGL(k_tiny_estimate<3>, dim3(1), dim3(1024), lds, h->stream, d_src, (unsigned)n, h->d_dst,
-                       (unsigned)h->m, T0, (unsigned)max_iter, cx, cy, cz, g.scale, res, inner, d_last_idx);
-  else
-    hipLaunchKernelGGL(k_tiny_estimate<2>, dim3(1), dim3(1024), lds, h->stream, d_src, (unsigned)n, h->d_dst,
-                       (unsigned)h->m, T0, (unsigned)max_iter, cx, cy, cz, g.scale, res, inner, d_last_idx);
+  // the smallest workgroup with a thread per source point: fewer waves per barrier, and registers
+  // enough (1024 threads leave 128 per thread, and spill)
+  static const unsigned forced = getenv("ICP_TINY_THREADS") ? (unsigned)atoi(getenv("ICP_TINY_THREADS")) : 0u;
+  unsigned threads = n <= 512 ? 512u : (n <= 768 ? 768u : 1024u);
+  if ((forced == 768u || forced == 1024u) && forced >= threads) threads = forced;
+#define ICP_TINY_LAUNCH(D, BB)                                                                                       \
+  hipLaunchKernelGGL((k_tiny_estimate<D, BB>), dim3(1), dim3(BB), lds, h->stream, d_src, (unsigned)n, h->d_dst, \
+                     (unsigned)h->m, T0, (unsigned)max_iter, cx, cy, cz, g.scale, res, inner, d_last_idx)
+  if (h->dim == 3) {
+    if (threads == 512u) ICP_TINY_LAUNCH(3, 512);
+    else if (threads == 768u) ICP_TINY_LAUNCH(3, 768);
+    else ICP_TINY_LAUNCH(3, 1024);
+  } else {
+    if (threads == 512u) ICP_TINY_LAUNCH(2, 512);
+    else if (threads == 768u) ICP_TINY_LAUNCH(2, 768);
+    else ICP_TINY_LAUNCH(2, 1024);
+  }
+#undef ICP_TINY_LAUNCH
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
   *status = res->status;
@@ -791,8 +870,10 @@ hipError_t launch_tiny_estimate(icp_handle *h, const double *d_src, size_t n, co
     w.tiny_sorted += res->sorted;
 #ifdef ICP_TINY_PROFILE
     if (getenv("ICP_TINY_PRINT"))
-      fprintf(stderr, "[tiny] evals %u sorted %u; cycles: setup %llu search %llu select %llu sums %llu step %llu all %llu\n",
-              res->evals, res->sorted, res->t[0], res->t[1], res->t[2], res->t[3], res->t[4], res->t[5]);
+      fprintf(stderr, "[tiny] evals %u sorted %u; cycles: setup %llu search %llu select %llu sums %llu step %llu all %llu; "
+              "selection phases (keys, sample ranks, buckets, scan+list, ranks): %llu %llu %llu %llu %llu\n",
+              res->evals, res->sorted, res->t[0], res->t[1], res->t[2], res->t[3], res->t[4], res->t[5], res->ts[0], res->ts[1],
+              res->ts[2], res->ts[3], res->ts[4]);
 #endif
   }
   return hipSuccess;

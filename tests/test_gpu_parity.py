@@ -439,6 +439,38 @@ def test_estimate_transform_small_inputs_use_the_single_launch_stages():
         assert_pose_close(got, want)
 
 
+@pytest.mark.parametrize("n", [300, 700, 1000])
+def test_single_launch_estimate_with_a_run_of_equal_residuals_at_the_median(n):
+    """40 % or more of the source points sit exactly (0.5, 0.25) from their nearest target, the rest evenly
+    either side: every median is a run of equal keys longer than the in-kernel selection lists.  The
+    1024-thread workgroup (n > 768) sorts instead; the smaller workgroups hand the call back to the
+    host-driven path.  Same bits as the oracle either way, for each of the three workgroup sizes."""
+    rng = np.random.default_rng(n)
+    side = int(np.ceil(np.sqrt(n)))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    dst = (np.stack([gx.ravel(), gy.ravel()], axis=1)[:n] * 4.0 + rng.integers(0, 8, size=(n, 2)) / 8.0).astype(np.float64)
+    off = np.empty((n, 2))
+    k = max(int(0.4 * n), 160)  # (the lists hold 128 keys)
+    off[:k] = (0.5, 0.25)
+    h = (n - k) // 2
+    off[k:k + h] = (0.5, 0.25) - rng.integers(1, 64, size=(h, 2)) / 128.0
+    off[k + h:] = (0.5, 0.25) + rng.integers(1, 64, size=(n - k - h, 2)) / 128.0
+    src = dst + off  # exact: multiples of 1/128 of moderate size
+    icp = I.Icp2d(dst)
+    got, idx, inner = icp.estimate(src, I.Transform(), 3, return_info=True)
+    served, evals, sorted_evals = icp.single_launch_counters()
+    if n > 768:
+        assert served == 1 and sorted_evals >= 1
+    else:
+        assert served == 0
+    blocks, threads = I.reduce_geometry(n)
+    rc, want, oidx, oinner = O.icp_estimate(2, dst, src, opose(I.Transform()), 3, use_kdtree=False, sum_mode=1,
+                                            reduce_blocks=blocks, reduce_threads=threads)
+    assert rc == O.OK
+    assert np.array_equal(got.as_array(), want.as_array())
+    assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
+
+
 def test_stage_calls_on_the_default_stream_are_ordered_and_shards_equal_the_whole():
     """Two handles each matching half of the source cloud into one pair buffer, then the
     replicated inner loop -- all on torch's default (NULL) stream with no explicit

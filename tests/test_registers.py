@@ -15,7 +15,8 @@ CSRC = os.path.join(ROOT, "icp_rust_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 BUDGET = {  # demangled-name fragment -> max VGPRs
-    "k_nn_gridILi3ELb1ELb0E": 120,       # warm 3-D search with the pose applied
+    "k_nn_gridILi3ELb1ELb0E": 120,       # 3-D search with the pose applied, f64 geometry (cold calls, extreme cell sizes)
+    "k_nn_grid_warmILi3E": 96,           # the warm search in f32 geometry: 5 waves per SIMD alone, 3 beside an evaluation
     "k_win_hist": 56,
     "k_win_compactILb0E": 56,            # (the list variant of the refined windows runs alone)
     "k_win_select": 72,
@@ -58,3 +59,15 @@ def test_kernels_that_share_a_simd_stay_within_their_register_budget():
     # 3 search waves + 2 evaluation waves per SIMD: allocation granule 8
     up8 = lambda x: (x + 7) // 8 * 8
     assert 3 * up8(BUDGET["k_nn_gridILi3ELb1ELb0E"]) + 2 * up8(BUDGET["k_win_select"]) <= 512
+    assert 3 * up8(BUDGET["k_nn_grid_warmILi3E"]) + 2 * up8(BUDGET["k_win_select"]) <= 512
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_small_cloud_kernel_does_not_spill_in_the_workgroup_sizes_the_reference_scans_use():
+    """the one-launch estimate holds a thread per source point; 1024 threads leave 128 registers each
+    and spill (measured 14 % slower), so clouds of up to 512 / 768 points run in smaller workgroups"""
+    regs = usage("gn_fast.hip")
+    for b, spill_cap in ((512, 0), (768, 96)):
+        names = [k for k in regs if "k_tiny_estimateILi2ELj%dE" % b in k and not k.endswith("#scratch")]
+        assert len(names) == 1, names
+        assert regs.get(names[0] + "#scratch", 0) <= spill_cap, (names[0], regs.get(names[0] + "#scratch"))
