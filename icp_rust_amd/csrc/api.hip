@@ -403,7 +403,7 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->normals_m = 0;
     h->normals_k = 0;
     w.win_valid = w.win_wide = false;
-    w.win_kind[0] = w.win_kind[1] = Workspace::WinPred();
+    for (auto &wk : w.win_kind) wk = Workspace::WinPred();
     w.win_tried = w.win_missed = w.short_evals = w.radix_evals = 0;
     w.spec_hits = w.spec_misses = w.pre_evals = 0;
     w.tiny_calls = w.tiny_evals = w.tiny_sorted = 0;
@@ -584,14 +584,19 @@ static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
 // kind of evaluation (common.hpp, Workspace::win_kind) and as "the most recent one"
 static void record_statistics(Workspace &w, int kind, bool has_median, const GnResult &r) {
   w.win_valid = has_median;
-  if (kind >= 0 && kind < 2) w.win_kind[kind].valid = has_median;
+  if (Workspace::kind_has_slot(kind)) w.win_kind[kind].valid = has_median;
+  if (kind == 3 || kind == 4) w.win_kind[kind - 3].valid = has_median;  // (the next iteration's evaluations follow on from these)
   if (has_median)
     for (int d = 0; d < 2; ++d) {
       w.win_med[d] = r.median[d];
       w.win_sigma[d] = r.sigma[d];
-      if (kind >= 0 && kind < 2) {
+      if (Workspace::kind_has_slot(kind)) {
         w.win_kind[kind].med[d] = r.median[d];
         w.win_kind[kind].sigma[d] = r.sigma[d];
+      }
+      if (kind == 3 || kind == 4) {
+        w.win_kind[kind - 3].med[d] = r.median[d];
+        w.win_kind[kind - 3].sigma[d] = r.sigma[d];
       }
     }
 }
@@ -611,7 +616,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   bool done = false, has_median = false, hooked = false;
   // the prediction this evaluation's window is (or, pre-launched, was) centred on: its own kind's
   // previous evaluation if there is one, else the most recent evaluation (window_usable)
-  const bool own = kind >= 0 && kind < 2 && w.win_kind[kind].valid;
+  const bool own = Workspace::kind_has_slot(kind) && w.win_kind[kind].valid;
   bool &wide = own ? w.win_kind[kind].wide : w.win_wide;
   double p_med[2], p_sigma[2];
   for (int d = 0; d < 2; ++d) {
@@ -634,6 +639,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
       HIP_TRY(wait_result(h));
       done = has_median = !w.h_res->overflow;
       if (!done) {
+        if (getenv("ICP_WIN_TRACE")) fprintf(stderr, "[win] kind %d: the window missed\n", kind);
         ++w.win_missed;
         wide = true;
       } else if (wide) {  // back to narrow windows once the statistics have settled
@@ -691,6 +697,11 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
     w.gn_dirty = true;
   }
   const GnResult &r = *w.h_res;
+  static const bool win_trace = getenv("ICP_WIN_TRACE") != nullptr;
+  if (win_trace)
+    fprintf(stderr, "[win] kind %d own %d predicted med %.6g %.6g sigma %.6g %.6g -> med %.6g %.6g sigma %.6g %.6g%s\n", kind,
+            (int)own, p_med[0], p_med[1], p_sigma[0], p_sigma[1], r.median[0], r.median[1], r.sigma[0], r.sigma[1],
+            has_median ? "" : " (no statistics)");
   record_statistics(w, kind, has_median, r);
   if (r.nan_flag) {
     w.gn_dirty = true;
@@ -715,7 +726,7 @@ template <typename Hook>
 static int estimate_transform_loop(icp_handle *h, const double *d_a, const double *d_b, size_t n, Pose *out,
                                    uint32_t *inner_iters, Hook &&second_eval_hook,
                                    hipStream_t eval_stream = nullptr, bool hook_first = false,
-                                   bool first_pre_launched = false) {
+                                   bool first_pre_launched = false, int first_kind = 0, int second_kind = 1) {
   Pose T = transform_identity();
   uint32_t applied = 0;
   if (input_size_ok(n)) {
@@ -739,8 +750,9 @@ static int estimate_transform_loop(icp_handle *h, const double *d_a, const doubl
         }
       }
       const int rc = (it == 1 && !hook_first)
-                         ? wgn_step(h, d_a, d_b, n, T, delta, &err, [&] { return second_eval_hook(T); }, false, 1)
-                         : wgn_step(h, d_a, d_b, n, T, delta, &err, it == 0 && first_pre_launched, it < 2 ? it : 2);
+                         ? wgn_step(h, d_a, d_b, n, T, delta, &err, [&] { return second_eval_hook(T); }, false, second_kind)
+                         : wgn_step(h, d_a, d_b, n, T, delta, &err, it == 0 && first_pre_launched,
+                                    it == 0 ? first_kind : (it == 1 ? second_kind : 2));
       if (on_eval_stream) {
         h->stream = first_stream;
         h->ws.swap_ctx();
@@ -885,7 +897,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     // high-priority stream and are placed as soon as a CU has room
     const int rc = estimate_transform_loop(h, A[cur], B[cur], n, &dT, &inner, hook,
                                            two_streams ? w.spec_stream : nullptr, two_streams && nn_first,
-                                           first_pre_launched);
+                                           first_pre_launched, it == 0 ? 3 : 0, it == 0 ? 4 : 1);
     if (rc != ICP_OK) return rc;
     if (inner_iters) inner_iters[it] = inner;
     prev_inner = inner;
@@ -1398,7 +1410,7 @@ static int shard_finish_common(icp_handle *h, double delta[3], double *huber_err
   S.active = false;
   const GnResult &r = *w.h_res;
   const int kind = S.kind;
-  const bool own = kind >= 0 && kind < 2 && w.win_kind[kind].valid;
+  const bool own = Workspace::kind_has_slot(kind) && w.win_kind[kind].valid;
   bool &wide = own ? w.win_kind[kind].wide : w.win_wide;
   if (r.nan_flag) {
     w.gn_dirty = true;

@@ -165,7 +165,12 @@ struct Workspace : GnCtx {
     bool valid = false, wide = false;
     double med[2] = {0., 0.}, sigma[2] = {0., 0.};
   };
-  WinPred win_kind[2];
+  // kinds 3 and 4 = the first and the second evaluation of a CALL's first outer iteration: a new call
+  // (the next frame, or the same cloud again) starts from a pose the previous call's last evaluations
+  // say nothing about, but it usually resembles the start of the previous call.  Their statistics also
+  // seed kinds 0 and 1 for the call's second iteration.
+  WinPred win_kind[5];
+  static bool kind_has_slot(int kind) { return kind == 0 || kind == 1 || kind == 3 || kind == 4; }
   unsigned long long win_tried = 0, win_missed = 0, short_evals = 0, radix_evals = 0;
 };
 

@@ -890,7 +890,7 @@ bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind, bool a
   // instead of giving up -- api.hip, shard_finish_common -- and so serves any number of points)
   if (off || n < kWinMinN || (n > kWinMaxN && !any_n)) return false;
   // the evaluation's own kind first (common.hpp, Workspace::win_kind), else the most recent evaluation
-  const bool own = kind >= 0 && kind < 2 && w.win_kind[kind].valid;
+  const bool own = Workspace::kind_has_slot(kind) && w.win_kind[kind].valid;
   if (!own && !w.win_valid) return false;
   const double *p_med = own ? w.win_kind[kind].med : w.win_med;
   const double *p_sigma = own ? w.win_kind[kind].sigma : w.win_sigma;

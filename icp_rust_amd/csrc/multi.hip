@@ -313,6 +313,21 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
   const int W = M->world, dim = M->dim;
   Pose T = *init;
   if (n > 0 && max_iter > 0 && M->m == 0) return ICP_EMPTY_DST;  // index.unwrap(), src/lib.rs:122,165
+  // whatever way this call ends (an error half-way through an evaluation leaves kernels of the other
+  // ranks enqueued, some of them waiting on flags), nothing of it is in flight afterwards and no
+  // rank keeps a cell-sorted snapshot of a source buffer that the next call overwrites
+  struct Quiesce {
+    icp_multi *M;
+    ~Quiesce() {
+      for (auto &R : M->r)
+        if (R.h) {
+          (void)hipSetDevice(R.device);
+          (void)hipStreamSynchronize(R.h->stream);
+          R.h->qsort.valid = false;
+          R.h->qsort.have_prev = false;
+        }
+    }
+  } quiesce_on_exit{M};
   // every rank's share of the source cloud, compacted in fold order on the host (the reference hands
   // over a host slice; device-resident sources shard with icp_shard_take_device)
   std::vector<size_t> n_local(W);

@@ -960,6 +960,84 @@ __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(con
   if (b) b[i] = make_double2(bx, by);
 }
 
+// ---------------------------------------------------------------- seeds ----------
+// The FIRST search of a snapshot has no previous matches.  The general kernel above then starts every
+// query with an infinite radius and sweeps its whole 3 x 3 x 3 block before it can prune anything
+// (242 us at 1M x 1M against 86 us for a warm search).  Instead: this kernel hands every query SOME
+// nearby target -- the best-screened record of its own row segment, or of the smallest block of cells
+// around it that holds any record -- as if it were its previous match, and the warm kernel does the
+// search proper from that radius.  Nothing here needs to be exact or even good: the warm kernel's
+// result does not depend on where it starts (a poor seed only costs it time).
+template <int DIM>
+__global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__restrict__ src, unsigned n, Pose T,
+                                                               GridParams g, const uint32_t *__restrict__ start,
+                                                               const GridPoint *__restrict__ pts,
+                                                               const double *__restrict__ dst,
+                                                               PrevMatch *__restrict__ prev) {
+  const unsigned k = blockIdx.x * kGridThreads + threadIdx.x;
+  if (k >= n) return;
+  double q[3];
+  q[0] = src[(size_t)k * DIM + 0];
+  q[1] = src[(size_t)k * DIM + 1];
+  q[2] = DIM == 3 ? src[(size_t)k * DIM + 2] : 0.;
+  {  // Transform::transform, src/transform.rs:22-24
+    const double nx = (T.r00 * q[0] + T.r01 * q[1]) + T.tx;
+    const double ny = (T.r10 * q[0] + T.r11 * q[1]) + T.ty;
+    q[0] = nx;
+    q[1] = ny;
+  }
+  PrevMatch out;
+  out.x = out.y = out.z = 0.;
+  out.idx = 0xffffffffu;  // (the warm kernel: "no finite distance", index 0)
+  out.pad = 0;
+  const bool finite = fabs(q[0]) <= 1.7976931348623157e308 && fabs(q[1]) <= 1.7976931348623157e308 &&
+                      (DIM < 3 || fabs(q[2]) <= 1.7976931348623157e308);
+  if (finite) {
+    float qf[3] = {0.f, 0.f, 0.f};
+    int c[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      qf[d] = (float)(q[d] - g.lo[d]);
+      c[d] = (int)fminf(fmaxf(__builtin_floorf(qf[d] * (float)g.inv_h[d]), 0.f), (float)(g.n[d] - 1));
+    }
+    const int hx = g.fx > 1 ? g.fx / 2 : 1;
+    float best = __builtin_huge_valf();
+    uint32_t bi = 0xffffffffu;
+    // blocks of cells growing around the query's own until one holds a record (the first: its own row,
+    // half a cubic cell either way along x)
+    for (int r = 0;; ++r) {
+      const int wx = r * g.fx + hx;
+      const int x0 = max(c[0] - wx, 0), x1 = min(c[0] + wx, g.n[0] - 1);
+      const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
+      const int z0 = DIM == 3 ? max(c[2] - r, 0) : 0, z1 = DIM == 3 ? min(c[2] + r, g.n[2] - 1) : 0;
+      for (int iz = z0; iz <= z1; ++iz)
+        for (int iy = y0; iy <= y1; ++iy) {
+          const uint32_t rb = ((uint32_t)iz * g.n[1] + iy) * g.n[0];
+          const uint32_t s0 = start[rb + x0], e0 = start[rb + x1 + 1];
+          for (uint32_t j = s0; j < e0; ++j) {
+            const uint4 w = reinterpret_cast<const uint4 *>(pts)[j];
+            const float fx = qf[0] - __uint_as_float(w.x), fy = qf[1] - __uint_as_float(w.y);
+            const float fz = DIM == 3 ? qf[2] - __uint_as_float(w.z) : 0.f;
+            const float s2 = fx * fx + fy * fy + fz * fz;
+            if (s2 < best || bi == 0xffffffffu) {
+              best = s2;
+              bi = w.w;
+            }
+          }
+        }
+      if (bi != 0xffffffffu) break;
+      if (x0 == 0 && x1 == g.n[0] - 1 && y0 == 0 && y1 == g.n[1] - 1 && z0 == 0 && z1 == (DIM == 3 ? g.n[2] - 1 : 0)) break;
+    }
+    if (bi != 0xffffffffu) {
+      out.x = dst[(size_t)bi * DIM + 0];
+      out.y = dst[(size_t)bi * DIM + 1];
+      out.z = DIM == 3 ? dst[(size_t)bi * DIM + 2] : 0.;
+      out.idx = bi;
+    }
+  }
+  prev[k] = out;
+}
+
 // ------------------------------------------------ query locality (optional) -------
 // Counting-sort the source cloud by the target-grid cell of T*src.  The sorted copy keeps
 // the ORIGINAL coordinates (the search kernel applies the current pose with the same
@@ -1076,7 +1154,18 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   // the warm search beyond the four-lanes-per-query sizes: the f32-geometry kernel (ICP_NN_OLD_WARM: the
   // round-1 kernel, for A/B runs; both return the same indices)
   static const bool old_warm = getenv("ICP_NN_OLD_WARM") != nullptr;
-  if (q_prev && !coop && xform && G.p.f32_ok && !old_warm) {
+  // the first search of a snapshot: seeds, then the same warm kernel (ICP_NN_OLD_COLD: the general kernel)
+  static const bool old_cold = getenv("ICP_NN_OLD_COLD") != nullptr;
+  const bool seeded = sorted && !q_prev && !coop && xform && G.p.f32_ok && !old_warm && !old_cold && h->m > 0;
+  if (seeded) {
+    if (h->dim == 3)
+      hipLaunchKernelGGL(k_nn_grid_seed<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, n, T, G.p, G.d_start,
+                         G.d_pts, h->d_dst, Q.d_prev);
+    else
+      hipLaunchKernelGGL(k_nn_grid_seed<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, n, T, G.p, G.d_start,
+                         G.d_pts, h->d_dst, Q.d_prev);
+  }
+  if ((q_prev || seeded) && !coop && xform && G.p.f32_ok && !old_warm) {
     if (h->dim == 3)
       hipLaunchKernelGGL(k_nn_grid_warm<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
                          G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev);
