@@ -124,7 +124,10 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     if ((e = alloc_ctx(w.alt, h->stream)) != hipSuccess) return e;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if ((e = hipStreamCreateWithPriority(&w.spec_stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess) return e;
+    // ICP_EVAL_PRIORITY=low|normal: A/B switch for the evaluation stream's priority (default: highest)
+    int prio = prio_greatest;
+    if (const char *pe = getenv("ICP_EVAL_PRIORITY")) prio = pe[0] == 'l' ? prio_least : (pe[0] == 'n' ? 0 : prio_greatest);
+    if ((e = hipStreamCreateWithPriority(&w.spec_stream, hipStreamNonBlocking, prio)) != hipSuccess) return e;
     // the memsets above must have landed before either stream uses the scratch
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
   }

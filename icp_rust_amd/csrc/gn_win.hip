@@ -615,6 +615,40 @@ __device__ __forceinline__ void select_n(const double (&v)[ND][NV], const unsign
   for (int d = 0; d < ND; ++d)
     if (rlo[d] < 0 || rhi[d] >= (long long)cnt[d] || rhi[d] < rlo[d] || cnt[d] > 0xffffu) fail = true;
   if (fail) return;  // uniform
+  // a handful of candidates (clouds of tens of thousands of points: a fine bin holds one or two): rank
+  // them against each other directly -- two barriers instead of the sub-bin machinery's seven
+  constexpr unsigned kDirect = 128;
+  bool direct = true;
+#pragma unroll
+  for (int d = 0; d < ND; ++d) direct = direct && cnt[d] <= kDirect;
+  if (direct) {  // uniform
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+      if (tid < cnt[d]) s_small[d][tid] = f2k(v[d][0]);
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+      if (tid < cnt[d]) {
+        const unsigned long long ki = s_small[d][tid];
+        const unsigned rl = (unsigned)rlo[d], rh = (unsigned)rhi[d];
+        unsigned less = 0, eq = 0;
+        for (unsigned j = 0; j < cnt[d]; ++j) {
+          const unsigned long long kj = s_small[d][j];
+          less += kj < ki;
+          eq += kj == ki;
+        }
+        if (less <= rl && rl < less + eq) s_out[d][0] = ki;
+        if (less <= rh && rh < less + eq) s_out[d][1] = ki;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      out[d][0] = s_out[d][0];
+      out[d][1] = s_out[d][1];
+    }
+    __syncthreads();  // the next call reuses the LDS
+    return;
+  }
   for (unsigned i = tid; i < (unsigned)ND * kSubBins; i += kReduceThreads) (&s_hist[0][0])[i] = 0;
   if (tid < (unsigned)ND) {
     s_nsmall[tid] = 0;
