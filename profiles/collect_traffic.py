@@ -52,36 +52,32 @@ def main():
             "gathers (uncalibrated width): reported uncorrected. Infinity-Cache hits are counted by these "
             "fabric-side counters, so at this 1M size (working set < 256 MiB) they are an upper bound on HBM bytes.")
     doc = {"note": note, "kernels": kernels}
-    # the search kernel: warm <3, true, false> and cold <3, true, true> instantiations, launch-weighted
-    # (the benchmark's timed region holds one cold search per 20 launches; a short PMC run holds more)
-    tot = {"f": 0.0, "w": 0.0, "nf": 0, "nw": 0}
+    # one SEARCH = one launch of k_nn_grid_warm or of the general k_nn_grid; the first search of an
+    # estimate call is a k_nn_grid_seed launch followed by a warm launch (bench.py's HIP events bracket
+    # the pair), so the seeds' bytes are spread over all searches: with bench.py's calls of 20 outer
+    # iterations that is the 1-in-20 share the timed region has
+    tot = {"f": 0.0, "w": 0.0, "searches_f": 0, "searches_w": 0}
     for k, e in kernels.items():
-        if not (k.startswith("icp::k_nn_grid<3, true") or k.startswith("icp::k_nn_grid_warm<3")):
+        is_search = k.startswith("icp::k_nn_grid<3, true") or k.startswith("icp::k_nn_grid_warm<3")
+        if not (is_search or k.startswith("icp::k_nn_grid_seed<3")):
             continue
         tot["f"] += e.get("FETCH_SIZE_KB_avg_per_launch", 0.0) * e.get("launches_FETCH_SIZE", 0)
-        tot["nf"] += e.get("launches_FETCH_SIZE", 0)
         tot["w"] += e.get("WRITE_SIZE_KB_avg_per_launch", 0.0) * e.get("launches_WRITE_SIZE", 0)
-        tot["nw"] += e.get("launches_WRITE_SIZE", 0)
-    if tot["nf"] and tot["nw"]:
-        fb, wb = tot["f"] / tot["nf"] * 1024, tot["w"] / tot["nw"] * 1024
+        if is_search:
+            tot["searches_f"] += e.get("launches_FETCH_SIZE", 0)
+            tot["searches_w"] += e.get("launches_WRITE_SIZE", 0)
+    if tot["searches_f"] and tot["searches_w"]:
+        fb, wb = tot["f"] / tot["searches_f"] * 1024, tot["w"] / tot["searches_w"] * 1024
         doc["k_nn_grid"] = {"traffic_bytes_per_launch": fb + wb, "fetch_bytes": fb, "write_bytes": wb,
-                            "corrected": False, "launches": tot["nf"]}
-        def pick(prefix):  # (a trailing template argument: lanes per query)
-            for k, e in kernels.items():
-                if k.startswith(prefix) and "FETCH_SIZE_KB_avg_per_launch" in e and "WRITE_SIZE_KB_avg_per_launch" in e:
-                    return e
-            return None
-        warm = pick("icp::k_nn_grid_warm<3") or pick("icp::k_nn_grid<3, true, false")
-        if warm and "FETCH_SIZE_KB_avg_per_launch" in warm and "WRITE_SIZE_KB_avg_per_launch" in warm:
-            wb_ = 1024 * (warm["FETCH_SIZE_KB_avg_per_launch"] + warm["WRITE_SIZE_KB_avg_per_launch"])
-            doc["k_nn_grid"]["warm_only_bytes_per_launch"] = wb_
-            cold = pick("icp::k_nn_grid<3, true, true")
-            if cold and "FETCH_SIZE_KB_avg_per_launch" in cold and "WRITE_SIZE_KB_avg_per_launch" in cold:
-                cb_ = 1024 * (cold["FETCH_SIZE_KB_avg_per_launch"] + cold["WRITE_SIZE_KB_avg_per_launch"])
-                doc["k_nn_grid"]["cold_only_bytes_per_launch"] = cb_
-                # bench.py's timed region: estimate calls of 20 outer iterations = 1 cold + 19 warm searches
-                doc["k_nn_grid"]["traffic_bytes_per_launch"] = (19 * wb_ + cb_) / 20
-                doc["k_nn_grid"]["weighting"] = "19 warm + 1 cold search per 20 launches, as in bench.py's timed region"
+                            "corrected": False, "launches": tot["searches_f"],
+                            "weighting": "all search kernels (seed + warm + general) over the number of searches of the run"}
+        for k, e in kernels.items():
+            if k.startswith("icp::k_nn_grid_warm<3") and "FETCH_SIZE_KB_avg_per_launch" in e and "WRITE_SIZE_KB_avg_per_launch" in e:
+                doc["k_nn_grid"]["warm_kernel_bytes_per_launch"] = 1024 * (e["FETCH_SIZE_KB_avg_per_launch"] +
+                                                                            e["WRITE_SIZE_KB_avg_per_launch"])
+            if k.startswith("icp::k_nn_grid_seed<3") and "FETCH_SIZE_KB_avg_per_launch" in e and "WRITE_SIZE_KB_avg_per_launch" in e:
+                doc["k_nn_grid"]["seed_kernel_bytes_per_launch"] = 1024 * (e["FETCH_SIZE_KB_avg_per_launch"] +
+                                                                            e["WRITE_SIZE_KB_avg_per_launch"])
     json.dump(doc, open(out, "w"), indent=1)
     for k, e in kernels.items():
         print(k, e)
