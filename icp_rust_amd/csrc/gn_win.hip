@@ -32,6 +32,9 @@ namespace icp {
 constexpr int kWinThreads = 512;  // workgroups small enough to be placed beside the search kernel's waves
 constexpr int kWinBatch = 4;
 constexpr int kWinAccBatch = 4;  // loads in flight per lane in A (2 saves 16 VGPRs but loses more than the better placement gains)
+#ifndef ICP_SELECT_DIRECT
+#define ICP_SELECT_DIRECT 128  // select_n: lists up to this long are ranked directly
+#endif
 constexpr int kSubBins = 1024;   // select_n: linear sub-bins over the candidates
 constexpr int kSmallCap = 1024;  // select_n: keys ranked by counting, per dimension (a run of equal keys lands here)
 constexpr size_t kWinMinN = 1u << 12;
@@ -617,7 +620,7 @@ __device__ __forceinline__ void select_n(const double (&v)[ND][NV], const unsign
   if (fail) return;  // uniform
   // a handful of candidates (clouds of tens of thousands of points: a fine bin holds one or two): rank
   // them against each other directly -- two barriers instead of the sub-bin machinery's seven
-  constexpr unsigned kDirect = 128;
+  constexpr unsigned kDirect = ICP_SELECT_DIRECT;
   bool direct = true;
 #pragma unroll
   for (int d = 0; d < ND; ++d) direct = direct && cnt[d] <= kDirect;

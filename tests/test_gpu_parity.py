@@ -369,6 +369,42 @@ def test_grid_nn_both_lane_layouts_agree(name):
     assert rc == O.OK and np.array_equal(small, want)
 
 
+@pytest.mark.parametrize("name", ["far3", "lattice3", "clusters3", "lattice2", "line3", "same3", "single3", "flat3", "far2"])
+def test_seeded_first_search_and_the_warm_search_after_it_on_hostile_clouds(name):
+    """beyond 65536 queries the first search of a source snapshot is a seed pass (some nearby target per
+    query) followed by the warm kernel, and later searches start from the previous matches: on clouds
+    with empty regions, ties everywhere, a single target, queries far outside the grid -- and under a pose
+    that moves the queries between the two searches -- every index must equal the kd-tree oracle's."""
+    import torch
+
+    dst, q = _grid_cases()[name]
+    dim = dst.shape[1]
+    reps = 65536 // len(q) + 1
+    big = np.ascontiguousarray(np.tile(q, (reps, 1)))
+    assert len(big) > 65536
+    icp = (I.Icp3d if dim == 3 else I.Icp2d)(dst, nn_mode=I.NN_GRID)
+    d_q = torch.from_numpy(big).cuda()
+    idx = torch.empty(len(big), dtype=torch.int32, device="cuda")
+    a = torch.empty((len(big), 2), dtype=torch.float64, device="cuda")
+    b = torch.empty_like(a)
+    tree = O.KdTree(dst)
+    poses = [I.Transform(), I.Transform(np.array([0.3, -0.2, 0.05])), I.Transform(np.array([-2.0, 1.0, -0.4]))]
+    icp.prepare_source_device(d_q, poses[0])
+    for T in poses:  # the first: seeds + warm; the others: warm from the previous matches
+        icp.correspond_device(d_q, T, a, b, idx)
+        icp.synchronize()
+        p = T.pose
+        moved = q.copy()
+        moved[:, 0] = (p.r00 * q[:, 0] + p.r01 * q[:, 1]) + p.tx  # Transform::transform, src/transform.rs:22-24
+        moved[:, 1] = (p.r10 * q[:, 0] + p.r11 * q[:, 1]) + p.ty
+        rc, want = tree.search(moved)
+        assert rc == O.OK
+        got = idx.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, np.tile(want, reps))
+        assert np.array_equal(a.cpu().numpy(), np.tile(moved[:, :2], (reps, 1)))
+        assert np.array_equal(b.cpu().numpy(), np.tile(dst[want][:, :2], (reps, 1)))
+
+
 def test_warm_search_with_four_lanes_per_query_tracks_the_oracle_over_a_large_motion():
     """the pose moves a lot in the first iterations: boxes of many rows, dealt to the four lanes"""
     pk = synth.synthetic_scan3d_packets(150)
