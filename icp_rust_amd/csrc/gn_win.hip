@@ -437,13 +437,34 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
 #endif
   __shared__ int s_t[2][2];
   WinGeom geo = {};
+#ifdef ICP_WIN_DEBUG
+  long long rst[4] = {0, 0, 0, 0};
+  __shared__ long long s_rst[4][4];
+#endif
   if (wave < 4) {  // waves 0,1: t1 of x,y; waves 2,3: t2 of x,y -- the two halves of the bracket side by side
     const int d = wave & 1, role = wave >> 1;
+#ifdef ICP_WIN_DEBUG
+    rst[0] = wall_clock64();
+#endif
     geo = window_geometry(cum + d * kWinBins, n, P.d[d]);
+#ifdef ICP_WIN_DEBUG
+    rst[1] = wall_clock64();
+#endif
     const int t = geo.ok ? bracket_search(cum + d * kWinBins, n, P.d[d], geo, role) : -1;
+#ifdef ICP_WIN_DEBUG
+    rst[2] = wall_clock64();
+    if (lane == 0) {
+      s_rst[wave][0] = rst[0];
+      s_rst[wave][1] = rst[1];
+      s_rst[wave][2] = rst[2];
+    }
+#endif
     if (lane == 0) s_t[role][d] = t;
   }
   __syncthreads();
+#ifdef ICP_WIN_DEBUG
+  const long long t_b1 = wall_clock64();
+#endif
   if (wave < 2) {  // one wave per dimension
     const int d = wave;
     WinRanges R = {};
@@ -477,9 +498,16 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
       }
     }
   }
+#ifdef ICP_WIN_DEBUG
+  const long long t_b2 = wall_clock64();
+#endif
   __syncthreads();
 #ifdef ICP_WIN_DEBUG
   cst[2] = wall_clock64();
+  if (tid == 0 && blockIdx.x == 100)
+    printf("[C resolve] start->geo %lld geometry %lld bracket %lld (wave 3: %lld %lld) barrier1 %lld resolve_window %lld barrier2 %lld (x10ns)\n",
+           s_rst[0][0] - cst[1], s_rst[0][1] - s_rst[0][0], s_rst[0][2] - s_rst[0][1], s_rst[3][1] - s_rst[3][0],
+           s_rst[3][2] - s_rst[3][1], t_b1 - s_rst[0][2], t_b2 - t_b1, cst[2] - t_b2);
 #endif
   const bool fail = (s_rng[0][6] | s_rng[1][6]) != 0;
   if (blockIdx.x == 0 && tid == 0) st->fail = fail ? 1u : 0u;

@@ -1,6 +1,6 @@
 """Consecutive kernels of the steady state of bench.py's timed region from a rocprofv3 kernel trace:
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -- python3 bench.py --brute-steps 0 --cpu-iters 0 --gn-points 0
-    python3 profiles/steady_state_timeline.py gpurun_out/kt > profiles/r01_timeline_steady_state.txt
+    python3 profiles/steady_state_timeline.py gpurun_out/kt > profiles/r02_timeline_steady_state.txt
 """
 import csv, glob, os, sys
 rows = []
@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""),
                      r.get("Queue_Id", "?")))
 rows.sort()
-warm = [i for i, r in enumerate(rows) if r[2].startswith("icp::k_nn_grid<3, true, false")]
+warm = [i for i, r in enumerate(rows) if r[2].startswith("icp::k_nn_grid<3, true, false") or r[2].startswith("icp::k_nn_grid_warm<3")]
 start = warm[len(warm) * 2 // 3]  # well inside a 20-iteration call
 while not rows[start][2].startswith("icp::k_win_compact"):
     start -= 1
