@@ -916,7 +916,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
     __hip_atomic_store(&whist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   STAMP();
 #ifdef ICP_WIN_DEBUG
-  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && seq % 64 == 50)
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && seq % 8 == 2)
     printf("[A blk %d] loads %lld sel1 %lld sel2 %lld acc %lld red %lld (x10ns)\n", blockIdx.x, stamp[1] - stamp[0],
            stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4]);
 #endif
