@@ -99,6 +99,8 @@ class PacketFile:
             raise ValueError(f"{path}: datasets of {self.dims} do not reshape to ({N_POINTS_IN_PACKET}, 3)")
         self.names, self._off = [], []
         size = self._mm.size
+        if _HEADER.size + n * _ENTRY.size > size:
+            raise ValueError(f"{path}: the table of {n} datasets does not fit the file")
         for k in range(n):
             lo = _HEADER.size + k * _ENTRY.size
             name, off, nbytes = _ENTRY.unpack(self._mm[lo:lo + _ENTRY.size].tobytes())

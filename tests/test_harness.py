@@ -172,6 +172,9 @@ def test_packet_container_round_trip(tmp_path):
     bad.write_bytes(open(f, "rb").read()[:5000])
     with pytest.raises(ValueError):
         scans.PacketFile(str(bad))
+    bad.write_bytes(open(f, "rb").read()[:400])  # cut inside the dataset table
+    with pytest.raises(ValueError):
+        scans.PacketFile(str(bad))
     with pytest.raises(ValueError):
         scans.PacketFile(os.path.join(GOLDEN, "001.txt"))
     with pytest.raises(ValueError):
