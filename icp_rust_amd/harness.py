@@ -92,6 +92,7 @@ def run_scan3d(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=None, p
         while index + step <= scan.size():
             t0 = time.perf_counter()
             icp = ahead.result() if ahead is not None else make(index)
+            ahead = None
             index += step
             ahead = pool.submit(make, index) if pool and index + step <= scan.size() else None
             transform = icp.estimate(src, transform, max_iter)
@@ -106,6 +107,9 @@ def run_scan3d(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=None, p
     finally:
         if pool:
             pool.shutdown(wait=True)
+        # (an error above can leave the prefetched handle of the next frame unconsumed)
+        if ahead is not None and ahead.done() and ahead.exception() is None and hasattr(ahead.result(), "close"):
+            ahead.result().close()
     return transforms, inverses, np.array(path).reshape(-1, 2)
 
 
