@@ -3,7 +3,8 @@
 section 6): frames of 28 800 points registered with the reference's estimator (Icp3d::estimate, 20
 iterations, warm-started) against a map of more than 10 M points that every registered frame is
 appended to.  One GPU; the map is device resident.  Not the headline benchmark (bench.py) -- there is
-no reference number for it, and point-to-plane (no definition in the reference) is not built.
+no reference number for it.  `--point-to-plane K` adds the same loop with the point-to-plane residual
+(the other labelled extension: normals from K nearest map points, computed when a point is inserted).
 
 Prints one JSON line: per-frame registration time, per-frame append time (= rebuilding the search
 grid over the whole map), map build time, frames/s.
@@ -26,6 +27,8 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--frame-points", type=int, default=75 * 384)
     ap.add_argument("--max-iter", type=int, default=20)
+    ap.add_argument("--point-to-plane", type=int, default=0, metavar="K",
+                    help="also run the loop with point-to-plane residuals, normals from K nearest map points (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -89,8 +92,45 @@ def main():
         "pose_abs_err_vs_truth_last_frame": err[-1],
         "dtype": "f64", "data": "synthetic",
     }
-    print(json.dumps(out), flush=True)
     world.close()
+    if args.point_to_plane:
+        # the same frames against a fresh copy of the map, registered point-to-plane
+        k_nn = args.point_to_plane
+        d_map = torch.empty((m0, 3), dtype=torch.float64, device="cuda")
+        for first in range(0, m0, chunk):
+            cnt = min(chunk, m0 - first)
+            d_map[first:first + cnt] = torch.from_numpy(synth.box_cloud(synth.SEED + 200, cnt, first=first)).cuda()
+        world = I.Icp3d(d_map)
+        world.reserve(m0 + (args.frames + 1) * args.frame_points)
+        del d_map
+        world.synchronize()
+        t0 = time.perf_counter()
+        world.compute_normals(k_nn)
+        t_normals = time.perf_counter() - t0
+        world.estimate_point_to_plane(scans[0], I.Transform(), 1)  # untimed: first-call allocations
+        T = I.Transform()
+        est, app, upd, perr = [], [], [], []
+        for k, scan in enumerate(scans, start=1):
+            t0 = time.perf_counter()
+            T = world.estimate_point_to_plane(scan, T, args.max_iter)
+            t1 = time.perf_counter()
+            world.append(scan, T)
+            t2 = time.perf_counter()
+            world.update_normals(k_nn)
+            t3 = time.perf_counter()
+            est.append(1e3 * (t1 - t0))
+            app.append(1e3 * (t2 - t1))
+            upd.append(1e3 * (t3 - t2))
+            perr.append(float(np.max(np.abs(T.as_array() - I.Transform(tuple(k * motion)).as_array()))))
+        out["point_to_plane"] = {
+            "k": k_nn, "normals_of_the_initial_map_ms": 1e3 * t_normals,
+            "estimate_ms": float(np.mean(est)), "append_ms": float(np.mean(app)),
+            "normals_of_the_appended_points_ms": float(np.mean(upd)),
+            "ms_per_frame": float(np.mean(est) + np.mean(app) + np.mean(upd)),
+            "pose_abs_err_vs_truth_last_frame": perr[-1],
+            "note": "labelled extension, no reference behaviour: normals at insertion time (icp_update_target_normals)"}
+        world.close()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -115,6 +115,7 @@ SIGNATURES = {
     "icp_target_count": (_sz, [_vp]),
     "icp_read_targets": (C.c_int, [_vp, _sz, _sz, _vp]),
     "icp_compute_target_normals": (C.c_int, [_vp, C.c_int]),
+    "icp_update_target_normals": (C.c_int, [_vp, C.c_int]),
     "icp_read_target_normals": (C.c_int, [_vp, _sz, _sz, _vp]),
     "icp_estimate_point_to_plane": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
     "icp_estimate_point_to_plane_device": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),

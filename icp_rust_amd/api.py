@@ -472,6 +472,11 @@ class _Icp:
         """Unit normals of the target points from their k nearest targets (3-D handles)."""
         check(lib().icp_compute_target_normals(self._h, int(k)), "icp_compute_target_normals")
 
+    def update_normals(self, k=10):
+        """Normals for the targets appended since compute_normals / update_normals (from the cloud as it is
+        now); the older targets keep theirs."""
+        check(lib().icp_update_target_normals(self._h, int(k)), "icp_update_target_normals")
+
     def read_normals(self, first=0, count=None):
         count = self.target_count - first if count is None else count
         out = np.empty((count, 3), dtype=np.float64)

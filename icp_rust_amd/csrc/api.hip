@@ -1149,7 +1149,8 @@ int append_common(icp_handle *h, const double *pts, size_t k, const icp_pose *T,
   HIP_TRY(hipGetLastError());
   const size_t m_before = h->m;
   h->m += k;
-  h->normals_m = 0;  // (extension) normals describe the cloud before the append
+  // (extension) the normals of the targets that were there stay; the new ones have none until
+  // icp_update_target_normals / icp_compute_target_normals (normals_m < m: point-to-plane calls refuse)
   h->qsort.valid = false;  // snapshots and previous matches refer to the old grid
   h->qsort.have_prev = false;
   h->brute_valid = h->screen_valid = false;
@@ -1207,6 +1208,37 @@ extern "C" int icp_compute_target_normals(icp_handle *h, int k) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(reserve(h->d_normals, h->cap_normals, h->m * 3));
   HIP_TRY(launch_target_normals(h, k, h->d_normals));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->normals_m = h->m;
+  h->normals_k = k;
+  return ICP_OK;
+}
+
+// The targets appended since the normals were last computed get theirs (from their k nearest targets in the cloud
+// as it is NOW); the older targets keep the normals they have -- "normals at insertion time", the definition a map that
+// grows frame by frame uses (a full icp_compute_target_normals re-derives all of them from the current cloud).
+extern "C" int icp_update_target_normals(icp_handle *h, int k) {
+  if (!h || h->dim != 3 || k < 3 || k > 16) return ICP_BAD_ARGUMENT;
+  if (h->m == 0) return ICP_EMPTY_DST;
+  if (!h->grid.built || h->normals_m > h->m) return ICP_BAD_ARGUMENT;
+  if (h->normals_m > 0 && h->normals_k != k) return ICP_BAD_ARGUMENT;  // one neighbourhood size per cloud
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->m * 3 > h->cap_normals || !h->d_normals) {  // grow, keeping the normals that exist
+    double *old = h->d_normals;
+    const size_t keep = h->normals_m * 3;
+    h->d_normals = nullptr;
+    h->cap_normals = 0;
+    hipError_t e = reserve(h->d_normals, h->cap_normals, h->m * 3);
+    if (e == hipSuccess && old && keep)
+      e = hipMemcpyAsync(h->d_normals, old, keep * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(old);
+    if (e != hipSuccess) {
+      h->normals_m = 0;
+      return map_hip(e);
+    }
+  }
+  HIP_TRY(launch_target_normals(h, k, h->d_normals, h->normals_m));
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->normals_m = h->m;
   h->normals_k = k;

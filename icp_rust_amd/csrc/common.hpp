@@ -258,7 +258,8 @@ struct icp_handle {
     icp::WinParams P2;            // the window refined from a missed attempt's global counts
     bool refined_ready = false, attempt_refined = false;
   } shard;
-  // EXTENSION (p2plane.hip): unit normals of the target points (m x 3), valid while normals_m == m
+  // EXTENSION (p2plane.hip): unit normals of the target points (m x 3): those of targets [0, normals_m) exist;
+  // usable while normals_m == m (an append leaves the new targets without one: icp_update_target_normals)
   double *d_normals = nullptr;
   size_t cap_normals = 0, normals_m = 0;
   int normals_k = 0;
@@ -361,7 +362,7 @@ hipError_t multi_sum_hist(hipStream_t s, const void *const *hists, int world, ui
 hipError_t multi_put_pairs(hipStream_t s, const double *a_loc, const double *b_loc, size_t n_total, int rank, int world,
                            double *a_full, double *b_full);
 // EXTENSION: point-to-plane residuals (p2plane.hip)
-hipError_t launch_target_normals(icp_handle *h, int k, double *d_normals);
+hipError_t launch_target_normals(icp_handle *h, int k, double *d_normals, size_t first = 0);
 hipError_t launch_p2pl_gather(icp_handle *h, const double *d_src, size_t n, const Pose &T, const uint32_t *d_idx,
                               const double *d_normals, void *d_pairs);
 hipError_t launch_p2pl_eval(icp_handle *h, const void *d_pairs, size_t n, const Pose &T, double *d_fa, double *d_fb);

@@ -64,10 +64,10 @@ __device__ inline void jacobi3(double a[3][3], double v[3][3]) {
 __global__ __launch_bounds__(64) void k_target_normals(const double *__restrict__ dst, unsigned m, GridParams g,
                                                        const uint32_t *__restrict__ start,
                                                        const GridPoint *__restrict__ pts, int kk,
-                                                       double *__restrict__ normals) {
+                                                       double *__restrict__ normals, unsigned first) {
   __shared__ double s_d[64][kNormalKMax];
   __shared__ uint32_t s_i[64][kNormalKMax];
-  const unsigned i = blockIdx.x * 64 + threadIdx.x;
+  const unsigned i = first + blockIdx.x * 64 + threadIdx.x;  // (targets [first, m): all of them, or the appended ones)
   if (i >= m) return;
   double *bd = s_d[threadIdx.x];
   uint32_t *bi = s_i[threadIdx.x];
@@ -232,10 +232,11 @@ __global__ __launch_bounds__(kReduceThreads) void k_p2pl_accumulate(const PlaneP
   block_reduce_store<kNAcc>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
 }
 
-hipError_t launch_target_normals(icp_handle *h, int k, double *d_normals) {
+hipError_t launch_target_normals(icp_handle *h, int k, double *d_normals, size_t first) {
   const unsigned m = (unsigned)h->m;
-  hipLaunchKernelGGL(k_target_normals, dim3((m + 63) / 64), dim3(64), 0, h->stream, h->d_dst, m, h->grid.p,
-                     (const uint32_t *)h->grid.d_start, (const GridPoint *)h->grid.d_pts, k, d_normals);
+  if (first >= h->m) return hipSuccess;
+  hipLaunchKernelGGL(k_target_normals, dim3((m - (unsigned)first + 63) / 64), dim3(64), 0, h->stream, h->d_dst, m, h->grid.p,
+                     (const uint32_t *)h->grid.d_start, (const GridPoint *)h->grid.d_pts, k, d_normals, (unsigned)first);
   return hipGetLastError();
 }
 

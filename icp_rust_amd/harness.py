@@ -113,7 +113,8 @@ def run_scan3d(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=None, p
     return transforms, inverses, np.array(path).reshape(-1, 2)
 
 
-def run_scan_to_map(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=None, max_frames=None):
+def run_scan_to_map(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=None, max_frames=None,
+                    point_to_plane=None):
     """EXTENSION, not in the reference (BASELINE.json configs[4]): the
     scan3d frames registered against a map that grows.  The map starts as frame 0 (filtered as
     examples/scan3d.rs:63-69 does); every later frame is registered against the whole map with
@@ -121,18 +122,29 @@ def run_scan_to_map(packets, step=PACKETS_PER_FRAME, max_iter=20, icp_factory=No
     scan3d.rs:131 does) and then appended at its registered pose.  The pose maps the scan into
     the map frame, so the path is its translation directly (no inverse()).
     `icp_factory(dst)` must return an object with .estimate and .append(points, transform).
+    `point_to_plane=k` (BASELINE configs[4] names point-to-plane): the frames are registered with the
+    point-to-plane residual instead (Icp3d.estimate_point_to_plane, the other labelled extension); every
+    map point carries the normal of its k nearest map points AT THE TIME IT WAS INSERTED
+    (compute_normals for frame 0, update_normals after every append).
     Returns (transforms, path_xy, map_handle)."""
     icp_factory = icp_factory or Icp3d
     packets = np.asarray(packets, dtype=np.float64)
     world = icp_factory(remove_invalid_values(packets[0:step]))
+    if point_to_plane:
+        world.compute_normals(point_to_plane)
     transform = Transform.identity()
     transforms, path = [], []
     index = step
     while index + step <= packets.shape[0] and (max_frames is None or len(transforms) < max_frames):
         scan = remove_invalid_values(packets[index:index + step])
         index += step
-        transform = world.estimate(scan, transform, max_iter)
+        if point_to_plane:
+            transform = world.estimate_point_to_plane(scan, transform, max_iter)
+        else:
+            transform = world.estimate(scan, transform, max_iter)
         world.append(scan, transform)
+        if point_to_plane:
+            world.update_normals(point_to_plane)
         transforms.append(transform)
         path.append(transform.t.copy())
     return transforms, np.array(path).reshape(-1, 2), world

@@ -324,9 +324,12 @@ int icp_read_targets(icp_handle *h, size_t first, size_t k, double *out);
  *
  * icp_compute_target_normals: unit normal of every target = smallest-eigenvalue eigenvector of the
  * covariance of its k nearest targets (3 <= k <= 16, itself included), searched through the handle's
- * grid; must be called again after an append.  icp_estimate_point_to_plane*: Icp3d::estimate with the
- * scalar residual n_q . (T p - q) in place of the two-row point-to-point residual. */
+ * grid; after an append call it again, or icp_update_target_normals: only the appended targets get a
+ * normal (from the cloud as it is now), the older ones keep theirs ("normals at insertion time": what a
+ * map that grows frame by frame uses; same k as before).  icp_estimate_point_to_plane*: Icp3d::estimate
+ * with the scalar residual n_q . (T p - q) in place of the two-row point-to-point residual. */
 int icp_compute_target_normals(icp_handle *h, int k);
+int icp_update_target_normals(icp_handle *h, int k);
 int icp_read_target_normals(icp_handle *h, size_t first, size_t count, double *out_xyz);
 int icp_estimate_point_to_plane(icp_handle *h, const double *src, size_t n, const icp_pose *init,
                                 size_t max_iter, icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters);

@@ -836,10 +836,16 @@ static void p2pl_jacobi3(double a[3][3], double v[3][3]) {
 
 /* unit normals (m x 3) from the k nearest targets (itself included; ties by lowest index) */
 int orc_p2pl_normals(const double *dst, size_t m, int k_, double *normals) {
-  if (k_ < 3 || k_ > 16) return -1;
+  return orc_p2pl_normals_range(dst, m, 0, k_, normals);
+}
+
+/* normals of the targets [first, m) only, from their k nearest among ALL m targets; normals_out holds m x 3
+ * values and rows [0, first) are left alone (the growing map's "normals at insertion time") */
+int orc_p2pl_normals_range(const double *dst, size_t m, size_t first, int k_, double *normals) {
+  if (k_ < 3 || k_ > 16 || first > m) return -1;
   int k = (size_t)k_ < m ? k_ : (int)m;
 #pragma omp parallel for schedule(dynamic, 64) num_threads(g_threads) if (g_threads > 1)
-  for (size_t i = 0; i < m; ++i) {
+  for (size_t i = first; i < m; ++i) {
     double bd[16];
     uint32_t bi[16];
     int cnt = 0;

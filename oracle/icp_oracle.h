@@ -126,6 +126,7 @@ int orc_wgn_tree_fold(const double *partials_blocks_x_13, int blocks, int thread
 /* EXTENSION CHECKER (no reference counterpart, no parity claim): point-to-plane residuals as
  * include/icp_mi355x.h section 7 defines them; see the block comment in icp_oracle.c */
 int orc_p2pl_normals(const double *dst, size_t m, int k, double *normals_out);
+int orc_p2pl_normals_range(const double *dst, size_t m, size_t first, int k, double *normals_out);
 int orc_p2pl_estimate(const orc_kdtree *tree, const double *dst, size_t m, const double *normals,
                       const double *src, size_t n, const orc_pose *init, size_t max_iter, orc_pose *out,
                       uint32_t *last_idx, uint32_t *inner_iters);

@@ -103,6 +103,7 @@ def lib():
     sig("orc_wgn_tree_partials", C.c_int, pp, dp, dp, sz, C.c_int, C.c_int, dp, dp)
     sig("orc_wgn_tree_fold", C.c_int, dp, C.c_int, C.c_int, dp, dp)
     sig("orc_p2pl_normals", C.c_int, dp, sz, C.c_int, dp)
+    sig("orc_p2pl_normals_range", C.c_int, dp, sz, sz, C.c_int, dp)
     sig("orc_p2pl_estimate", C.c_int, C.c_void_p, dp, sz, dp, dp, sz, pp, sz, pp, u32p, u32p)
     _lib = L
     return L
@@ -324,6 +325,16 @@ def p2pl_normals(dst, k):
     dst, dp_ = _d(dst)
     out = np.zeros((dst.shape[0], 3))
     rc = lib().orc_p2pl_normals(dp_, dst.shape[0], int(k), out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == OK
+    return out
+
+
+def p2pl_normals_update(dst, first, k, normals_prev):
+    """normals of dst[first:] from the whole of dst; rows [0, first) copied from normals_prev"""
+    dst, dp_ = _d(dst)
+    out = np.zeros((dst.shape[0], 3))
+    out[:first] = normals_prev[:first]
+    rc = lib().orc_p2pl_normals_range(dp_, dst.shape[0], int(first), int(k), out.ctypes.data_as(C.POINTER(C.c_double)))
     assert rc == OK
     return out
 

@@ -150,3 +150,73 @@ def test_normals_must_be_recomputed_after_an_append_and_3d_only():
     assert icp.estimate_point_to_plane(dst[:100], I.Transform(), 1) is not None
     with pytest.raises(I.IcpError):
         I.Icp2d(dst[:, :2]).compute_normals(8)
+
+
+# ------------------------------------------------ a map that grows, registered point-to-plane ----
+class OraclePlaneMap:
+    """CPU statement of harness.run_scan_to_map(point_to_plane=k): concatenation, kd-tree rebuilt per frame,
+    normals of the appended points from the cloud at insertion time (tests only)."""
+
+    def __call__(self, dst):
+        self.dst = np.ascontiguousarray(dst, dtype=np.float64)
+        self.normals = None
+        return self
+
+    def compute_normals(self, k):
+        self.k = k
+        self.normals = O.p2pl_normals(self.dst, k)
+
+    def update_normals(self, k):
+        assert k == self.k
+        self.normals = O.p2pl_normals_update(self.dst, len(self.normals), k, self.normals)
+
+    def estimate_point_to_plane(self, src, transform, max_iter):
+        assert len(self.normals) == len(self.dst)
+        rc, T, _, _ = O.p2pl_estimate(O.KdTree(self.dst), self.normals, src, O.Pose(*transform.pose.as_tuple()), max_iter)
+        assert rc == O.OK
+        return I.Transform.from_pose(I.Pose(*[float(x) for x in T.as_array()]))
+
+    def append(self, points, transform=None):
+        p = moved(points, transform) if transform is not None else np.asarray(points, dtype=np.float64)
+        self.dst = np.ascontiguousarray(np.concatenate([self.dst, p]))
+
+
+@gpu
+def test_normals_of_appended_targets_only_and_the_older_ones_kept():
+    rng = np.random.default_rng(5)
+    dst = room(rng, 6000)
+    extra = room(rng, 1500)
+    icp = I.Icp3d(dst)
+    icp.compute_normals(8)
+    before = icp.read_normals()
+    icp.append(extra)
+    with pytest.raises(I.IcpError):  # a different neighbourhood size for the new points
+        icp.update_normals(10)
+    icp.update_normals(8)
+    got = icp.read_normals()
+    assert np.array_equal(got[:6000], before)  # kept, bit for bit
+    O.set_threads(16)
+    try:
+        want = O.p2pl_normals_update(np.concatenate([dst, extra]), 6000, 8, before)
+    finally:
+        O.set_threads(1)
+    assert np.max(np.abs(got - want)) < 1e-9
+    icp.estimate_point_to_plane(extra[:500], I.Transform(), 2)  # usable again
+
+
+@gpu
+def test_scan_to_map_point_to_plane_on_gpu_tracks_the_cpu_statement():
+    from icp_rust_amd import harness, synth
+
+    pk = synth.synthetic_scan3d_packets(4 * 12)
+    O.set_threads(16)
+    try:
+        Os, opath, oworld = harness.run_scan_to_map(pk, step=12, max_iter=4, icp_factory=OraclePlaneMap(), point_to_plane=8)
+    finally:
+        O.set_threads(1)
+    Ts, path, world = harness.run_scan_to_map(pk, step=12, max_iter=4, point_to_plane=8)
+    assert len(Ts) == len(Os) == 3
+    for a, b in zip(Ts, Os):
+        assert np.max(np.abs(a.as_array() - b.as_array())) < 1e-8  # tree sums vs left folds, carried through the map
+    assert np.max(np.abs(world.read_targets() - oworld.dst)) < 1e-7
+    assert np.max(np.abs(world.read_normals() - oworld.normals)) < 1e-6
