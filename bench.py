@@ -360,7 +360,7 @@ def main():
             # bounds it is the FP32 vector rate; the fraction of the FP64 rate is given beside it.
             flops = 8.0 * n_shard * m
             tf = flops / avg_s / 1e12 if avg_s > 0 else 0.0
-            return {"kernel": "k_nn_brute_scr", "bound": "fp32_valu", "achieved": tf, "peak": FP32_VALU_PEAK_TFLOPS,
+            return {"kernel": "k_nn_brute_dot", "bound": "fp32_valu", "achieved": tf, "peak": FP32_VALU_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TFLOPS,
                     "frac_of_fp64_valu_peak": tf / FP64_VALU_PEAK_TFLOPS, "traffic": None,
                     "avg_launch_ms": 1e3 * avg_s, "launches": int(r["nn_launches"]),
@@ -377,7 +377,7 @@ def main():
                 break
         if os.path.exists(tf_path) and world == 1 and n == 1_000_000 and m == 1_000_000:
             traffic = json.load(open(tf_path))["k_nn_grid"]["traffic_bytes_per_launch"]
-        return {"kernel": "k_nn_grid", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"kernel": "k_nn_grid_warm (one search = one launch; the first search of a call = k_nn_grid_seed + k_nn_grid_warm)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": f"profiles/{tf_name} (separate rocprofv3 --pmc passes of this command; a PMC pass "
                                   "cannot run inside the timed process)",
