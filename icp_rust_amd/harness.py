@@ -165,6 +165,8 @@ def main(argv=None):
                                                 "write-synth: packet container file")
     ap.add_argument("--frames", type=int, default=8, help="scan3d / scan2map: synthetic frames")
     ap.add_argument("--max-iter", type=int, default=20)
+    ap.add_argument("--point-to-plane", type=int, default=0, metavar="K",
+                    help="scan2map: register with point-to-plane residuals, normals from K nearest map points (extension)")
     args = ap.parse_args(argv)
     if args.loop == "scan2d":
         if not args.scan_dir:
@@ -182,7 +184,7 @@ def main(argv=None):
     else:
         stream = PacketFile(args.scan_dir).as_array() if args.scan_dir else \
             synth.synthetic_scan3d_packets(PACKETS_PER_FRAME * (args.frames + 1))
-        _, path, world = run_scan_to_map(stream, max_iter=args.max_iter)
+        _, path, world = run_scan_to_map(stream, max_iter=args.max_iter, point_to_plane=args.point_to_plane or None)
         print(f"# map: {world.target_count} points")
     for k, (x, y) in enumerate(path):
         print(f"{k:4d} {x:+.9f} {y:+.9f}")
