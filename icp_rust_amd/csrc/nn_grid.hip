@@ -763,6 +763,10 @@ __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(con
   double best = dist2(pm.x, pm.y, pm.z);
   uint32_t bi = pm.idx;
   double bx = pm.x, by = pm.y, bz = pm.z;
+  if (!(best == best)) {  // a NaN distance compares false with everything: start without a match instead
+    best = __builtin_huge_val();
+    bi = 0xffffffffu;
+  }
 
   // ---- f32 geometry relative to the grid origin ----
   float qf[3], amax = 0.f;
@@ -945,6 +949,12 @@ __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(con
 #endif
     }
   }
+  if (bi == 0xffffffffu) {  // no finite distance at all: index 0, as a scan from 0 would (k_nn_grid does the same)
+    bi = 0;
+    bx = dst[0];
+    by = dst[1];
+    bz = DIM == 3 ? dst[2] : 0.;
+  }
   // a slot whose match did not change already holds this record
   if (bi != pm.idx) {
     PrevMatch out;
@@ -1019,8 +1029,8 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__r
             const float fx = qf[0] - __uint_as_float(w.x), fy = qf[1] - __uint_as_float(w.y);
             const float fz = DIM == 3 ? qf[2] - __uint_as_float(w.z) : 0.f;
             const float s2 = fx * fx + fy * fy + fz * fz;
-            if (s2 < best || bi == 0xffffffffu) {
-              best = s2;
+            if (s2 < best) {  // (a target with a NaN or infinite coordinate never compares less: it cannot be a seed,
+              best = s2;      // and a seed at a NaN distance would never be displaced by the warm kernel)
               bi = w.w;
             }
           }

@@ -405,6 +405,30 @@ def test_seeded_first_search_and_the_warm_search_after_it_on_hostile_clouds(name
         assert np.array_equal(b.cpu().numpy(), np.tile(dst[want][:, :2], (reps, 1)))
 
 
+def test_seeded_search_never_settles_on_a_target_with_a_nan_coordinate():
+    """regression (profiles/extended_fuzz.py, seeds 10154 / 10654): the seed pass took the first record it saw,
+    even one at a NaN distance, and a match at a NaN distance is never displaced (every comparison with it is
+    false) -- two or three queries of 70 000 came back with the NaN target.  Such targets are still binned into
+    the grid (by their finite coordinates); they must simply never win."""
+    rng = np.random.default_rng(10154)
+    m, n = 9000, 70_000
+    dst = rng.normal(size=(m, 3)) * 5
+    src = dst[rng.integers(0, m, size=n)] + rng.normal(size=(n, 3)) * 0.05
+    dst[8603, 2] = np.nan
+    dst[17, 0] = np.nan
+    dst[4000, 1] = np.nan  # (an infinite coordinate leaves no grid at all: the sweep serves those clouds)
+    icp = I.Icp3d(dst)
+    assert I.lib().icp_get_nn_mode(icp._h) == I.NN_GRID
+    T, idx, inner = icp.estimate(src, I.Transform(), 3, return_info=True)
+    b, t = I.reduce_geometry(n)
+    rc, oT, oidx, oinner = O.icp_estimate(3, dst, src, O.transform_identity(), 3, use_kdtree=False, sum_mode=1,
+                                          reduce_blocks=b, reduce_threads=t)
+    assert rc == O.OK
+    assert not np.isin(idx, [8603, 17, 4000]).any()
+    assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
+    assert np.array_equal(T.as_array(), oT.as_array())
+
+
 def test_warm_search_with_four_lanes_per_query_tracks_the_oracle_over_a_large_motion():
     """the pose moves a lot in the first iterations: boxes of many rows, dealt to the four lanes"""
     pk = synth.synthetic_scan3d_packets(150)
