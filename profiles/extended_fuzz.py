@@ -156,5 +156,53 @@ for seed in range(first, first + max(count // 8, 1)):
         bad += 1
         print("NONFINITE MISMATCH seed", seed, "dim", dim, "n", n, "m", m, "case", case, "gpu", got[0], got[1] if got[0] == "err" else "",
               "oracle rc", rc)
+# 5. one handle, several calls beyond the one-lane-per-query threshold (seeded first search, warm searches, the
+#    per-call window predictions), on clouds with structure and from poses that are far off
+for seed in range(first, first + max(count // 16, 1)):
+    rng = np.random.default_rng(130_000 + seed)
+    dim = 2 if seed % 3 == 0 else 3
+    cls = I.Icp3d if dim == 3 else I.Icp2d
+    m = int(rng.choice([9000, 30_000, 70_000, 120_000]))
+    shape = int(rng.integers(0, 4))
+    if shape == 0:
+        dst = rng.normal(size=(m, dim)) * np.array([10.0, 10.0, 1.0][:dim])
+    elif shape == 1:  # lattice: ties and duplicates
+        dst = np.round(rng.normal(size=(m, dim)) * 6) / 2
+    elif shape == 2:  # two tight clusters and a sparse background
+        dst = np.concatenate([rng.normal(size=(m // 2, dim)) * 0.05, rng.normal(size=(m // 4, dim)) * 0.05 + 30,
+                              rng.uniform(-60, 60, size=(m - m // 2 - m // 4, dim))])
+    else:  # flat in the last coordinate
+        dst = rng.normal(size=(m, dim)) * 8
+        dst[:, dim - 1] = 1.25
+    dst = np.ascontiguousarray(dst)
+    icp = cls(dst)
+    T = I.Transform(rng.normal(size=3) * np.array([0.5, 0.5, 0.05]))
+    for call in range(3):
+        n = int(rng.choice([65_537, 70_000, 100_000]))
+        src = dst[rng.integers(0, m, size=n)] + rng.normal(size=(n, dim)) * 0.03
+        if call == 1:  # a different cloud in the same place: the previous call's predictions are of little use
+            src = src + rng.normal(size=(n, dim)) * 0.5
+        iters = int(rng.integers(1, 4))
+        note("calls seed", seed, "dim", dim, "m", m, "shape", shape, "call", call, "n", n, "iters", iters)
+        try:
+            Tn, idx, inner = icp.estimate(src, T, iters, return_info=True)
+            got = ("ok", Tn.as_array(), idx, inner)
+        except I._lib.IcpError as e:
+            got = ("err", e.status)
+        b, t = I.reduce_geometry(n)
+        rc, oT, oidx, oinner = O.icp_estimate(dim, dst, src, O.Pose(*T.pose.as_tuple()), iters, use_kdtree=True, sum_mode=1,
+                                              reduce_blocks=b, reduce_threads=t)
+        if rc == O.OK:
+            same = got[0] == "ok" and np.array_equal(got[1], oT.as_array()) and np.array_equal(got[2], oidx) and \
+                np.array_equal(got[3], oinner)
+        else:
+            same = got[0] == "err" and got[1] == rc
+        if not same:
+            bad += 1
+            print("CALLS MISMATCH seed", seed, "dim", dim, "m", m, "shape", shape, "call", call, "n", n, "iters", iters,
+                  "gpu", got[0], "oracle rc", rc)
+        if got[0] == "ok":
+            T = Tn
+    icp.close()
 print(f"extended fuzz: seeds {first}..{first + count - 1}, {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
