@@ -407,6 +407,10 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->normals_k = 0;
     w.win_valid = w.win_wide = false;
     for (auto &wk : w.win_kind) wk = Workspace::WinPred();
+    // whatever the previous owner's last evaluations left in the selection scratch (a parked flag, a
+    // half-consumed list) must not steer the next owner's first evaluation: one small launch per
+    // scratch at its first use
+    w.gn_dirty = w.alt.gn_dirty = true;
     w.win_tried = w.win_missed = w.short_evals = w.radix_evals = 0;
     w.spec_hits = w.spec_misses = w.pre_evals = 0;
     w.tiny_calls = w.tiny_evals = w.tiny_sorted = 0;
@@ -1359,9 +1363,13 @@ extern "C" size_t icp_shard_partials_bytes(int world) { return world >= 1 ? shar
 
 static int shard_copy(icp_handle *h, const void *src, void *dst, size_t n_total, int rank, int world, size_t elem_bytes,
                       bool take) {
-  if (!h || world < 1 || rank < 0 || rank >= world || elem_bytes == 0 || elem_bytes % 4 || n_total >= 0xffffffffull ||
-      (n_total > 0 && (!src || !dst)))
+  if (!h || world < 1 || rank < 0 || rank >= world || elem_bytes == 0 || elem_bytes % 4 || n_total >= 0xffffffffull)
     return ICP_BAD_ARGUMENT;
+  int b0, b1, blocks;
+  size_t n_local;
+  shard_geometry(n_total, rank, world, &b0, &b1, &blocks, &n_local);
+  if (n_local == 0) return ICP_OK;  // (more ranks than reduction blocks: this rank owns no point, its buffers may be empty)
+  if (!src || !dst) return ICP_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(launch_shard_copy(h, src, dst, n_total, rank, world, (unsigned)(elem_bytes / 4), take));
   return ICP_OK;

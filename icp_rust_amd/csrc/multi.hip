@@ -17,6 +17,8 @@
 // has not run on hardware -- no multi-GPU box is available to this build; its flags are bounded spins,
 // so a visibility problem would surface as ICP_HIP_ERROR, not as a hang.
 #include <cfloat>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -59,10 +61,18 @@ int map_hip(hipError_t e) {
     default: return ICP_HIP_ERROR;
   }
 }
-#define HIP_TRY(expr)                           \
-  do {                                          \
-    hipError_t e__ = (expr);                    \
-    if (e__ != hipSuccess) return map_hip(e__); \
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess) {                                                                           \
+      if (getenv("ICP_MULTI_DEBUG")) fprintf(stderr, "[multi] %s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return map_hip(e__);                                                                             \
+    }                                                                                                  \
+  } while (0)
+#define MULTI_FAIL(what)                                                                          \
+  do {                                                                                            \
+    if (getenv("ICP_MULTI_DEBUG")) fprintf(stderr, "[multi] %s:%d %s\n", __FILE__, __LINE__, what); \
+    return ICP_HIP_ERROR;                                                                         \
   } while (0)
 #define ICP_TRY(expr)              \
   do {                             \
@@ -131,8 +141,12 @@ int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta
   for (int q = 0; q < W; ++q) {
     auto &R = M->r[q];
     const int rc = icp_shard_eval_hist_device(R.h, R.d_a, R.d_b, n_total, q, W, &T, kind, refined, &hist[q]);
+    if (getenv("ICP_MULTI_DEBUG"))
+      fprintf(stderr, "[multi] hist rank %d kind %d refined %d -> rc %d (win_valid %d, kinds %d %d %d %d)\n", q, kind, refined, rc,
+              (int)R.h->ws.win_valid, (int)R.h->ws.win_kind[0].valid, (int)R.h->ws.win_kind[1].valid,
+              (int)R.h->ws.win_kind[3].valid, (int)R.h->ws.win_kind[4].valid);
     if (q == 0) rc0 = rc;
-    else if (rc != rc0) return ICP_HIP_ERROR;  // the ranks' prediction state diverged: cannot happen
+    else if (rc != rc0) MULTI_FAIL("the ranks' prediction state diverged");  // cannot happen
   }
   if (rc0 == ICP_OK) {
     const unsigned gen = ++M->seq;
@@ -182,11 +196,11 @@ int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta
         for (int k = 0; k < 3; ++k) delta[k] = dq[k];
         if (err) *err = eq;
       } else if (rc != rcf) {
-        return ICP_HIP_ERROR;
+        MULTI_FAIL("the ranks finished an evaluation differently");
       }
     }
     for (auto &R : M->r)  // a peer that never arrived?
-      if (__atomic_load_n(R.d_err, __ATOMIC_ACQUIRE)) return ICP_HIP_ERROR;
+      if (__atomic_load_n(R.d_err, __ATOMIC_ACQUIRE)) MULTI_FAIL("a wait on a peer's flag gave up");
     if (rcf == ICP_RETRY_SHARDED) return evaluate(M, n_total, T, kind, delta, err, 1);  // refined window
     if (rcf != ICP_RETRY_REPLICATED) {
       ++M->sharded;
@@ -216,7 +230,7 @@ int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta
       for (int k = 0; k < 3; ++k) delta[k] = dq[k];
       if (err) *err = eq;
     } else if (rc != rcr) {
-      return ICP_HIP_ERROR;
+      MULTI_FAIL("the ranks finished a replicated evaluation differently");
     }
   }
   return rcr;

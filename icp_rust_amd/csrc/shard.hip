@@ -167,7 +167,7 @@ __global__ void k_shard_merge_candidates(ShardPtrs srcs, int world, WinState *st
 }
 
 __global__ void k_shard_pack_partials(const double *__restrict__ partials, int blocks_local, int rows,
-                                      const GnScalars *__restrict__ scal, double *__restrict__ out) {
+                                      GnScalars *__restrict__ scal, double *__restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int W = kNAcc + 1;
   if (t >= rows * W) return;
@@ -176,7 +176,14 @@ __global__ void k_shard_pack_partials(const double *__restrict__ partials, int b
   if (row < blocks_local) v = k < kNAcc ? partials[(size_t)row * W + k] : 0.;
   else if (row == rows - 1) {
     if (k == 0) v = (double)scal->nan_flag;
-    else if (k == 1) v = (double)scal->overflow;
+    else if (k == 1) {
+      v = (double)scal->overflow;
+      // consumed: k_win_accumulate<true, false> parks a missed window here, and the one-GPU pipelines OR
+      // whatever they find in this word into their own verdict (a stale 2 sent the next un-sharded
+      // evaluation of this handle to the radix pipeline -- and left the ranks of a later sharded run with
+      // different prediction states; found by profiles/multi_fuzz.py)
+      scal->overflow = 0;
+    }
     else if (k == 2) v = scal->median[0];
     else if (k == 3) v = scal->median[1];
     else if (k == 4) v = scal->sigma[0];
@@ -264,7 +271,7 @@ static hipError_t accumulate_from(icp_handle *h, const double *d_a, size_t n_loc
                        (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, 0u);
   const int rows = shard_part_rows(world);
   hipLaunchKernelGGL(k_shard_pack_partials, dim3((rows * (kNAcc + 1) + 255) / 256), dim3(256), 0, h->stream,
-                     (const double *)w.d_partials, blocks_local, rows, (const GnScalars *)w.d_scal, (double *)d_out);
+                     (const double *)w.d_partials, blocks_local, rows, w.d_scal, (double *)d_out);
   return hipGetLastError();
 }
 hipError_t shard_launch_accumulate(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,

@@ -3,6 +3,8 @@
 reproduce the one-handle registration bit for bit -- pose, inner-iteration counts, correspondence
 indices.  (8 real GPUs are the driver's to launch; tests/test_dist_gloo.py covers the same
 orchestration over gloo with a CPU stand-in for the stages.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -126,3 +128,19 @@ def test_virtual_ranks_beyond_4m_points_use_refined_windows_not_gathered_pairs()
     assert np.array_equal(inner, inner1) and np.array_equal(idx, idx1)
     assert drv.counters["sharded"] >= 3, drv.counters
     assert drv.counters["replicated"] <= 2, drv.counters
+
+
+def test_recycled_handles_start_their_sharded_evaluations_in_step():
+    """regression (profiles/multi_fuzz.py, seeds 40 .. 47): a sharded evaluation whose window missed parked its
+    verdict in the handle's selection scratch; recycled through the handle pool, that handle sent its next owner's
+    first un-sharded evaluation to the radix pipeline (no statistics recorded), and as one rank of a later sharded
+    run it then disagreed with its peers about whether a window could be predicted (`icp_multi_estimate` refused
+    with ICP_HIP_ERROR; over torch.distributed the ranks would have entered different collectives)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "multi_fuzz.py"), "40", "8"], capture_output=True,
+                         text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "8 seeds" in out.stdout or "0 mismatches" in out.stdout
