@@ -225,9 +225,14 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         if share_gpu:
-            dist.init_process_group("gloo")
+            import datetime
+
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=240))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # (a collective that some rank never enters must end the run with an error within minutes, not hang it)
+            import datetime
+
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
 
     I.build()
     n, m = args.n_src, args.n_dst
