@@ -30,10 +30,22 @@ def build(force=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)]
     srcs += [os.path.join(os.path.dirname(_HERE), "include", f) for f in ("icp_mi355x.h", "icp_trig.h")]
-    stale = (not os.path.exists(LIB_PATH)) or any(
-        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if force or stale:
-        subprocess.check_call(["make", "-C", _CSRC, "-j4", "-s"])
+
+    def stale():
+        return (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+
+    if force or stale():
+        # one builder at a time: the ranks of a multi-process run all import this module together
+        import fcntl
+
+        os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+        with open(os.path.join(os.path.dirname(LIB_PATH), ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if force or stale():  # (another rank may have built it while this one waited)
+                    subprocess.check_call(["make", "-C", _CSRC, "-j4", "-s"])
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
