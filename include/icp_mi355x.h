@@ -35,7 +35,9 @@
 extern "C" {
 #endif
 
-#define ICP_ABI_VERSION 1
+/* 2: additions only (sharded stage calls, icp_multi, single-launch switch, point-to-plane extension, icp_f64_sin/cos);
+ * everything of version 1 is unchanged */
+#define ICP_ABI_VERSION 2
 
 typedef enum icp_status {
   ICP_OK = 0,

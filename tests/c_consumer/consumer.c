@@ -30,7 +30,7 @@ int main(void) {
     icp_transform_apply(&truth, src[i], dst[i]);
     dst[i][2] = src[i][2];
   }
-  if (icp_abi_version() != 1) { fprintf(stderr, "unexpected ABI version %d\n", icp_abi_version()); return 1; }
+  if (icp_abi_version() < 1) { fprintf(stderr, "unexpected ABI version %d\n", icp_abi_version()); return 1; }
   icp_handle *h = NULL;
   int rc = icp_create(&h, 3, &dst[0][0], 21, -1);
   if (rc == ICP_NO_DEVICE) { printf("no HIP device: %s\n", icp_status_string(rc)); return 77; }

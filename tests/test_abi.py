@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version_and_status_strings():
-    assert I.lib().icp_abi_version() == 1
+    assert I.lib().icp_abi_version() == 2
     for s in range(8):
         assert I.lib().icp_status_string(s)
 
