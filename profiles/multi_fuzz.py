@@ -21,7 +21,7 @@ for seed in range(first, first + count):
     dim = 2 if seed % 4 == 0 else 3
     n = int(rng.choice([3, 600, 5000, 40_000, 70_000, 300_000, int(rng.integers(2000, 200_000))]))
     m = int(rng.choice([50, 3000, 9000, 60_000, int(rng.integers(100, 100_000))]))
-    world = int(rng.choice([1, 2, 3, 5, 8]))
+    world = int(rng.choice([1, 2, 3, 5, 8, 12, 16]))
     dst = rng.normal(size=(m, dim)) * np.array([10.0, 10.0, 1.0][:dim])
     if seed % 5 == 0:
         dst = np.round(dst * 2) / 2
