@@ -37,7 +37,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version_and_status_strings():
-    assert I.lib().icp_abi_version() == 2
+    import __graft_entry__ as G
+
+    assert I.lib().icp_abi_version() == G.header_abi_version()
     for s in range(8):
         assert I.lib().icp_status_string(s)
 
@@ -107,3 +109,20 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
                 text = open(os.path.join(d, f)).read()
                 assert "oracle_ffi" not in text and "icp_oracle" not in text and "orc_" not in text, f
+
+
+def test_driver_entry_build_is_green():
+    """The driver runs __graft_entry__.build() on the CPU box every round: run exactly that, so an
+    ABI bump (or anything else build() asserts) cannot pass pytest and fail the driver."""
+    import __graft_entry__ as G
+
+    G.build()
+
+
+@pytest.mark.gpu
+def test_driver_entry_smoke_is_green():
+    """The driver runs __graft_entry__.smoke() on the GPU box at round end (the one oracle
+    comparison outside pytest; loop it checks: /root/reference/src/lib.rs:148-173)."""
+    import __graft_entry__ as G
+
+    G.smoke()
