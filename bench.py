@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 MAX_ITER = 20                  # outer iterations per estimate() call (both reference examples pass 20)
 
 
-def parity_vs_oracle(tree, src, gpu, n_iter, blocks, threads):
+def parity_vs_oracle(tree, src, gpu, n_iter, blocks, threads, perm=None):
     """Part of the CPU-baseline leg, outside every timed region: the registration the GPU just ran
     (`n_iter` outer iterations from the identity pose), repeated by the oracle in the device's
     documented summation order.  Pose, correspondence indices and inner-iteration counts must be
@@ -37,10 +37,17 @@ def parity_vs_oracle(tree, src, gpu, n_iter, blocks, threads):
 
     cores = os.cpu_count() or 1
     O.set_threads(cores)
+    # the device folds its sums over the source cloud in fold order (icp_last_fold_order: the cell-sorted
+    # snapshot of the call); the oracle folds over the order of the cloud it is handed
+    if perm is None:
+        perm = np.arange(len(src))
     try:
-        rc, oT, oidx, oinner = tree.estimate(src, O.transform_identity(), n_iter, O.IcpOpts(1, 1, blocks, threads))
+        rc, oT, oidx_s, oinner = tree.estimate(np.ascontiguousarray(src[perm]), O.transform_identity(), n_iter,
+                                               O.IcpOpts(1, 1, blocks, threads))
     finally:
         O.set_threads(1)
+    oidx = np.empty_like(oidx_s)
+    oidx[perm] = oidx_s
     T, idx, inner = gpu
     return {"checked": "estimate(src, identity, %d) on the benchmark pair vs the oracle in device summation order "
                        "(%d x %d)" % (n_iter, blocks, threads),
@@ -274,10 +281,9 @@ def main():
             if weak:
                 full = torch.from_numpy(synth.synthetic_pair(n_run, 1)[0]).cuda()
             driver = BlockShardedIcp({rank: HipStages(icp)}, n_run, world, comm)
-            local = driver.take_source(full)
-            torch.cuda.synchronize()
-            del full
-            T, _ = driver.estimate(local, T, max(warmup, 2))  # (also seeds the window predictions)
+            # every call: fold order of the whole cloud (the sort one GPU does per call), this rank's blocks out
+            # of it, then the iterations -- all inside the timed region, like the one-GPU call's snapshot
+            T, _, _ = driver.estimate_full(full, T, max(warmup, 2))  # (also seeds the window predictions)
         else:
             driver = ShardedIcp(HipStages(icp), n, rank, world, src_full=d_src_full)
             driver.stages.prepare(d_src, T)
@@ -306,7 +312,7 @@ def main():
             done = 0
             while done < steps:
                 k_iters = min(MAX_ITER, steps - done)
-                T, k = driver.estimate(local, I.Transform(), k_iters)
+                T, k, _ = driver.estimate_full(full, I.Transform(), k_iters)
                 inner.extend(int(x) for x in k[:k_iters])
                 done += k_iters
         else:
@@ -347,7 +353,7 @@ def main():
             # outside the timed region: the same call once more with the index buffer handed back, for the
             # comparison with the oracle in the cpu_baseline leg
             k_last = min(MAX_ITER, steps)
-            checked = (icp.estimate(d_src, I.Transform(), k_last, return_info=True), k_last)
+            checked = (icp.estimate(d_src, I.Transform(), k_last, return_info=True), k_last, icp.last_fold_order(n))
         counters = dict(driver.counters) if block else None
         icp.close()
         return dict(elapsed=elapsed, steps=steps, inner=inner, nn_ms=nn_ms, nn_launches=nn_launches, T=T,
@@ -471,7 +477,7 @@ def main():
             par = None
             if res["checked"] is not None:
                 blocks, threads = I.reduce_geometry(n)
-                par = (res["checked"][0], res["checked"][1], blocks, threads)
+                par = (res["checked"][0], res["checked"][1], blocks, threads, res["checked"][2])
             out["cpu_baseline"] = cpu_baseline(src_np, dst_np, args.cpu_iters, parity_of=par)
             out["parity"] = out["cpu_baseline"].pop("parity")
             # (the CPU side of these is the oracle too: part of the same baseline leg)

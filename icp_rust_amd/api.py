@@ -330,6 +330,31 @@ class _Icp:
         self._after_producer(t)
         return t
 
+    def last_fold_order(self, n, with_cells=False):
+        """The order in which the last estimate() call on this handle folded its sums over the `n` source
+        points (icp_last_fold_order): perm[k] = caller's index of the k-th folded point (identity when the
+        call took no cell-sorted snapshot); with_cells=True also returns the sort keys."""
+        perm = np.zeros(max(n, 1), dtype=np.uint32)
+        cell = np.zeros(max(n, 1), dtype=np.uint32)
+        check(lib().icp_last_fold_order(self._h, n, C.c_void_p(perm.ctypes.data), C.c_void_p(cell.ctypes.data)),
+              "icp_last_fold_order")
+        perm = perm[:n].astype(np.int64)
+        return (perm, cell[:n]) if with_cells else perm
+
+    def sort_source_device(self, d_src, transform):
+        """(sorted copy, permutation) of a device-resident source cloud in the fold order of an estimate call
+        that starts at `transform` (icp_sort_source_device)."""
+        import torch
+
+        self._dev(d_src, "src")
+        out = torch.empty_like(d_src)
+        perm = torch.empty(max(d_src.shape[0], 1), dtype=torch.int32, device=d_src.device)
+        check(lib().icp_sort_source_device(self._h, C.c_void_p(d_src.data_ptr()), d_src.shape[0],
+                                           C.byref(transform.pose), C.c_void_p(out.data_ptr()),
+                                           C.c_void_p(perm.data_ptr())), "icp_sort_source_device")
+        check(lib().icp_synchronize(self._h), "icp_synchronize")  # (produced on the handle's stream)
+        return out, perm[:d_src.shape[0]]
+
     # -- the reference's method ------------------------------------------------------
     def estimate(self, src, initial_transform, max_iter, return_info=False):
         """Icp2d::estimate / Icp3d::estimate (src/lib.rs:105-130, 148-173).  return_info=True also

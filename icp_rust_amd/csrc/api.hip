@@ -72,6 +72,7 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_a2);
   (void)hipFree(w.d_b2);
   (void)hipFree(w.d_idx);
+  (void)hipFree(w.d_idx_slot);
   (void)hipFree(w.d_sa);
   (void)hipFree(w.d_sb);
   if (w.h_whist) (void)hipHostFree(w.h_whist);
@@ -147,6 +148,7 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     if ((e = grow(w.alt.d_rx, cap)) != hipSuccess) return e;
     if ((e = grow(w.alt.d_ry, cap)) != hipSuccess) return e;
     if ((e = grow(w.d_idx, cap)) != hipSuccess) return e;
+    if ((e = grow(w.d_idx_slot, cap)) != hipSuccess) return e;
     w.cap_n = cap;
   }
   if (need_src && !w.d_src) {
@@ -329,11 +331,9 @@ void free_handle(icp_handle *h) {  // really release everything
   (void)hipFree(h->grid.t_cnt);
   (void)hipFree(h->grid.t_btot);
   (void)hipFree(h->grid.t_part);
-  (void)hipFree(h->qsort.d_cnt);
-  (void)hipFree(h->qsort.d_start);
-  (void)hipFree(h->qsort.d_btot);
   (void)hipFree(h->qsort.d_cell_of);
-  (void)hipFree(h->qsort.d_rank_of);
+  (void)hipFree(h->qsort.d_cell);
+  (void)hipFree(h->qsort.d_tmp);
   (void)hipFree(h->qsort.d_perm);
   (void)hipFree(h->qsort.d_sorted);
   (void)hipFree(h->qsort.d_prev);
@@ -403,6 +403,8 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->grid.built = false;
     h->qsort.valid = false;
     h->qsort.have_prev = false;
+    h->qsort.slot_order = false;
+    h->qsort.fold_n = 0;
     h->normals_m = 0;
     h->normals_k = 0;
     w.win_valid = w.win_wide = false;
@@ -540,6 +542,41 @@ extern "C" int icp_prepare_source_device(icp_handle *h, const double *d_src, siz
   if (resolved_nn_mode(h) != ICP_NN_GRID || (long)n < min_n) return ICP_OK;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(prepare_queries(h, d_src, n, *T));
+  return ICP_OK;
+}
+
+namespace icp {
+__global__ void k_iota_u32(uint32_t *p, unsigned n) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+}  // namespace icp
+
+// The fold order of an estimate call that starts at pose T (icp_last_fold_order), applied: d_sorted[k] =
+// d_src[perm[k]].  For hosts that drive the stage calls themselves (the sharded drivers) and want the bits of
+// icp_estimate_device: sort first, then treat the sorted cloud as the source.  Where icp_estimate_device would
+// take no snapshot (sweep engine, n < 16384) this is a plain copy and the identity permutation.
+extern "C" int icp_sort_source_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T,
+                                      double *d_sorted, uint32_t *d_perm) {
+  if (!h || !T || (n > 0 && (!d_src || !d_sorted)) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  if (n == 0) return ICP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  bool sorted = false;
+  if ((long)n > grid_coop_max()) {  // exactly where icp_estimate_device folds in snapshot order
+    const int prc = icp_prepare_source_device(h, d_src, n, T);
+    if (prc != ICP_OK) return prc;
+    sorted = h->qsort.valid && h->qsort.src == d_src && h->qsort.n == n;
+  }
+  HIP_TRY(hipMemcpyAsync(d_sorted, sorted ? h->qsort.d_sorted : d_src, n * h->dim * sizeof(double),
+                         hipMemcpyDeviceToDevice, h->stream));
+  if (d_perm) {
+    if (sorted)
+      HIP_TRY(hipMemcpyAsync(d_perm, h->qsort.d_perm, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
+    else
+      hipLaunchKernelGGL(icp::k_iota_u32, dim3(((unsigned)n + 255) / 256), dim3(256), 0, h->stream, d_perm, (unsigned)n);
+  }
+  h->qsort.valid = false;  // (the snapshot belonged to this call)
+  h->qsort.have_prev = false;
   return ICP_OK;
 }
 
@@ -821,8 +858,10 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
       if (h->ws.spec_stream) (void)hipStreamSynchronize(h->ws.spec_stream);
       h->qsort.valid = false;
       h->qsort.have_prev = false;
+      h->qsort.slot_order = false;
     }
   } quiesce_on_exit{h};
+  h->qsort.fold_n = 0;  // (identity, until this call takes a snapshot)
   // the reference's own sizes (2-D scans of ~650 points): the whole call in one launch on one CU
   if (n > 0 && max_iter > 0 && h->m > 0) {
     int tiny_status = -1;
@@ -844,6 +883,16 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     const int prc = icp_prepare_source_device(h, d_src, n, init);
     if (prc != ICP_OK) return prc;
   }
+  // With a snapshot, the whole call lives in its order (QuerySort::slot_order): searches store the
+  // pairs of slot k at k, the evaluations fold them as they lie (the reduction order of DESIGN.md
+  // section 3 applied to the sorted cloud; icp_last_fold_order hands the permutation to whoever wants to
+  // reproduce the sums), and only the indices of the last search go back to the caller's order.
+  // (clouds small enough for the four-lanes-per-query search keep the caller's order: their scatter is cheap,
+  // and frame-sized registrations stay comparable with stage-call drivers point for point)
+  const bool slot = h->qsort.valid && h->qsort.src == d_src && h->qsort.n == n && (long)n > grid_coop_max();
+  h->qsort.slot_order = slot;
+  if (slot) h->qsort.fold_n = n;
+  uint32_t *const idx_target = slot ? w.d_idx_slot : d_last_idx;
   double *A[2] = {w.d_a, w.d_a2}, *B[2] = {w.d_b, w.d_b2};
   int cur = 0;
   bool spec_valid = false, pre_valid = false, first_pre_launched = false;
@@ -861,7 +910,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     } else {
       first_pre_launched = false;  // (a pre-launched evaluation of discarded pairs just runs out; nobody reads it)
       if (spec_valid) ++w.spec_misses;  // the discarded search precedes this one on the same stream
-      uint32_t *idx_out = (it + 1 == max_iter) ? d_last_idx : nullptr;
+      uint32_t *idx_out = (it + 1 == max_iter && d_last_idx) ? idx_target : nullptr;
       const int rc = icp_correspond_device(h, d_src, n, &T, A[cur], B[cur], idx_out);
       if (rc != ICP_OK) return rc;
     }
@@ -870,7 +919,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     const bool speculate = !no_spec && n > 0 && h->m > 0 && it + 1 < max_iter && prev_inner == 1;
     auto launch_spec = [&](const Pose &T1) -> hipError_t {
       spec_pose = transform_mul(T1, T);  // src/lib.rs:127, 170 -- what the outer loop will compute
-      uint32_t *idx_out = (it + 2 == max_iter) ? d_last_idx : nullptr;
+      uint32_t *idx_out = (it + 2 == max_iter && d_last_idx) ? idx_target : nullptr;
       spec_valid = true;
       pre_valid = false;
       hipStream_t eval_stream = h->stream;  // the hook runs inside the second evaluation
@@ -911,10 +960,31 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     w.last_inner = inner;
     T = transform_mul(dT, T);  // src/lib.rs:127, 170
   }
+  if (slot && d_last_idx && max_iter > 0 && n > 0) HIP_TRY(launch_unpermute_idx(h, w.d_idx_slot, n, d_last_idx));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (two_streams) HIP_TRY(hipStreamSynchronize(w.spec_stream));
   *out = T;
   return ICP_OK;  // (quiesce_on_exit invalidates the snapshot: the caller may reuse or rewrite the source buffer)
+}
+
+// The order in which the last icp_estimate[_device] call on `h` folded its sums (QuerySort::slot_order):
+// perm[k] = original index of the k-th point of that order, cell[k] = its sort key (the target-grid cell of
+// init * src[perm[k]]); the identity (cells 0) when that call took no snapshot.  Host buffers, either may be null.
+extern "C" int icp_last_fold_order(icp_handle *h, size_t n, uint32_t *perm, uint32_t *cell) {
+  if (!h || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  if (n == 0) return ICP_OK;
+  if (h->qsort.fold_n == n && h->qsort.d_perm && h->qsort.d_cell) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (perm) HIP_TRY(hipMemcpy(perm, h->qsort.d_perm, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (cell) HIP_TRY(hipMemcpy(cell, h->qsort.d_cell, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return ICP_OK;
+  }
+  for (size_t i = 0; i < n; ++i) {
+    if (perm) perm[i] = (uint32_t)i;
+    if (cell) cell[i] = 0;
+  }
+  return ICP_OK;
 }
 
 extern "C" int icp_estimate(icp_handle *h, const double *src, size_t n, const icp_pose *init, size_t max_iter,

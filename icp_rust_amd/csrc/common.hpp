@@ -139,6 +139,7 @@ struct Workspace : GnCtx {
   uint32_t last_inner = 0xffffffffu;  // updates the inner loop applied in the last outer iteration of the previous call
   hipStream_t spec_stream = nullptr;  // later evaluations of an inner loop run beside the speculative search
   uint32_t *d_idx = nullptr;
+  uint32_t *d_idx_slot = nullptr;  // the last search's indices in slot order (icp_estimate_device, QuerySort::slot_order)
   // refined windows (n > 4M, gn_win.hip): a strided sample of the pairs and a host copy of the histograms
   double *d_sa = nullptr, *d_sb = nullptr;
   uint32_t *h_whist = nullptr;
@@ -212,17 +213,30 @@ struct PrevMatch {  // a query's previous nearest neighbour, stored per sorted s
   uint32_t idx, pad;
 };
 
-// cell-sorted copy of a source cloud (prepare_queries): locality for the grid search
+// cell-sorted copy of a source cloud (prepare_queries): locality for the grid search.  The order is
+// DETERMINISTIC: ascending (target-grid cell of T0 * src[i], i) -- a stable sort -- so that it can serve
+// as the order in which icp_estimate_device folds its sums (`slot_order`).
 struct QuerySort {
   bool valid = false;
+  // icp_estimate_device: the searches of this call emit a / b / idx in SLOT order (coalesced stores, no
+  // scatter through `perm`) and the Gauss-Newton evaluations fold the pairs in that order
+  bool slot_order = false;
+  size_t fold_n = 0;           // > 0: d_perm / d_cell hold the fold order of the last estimate call on fold_n points
   const double *src = nullptr;  // the device buffer this snapshot was taken from
-  size_t n = 0, cap = 0, cap_cells = 0, cap_btot = 0;
-  uint32_t *d_cnt = nullptr, *d_start = nullptr, *d_btot = nullptr;
-  uint32_t *d_cell_of = nullptr, *d_rank_of = nullptr, *d_perm = nullptr;
+  size_t n = 0, cap = 0;
+  uint32_t *d_cell_of = nullptr;  // cell of every source point, original order (sort keys in)
+  uint32_t *d_cell = nullptr;     // the same, sorted (sort keys out)
+  uint32_t *d_perm = nullptr;     // slot -> original index
+  void *d_tmp = nullptr;          // the radix sort's temporary storage
+  size_t cap_tmp = 0;
   bool have_prev = false;      // d_prev holds the matches of an earlier search of this snapshot
   PrevMatch *d_prev = nullptr; // per sorted slot: the last match (idx = ~0u: none)
   double *d_sorted = nullptr;
 };
+
+// stable LSD radix sort of (cell, index) pairs by cell (qsort.hip); values in = 0 .. n-1
+hipError_t stable_sort_cells(const uint32_t *keys_in, uint32_t *keys_out, uint32_t *perm_out, unsigned n, unsigned bits,
+                             void *&tmp, size_t &cap_tmp, hipStream_t s);
 
 }  // namespace icp
 
@@ -303,6 +317,8 @@ hipError_t launch_materialize(icp_handle *h, const double *d_src, size_t n, cons
 // exact uniform-grid NN: same outputs, same results as launch_nn_brute
 hipError_t build_grid(icp_handle *h);
 hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n, const Pose &T);
+long grid_coop_max();
+hipError_t launch_unpermute_idx(icp_handle *h, const uint32_t *d_slot_idx, size_t n, uint32_t *d_out);
 hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n, const Pose *T, double *d_a,
                           double *d_b, uint32_t *d_idx);
 

@@ -46,6 +46,10 @@ struct icp_multi {
     unsigned *d_err = nullptr;
   };
   std::vector<Rank> r;
+  // rank 0's device: the whole source cloud, its sorted copy and the permutation (the fold order of the call)
+  double *d_sort_in = nullptr, *d_sort_out = nullptr;
+  uint32_t *d_sort_perm = nullptr;
+  size_t cap_sort = 0;
   unsigned seq = 0;  // generation of the exchanges
   uint64_t sharded = 0, replicated = 0;
 };
@@ -255,6 +259,10 @@ extern "C" void icp_destroy_multi(icp_multi *M) {
     (void)hipFree(R.x_flags);
     if (R.d_err) (void)hipHostFree(R.d_err);
   }
+  if (!M->r.empty()) (void)hipSetDevice(M->r[0].device);
+  (void)hipFree(M->d_sort_in);
+  (void)hipFree(M->d_sort_out);
+  (void)hipFree(M->d_sort_perm);
   delete M;
 }
 
@@ -342,8 +350,39 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
         }
     }
   } quiesce_on_exit{M};
-  // every rank's share of the source cloud, compacted in fold order on the host (the reference hands
-  // over a host slice; device-resident sources shard with icp_shard_take_device)
+  // One handle folds its sums over the source cloud in FOLD ORDER (icp_last_fold_order: the cell-sorted
+  // snapshot of the call); the ranks shard THAT order, so that N ranks return the bits of one.  Rank 0's
+  // device sorts the whole cloud once per call (icp_sort_source_device: the same sort, the identity where
+  // one handle would keep the caller's order) and the host deals the sorted copy.
+  std::vector<double> sorted_host;
+  std::vector<uint32_t> perm_host;
+  if (n > 0 && max_iter > 0) {
+    auto &R0 = M->r[0];
+    HIP_TRY(hipSetDevice(R0.device));
+    if (n > M->cap_sort) {
+      (void)hipFree(M->d_sort_in);
+      (void)hipFree(M->d_sort_out);
+      (void)hipFree(M->d_sort_perm);
+      M->d_sort_in = M->d_sort_out = nullptr;
+      M->d_sort_perm = nullptr;
+      M->cap_sort = 0;
+      const size_t cap = n + n / 8 + 1;
+      HIP_TRY(hipMalloc(&M->d_sort_in, cap * 3 * sizeof(double)));
+      HIP_TRY(hipMalloc(&M->d_sort_out, cap * 3 * sizeof(double)));
+      HIP_TRY(hipMalloc(&M->d_sort_perm, cap * sizeof(uint32_t)));
+      M->cap_sort = cap;
+    }
+    HIP_TRY(hipMemcpyAsync(M->d_sort_in, src, n * dim * sizeof(double), hipMemcpyHostToDevice, R0.h->stream));
+    ICP_TRY(icp_sort_source_device(R0.h, M->d_sort_in, n, init, M->d_sort_out, M->d_sort_perm));
+    sorted_host.resize(n * dim);
+    perm_host.resize(n);
+    HIP_TRY(hipMemcpyAsync(sorted_host.data(), M->d_sort_out, n * dim * sizeof(double), hipMemcpyDeviceToHost, R0.h->stream));
+    HIP_TRY(hipMemcpyAsync(perm_host.data(), M->d_sort_perm, n * sizeof(uint32_t), hipMemcpyDeviceToHost, R0.h->stream));
+    HIP_TRY(hipStreamSynchronize(R0.h->stream));
+    src = sorted_host.data();
+  }
+  // every rank's share of the (sorted) source cloud, compacted in fold order on the host (the reference
+  // hands over a host slice; device-resident sources shard with icp_shard_take_device)
   std::vector<size_t> n_local(W);
   std::vector<double> stage;
   for (int q = 0; q < W; ++q) {
@@ -408,7 +447,7 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
       size_t l = 0;
       for (size_t base = 0; base < n; base += G) {
         const size_t s = base + c0, e = base + c1 < n ? base + c1 : n;
-        for (size_t i = s; i < e; ++i) last_idx[i] = li[l++];
+        for (size_t i = s; i < e; ++i) last_idx[perm_host.empty() ? i : perm_host[i]] = li[l++];
       }
     }
   }

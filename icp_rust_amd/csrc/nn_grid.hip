@@ -732,7 +732,7 @@ __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(con
                                                                PrevMatch *prev) {
   const unsigned k = blockIdx.x * kGridThreads + threadIdx.x;
   if (k >= n) return;
-  const unsigned i = perm[k];
+  const unsigned i = perm ? perm[k] : k;  // null: outputs in slot order
   double q[3];
   q[0] = src[(size_t)k * DIM + 0];
   q[1] = src[(size_t)k * DIM + 1];
@@ -1049,14 +1049,15 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__r
 }
 
 // ------------------------------------------------ query locality (optional) -------
-// Counting-sort the source cloud by the target-grid cell of T*src.  The sorted copy keeps
-// the ORIGINAL coordinates (the search kernel applies the current pose with the same
-// arithmetic as always) plus the permutation, so outputs land at the original indices and
-// nothing downstream can tell the difference -- except the memory system: a wave's 64
-// queries now walk the same few cells.
-__global__ void k_query_count(const double *__restrict__ src, unsigned n, int dim, Pose T, GridParams g,
-                              uint32_t *__restrict__ cell_of, uint32_t *__restrict__ rank_of,
-                              uint32_t *__restrict__ cnt) {
+// Sort the source cloud by the target-grid cell of T*src, stably (ties keep the original order: the
+// slot order is a pure function of the inputs, qsort.hip).  The sorted copy keeps the ORIGINAL
+// coordinates (the search kernel applies the current pose with the same arithmetic as always) plus
+// the permutation.  A wave's 64 queries then walk the same few cells; and because the order is
+// deterministic, icp_estimate_device lets everything downstream of the search live in it
+// (QuerySort::slot_order): the search stores its pairs with full-line writes instead of scattering
+// them back through `perm`, and the Gauss-Newton evaluations fold them as they lie.
+__global__ void k_query_cell(const double *__restrict__ src, unsigned n, int dim, Pose T, GridParams g,
+                             uint32_t *__restrict__ cell_of) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double q[3] = {src[(size_t)i * dim], src[(size_t)i * dim + 1], dim == 3 ? src[(size_t)i * dim + 2] : 0.};
@@ -1066,20 +1067,28 @@ __global__ void k_query_count(const double *__restrict__ src, unsigned n, int di
   q[1] = ny;
   int c[3] = {0, 0, 0};
   for (int d = 0; d < dim; ++d) c[d] = cell_coord(q[d], g.lo[d], g.inv_h[d], g.n[d]);
-  const uint32_t cell = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0] + c[0];
-  cell_of[i] = cell;
-  rank_of[i] = atomicAdd(&cnt[cell], 1u);  // arrival order inside the cell: the scatter needs no second counter
+  cell_of[i] = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0] + c[0];
 }
 
-__global__ void k_query_scatter(const double *__restrict__ src, unsigned n, int dim,
-                                const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ rank_of,
-                                const uint32_t *__restrict__ start, double *__restrict__ sorted,
-                                uint32_t *__restrict__ perm) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t pos = start[cell_of[i]] + rank_of[i];
-  perm[pos] = i;
-  for (int d = 0; d < dim; ++d) sorted[(size_t)pos * dim + d] = src[(size_t)i * dim + d];
+__global__ void k_query_gather(const double *__restrict__ src, unsigned n, int dim, const uint32_t *__restrict__ perm,
+                               double *__restrict__ sorted) {
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t i = perm[k];
+  for (int d = 0; d < dim; ++d) sorted[(size_t)k * dim + d] = src[(size_t)i * dim + d];
+}
+
+__global__ void k_unpermute_idx(const uint32_t *__restrict__ slot_idx, const uint32_t *__restrict__ perm, unsigned n,
+                                uint32_t *__restrict__ out) {
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[perm[k]] = slot_idx[k];
+}
+
+hipError_t launch_unpermute_idx(icp_handle *h, const uint32_t *d_slot_idx, size_t n, uint32_t *d_out) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_unpermute_idx, dim3(((unsigned)n + 255) / 256), dim3(256), 0, h->stream, d_slot_idx,
+                     (const uint32_t *)h->qsort.d_perm, (unsigned)n, d_out);
+  return hipGetLastError();
 }
 
 hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const Pose &T) {
@@ -1090,29 +1099,20 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   const unsigned n = (unsigned)n_;
   hipError_t e;
   hipStream_t s = h->stream;
-  const unsigned nscan = G.ncell + 1;
-  const unsigned nb = (nscan + kScanItems - 1) / kScanItems;
-  if ((size_t)nscan > Q.cap_cells || (size_t)nb + 1 > Q.cap_btot) {
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-    size_t c1 = Q.cap_cells, c2 = Q.cap_cells;
-    if ((e = reserve(Q.d_cnt, c1, (size_t)nscan)) != hipSuccess) return e;
-    if ((e = reserve(Q.d_start, c2, (size_t)nscan)) != hipSuccess) return e;
-    Q.cap_cells = c1 < c2 ? c1 : c2;
-    if ((e = reserve(Q.d_btot, Q.cap_btot, (size_t)nb + 1)) != hipSuccess) return e;
-  }
   if (n_ > Q.cap) {
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     (void)hipFree(Q.d_cell_of);
-    (void)hipFree(Q.d_rank_of);
+    (void)hipFree(Q.d_cell);
     (void)hipFree(Q.d_perm);
     (void)hipFree(Q.d_sorted);
     (void)hipFree(Q.d_prev);
     Q.d_prev = nullptr;
-    Q.d_cell_of = Q.d_perm = Q.d_rank_of = nullptr;
+    Q.d_cell_of = Q.d_cell = Q.d_perm = nullptr;
     Q.d_sorted = nullptr;
     Q.cap = 0;
+    Q.fold_n = 0;
     if ((e = hipMalloc(&Q.d_cell_of, n_ * 4)) != hipSuccess) return e;
-    if ((e = hipMalloc(&Q.d_rank_of, n_ * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&Q.d_cell, n_ * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_perm, n_ * 4)) != hipSuccess) return e;
     // three doubles per point whatever this handle's dimension: the buffers outlive it in the handle
     // pool, and a 2-D owner followed by a 3-D one of the same size must not find them short
@@ -1120,21 +1120,24 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     if ((e = hipMalloc(&Q.d_prev, n_ * sizeof(PrevMatch))) != hipSuccess) return e;
     Q.cap = n_;
   }
-  if ((e = hipMemsetAsync(Q.d_cnt, 0, (size_t)nscan * 4, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_query_count, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, T, G.p,
-                     Q.d_cell_of, Q.d_rank_of, Q.d_cnt);
-  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, s, Q.d_cnt, Q.d_start, nscan, Q.d_btot);
-  hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, Q.d_btot, nb, Q.d_btot + nb);
-  hipLaunchKernelGGL(k_scan_add, dim3((nscan + 255) / 256), dim3(256), 0, s, Q.d_start, nscan, Q.d_btot);
-  hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim,
-                     (const uint32_t *)Q.d_cell_of, (const uint32_t *)Q.d_rank_of, (const uint32_t *)Q.d_start,
-                     Q.d_sorted, Q.d_perm);
+  hipLaunchKernelGGL(k_query_cell, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, T, G.p, Q.d_cell_of);
+  unsigned bits = 1;
+  while (bits < 32 && (1ull << bits) < (unsigned long long)G.ncell) ++bits;
+  if ((e = stable_sort_cells(Q.d_cell_of, Q.d_cell, Q.d_perm, n, bits, Q.d_tmp, Q.cap_tmp, s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_query_gather, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim,
+                     (const uint32_t *)Q.d_perm, Q.d_sorted);
   Q.have_prev = false;  // the first search of this snapshot reads no previous matches, it only records them
   if ((e = hipGetLastError()) != hipSuccess) return e;
   Q.src = d_src;
   Q.n = n_;
   Q.valid = true;
   return hipSuccess;
+}
+
+// four lanes per query while one lane per query cannot fill the chip (ICP_NN_COOP_MAX_N: largest n that gets them)
+long grid_coop_max() {
+  static const long coop_max = getenv("ICP_NN_COOP_MAX_N") ? atol(getenv("ICP_NN_COOP_MAX_N")) : 65536;
+  return coop_max;
 }
 
 hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const Pose *Tp, double *d_a,
@@ -1147,7 +1150,8 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   const QuerySort &Q = h->qsort;
   const bool sorted = xform && Q.valid && Q.src == d_src && Q.n == n_;
   const double *q_src = sorted ? Q.d_sorted : d_src;
-  const uint32_t *q_perm = sorted ? Q.d_perm : nullptr;
+  // slot order (icp_estimate_device): outputs stay in the snapshot's order -- k-th pair = k-th sorted point
+  const uint32_t *q_perm = (sorted && !Q.slot_order) ? Q.d_perm : nullptr;
   PrevMatch *q_prev_out = sorted ? Q.d_prev : nullptr;
   const PrevMatch *q_prev = (sorted && Q.have_prev) ? Q.d_prev : nullptr;
   if (sorted) h->qsort.have_prev = true;
@@ -1158,8 +1162,7 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   }
   // four lanes per query while one lane per query cannot fill the chip (8 lanes measured the same, 16
   // slower; ICP_NN_COOP_MAX_N: largest n that gets them, 0 = never)
-  static const long coop_max = getenv("ICP_NN_COOP_MAX_N") ? atol(getenv("ICP_NN_COOP_MAX_N")) : 65536;
-  const bool coop = (long)n <= coop_max;
+  const bool coop = (long)n <= grid_coop_max();
   const unsigned blocks = (unsigned)(((size_t)n * (coop ? 4 : 1) + kGridThreads - 1) / kGridThreads);
   // the warm search beyond the four-lanes-per-query sizes: the f32-geometry kernel (ICP_NN_OLD_WARM: the
   // round-1 kernel, for A/B runs; both return the same indices)

@@ -145,6 +145,11 @@ class HipStages:
     def estimate_transform(self, a_full, b_full):
         return self.icp.estimate_transform_device(a_full, b_full)
 
+    def sort_source(self, src_full, T):
+        """(sorted cloud, permutation): the fold order of a one-GPU estimate call that starts at T
+        (icp_sort_source_device); every rank computes the same one from the same inputs"""
+        return self.icp.sort_source_device(src_full, T)
+
     # -- block-sharded evaluation --
     def take(self, full, local, n_total, rank, world):
         _lib.check(lib().icp_shard_take_device(self.icp._h, C.c_void_p(full.data_ptr()), C.c_void_p(local.data_ptr()),
@@ -237,6 +242,29 @@ class BlockShardedIcp:
             rk.stages.take(full, loc, self.n, rk.rank, self.world)
             out[rk.rank] = loc
         return out
+
+    def sort_source(self, src_full_by_rank, T):
+        """The one-GPU path folds its sums over the source cloud in FOLD ORDER (include/icp_mi355x.h,
+        icp_last_fold_order: a deterministic sort by target-grid cell under the call's initial pose).  To
+        return the same bits, the sharded path shards THAT order: every local rank sorts the full cloud
+        (same inputs, same result everywhere, no communication) -> ({rank: sorted cloud}, {rank: permutation});
+        stages without a sort (the CPU stand-ins of the tests) keep the caller's order."""
+        out, perms = {}, {}
+        for rk in self.ranks:
+            full = src_full_by_rank[rk.rank] if isinstance(src_full_by_rank, dict) else src_full_by_rank
+            if hasattr(rk.stages, "sort_source"):
+                out[rk.rank], perms[rk.rank] = rk.stages.sort_source(full, T)
+            else:
+                out[rk.rank], perms[rk.rank] = full, None
+        return out, perms
+
+    def estimate_full(self, src_full_by_rank, initial_transform, max_iter):
+        """Icp::estimate from the full source cloud, as one GPU runs it: fold order, shard, iterate.
+        Returns (T, inner, {rank: permutation of the fold order or None})."""
+        srt, perms = self.sort_source(src_full_by_rank, initial_transform)
+        local = self.take_source(srt)
+        T, inner = self.estimate(local, initial_transform, max_iter)
+        return T, inner, perms
 
     def _buffers(self, rk, like):
         if rk.bufs is None:

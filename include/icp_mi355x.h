@@ -37,7 +37,10 @@ extern "C" {
 
 /* 2: additions only (sharded stage calls, icp_multi, single-launch switch, point-to-plane extension, icp_f64_sin/cos);
  * everything of version 1 is unchanged */
-#define ICP_ABI_VERSION 2
+/* 3: additions only (icp_last_fold_order; icp_sort_source_device).  Behavioural note: icp_estimate[_device] on the grid
+ * engine now folds its sums over the source cloud in FOLD ORDER (a deterministic sort by target-grid cell, section 9a)
+ * instead of the caller's order -- same correspondences, pose equal within the rounding of a re-ordered sum (~1e-12) */
+#define ICP_ABI_VERSION 3
 
 typedef enum icp_status {
   ICP_OK = 0,
@@ -272,6 +275,22 @@ int icp_profile_read(icp_handle *h, double *nn_kernel_ms, uint64_t *nn_kernel_la
  * deterministic tree; this reports its geometry for n points so a checker can
  * reproduce the exact association order (DESIGN.md "GN reduction order"). */
 void icp_reduce_geometry(size_t n, int *blocks, int *threads);
+/* ... over the source points in FOLD ORDER.  The reference folds over the caller's order
+ * (src/lib.rs:240-255, a left fold); the sum is the same up to rounding, so any fixed order meets the
+ * 1e-5 pose bar.  When icp_estimate[_device] takes a cell-sorted snapshot of the source cloud (grid
+ * engine, n >= 16384) the fold order IS the snapshot order -- ascending (target-grid cell of
+ * init * src[i], i), a stable sort, hence a pure function of the inputs -- so that the search can store
+ * its pairs with full-line writes and nothing is ever scattered back; otherwise it is the caller's order.
+ * icp_last_fold_order reports it for the last estimate call on `h` (host buffers of n words, either may be
+ * NULL): perm[k] = caller's index of the k-th folded point, cell[k] = its sort key (all 0 for the identity).
+ * A checker reproduces the device sums by folding the pairs of src[perm[0]], src[perm[1]], ... in the
+ * tree of icp_reduce_geometry. */
+int icp_last_fold_order(icp_handle *h, size_t n, uint32_t *perm, uint32_t *cell);
+/* The fold order of an estimate call that starts at pose T, applied (device buffers): d_sorted[k] = d_src[perm[k]],
+ * d_perm nullable.  For hosts that drive the stage calls of sections 4 and 5 themselves and want the bits of
+ * icp_estimate_device: sort first, then treat the sorted cloud as the source (sorting it again is the identity). */
+int icp_sort_source_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T, double *d_sorted,
+                           uint32_t *d_perm);
 
 /* Observability for tests: which pipeline served the weighted Gauss-Newton evaluations of
  * this handle (NULL: the scratch handle behind the free functions) since it was created.

@@ -40,11 +40,13 @@ for seed in range(first, first + count):
     d_dst = torch.from_numpy(dst).cuda()
     handles = {r: cls(d_dst) for r in range(world)}
     drv = BlockShardedIcp({r: HipStages(h) for r, h in handles.items()}, n, world, LocalComm(world))
-    local = drv.take_source(torch.from_numpy(src).cuda())
-    T3, in3 = drv.estimate(local, T0, iters)
-    idx3 = np.zeros(max(n, 1), dtype=np.uint32)
+    T3, in3, perms = drv.estimate_full(torch.from_numpy(src).cuda(), T0, iters)  # (fold order of the call, then shards)
+    idx3s = np.zeros(max(n, 1), dtype=np.uint32)
     for r, li in drv.last_indices().items():
-        idx3[local_indices(n, r, world)] = li.cpu().numpy().view(np.uint32)
+        idx3s[local_indices(n, r, world)] = li.cpu().numpy().view(np.uint32)
+    idx3 = np.zeros(max(n, 1), dtype=np.uint32)
+    if n:
+        idx3[perms[0].cpu().numpy().astype(np.int64)] = idx3s[:n]
     for h in handles.values():
         h.close()
     ok_drv = np.array_equal(T1.as_array(), T3.as_array()) and np.array_equal(np.asarray(in1), np.asarray(in3)) and \

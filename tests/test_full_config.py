@@ -13,6 +13,7 @@ import pytest
 
 import icp_rust_amd as I
 import oracle_ffi as O
+from parity_util import check_fold_order
 from icp_rust_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -27,11 +28,18 @@ def test_estimate_1m_x_1m_is_bit_equal_to_the_oracle_in_device_order():
     T, idx, inner = icp.estimate(torch.from_numpy(src).cuda(), I.Transform(), 20, return_info=True)
     blocks, threads = I.reduce_geometry(n)
     assert (blocks, threads) == (256, 512)
+    # the order the call folded its sums in: the cell-sorted snapshot of the source cloud (icp_last_fold_order)
+    perm, cell = icp.last_fold_order(n, with_cells=True)
+    check_fold_order(perm, cell)
+    assert not np.array_equal(perm, np.arange(n))
     tree = O.KdTree(dst)
     O.set_threads(16)  # the independent kd queries of one search over host cores; results do not depend on it
     try:
-        rc, oT, oidx, oinner = tree.estimate(src, O.transform_identity(), 20, O.IcpOpts(1, 1, blocks, threads))
+        rc, oT, oidx_s, oinner = tree.estimate(np.ascontiguousarray(src[perm]), O.transform_identity(), 20,
+                                               O.IcpOpts(1, 1, blocks, threads))
         assert rc == O.OK
+        oidx = np.empty_like(oidx_s)
+        oidx[perm] = oidx_s
         assert np.array_equal(T.as_array(), oT.as_array()), (T.as_array(), oT.as_array())
         assert np.array_equal(idx, oidx)
         assert np.array_equal(inner, oinner)

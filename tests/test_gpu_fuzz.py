@@ -7,6 +7,7 @@ import pytest
 
 import icp_rust_amd as I
 import oracle_ffi as O
+from parity_util import oracle_in_device_order
 
 pytestmark = pytest.mark.gpu
 
@@ -81,9 +82,7 @@ def test_random_registrations_equal_the_oracle(seed):
     iters = int(rng.integers(3, 9))
     icp = I.Icp3d(dst)
     T, idx, inner = icp.estimate(src, init, iters, return_info=True)
-    blocks, threads = I.reduce_geometry(n)
-    rc, oT, oidx, oinner = O.icp_estimate(3, dst, src, opose(init), iters, use_kdtree=True, sum_mode=1,
-                                           reduce_blocks=blocks, reduce_threads=threads)
+    rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, dst, src, opose(init), iters)
     assert rc == O.OK
     assert np.array_equal(idx, oidx)
     assert np.array_equal(inner, oinner)

@@ -14,6 +14,7 @@ import icp_rust_amd as I
 import oracle_ffi as O
 from icp_rust_amd import _lib, synth
 from icp_rust_amd.scans import load_scan2d
+from parity_util import oracle_in_device_order
 
 pytestmark = pytest.mark.gpu
 
@@ -60,11 +61,23 @@ def test_nn_ties_resolve_to_lowest_index(dim):
 
 @pytest.mark.parametrize("n", [300_000, 600_000, 1_100_000])
 def test_nn_large_query_counts_vs_kdtree(n):
-    """exercises the 2/4/8 queries-per-lane kernels; the oracle kd-tree equals its brute force
+    """The sweep's 2 / 4 / 8 queries-per-lane instantiations (n >= 256k / 512k / 900k source points,
+    nn_brute.hip:launch_nn_brute), FORCED to the sweep: with 6 000 targets AUTO would stay on it, with
+    20 000 it resolves to the grid.  The oracle kd-tree equals its brute force
     (tests/test_oracle_kat.py::test_kdtree_equals_brute_force_including_ties)."""
-    src, dst = synth.synthetic_pair(n, 20_000)
-    icp = I.Icp3d(dst)
-    got = icp.nn_search(src)
+    src, dst = synth.synthetic_pair(n, 6_000)
+    got = _nn(dst, src, I.NN_BRUTE)
+    rc, want = O.KdTree(dst).search(src)
+    assert rc == O.OK
+    assert np.array_equal(got, want)
+
+
+def test_brute_force_nn_full_size_vs_kdtree():
+    """BASELINE configs[2] as it is worded ("brute-force NN") at its own size: the LDS-tiled sweep
+    (k_nn_brute_dot<3, 8>) on the 1M x 1M synthetic pair, every index against the oracle
+    (search semantics: /root/reference/src/lib.rs:161-167)."""
+    src, dst = synth.synthetic_pair(1_000_000, 1_000_000)
+    got = _nn(dst, src, I.NN_BRUTE)
     rc, want = O.KdTree(dst).search(src)
     assert rc == O.OK
     assert np.array_equal(got, want)
@@ -199,9 +212,7 @@ def icp_vs_oracle(dim, dst, src, init, max_iter, kd=True):
     n = len(src)
     rc, want, oidx, oinner = O.icp_estimate(dim, dst, src, opose(init), max_iter, use_kdtree=kd)
     assert rc == O.OK
-    blocks, threads = I.reduce_geometry(n)
-    rc, want_t, oidx_t, oinner_t = O.icp_estimate(dim, dst, src, opose(init), max_iter, use_kdtree=kd,
-                                                  sum_mode=1, reduce_blocks=blocks, reduce_threads=threads)
+    rc, want_t, oidx_t, oinner_t = oracle_in_device_order(icp, dim, dst, src, opose(init), max_iter, use_kdtree=kd)
     assert rc == O.OK
     # bit-exact against the oracle in the device's summation order
     assert np.array_equal(got.as_array(), want_t.as_array())
@@ -420,9 +431,7 @@ def test_seeded_search_never_settles_on_a_target_with_a_nan_coordinate():
     icp = I.Icp3d(dst)
     assert I.lib().icp_get_nn_mode(icp._h) == I.NN_GRID
     T, idx, inner = icp.estimate(src, I.Transform(), 3, return_info=True)
-    b, t = I.reduce_geometry(n)
-    rc, oT, oidx, oinner = O.icp_estimate(3, dst, src, O.transform_identity(), 3, use_kdtree=False, sum_mode=1,
-                                          reduce_blocks=b, reduce_threads=t)
+    rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, dst, src, O.transform_identity(), 3, use_kdtree=False)
     assert rc == O.OK
     assert not np.isin(idx, [8603, 17, 4000]).any()
     assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
@@ -433,10 +442,9 @@ def test_warm_search_with_four_lanes_per_query_tracks_the_oracle_over_a_large_mo
     """the pose moves a lot in the first iterations: boxes of many rows, dealt to the four lanes"""
     pk = synth.synthetic_scan3d_packets(150)
     s3, d3 = synth.remove_invalid_values(pk[:75]), synth.remove_invalid_values(pk[75:150])
-    T, idx, inner = I.Icp3d(d3).estimate(s3, I.Transform(), 8, return_info=True)
-    b, t = I.reduce_geometry(len(s3))
-    rc, oT, oidx, oinner = O.icp_estimate(3, d3, s3, O.transform_identity(), 8, use_kdtree=True, sum_mode=1,
-                                          reduce_blocks=b, reduce_threads=t)
+    icp = I.Icp3d(d3)
+    T, idx, inner = icp.estimate(s3, I.Transform(), 8, return_info=True)
+    rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, d3, s3, O.transform_identity(), 8)
     assert rc == O.OK
     assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
     assert np.array_equal(T.as_array(), oT.as_array())
@@ -523,9 +531,7 @@ def test_single_launch_estimate_with_a_run_of_equal_residuals_at_the_median(n):
         assert served == 1 and sorted_evals >= 1
     else:
         assert served == 0
-    blocks, threads = I.reduce_geometry(n)
-    rc, want, oidx, oinner = O.icp_estimate(2, dst, src, opose(I.Transform()), 3, use_kdtree=False, sum_mode=1,
-                                            reduce_blocks=blocks, reduce_threads=threads)
+    rc, want, oidx, oinner = oracle_in_device_order(icp, 2, dst, src, opose(I.Transform()), 3, use_kdtree=False)
     assert rc == O.OK
     assert np.array_equal(got.as_array(), want.as_array())
     assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
@@ -578,9 +584,10 @@ def test_distinct_handles_are_independent_across_host_threads():
         rng = np.random.default_rng(900 + k)
         dst = rng.normal(size=(m, dim)) * 8
         src = dst[rng.integers(0, m, size=n)] + rng.normal(size=(n, dim)) * 0.04
-        b, t = I.reduce_geometry(n)
-        rc, oT, oidx, oinner = O.icp_estimate(dim, dst, src, O.transform_identity(), 4, use_kdtree=True, sum_mode=1,
-                                              reduce_blocks=b, reduce_threads=t)
+        probe = (I.Icp3d if dim == 3 else I.Icp2d)(dst)  # (one call up front: the order its sums are folded in)
+        probe.estimate(src, I.Transform(), 4)
+        rc, oT, oidx, oinner = oracle_in_device_order(probe, dim, dst, src, O.transform_identity(), 4)
+        probe.close()
         assert rc == O.OK
         jobs.append((dim, dst, src, oT.as_array(), oidx, oinner))
     errors = []

@@ -10,6 +10,7 @@ import pytest
 
 import icp_rust_amd as I
 import oracle_ffi as O
+from parity_util import oracle_in_device_order
 from icp_rust_amd import synth
 from icp_rust_amd.dist import BlockShardedIcp, HipStages, LocalComm, block_shard, local_indices
 
@@ -29,20 +30,30 @@ def _run(world, n, m, max_iter, dim=3):
     handles = [cls(d_dst) for _ in range(world)]
     stages = {r: HipStages(handles[r]) for r in range(world)}
     drv = BlockShardedIcp(stages, n, world, LocalComm(world))
-    local = drv.take_source(d_src)
+    # the one-GPU call folds its sums over the cell-sorted cloud (icp_last_fold_order); the sharded driver
+    # shards that order: every rank sorts the full cloud the same way, then takes its blocks' points
+    srt, perms = drv.sort_source(d_src, I.Transform())
+    perm = perms[0].cpu().numpy().astype(np.int64)
+    assert np.array_equal(perm, one.last_fold_order(n))
     for r in range(world):
-        assert np.array_equal(local[r].cpu().numpy(), src[local_indices(n, r, world)])
+        assert torch.equal(perms[r], perms[0]) and torch.equal(srt[r], srt[0])
+    assert np.array_equal(srt[0].cpu().numpy(), src[perm])
+    local = drv.take_source(srt)
+    for r in range(world):
+        assert np.array_equal(local[r].cpu().numpy(), src[perm][local_indices(n, r, world)])
     T, inner = drv.estimate(local, I.Transform(), max_iter)
     torch.cuda.synchronize()
-    idx = np.zeros(n, dtype=np.uint32)
+    idx_s = np.zeros(n, dtype=np.uint32)
     for r, ix in drv.last_indices().items():
-        idx[local_indices(n, r, world)] = ix.cpu().numpy().view(np.uint32)
-    return (T1, idx1, inner1), (T, idx, inner), drv, (src, dst)
+        idx_s[local_indices(n, r, world)] = ix.cpu().numpy().view(np.uint32)
+    idx = np.zeros(n, dtype=np.uint32)
+    idx[perm] = idx_s
+    return (T1, idx1, inner1), (T, idx, inner), drv, (src, dst), one
 
 
 @pytest.mark.parametrize("world,n,m", [(2, 150_000, 120_000), (3, 70_001, 50_000), (8, 150_000, 120_000), (4, 20_000, 9_000)])
 def test_virtual_ranks_reproduce_one_rank_bit_for_bit(world, n, m):
-    (T1, idx1, inner1), (T, idx, inner), drv, _ = _run(world, n, m, 6)
+    (T1, idx1, inner1), (T, idx, inner), drv, _, _ = _run(world, n, m, 6)
     assert np.array_equal(T.as_array(), T1.as_array())
     assert np.array_equal(inner, inner1)
     assert np.array_equal(idx, idx1)
@@ -52,18 +63,16 @@ def test_virtual_ranks_reproduce_one_rank_bit_for_bit(world, n, m):
 
 
 def test_virtual_ranks_2d_and_against_the_oracle():
-    (T1, idx1, inner1), (T, idx, inner), drv, (src, dst) = _run(4, 60_000, 40_000, 4, dim=2)
+    (T1, idx1, inner1), (T, idx, inner), drv, (src, dst), one = _run(4, 70_000, 40_000, 4, dim=2)
     assert np.array_equal(T.as_array(), T1.as_array()) and np.array_equal(idx, idx1) and np.array_equal(inner, inner1)
-    b, t = I.reduce_geometry(len(src))
-    rc, oT, oidx, oinner = O.icp_estimate(2, dst, src, O.transform_identity(), 4, use_kdtree=True, sum_mode=1,
-                                          reduce_blocks=b, reduce_threads=t)
+    rc, oT, oidx, oinner = oracle_in_device_order(one, 2, dst, src, O.transform_identity(), 4)
     assert rc == O.OK
     assert np.array_equal(T.as_array(), oT.as_array()) and np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
 
 
 def test_eight_virtual_ranks_at_the_full_size():
     """BASELINE configs[3] (1M x 1M over 8 ranks), as far as one GPU can rehearse it"""
-    (T1, idx1, inner1), (T, idx, inner), drv, _ = _run(8, 1_000_000, 1_000_000, 5)
+    (T1, idx1, inner1), (T, idx, inner), drv, _, _ = _run(8, 1_000_000, 1_000_000, 5)
     assert np.array_equal(T.as_array(), T1.as_array())
     assert np.array_equal(inner, inner1) and np.array_equal(idx, idx1)
     assert drv.counters["sharded"] >= 6
@@ -123,7 +132,7 @@ def test_icp_create_multi_argument_checks():
 def test_virtual_ranks_beyond_4m_points_use_refined_windows_not_gathered_pairs():
     """past 4M points the one-GPU path finds its windows in two passes; the sharded path instead refines
     a window that missed from that attempt's own (global, exact) counts and stays sharded"""
-    (T1, idx1, inner1), (T, idx, inner), drv, _ = _run(2, 4_500_000, 400_000, 3)
+    (T1, idx1, inner1), (T, idx, inner), drv, _, _ = _run(2, 4_500_000, 400_000, 3)
     assert np.array_equal(T.as_array(), T1.as_array())
     assert np.array_equal(inner, inner1) and np.array_equal(idx, idx1)
     assert drv.counters["sharded"] >= 3, drv.counters

@@ -10,6 +10,7 @@ import pytest
 
 import icp_rust_amd as I
 import oracle_ffi as O
+from parity_util import oracle_in_device_order
 
 pytestmark = pytest.mark.gpu
 
@@ -141,9 +142,7 @@ def test_estimate_uses_the_window_pipeline_and_stays_bit_exact():
     tried, missed, short, radix, spec_hit, spec_miss = I.gn_path_counters(icp)
     assert tried > 8 and missed <= tried // 2
     assert spec_hit + spec_miss > 0  # the outer loop bet on at least one next pose
-    blocks, threads = I.reduce_geometry(n)
-    rc, oT, oidx, oinner = O.icp_estimate(3, dst, src, O.transform_identity(), 8, use_kdtree=True,
-                                           sum_mode=1, reduce_blocks=blocks, reduce_threads=threads)
+    rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, dst, src, O.transform_identity(), 8)
     assert rc == O.OK
     assert np.array_equal(idx, oidx)
     assert np.array_equal(inner, oinner)
@@ -162,9 +161,7 @@ def test_speculative_search_hits_and_misses_leave_the_result_alone():
     _, _, _, _, hit, miss = I.gn_path_counters(icp)
     assert hit + miss > 0
     assert len(set(int(x) for x in inner)) > 1 or hit > 0
-    blocks, threads = I.reduce_geometry(n)
-    rc, oT, oidx, oinner = O.icp_estimate(3, dst, src, O.transform_identity(), 12, use_kdtree=True,
-                                           sum_mode=1, reduce_blocks=blocks, reduce_threads=threads)
+    rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, dst, src, O.transform_identity(), 12)
     assert rc == O.OK
     assert np.array_equal(idx, oidx)
     assert np.array_equal(inner, oinner)
@@ -185,7 +182,10 @@ def test_two_stream_estimate_equals_single_stream_stage_calls_repeatedly():
     src, dst = synth.synthetic_pair(n, m)
     d_src, d_dst = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
     staged = I.Icp3d(d_dst)
-    T_ref, inner_ref = ShardedIcp(HipStages(staged), n).estimate(d_src, I.Transform(), 10)
+    # (the fused call folds its sums over the cell-sorted cloud, icp_last_fold_order: the stage calls get that
+    # cloud as their source -- sorting it again is the identity)
+    d_sorted, _ = staged.sort_source_device(d_src, I.Transform())
+    T_ref, inner_ref = ShardedIcp(HipStages(staged), n).estimate(d_sorted, I.Transform(), 10)
     fused = I.Icp3d(d_dst)
     for rep in range(12):
         T, inner = fused.estimate(d_src, I.Transform(), 10, return_info="inner")
@@ -264,10 +264,8 @@ def test_pooled_handles_start_clean():
         src, dst = synth.synthetic_pair(n, m, seed=synth.SEED + seed)
         icp = I.Icp3d(dst)
         T, idx, inner = icp.estimate(src, I.Transform(), iters, return_info=True)
+        rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, dst, src, O.transform_identity(), iters)
         icp.close()
-        b, t = I.reduce_geometry(n)
-        rc, oT, oidx, oinner = O.icp_estimate(3, dst, src, O.transform_identity(), iters, use_kdtree=True,
-                                               sum_mode=1, reduce_blocks=b, reduce_threads=t)
         assert rc == O.OK
         assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
         assert np.array_equal(T.as_array(), oT.as_array())
@@ -277,10 +275,8 @@ def test_pooled_handles_start_clean():
         src, dst = load_scan2d(os.path.join(d, "001.txt")), load_scan2d(os.path.join(d, "002.txt"))
         icp = I.Icp2d(dst)
         T, idx, inner = icp.estimate(src, I.Transform(), 6, return_info=True)
+        rc, oT, oidx, oinner = oracle_in_device_order(icp, 2, dst, src, O.transform_identity(), 6)
         icp.close()
-        b, t = I.reduce_geometry(len(src))
-        rc, oT, oidx, oinner = O.icp_estimate(2, dst, src, O.transform_identity(), 6, use_kdtree=True,
-                                               sum_mode=1, reduce_blocks=b, reduce_threads=t)
         assert rc == O.OK
         assert np.array_equal(inner, oinner)
         assert np.array_equal(T.as_array(), oT.as_array())
@@ -307,10 +303,8 @@ def test_a_pooled_handle_changes_dimension():
         src = dst[rng.integers(0, m, size=n)] + rng.normal(size=(n, dim)) * 0.05
         icp = (I.Icp3d if dim == 3 else I.Icp2d)(dst)
         T, idx, inner = icp.estimate(src, I.Transform([0.05, -0.03, 0.01]), 3, return_info=True)
+        rc, oT, oidx, oinner = oracle_in_device_order(icp, dim, dst, src, opose(I.Transform([0.05, -0.03, 0.01])), 3)
         icp.close()  # parked: the next handle, of the other dimension, reuses its buffers
-        b, t = I.reduce_geometry(n)
-        rc, oT, oidx, oinner = O.icp_estimate(dim, dst, src, opose(I.Transform([0.05, -0.03, 0.01])), 3, use_kdtree=True,
-                                              sum_mode=1, reduce_blocks=b, reduce_threads=t)
         assert rc == O.OK
         assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
         assert np.array_equal(T.as_array(), oT.as_array())

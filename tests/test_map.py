@@ -7,6 +7,7 @@ import pytest
 
 import icp_rust_amd as I
 import oracle_ffi as O
+from parity_util import oracle_in_device_order
 from icp_rust_amd import _lib, harness, synth
 
 
@@ -128,9 +129,7 @@ def test_repeated_appends_between_estimates_track_the_oracle():
     T = I.Transform([0.05, -0.04, 0.01])
     for part in parts[1:]:
         Tg, idx, inner = grown.estimate(scan, T, 3, return_info=True)
-        b, t = I.reduce_geometry(len(scan))
-        rc, oT, oidx, oinner = O.icp_estimate(3, dst, scan, O.Pose(*T.pose.as_tuple()), 3, use_kdtree=True,
-                                              sum_mode=1, reduce_blocks=b, reduce_threads=t)
+        rc, oT, oidx, oinner = oracle_in_device_order(grown, 3, dst, scan, O.Pose(*T.pose.as_tuple()), 3)
         assert rc == O.OK
         assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
         assert np.array_equal(Tg.as_array(), oT.as_array())
