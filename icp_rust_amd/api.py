@@ -281,6 +281,13 @@ def gn_path_counters(icp=None):
     return tuple(int(x) for x in out)
 
 
+def nn_tile_counters(icp):
+    """(waves launched, waves handed to the per-lane gather walk) of the handle's last LDS-tile search"""
+    out = (C.c_uint64 * 2)()
+    check(lib().icp_nn_tile_counters(icp._h, out), "icp_nn_tile_counters")
+    return int(out[0]), int(out[1])
+
+
 class _Icp:
     DIM = 0
 

@@ -723,15 +723,11 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid(const double *__restri
 #define ICP_WARM_QUADS 2  // aligned quads (of four records) in flight per lane
 #endif
 template <int DIM>
-__global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(const double *__restrict__ src,
-                                                               const uint32_t *__restrict__ perm, unsigned n, Pose T,
-                                                               GridParams g, const uint32_t *__restrict__ start,
-                                                               const GridPoint *__restrict__ pts,
-                                                               const double *__restrict__ dst, uint32_t *__restrict__ idx,
-                                                               double2 *__restrict__ a, double2 *__restrict__ b,
-                                                               PrevMatch *prev) {
-  const unsigned k = blockIdx.x * kGridThreads + threadIdx.x;
-  if (k >= n) return;
+__device__ __forceinline__ void warm_query(const unsigned k, const double *__restrict__ src,
+                                           const uint32_t *__restrict__ perm, Pose T, const GridParams &g,
+                                           const uint32_t *__restrict__ start, const GridPoint *__restrict__ pts,
+                                           const double *__restrict__ dst, uint32_t *__restrict__ idx,
+                                           double2 *__restrict__ a, double2 *__restrict__ b, PrevMatch *prev) {
   const unsigned i = perm ? perm[k] : k;  // null: outputs in slot order
   double q[3];
   q[0] = src[(size_t)k * DIM + 0];
@@ -970,6 +966,48 @@ __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(con
   if (b) b[i] = make_double2(bx, by);
 }
 
+template <int DIM>
+__global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(const double *__restrict__ src,
+                                                               const uint32_t *__restrict__ perm, unsigned n, Pose T,
+                                                               GridParams g, const uint32_t *__restrict__ start,
+                                                               const GridPoint *__restrict__ pts,
+                                                               const double *__restrict__ dst, uint32_t *__restrict__ idx,
+                                                               double2 *__restrict__ a, double2 *__restrict__ b,
+                                                               PrevMatch *prev) {
+  const unsigned k = blockIdx.x * kGridThreads + threadIdx.x;
+  if (k >= n) return;
+  warm_query<DIM>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev);
+}
+
+// The same search for the waves the tile kernel (nn_tile.hip) handed back (a flag per wave): one workgroup
+// per wave of queries, the unflagged ones leave at once.
+template <int DIM>
+__global__ __launch_bounds__(kGridThreads) void k_nn_grid_warm_flagged(const double *__restrict__ src,
+                                                                       const uint32_t *__restrict__ perm, unsigned n, Pose T,
+                                                                       GridParams g, const uint32_t *__restrict__ start,
+                                                                       const GridPoint *__restrict__ pts,
+                                                                       const double *__restrict__ dst,
+                                                                       uint32_t *__restrict__ idx, double2 *__restrict__ a,
+                                                                       double2 *__restrict__ b, PrevMatch *prev,
+                                                                       const uint32_t *__restrict__ flags) {
+  if (flags[blockIdx.x] == 0u) return;
+  const unsigned k = blockIdx.x * kGridThreads + threadIdx.x;
+  if (k < n) warm_query<DIM>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev);
+}
+
+hipError_t launch_nn_warm_flagged(icp_handle *h, const double *q_src, const uint32_t *q_perm, unsigned n, const Pose &T,
+                                  uint32_t *d_idx, double2 *d_a, double2 *d_b, const uint32_t *flags) {
+  const Grid &G = h->grid;
+  const unsigned blocks = (n + kGridThreads - 1) / kGridThreads;
+  if (h->dim == 3)
+    hipLaunchKernelGGL(k_nn_grid_warm_flagged<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
+                       G.d_start, G.d_pts, h->d_dst, d_idx, d_a, d_b, h->qsort.d_prev, flags);
+  else
+    hipLaunchKernelGGL(k_nn_grid_warm_flagged<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
+                       G.d_start, G.d_pts, h->d_dst, d_idx, d_a, d_b, h->qsort.d_prev, flags);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- seeds ----------
 // The FIRST search of a snapshot has no previous matches.  The general kernel above then starts every
 // query with an infinite radius and sweeps its whole 3 x 3 x 3 block before it can prune anything
@@ -1056,7 +1094,12 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__r
 // deterministic, icp_estimate_device lets everything downstream of the search live in it
 // (QuerySort::slot_order): the search stores its pairs with full-line writes instead of scattering
 // them back through `perm`, and the Gauss-Newton evaluations fold them as they lie.
-__global__ void k_query_cell(const double *__restrict__ src, unsigned n, int dim, Pose T, GridParams g,
+// `blk`: sort key = the cell index with the ROWS grouped in blocks of 2^blk x 2^blk (y, z) and the rows of a block
+// interleaved -- ((block row, x cell), row in block) -- instead of row after row: 64 consecutive queries then
+// come from a stretch of a 2^blk x 2^blk bundle of rows, a fraction as long as the stretch of ONE row that holds
+// 64 queries, and the union of their search boxes (nn_tile.hip) is that much more compact.  Any key is exact;
+// this one only shapes the waves.
+__global__ void k_query_cell(const double *__restrict__ src, unsigned n, int dim, Pose T, GridParams g, int blk,
                              uint32_t *__restrict__ cell_of) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1067,7 +1110,10 @@ __global__ void k_query_cell(const double *__restrict__ src, unsigned n, int dim
   q[1] = ny;
   int c[3] = {0, 0, 0};
   for (int d = 0; d < dim; ++d) c[d] = cell_coord(q[d], g.lo[d], g.inv_h[d], g.n[d]);
-  cell_of[i] = ((uint32_t)c[2] * g.n[1] + c[1]) * g.n[0] + c[0];
+  const uint32_t nyb = ((uint32_t)g.n[1] + (1u << blk) - 1) >> blk, m = (1u << blk) - 1;
+  const uint32_t brow = ((uint32_t)c[2] >> blk) * nyb + ((uint32_t)c[1] >> blk);
+  const uint32_t sub = (((uint32_t)c[2] & m) << blk) | ((uint32_t)c[1] & m);
+  cell_of[i] = ((brow * (uint32_t)g.n[0] + (uint32_t)c[0]) << (2 * blk)) | sub;
 }
 
 __global__ void k_query_gather(const double *__restrict__ src, unsigned n, int dim, const uint32_t *__restrict__ perm,
@@ -1106,7 +1152,9 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     (void)hipFree(Q.d_perm);
     (void)hipFree(Q.d_sorted);
     (void)hipFree(Q.d_prev);
+    (void)hipFree(Q.d_list);
     Q.d_prev = nullptr;
+    Q.d_list = nullptr;
     Q.d_cell_of = Q.d_cell = Q.d_perm = nullptr;
     Q.d_sorted = nullptr;
     Q.cap = 0;
@@ -1118,11 +1166,25 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     // pool, and a 2-D owner followed by a 3-D one of the same size must not find them short
     if ((e = hipMalloc(&Q.d_sorted, n_ * 3 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_prev, n_ * sizeof(PrevMatch))) != hipSuccess) return e;
+    if ((e = hipMalloc(&Q.d_list, (n_ / 64 + 1) * sizeof(uint32_t))) != hipSuccess) return e;
     Q.cap = n_;
   }
-  hipLaunchKernelGGL(k_query_cell, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, T, G.p, Q.d_cell_of);
+  // ICP_QSORT_BLOCK: log2 of the row bundle's side (0: row after row); the key must fit 32 bits
+  // (row after row serves the gather walk best: 84.1 / 86.3 / 90.4 / 94.3 us per search for 0 / 1 / 2 / 3; the
+  // LDS-tile search wants 1: 5 100 -> 700 of 15 625 waves beyond its LDS budget)
+  static const bool tile_on = getenv("ICP_NN_TILE") != nullptr && atoi(getenv("ICP_NN_TILE")) != 0;
+  static const int blk_env = getenv("ICP_QSORT_BLOCK") ? atoi(getenv("ICP_QSORT_BLOCK")) : (tile_on ? 1 : 0);
+  int blk = blk_env < 0 ? 0 : (blk_env > 3 ? 3 : blk_env);
+  unsigned long long keys;
+  for (;; --blk) {
+    const unsigned long long nyb = ((unsigned long long)G.p.n[1] + (1ull << blk) - 1) >> blk;
+    const unsigned long long nzb = ((unsigned long long)G.p.n[2] + (1ull << blk) - 1) >> blk;
+    keys = (nzb * nyb * (unsigned long long)G.p.n[0]) << (2 * blk);
+    if (keys <= (1ull << 32) || blk == 0) break;
+  }
+  hipLaunchKernelGGL(k_query_cell, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, T, G.p, blk, Q.d_cell_of);
   unsigned bits = 1;
-  while (bits < 32 && (1ull << bits) < (unsigned long long)G.ncell) ++bits;
+  while (bits < 32 && (1ull << bits) < keys) ++bits;
   if ((e = stable_sort_cells(Q.d_cell_of, Q.d_cell, Q.d_perm, n, bits, Q.d_tmp, Q.cap_tmp, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_query_gather, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim,
                      (const uint32_t *)Q.d_perm, Q.d_sorted);
@@ -1177,6 +1239,18 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
     else
       hipLaunchKernelGGL(k_nn_grid_seed<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, n, T, G.p, G.d_start,
                          G.d_pts, h->d_dst, Q.d_prev);
+  }
+  // ICP_NN_TILE=1: the LDS-tile search of nn_tile.hip (round 3; same indices).  Built, parity-green at 1M x 1M and
+  // measured slower than the gather walk on the benchmark pair (109 + 42 us against 84 us: DESIGN.md section 5),
+  // so it is opt-in
+  static const bool use_tile = getenv("ICP_NN_TILE") != nullptr && atoi(getenv("ICP_NN_TILE")) != 0;
+  if ((q_prev || seeded) && !coop && xform && G.p.f32_ok && !old_warm && use_tile) {
+    hipError_t we = launch_nn_tile(h, q_src, q_perm, n, T, d_idx, (double2 *)d_a, (double2 *)d_b);
+    if (ev0 && ev1) {
+      (void)hipEventRecord(ev1, h->stream);
+      h->prof_events.emplace_back(ev0, ev1);
+    }
+    return we;
   }
   if ((q_prev || seeded) && !coop && xform && G.p.f32_ok && !old_warm) {
     if (h->dim == 3)

@@ -292,6 +292,10 @@ int icp_last_fold_order(icp_handle *h, size_t n, uint32_t *perm, uint32_t *cell)
 int icp_sort_source_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T, double *d_sorted,
                            uint32_t *d_perm);
 
+/* Observability: the last LDS-tile search of `h` (the warm grid search beyond 65 536 source points): out[0] = waves
+ * launched, out[1] = waves handed to the per-lane gather walk because their unions exceeded the LDS budget. */
+int icp_nn_tile_counters(icp_handle *h, uint64_t out[2]);
+
 /* Observability for tests: which pipeline served the weighted Gauss-Newton evaluations of
  * this handle (NULL: the scratch handle behind the free functions) since it was created.
  * out[0] evaluations started with the three-launch window pipeline, out[1] how many of those
