@@ -101,7 +101,7 @@ hipError_t alloc_ctx(GnCtx &c, hipStream_t s) {
   if ((e = hipMalloc(&c.d_sel, 2 * kSelProblems * sizeof(SelState))) != hipSuccess) return e;
   if ((e = hipMalloc(&c.d_scal, sizeof(GnScalars))) != hipSuccess) return e;
   if ((e = hipMalloc(&c.d_partials, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double))) != hipSuccess) return e;
-  const size_t whist_bytes = (size_t)2 * kWinBins * sizeof(uint32_t);
+  const size_t whist_bytes = ((size_t)2 * kWinBins + kShardStatusWords) * sizeof(uint32_t);  // (+ the sharded status words)
   if ((e = hipMalloc(&c.d_whist, whist_bytes)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(c.d_whist, 0, whist_bytes, s)) != hipSuccess) return e;
   if ((e = hipMalloc(&c.d_wstate, sizeof(WinState))) != hipSuccess) return e;
@@ -1443,7 +1443,7 @@ extern "C" int icp_shard_geometry(size_t n_total, int rank, int world, int *b0, 
   shard_geometry(n_total, rank, world, b0, b1, blocks, n_local);
   return ICP_OK;
 }
-extern "C" size_t icp_shard_histogram_words(void) { return (size_t)2 * kWinBins; }
+extern "C" size_t icp_shard_histogram_words(void) { return (size_t)2 * kWinBins + kShardStatusWords; }
 extern "C" size_t icp_shard_candidates_bytes(void) { return shard_cand_bytes(); }
 extern "C" size_t icp_shard_partials_bytes(int world) { return world >= 1 ? shard_part_bytes(world) : 0; }
 
@@ -1469,16 +1469,62 @@ extern "C" int icp_shard_put_device(icp_handle *h, const void *d_local, void *d_
   return shard_copy(h, d_local, d_full, n_total, rank, world, elem_bytes, false);
 }
 
+static int shard_eval_hist_impl(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, int rank, int world,
+                                const icp_pose *T, int kind, int refined, uint32_t **d_hist);
+
+// Whatever this returns (short of ICP_BAD_ARGUMENT / ICP_NO_DEVICE), *d_hist is the buffer to sum over the ranks --
+// histograms (all zero unless ICP_OK) followed by four status words, one-hot by the answer -- and EVERY rank is
+// expected to take part in that sum: icp_shard_eval_status then tells every rank the same four counts.
 extern "C" int icp_shard_eval_hist_device(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, int rank,
                                           int world, const icp_pose *T, int kind, int refined, uint32_t **d_hist) {
   if (!h || !T || !d_hist || world < 1 || rank < 0 || rank >= world || n_total >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(ensure_workspace(h, 1, false));
+  const int rc = shard_eval_hist_impl(h, d_a, d_b, n_total, rank, world, T, kind, refined, d_hist);
+  if (rc == ICP_BAD_ARGUMENT) return rc;
+  *d_hist = h->ws.d_whist;
+  if (shard_launch_status(h, rc) != hipSuccess) return ICP_HIP_ERROR;
+  return rc;
+}
+
+// The four counts {ranks that answered OK, RETRY_REPLICATED, NONE, anything else} of the evaluation in flight.
+// from_device = 0: as the fold kernel of icp_shard_eval_finish_device left them in host memory (no wait: valid once
+// finish has returned); 1: read from the summed buffer behind the stream (a rank whose own answer was not OK and
+// which therefore ran no finish).
+extern "C" int icp_shard_eval_status(icp_handle *h, uint32_t out[4], int from_device) {
+  if (!h || !out) return ICP_BAD_ARGUMENT;
+  if (!from_device) {
+    if (!h->ws.h_res) return ICP_BAD_ARGUMENT;
+    for (int k = 0; k < kShardStatusWords; ++k) out[k] = h->ws.h_res->status[k];
+    return ICP_OK;
+  }
+  if (!h->ws.d_whist) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(out, h->ws.d_whist + 2 * kWinBins, kShardStatusWords * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                         h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ICP_OK;
+}
+
+// After an evaluation that the ranks did NOT all answer with ICP_OK: the summed buffer of a rank that had no
+// histogram of its own holds its peers' counts; back to the all-zero rest state the next evaluation expects.
+extern "C" int icp_shard_eval_abort_device(icp_handle *h) {
+  if (!h || !h->ws.d_whist) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemsetAsync(h->ws.d_whist, 0, ((size_t)2 * kWinBins + kShardStatusWords) * sizeof(uint32_t), h->stream));
+  h->shard.active = false;
+  h->ws.gn_dirty = true;  // (the stages that did run may have left selection state behind)
+  return ICP_OK;
+}
+
+static int shard_eval_hist_impl(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, int rank, int world,
+                                const icp_pose *T, int kind, int refined, uint32_t **d_hist) {
   icp_handle::ShardEval &S = h->shard;
   S.active = false;
   if (refined && !S.refined_ready) return ICP_BAD_ARGUMENT;  // only right after ICP_RETRY_SHARDED
   if (!input_size_ok(n_total)) return ICP_NONE;  // check_input_size, src/lib.rs:225-228
   shard_geometry(n_total, rank, world, &S.b0, &S.b1, &S.blocks, &S.n_local);
   if (S.blocks < world || (S.n_local > 0 && (!d_a || !d_b))) return S.blocks < world ? ICP_RETRY_REPLICATED : ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(ensure_workspace(h, S.n_local, false));
   Workspace &w = h->ws;
   if (refined) {

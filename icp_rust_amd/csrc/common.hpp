@@ -100,6 +100,9 @@ struct GnResult {
   int overflow;  // 1: too many candidates (radix path needed), 2: the window missed (gn_pull.hip needed)
   unsigned seq;  // written last, system scope: the host polls it instead of waiting for the stream
   unsigned pad;
+  // sharded evaluations: how many ranks answered {OK, RETRY_REPLICATED, NONE, anything else} in the hist stage
+  // (the status words behind the histograms, summed over the ranks with them; shard.hip:k_shard_fold)
+  unsigned status[4];
 };
 
 // Scratch of ONE Gauss-Newton evaluation in flight.  A handle has two of them, one per stream of
@@ -205,6 +208,7 @@ struct Grid {
   double *t_part = nullptr;     // bounding-box partials
 };
 
+constexpr int kShardStatusWords = 4;  // behind the 2 x kWinBins histogram words of a sharded evaluation
 constexpr int kShardMaxWorld = 16;  // ranks of one sharded evaluation (a node has 8 GPUs)
 constexpr unsigned kGridPad = 8;  // records past the last target that a quad-aligned read may touch
 
@@ -369,6 +373,7 @@ hipError_t shard_launch_compact(icp_handle *h, size_t n_local, size_t n_total, c
 hipError_t shard_launch_accumulate(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
                                    const void *d_cand_all, int world, int blocks_local, void *d_out);
 hipError_t shard_launch_fold(icp_handle *h, const void *d_part_all, int world, int blocks_total, double *d_ordered);
+hipError_t shard_launch_status(icp_handle *h, int rc);
 // ... the same from one pointer per rank (peer memory read in place), and the flag exchange of icp_create_multi
 hipError_t shard_launch_accumulate_ptrs(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
                                         const void *const *cand_ptrs, int world, int blocks_local, void *d_out);

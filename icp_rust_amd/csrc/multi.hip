@@ -351,12 +351,15 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
     }
   } quiesce_on_exit{M};
   // One handle folds its sums over the source cloud in FOLD ORDER (icp_last_fold_order: the cell-sorted
-  // snapshot of the call); the ranks shard THAT order, so that N ranks return the bits of one.  Rank 0's
-  // device sorts the whole cloud once per call (icp_sort_source_device: the same sort, the identity where
-  // one handle would keep the caller's order) and the host deals the sorted copy.
-  std::vector<double> sorted_host;
+  // snapshot of the call); the ranks shard THAT order, so that N ranks return the bits of one.  The whole
+  // cloud goes to rank 0's device once, is sorted there (icp_sort_source_device: the same sort, the identity
+  // where one handle would keep the caller's order), and every rank compacts its blocks' points out of the
+  // sorted copy on its own device -- a peer read over xGMI between devices; nothing returns to the host
+  // (a first version dealt the shards on the host: two more 24 MB pageable transfers per call).
   std::vector<uint32_t> perm_host;
-  if (n > 0 && max_iter > 0) {
+  std::vector<size_t> n_local(W);
+  const double *d_full = nullptr;
+  if (n > 0) {
     auto &R0 = M->r[0];
     HIP_TRY(hipSetDevice(R0.device));
     if (n > M->cap_sort) {
@@ -373,37 +376,25 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
       M->cap_sort = cap;
     }
     HIP_TRY(hipMemcpyAsync(M->d_sort_in, src, n * dim * sizeof(double), hipMemcpyHostToDevice, R0.h->stream));
-    ICP_TRY(icp_sort_source_device(R0.h, M->d_sort_in, n, init, M->d_sort_out, M->d_sort_perm));
-    sorted_host.resize(n * dim);
-    perm_host.resize(n);
-    HIP_TRY(hipMemcpyAsync(sorted_host.data(), M->d_sort_out, n * dim * sizeof(double), hipMemcpyDeviceToHost, R0.h->stream));
-    HIP_TRY(hipMemcpyAsync(perm_host.data(), M->d_sort_perm, n * sizeof(uint32_t), hipMemcpyDeviceToHost, R0.h->stream));
-    HIP_TRY(hipStreamSynchronize(R0.h->stream));
-    src = sorted_host.data();
+    d_full = M->d_sort_in;
+    if (max_iter > 0) {
+      ICP_TRY(icp_sort_source_device(R0.h, M->d_sort_in, n, init, M->d_sort_out, M->d_sort_perm));
+      d_full = M->d_sort_out;
+      if (last_idx) {
+        perm_host.resize(n);
+        HIP_TRY(hipMemcpyAsync(perm_host.data(), M->d_sort_perm, n * sizeof(uint32_t), hipMemcpyDeviceToHost, R0.h->stream));
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(R0.h->stream));  // the peers read the sorted cloud
   }
-  // every rank's share of the (sorted) source cloud, compacted in fold order on the host (the reference
-  // hands over a host slice; device-resident sources shard with icp_shard_take_device)
-  std::vector<size_t> n_local(W);
-  std::vector<double> stage;
   for (int q = 0; q < W; ++q) {
     int b0, b1, B;
     shard_geometry(n, q, W, &b0, &b1, &B, &n_local[q]);
     auto &R = M->r[q];
     ICP_TRY(ensure_rank_buffers(M, R, n_local[q], n));
     if (n_local[q] == 0) continue;
-    stage.resize(n_local[q] * dim);
-    const size_t G = (size_t)B * kReduceThreads, c0 = (size_t)b0 * kReduceThreads, c1 = (size_t)b1 * kReduceThreads;
-    size_t l = 0;
-    for (size_t base = 0; base < n; base += G) {
-      const size_t s = base + c0, e = base + c1 < n ? base + c1 : n;
-      if (e > s) {
-        memcpy(stage.data() + l * dim, src + s * dim, (e - s) * dim * sizeof(double));
-        l += e - s;
-      }
-    }
     HIP_TRY(hipSetDevice(R.device));
-    HIP_TRY(hipMemcpyAsync(R.d_src, stage.data(), n_local[q] * dim * sizeof(double), hipMemcpyHostToDevice, R.h->stream));
-    HIP_TRY(hipStreamSynchronize(R.h->stream));  // `stage` is reused for the next rank
+    HIP_TRY(launch_shard_copy(R.h, d_full, R.d_src, n, q, W, (unsigned)(dim * 2), true));
     if (max_iter > 0) ICP_TRY(icp_prepare_source_device(R.h, R.d_src, n_local[q], init));
   }
   for (size_t it = 0; it < max_iter; ++it) {

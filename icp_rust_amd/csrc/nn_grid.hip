@@ -1116,12 +1116,22 @@ __global__ void k_query_cell(const double *__restrict__ src, unsigned n, int dim
   cell_of[i] = ((brow * (uint32_t)g.n[0] + (uint32_t)c[0]) << (2 * blk)) | sub;
 }
 
+// one 16-byte store per lane (two consecutive doubles of the sorted array, each gathered on its own): stores of
+// 8 bytes at a 24-byte stride wrote 64 MB for 24 MB of payload
 __global__ void k_query_gather(const double *__restrict__ src, unsigned n, int dim, const uint32_t *__restrict__ perm,
                                double *__restrict__ sorted) {
-  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const uint32_t i = perm[k];
-  for (int d = 0; d < dim; ++d) sorted[(size_t)k * dim + d] = src[(size_t)i * dim + d];
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair of doubles
+  const size_t tot = (size_t)n * dim;
+  const size_t e0 = 2 * c, e1 = e0 + 1;
+  if (e0 >= tot) return;
+  const size_t k0 = e0 / (unsigned)dim, k1 = e1 / (unsigned)dim;
+  const double v0 = src[(size_t)perm[k0] * dim + (e0 - k0 * dim)];
+  if (e1 < tot) {
+    const double v1 = src[(size_t)perm[k1] * dim + (e1 - k1 * dim)];
+    reinterpret_cast<double2 *>(sorted)[c] = make_double2(v0, v1);
+  } else {
+    sorted[e0] = v0;
+  }
 }
 
 __global__ void k_unpermute_idx(const uint32_t *__restrict__ slot_idx, const uint32_t *__restrict__ perm, unsigned n,
@@ -1186,8 +1196,11 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   unsigned bits = 1;
   while (bits < 32 && (1ull << bits) < keys) ++bits;
   if ((e = stable_sort_cells(Q.d_cell_of, Q.d_cell, Q.d_perm, n, bits, Q.d_tmp, Q.cap_tmp, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_query_gather, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim,
-                     (const uint32_t *)Q.d_perm, Q.d_sorted);
+  {
+    const size_t pairs = ((size_t)n * h->dim + 1) / 2;
+    hipLaunchKernelGGL(k_query_gather, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, d_src, n, h->dim,
+                       (const uint32_t *)Q.d_perm, Q.d_sorted);
+  }
   Q.have_prev = false;  // the first search of this snapshot reads no previous matches, it only records them
   if ((e = hipGetLastError()) != hipSuccess) return e;
   Q.src = d_src;

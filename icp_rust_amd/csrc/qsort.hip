@@ -19,8 +19,11 @@ hipError_t stable_sort_cells(const uint32_t *keys_in, uint32_t *keys_out, uint32
   if (bits < 1) bits = 1;
   if (bits > 32) bits = 32;
   rocprim::counting_iterator<uint32_t> iota(0u);
+  // (the default configuration merge-sorts up to 2^20 items -- ~20 launches, ~150 us for the benchmark's 10^6
+  // points; Onesweep needs three passes for its 21-bit keys.  Both are stable.)
+  using cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 32768>;
   size_t need = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, iota, perm_out, n, 0u, bits, s);
+  hipError_t e = rocprim::radix_sort_pairs<cfg>(nullptr, need, keys_in, keys_out, iota, perm_out, n, 0u, bits, s);
   if (e != hipSuccess) return e;
   if (need > cap_tmp || !tmp) {
     if (tmp) {
@@ -33,7 +36,7 @@ hipError_t stable_sort_cells(const uint32_t *keys_in, uint32_t *keys_out, uint32
     if ((e = hipMalloc(&tmp, want)) != hipSuccess) return e;
     cap_tmp = want;
   }
-  return rocprim::radix_sort_pairs(tmp, need, keys_in, keys_out, iota, perm_out, n, 0u, bits, s);
+  return rocprim::radix_sort_pairs<cfg>(tmp, need, keys_in, keys_out, iota, perm_out, n, 0u, bits, s);
 }
 
 }  // namespace icp

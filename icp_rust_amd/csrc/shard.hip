@@ -195,8 +195,10 @@ __global__ void k_shard_pack_partials(const double *__restrict__ partials, int b
 // second stage of the tree over the block sums of every rank, in block order; one workgroup
 __global__ __launch_bounds__(kReduceThreads) void k_shard_fold(ShardPtrs srcs, int rows, int world,
                                                                int blocks_total, double *__restrict__ ordered,
-                                                               GnResult *res, unsigned seq) {
+                                                               GnResult *res, unsigned seq,
+                                                               const uint32_t *__restrict__ status) {
   const int W = kNAcc + 1;
+  if (threadIdx.x < kShardStatusWords) res->status[threadIdx.x] = status[threadIdx.x];  // (ahead of the fence + seq below)
   // gather the rows into block order (rank r owns blocks [B r / world, B (r + 1) / world))
   for (int b = threadIdx.x; b < blocks_total; b += kReduceThreads) {
     int r = (int)(((long long)(b + 1) * world - 1) / blocks_total);  // the rank whose range holds b
@@ -288,14 +290,27 @@ hipError_t shard_launch_fold(icp_handle *h, const void *d_part_all, int world, i
   Workspace &w = h->ws;
   hipLaunchKernelGGL(k_shard_fold, dim3(1), dim3(kReduceThreads), 0, h->stream,
                      slices(d_part_all, shard_part_bytes(world), world), shard_part_rows(world), world, blocks_total,
-                     d_ordered, w.h_res, ++w.seq);
+                     d_ordered, w.h_res, ++w.seq, (const uint32_t *)(w.d_whist + 2 * kWinBins));
   return hipGetLastError();
 }
 hipError_t shard_launch_fold_ptrs(icp_handle *h, const void *const *part_ptrs, int world, int blocks_total,
                                   double *d_ordered) {
   Workspace &w = h->ws;
   hipLaunchKernelGGL(k_shard_fold, dim3(1), dim3(kReduceThreads), 0, h->stream, table(part_ptrs, world),
-                     shard_part_rows(world), world, blocks_total, d_ordered, w.h_res, ++w.seq);
+                     shard_part_rows(world), world, blocks_total, d_ordered, w.h_res, ++w.seq,
+                     (const uint32_t *)(w.d_whist + 2 * kWinBins));
+  return hipGetLastError();
+}
+
+// The status words behind the histograms: one-hot by what this rank's hist stage answered.  They travel with the
+// histograms through the ranks' sum, so that after it every rank holds the same four counts and takes the same
+// branch -- also when a rank-local condition (an error, a stale prediction) made one rank answer differently.
+__global__ void k_shard_status(uint32_t *st, int cls) {
+  if (threadIdx.x < kShardStatusWords) st[threadIdx.x] = (int)threadIdx.x == cls ? 1u : 0u;
+}
+hipError_t shard_launch_status(icp_handle *h, int rc) {
+  const int cls = rc == ICP_OK ? 0 : (rc == ICP_RETRY_REPLICATED ? 1 : (rc == ICP_NONE ? 2 : 3));
+  hipLaunchKernelGGL(k_shard_status, dim3(1), dim3(64), 0, h->stream, h->ws.d_whist + 2 * kWinBins, cls);
   return hipGetLastError();
 }
 
@@ -355,7 +370,7 @@ hipError_t multi_wait(hipStream_t s, const unsigned *const *flags, int world, un
   return hipGetLastError();
 }
 hipError_t multi_sum_hist(hipStream_t s, const void *const *hists, int world, uint32_t *out) {
-  const unsigned words = 2 * kWinBins;
+  const unsigned words = 2 * kWinBins + kShardStatusWords;
   hipLaunchKernelGGL(k_multi_sum_hist, dim3((words + 255) / 256), dim3(256), 0, s, table(hists, world), world, out, words);
   return hipGetLastError();
 }

@@ -61,7 +61,9 @@ def local_indices(n_total, rank, world, threads=512):
 
 # ------------------------------------------------------------------------------------ comms ----
 class TorchComm:
-    """One local rank per process; collectives through torch.distributed (nccl = RCCL, or gloo)."""
+    """One local rank per process; collectives through torch.distributed (nccl = RCCL, or gloo).  Create the process
+    group with a timeout (bench.py: 240 s): the sharded driver keeps the ranks in the same collectives by
+    construction (BlockShardedIcp._evaluate), but a rank that dies can only be noticed by its peers that way."""
 
     def __init__(self, rank, world, group=None):
         self.rank, self.world, self.group = rank, world, group
@@ -165,11 +167,21 @@ class HipStages:
         ptr = C.c_void_p()
         rc = lib().icp_shard_eval_hist_device(self.icp._h, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), n_total,
                                               rank, world, C.byref(T.pose), kind, int(refined), C.byref(ptr))
-        if rc != _lib.OK:
+        if not ptr.value:
             return rc, None
-        # a tensor view of the handle's histogram buffer, for the collective (no copy)
+        # a tensor view of the handle's histogram buffer (+ its four status words), for the collective (no copy);
+        # valid whatever the answer: every rank takes part in the sum
         hist = self._wrap(ptr.value, self.hist_words, a.device)
         return rc, hist
+
+    def eval_status(self, from_device):
+        """(ranks that answered OK, RETRY_REPLICATED, NONE, anything else) in the hist stage of the evaluation in flight"""
+        out = (C.c_uint32 * 4)()
+        _lib.check(lib().icp_shard_eval_status(self.icp._h, out, int(from_device)), "icp_shard_eval_status")
+        return tuple(int(x) for x in out)
+
+    def eval_abort(self):
+        _lib.check(lib().icp_shard_eval_abort_device(self.icp._h), "icp_shard_eval_abort_device")
 
     def _wrap(self, ptr, words, device):
         key = (ptr, words)
@@ -287,7 +299,54 @@ class BlockShardedIcp:
         res = [rk.stages.eval_hist(rk.bufs["a"][:self.geom[rk.rank][3]], rk.bufs["b"][:self.geom[rk.rank][3]], self.n,
                                    rk.rank, self.world, T, kind, refined) for rk in rks]
         rcs = {rc for rc, _ in res}
-        if rcs == {_lib.OK}:
+        if all(hasattr(rk.stages, "eval_status") for rk in rks):
+            # Every rank takes part in the SAME three exchanges whatever its own hist stage answered; the answers travel
+            # as four status counters behind the histograms, so after the sum all ranks know all answers and branch
+            # alike.  Each rank decides its answer from state that is replicated by construction (the window
+            # prediction comes from global statistics), but a rank-local condition -- a HIP error, a handle with
+            # stale state -- would otherwise send it into a different collective than its peers, which hang.
+            for rc, h in res:
+                if h is None:
+                    _lib.check(rc, "icp_shard_eval_hist_device")  # (bad arguments: the same on every rank)
+            self.comm.sum_([h for _, h in res])
+            ok = [rc == _lib.OK for rc, _ in res]
+            for rk, o in zip(rks, ok):
+                if o:
+                    _lib.check(rk.stages.eval_compact(rk.bufs["cand"]), "icp_shard_eval_compact_device")
+                else:
+                    rk.bufs["cand"].zero_()
+            self.comm.gather([rk.bufs["cand"] for rk in rks], [rk.bufs["cand_all"] for rk in rks])
+            for rk, o in zip(rks, ok):
+                if o:
+                    _lib.check(rk.stages.eval_accumulate(rk.bufs["cand_all"], rk.bufs["part"]),
+                               "icp_shard_eval_accumulate_device")
+                else:
+                    rk.bufs["part"].zero_()
+            self.comm.gather([rk.bufs["part"] for rk in rks], [rk.bufs["part_all"] for rk in rks])
+            outs, sts = [], []
+            for rk, o in zip(rks, ok):
+                outs.append(rk.stages.eval_finish(rk.bufs["part_all"]) if o else None)
+                sts.append(rk.stages.eval_status(not o))
+            st = sts[0]
+            assert all(s == st for s in sts)
+            if st[0] == self.world:  # every rank evaluated its share
+                rc = outs[0][0]
+                assert all(o[0] == rc for o in outs)  # every rank folds the same numbers
+                if rc == _lib.RETRY_SHARDED:  # the window missed; its counts place one that will not
+                    self.counters["refined"] = self.counters.get("refined", 0) + 1
+                    return self._evaluate(T, kind, refined=True)
+                if rc != _lib.RETRY_REPLICATED:
+                    self.counters["sharded"] += 1
+                    return outs[0]
+            else:
+                for rk in rks:
+                    rk.stages.eval_abort()
+                if st[2] == self.world:
+                    return _lib.NONE, None, 0.0
+                if st[1] != self.world:  # the ranks disagree (or one failed): the same exception on every rank
+                    raise RuntimeError(f"sharded evaluation: the ranks' hist stages answered differently "
+                                       f"(OK, RETRY_REPLICATED, NONE, other) = {st}")
+        elif rcs == {_lib.OK}:
             self.comm.sum_([h for _, h in res])
             for rk in rks:
                 _lib.check(rk.stages.eval_compact(rk.bufs["cand"]), "icp_shard_eval_compact_device")

@@ -219,7 +219,11 @@ int icp_weighted_gn_step_device(icp_handle *h, const double *d_a_xy, const doubl
  * them out of a full array in fold order, icp_shard_put_device is the inverse).  It searches their
  * nearest neighbours (icp_correspond_device on its compact source cloud) and evaluates them with
  *   icp_shard_eval_hist_device        residuals + window histograms of its points   -> *d_hist
- *      [host: SUM the icp_shard_histogram_words() u32 at *d_hist over all ranks, in place]
+ *      [host: SUM the icp_shard_histogram_words() u32 at *d_hist over all ranks, in place -- EVERY rank, whatever
+ *       its hist call answered (short of ICP_BAD_ARGUMENT): the last four words are status counters, one-hot per
+ *       rank {OK, RETRY_REPLICATED, NONE, other}; after the sum every rank reads the same four counts
+ *       (icp_shard_eval_status) and takes the same branch, also when a rank-local condition made one rank answer
+ *       differently from its peers -- the ranks must never enter different collectives]
  *   icp_shard_eval_compact_device     its candidates around the median / the MAD    -> d_candidates_out
  *      [host: ALL-GATHER icp_shard_candidates_bytes() bytes per rank, rank order]
  *   icp_shard_eval_accumulate_device  exact statistics + the sums of its blocks     -> d_partials_out
@@ -248,6 +252,13 @@ int icp_shard_eval_hist_device(icp_handle *h, const double *d_a_xy_local, const 
 int icp_shard_eval_compact_device(icp_handle *h, void *d_candidates_out);
 int icp_shard_eval_accumulate_device(icp_handle *h, const void *d_candidates_all, void *d_partials_out);
 int icp_shard_eval_finish_device(icp_handle *h, const void *d_partials_all, double delta[3], double *huber_err);
+/* the four status counts of the evaluation in flight.  from_device = 0: as finish left them in host memory (valid once
+ * finish has returned, no wait); 1: read from the summed buffer behind the stream (a rank whose own hist call was not
+ * ICP_OK and which ran no finish).  icp_shard_eval_abort_device: after an evaluation the ranks did not ALL answer with
+ * ICP_OK, back to the rest state the next evaluation expects (a rank without a histogram of its own holds its peers'
+ * counts after the sum). */
+int icp_shard_eval_status(icp_handle *h, uint32_t out[4], int from_device);
+int icp_shard_eval_abort_device(icp_handle *h);
 
 /* The same from ONE host process over the GPUs of a node (SURVEY.md 8(b) sketch: device_ids /
  * n_devices): rank r is a handle on device_ids[r], the target cloud is replicated, the source cloud

@@ -78,6 +78,34 @@ def test_eight_virtual_ranks_at_the_full_size():
     assert drv.counters["sharded"] >= 6
 
 
+def test_ranks_that_answer_differently_raise_together_instead_of_hanging():
+    """every rank picks its branch from its own hist stage's answer.  The answers travel as status
+    counters behind the histograms (include/icp_mi355x.h section 5), every rank joins the same three exchanges
+    whatever it answered, and a disagreement -- here: rank 1's handle replaced by a fresh one without any window
+    prediction, so it answers RETRY_REPLICATED while rank 0 answers OK -- is the same exception on every rank."""
+    import torch
+
+    n, m, world = 150_000, 120_000, 2
+    src, dst = synth.synthetic_pair(n, m)
+    d_src, d_dst = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+    handles = [I.Icp3d(d_dst) for _ in range(world)]
+    drv = BlockShardedIcp({r: HipStages(handles[r]) for r in range(world)}, n, world, LocalComm(world))
+    T, inner, _ = drv.estimate_full(d_src, I.Transform(), 4)
+    assert drv.counters["sharded"] >= 4
+    srt, _ = drv.sort_source(d_src, I.Transform())
+    local = drv.take_source(srt)
+    fresh = I.Icp3d(d_dst)
+    drv.ranks[1].stages = HipStages(fresh)
+    drv.ranks[1].bufs = None
+    with pytest.raises(RuntimeError, match="answered differently"):
+        drv.step(local, T)
+    # both handles are back in their rest state: an ordinary registration on each of them still equals the oracle's
+    for h in (handles[0], fresh):
+        Tq, idx, inn = h.estimate(d_src, I.Transform(), 3, return_info=True)
+        rc, oT, oidx, oinn = oracle_in_device_order(h, 3, dst, src, O.transform_identity(), 3)
+        assert rc == O.OK and np.array_equal(Tq.as_array(), oT.as_array()) and np.array_equal(idx, oidx)
+
+
 def test_stage_calls_refuse_what_they_cannot_serve():
     import torch
 
