@@ -152,6 +152,40 @@ def gn_large(npts):
                     "prices them, selection passes not counted"}
 
 
+def converging(calls, n, m, nn_mode):
+    """Side line: the same 1M x 1M size on a pair that CONVERGES, in the regime of the reference's
+    real scans (synth.converging_pair: millimetre coordinates, re-observed points + clutter), where the inner
+    Gauss-Newton loops run from tens of updates per outer iteration down to none; the headline pair applies exactly
+    one update per outer iteration.  Same call as the headline: estimate(src, I, 20)."""
+    import torch
+    import icp_rust_amd as I
+    from icp_rust_amd import synth
+
+    src, dst, truth_param = synth.converging_pair(n, m)
+    d_src, d_dst = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+    icp = I.Icp3d(d_dst, nn_mode=nn_mode)
+    icp.estimate(d_src, I.Transform(), 3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        T, inner = icp.estimate(d_src, I.Transform(), MAX_ITER, return_info="inner")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    icp.close()
+    steps = calls * MAX_ITER
+    evals = [int(k) + 1 for k in inner]
+    step_bytes = 28.0 * n + 24.0 * m + float(np.mean(evals)) * 96.0 * n
+    truth = I.Transform(truth_param).as_array()
+    return {"workload": f"converging pair, millimetres: src = {n} points, 70 % re-observed points of the {m}-point target cloud "
+                        "moved by the inverse truth pose + noise, 30 % clutter (synth.converging_pair)",
+            "gn_evaluations_per_step": float(np.mean(evals)),
+            "value": steps / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "inner_iterations_per_step": [int(k) for k in inner],
+            "step_hbm": {"algorithmic_bytes_per_step": step_bytes, "achieved_GBs": step_bytes / (dt / steps) / 1e9,
+                         "frac_of_8TBs": step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS},
+            "pose_abs_err_vs_truth": float(np.max(np.abs(T.as_array() - truth)))}
+
+
 def reference_sized():
     """Part of the CPU-baseline leg.  BASELINE configs[0] / configs[1] at the reference's own sizes,
     next to the single-thread CPU oracle: a 650-point 2-D scan pair of the reference's scans/2d and a 28.8k-point 3-D frame in the
@@ -206,6 +240,9 @@ def main():
                     help="N > 1: outer iterations of the weak-scaling line (N x n-src source points; 0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=10,
                     help="outer iterations of the CPU baseline: ~7 s on one core + ~3 s with all cores (0 = skip)")
+    ap.add_argument("--converging-calls", type=int, default=3,
+                    help="estimate(20) calls on the CONVERGING 1M pair (src re-observes points of dst: inner loops of "
+                         "several updates, the regime of the reference's real scans) timed as a side line (0 = skip)")
     ap.add_argument("--gn-points", type=int, default=64 * 1024 * 1024,
                     help="pairs of the separate 'reduce kernels alone, past the Infinity Cache' line (0 = skip)")
     args = ap.parse_args()
@@ -403,7 +440,7 @@ def main():
     res = measure(nn_mode, args.steps, args.warmup, want_parity=args.cpu_iters > 0)
     brute = None
     if args.brute_steps > 0 and res["engine"] != "brute":
-        brute = measure(I.NN_BRUTE, args.brute_steps, 1)
+        brute = measure(I.NN_BRUTE, args.brute_steps, 1, want_parity=args.cpu_iters > 0)
     weak = None
     if world > 1 and res["engine"] == "grid" and args.weak_steps > 0:
         weak = measure(nn_mode, args.weak_steps, 2, weak=True)
@@ -471,6 +508,8 @@ def main():
                 "inner_iterations_per_step": weak["inner"], "sharded_evaluations": weak["counters"],
                 "note": "compare source_points_per_second with n_src x value of the 1-GPU line",
             }
+        if world == 1 and args.converging_calls > 0:
+            out["converging_pair"] = converging(args.converging_calls, n, m, nn_mode)
         if world == 1 and args.gn_points > 0:
             out["gn_large"] = gn_large(args.gn_points)
         if world == 1 and args.cpu_iters > 0:
@@ -480,6 +519,13 @@ def main():
                 par = (res["checked"][0], res["checked"][1], blocks, threads, res["checked"][2])
             out["cpu_baseline"] = cpu_baseline(src_np, dst_np, args.cpu_iters, parity_of=par)
             out["parity"] = out["cpu_baseline"].pop("parity")
+            if brute is not None and brute.get("checked") is not None:
+                # the sweep at its own size: the same estimate(steps) against the oracle in device order
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_ffi as O
+                bg, bk, bperm = brute["checked"]
+                bb, bt = I.reduce_geometry(n)
+                out["brute_force"]["parity"] = parity_vs_oracle(O.KdTree(dst_np), src_np, bg, bk, bb, bt, bperm)
             # (the CPU side of these is the oracle too: part of the same baseline leg)
             out["cpu_baseline"]["reference_sized"] = reference_sized()
         else:

@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--frame-points", type=int, default=75 * 384)
     ap.add_argument("--max-iter", type=int, default=20)
+    ap.add_argument("--virtual-ranks", type=int, default=0, metavar="W",
+                    help="also run the point-to-point loop through icp_create_multi with W ranks on cuda:0 (the N-rank "
+                         "path of configs[4] rehearsed on one GPU; 0 = skip)")
     ap.add_argument("--point-to-plane", type=int, default=0, metavar="K",
                     help="also run the loop with point-to-plane residuals, normals from K nearest map points (0 = skip)")
     args = ap.parse_args()
@@ -93,6 +96,36 @@ def main():
         "dtype": "f64", "data": "synthetic",
     }
     world.close()
+    if args.virtual_ranks:
+        # the same loop across W ranks (replicated map, the scan's points sharded by reduction-tree block): host
+        # buffers, every rank appends the registered scan to its replica (icp_multi_append_targets)
+        W = args.virtual_ranks
+        host_map = np.concatenate([synth.box_cloud(synth.SEED + 200, min(chunk, m0 - f), first=f) for f in range(0, m0, chunk)])
+        t0 = time.perf_counter()
+        multi = I.IcpMulti(host_map, [0] * W)
+        t_build_multi = time.perf_counter() - t0
+        del host_map
+        host_scans = [s.cpu().numpy() for s in scans]
+        multi.estimate(host_scans[0], I.Transform(), 1)
+        T = I.Transform()
+        est, app, merr = [], [], []
+        for k, scan in enumerate(host_scans, start=1):
+            t0 = time.perf_counter()
+            T = multi.estimate(scan, T, args.max_iter)
+            t1 = time.perf_counter()
+            multi.append(scan, T)
+            t2 = time.perf_counter()
+            est.append(1e3 * (t1 - t0))
+            app.append(1e3 * (t2 - t1))
+            merr.append(float(np.max(np.abs(T.as_array() - I.Transform(tuple(k * motion)).as_array()))))
+        out["virtual_ranks"] = {
+            "ranks": W, "map_points_end": multi.target_count, "estimate_ms": float(np.mean(est)),
+            "append_ms": float(np.mean(app)), "ms_per_frame": float(np.mean(est) + np.mean(app)),
+            "create_ms": 1e3 * t_build_multi, "pose_abs_err_vs_truth_last_frame": merr[-1],
+            "sharded_replicated_evaluations": list(multi.counters()),
+            "note": "icp_create_multi with every rank on cuda:0, host buffers: a functional rehearsal of the N-rank loop "
+                    "(W replicas of the map on one GPU, W grid rebuilds per append), not a measurement of N GPUs"}
+        multi.close()
     if args.point_to_plane:
         # the same frames against a fresh copy of the map, registered point-to-plane
         k_nn = args.point_to_plane

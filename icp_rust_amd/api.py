@@ -599,6 +599,18 @@ class IcpMulti:
                                        C.c_void_p(idx.ctypes.data), C.c_void_p(inner.ctypes.data)), "icp_multi_estimate")
         return (o, idx[:n], inner[:max_iter]) if return_info else o
 
+    def append(self, points, transform=None):
+        """EXTENSION (icp_multi_append_targets): every rank appends the points, moved by `transform`, to its replica of
+        the target cloud"""
+        p = _host(points, self.dim)
+        check(lib().icp_multi_append_targets(self._h, _ptr(p), p.shape[0],
+                                             C.byref(transform.pose) if transform is not None else None),
+              "icp_multi_append_targets")
+
+    @property
+    def target_count(self):
+        return int(lib().icp_multi_target_count(self._h))
+
     def counters(self):
         out = (C.c_uint64 * 2)()
         check(lib().icp_multi_counters(self._h, out), "icp_multi_counters")

@@ -406,6 +406,8 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->qsort.have_prev = false;
     h->qsort.slot_order = false;
     h->qsort.fold_n = 0;
+    h->shard.active = false;
+    h->shard.refined_ready = h->shard.attempt_refined = false;
     h->normals_m = 0;
     h->normals_k = 0;
     w.win_valid = w.win_wide = false;

@@ -826,16 +826,26 @@ hipError_t launch_tiny_estimate(icp_handle *h, const double *d_src, size_t n, co
     return hipSuccess;
   Workspace &w = h->ws;
   hipError_t e;
-  if (!w.h_tiny) {
-    if ((e = hipHostMalloc(&w.h_tiny, sizeof(TinyResult) + kTinyMaxIter * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
-      return e;
+  // the 160 KB of dynamic LDS are granted once per process; if the runtime refuses, small clouds simply take the
+  // general path (*status stays -1) -- they must never launch with an LDS size that was not granted
+  static int lds_granted = 0;  // 0 not asked yet, 1 yes, -1 refused
+  if (lds_granted < 0) return hipSuccess;
+  if (lds_granted == 0) {
     const void *kernels[] = {
         reinterpret_cast<const void *>(&k_tiny_estimate<2, 512>),  reinterpret_cast<const void *>(&k_tiny_estimate<2, 768>),
         reinterpret_cast<const void *>(&k_tiny_estimate<2, 1024>), reinterpret_cast<const void *>(&k_tiny_estimate<3, 512>),
         reinterpret_cast<const void *>(&k_tiny_estimate<3, 768>),  reinterpret_cast<const void *>(&k_tiny_estimate<3, 1024>)};
+    lds_granted = 1;
     for (const void *k : kernels)
-      if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)) != hipSuccess) return e;
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) lds_granted = -1;
+    if (lds_granted < 0) {
+      (void)hipGetLastError();
+      return hipSuccess;
+    }
   }
+  if (!w.h_tiny &&
+      (e = hipHostMalloc(&w.h_tiny, sizeof(TinyResult) + kTinyMaxIter * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+    return e;
   TinyResult *res = reinterpret_cast<TinyResult *>(w.h_tiny);
   uint32_t *inner = reinterpret_cast<uint32_t *>(res + 1);
   const GridParams &g = h->grid.p;

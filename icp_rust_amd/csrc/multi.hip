@@ -244,6 +244,15 @@ int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta
 
 extern "C" void icp_destroy_multi(icp_multi *M) {
   if (!M) return;
+  // ranks that share a device run on rank 0's stream: quiesce everything and hand every handle its own stream
+  // back BEFORE any handle (and with it, possibly, that stream) is released
+  for (auto &R : M->r)
+    if (R.h) {
+      (void)hipSetDevice(R.device);
+      (void)hipStreamSynchronize(R.h->stream);
+    }
+  for (auto &R : M->r)
+    if (R.h) (void)icp_use_own_stream(R.h);
   for (auto &R : M->r) {
     (void)hipSetDevice(R.device);
     if (R.h) icp_destroy(R.h);
@@ -283,6 +292,13 @@ extern "C" int icp_create_multi(icp_multi **out, int dim, const double *dst, siz
   M->r.resize(n_devices);
   M->one_device = true;
   for (int q = 1; q < n_devices; ++q) M->one_device = M->one_device && device_ids[q] == device_ids[0];
+  if (!M->one_device)  // all ranks on one device, or every rank on a device of its own (nothing in between)
+    for (int q = 0; q < n_devices; ++q)
+      for (int p = 0; p < q; ++p)
+        if (device_ids[p] == device_ids[q]) {
+          delete M;
+          return ICP_BAD_ARGUMENT;
+        }
   int rc = ICP_OK;
   for (int q = 0; q < n_devices && rc == ICP_OK; ++q) {
     auto &R = M->r[q];
@@ -321,6 +337,20 @@ extern "C" int icp_create_multi(icp_multi **out, int dim, const double *dst, siz
   return ICP_OK;
 }
 
+// EXTENSION (BASELINE configs[4], the growing target cloud of include/icp_mi355x.h section 6, across the ranks): the
+// target cloud is replicated, so every rank appends the same k points (moved by T) and rebuilds its search grid;
+// afterwards the object is, bit for bit, a fresh icp_create_multi on the concatenated cloud.
+extern "C" int icp_multi_append_targets(icp_multi *M, const double *pts, size_t k, const icp_pose *T) {
+  if (!M || (k > 0 && !pts)) return ICP_BAD_ARGUMENT;
+  for (auto &R : M->r) {
+    const int rc = icp_append_targets(R.h, pts, k, T);
+    if (rc != ICP_OK) return rc;  // (a rank that failed leaves the replicas different: the object is then unusable)
+  }
+  M->m += k;
+  return ICP_OK;
+}
+extern "C" size_t icp_multi_target_count(const icp_multi *M) { return M ? M->m : 0; }
+
 extern "C" int icp_multi_counters(const icp_multi *M, uint64_t out[2]) {
   if (!M || !out) return ICP_BAD_ARGUMENT;
   out[0] = M->sharded;
@@ -350,6 +380,8 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
         }
     }
   } quiesce_on_exit{M};
+  for (auto &R : M->r)  // (a wait that gave up in an earlier call must not fail this one)
+    if (R.d_err) __atomic_store_n(R.d_err, 0u, __ATOMIC_RELEASE);
   // One handle folds its sums over the source cloud in FOLD ORDER (icp_last_fold_order: the cell-sorted
   // snapshot of the call); the ranks shard THAT order, so that N ranks return the bits of one.  The whole
   // cloud goes to rank 0's device once, is sorted there (icp_sort_source_device: the same sort, the identity

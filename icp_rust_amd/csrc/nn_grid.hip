@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__r
     }
     const int hx = g.fx > 1 ? g.fx / 2 : 1;
     float best = __builtin_huge_valf();
-    uint32_t bi = 0xffffffffu;
+    uint32_t bi = 0xffffffffu, any = 0xffffffffu;  // any: a finite target whose screened distance overflowed f32
     // blocks of cells growing around the query's own until one holds a record (the first: its own row,
     // half a cubic cell either way along x)
     for (int r = 0;; ++r) {
@@ -1070,12 +1070,18 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__r
             if (s2 < best) {  // (a target with a NaN or infinite coordinate never compares less: it cannot be a seed,
               best = s2;      // and a seed at a NaN distance would never be displaced by the warm kernel)
               bi = w.w;
+            } else if (s2 == __builtin_huge_valf() && any == 0xffffffffu && fabsf(__uint_as_float(w.x)) < __builtin_huge_valf() &&
+                       fabsf(__uint_as_float(w.y)) < __builtin_huge_valf() && fabsf(__uint_as_float(w.z)) < __builtin_huge_valf()) {
+              any = w.w;  // a finite query beyond ~1.8e19 of every target: the f32 screen overflows, the f64 distance does not
             }
           }
         }
-      if (bi != 0xffffffffu) break;
+      if (bi != 0xffffffffu || any != 0xffffffffu) break;
       if (x0 == 0 && x1 == g.n[0] - 1 && y0 == 0 && y1 == g.n[1] - 1 && z0 == 0 && z1 == (DIM == 3 ? g.n[2] - 1 : 0)) break;
     }
+    //  a finite query so far away that every screened distance overflowed still gets a real target: the
+    // warm kernel then finds no f32 geometry for the lane and walks the grid unpruned, with the exact f64 distances
+    if (bi == 0xffffffffu) bi = any;
     if (bi != 0xffffffffu) {
       out.x = dst[(size_t)bi * DIM + 0];
       out.y = dst[(size_t)bi * DIM + 1];

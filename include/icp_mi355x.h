@@ -260,7 +260,10 @@ int icp_shard_eval_finish_device(icp_handle *h, const void *d_partials_all, doub
 int icp_shard_eval_status(icp_handle *h, uint32_t out[4], int from_device);
 int icp_shard_eval_abort_device(icp_handle *h);
 
-/* The same from ONE host process over the GPUs of a node (SURVEY.md 8(b) sketch: device_ids /
+/* (STATUS: with every rank on ONE device -- "virtual ranks" -- this path runs in the test-suite; between DISTINCT
+ * devices it has never run on hardware (no multi-GPU box was available to the build): experimental there.  Mixed lists
+ * that repeat only some devices, e.g. {0, 0, 1, 1}, are refused.)
+ * The same from ONE host process over the GPUs of a node (SURVEY.md 8(b) sketch: device_ids /
  * n_devices): rank r is a handle on device_ids[r], the target cloud is replicated, the source cloud
  * sharded by reduction-tree block, and the three exchanges are peer reads over xGMI behind flags (no
  * collective library: there is no ICP_RCCL_ERROR).  The result equals icp_estimate's on one GPU bit
@@ -272,6 +275,11 @@ int icp_create_multi(icp_multi **out, int dim, const double *dst, size_t m, cons
 int icp_multi_estimate(icp_multi *M, const double *src, size_t n, const icp_pose *init, size_t max_iter,
                        icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters);
 int icp_multi_counters(const icp_multi *M, uint64_t out[2]);
+/* EXTENSION (section 6 across the ranks; BASELINE configs[4] on several GPUs): every rank appends the same k points,
+ * moved by T (NULL: as they are), to its replica of the target cloud and rebuilds its search grid; afterwards the
+ * object equals a fresh icp_create_multi on the concatenated cloud, bit for bit. */
+int icp_multi_append_targets(icp_multi *M, const double *pts, size_t k, const icp_pose *T);
+size_t icp_multi_target_count(const icp_multi *M);
 void icp_destroy_multi(icp_multi *M);
 
 /* Live kernel timing for the benchmark: with enable = k > 0, HIP events bracket every

@@ -38,5 +38,9 @@ def test_bench_line_carries_the_contract_fields_and_is_consistent():
     assert c["kind"] == "port" and c["cores"] == 1
     p = d["parity"]
     assert p["pose_bits_equal"] is True and p["idx_equal"] is True and p["inner_iterations_equal"] is True
+    bp = d["brute_force"]["parity"]  # the sweep engine checked at the size it was timed on
+    assert bp["pose_bits_equal"] is True and bp["idx_equal"] is True and bp["inner_iterations_equal"] is True
+    cv = d["converging_pair"]
+    assert cv["steps"] == 60 and max(cv["inner_iterations_per_step"]) >= 5 and cv["pose_abs_err_vs_truth"] < 1.0  # (mm)
     b = d["brute_force"]["roofline"]
     assert b["bound"] == "fp32_valu" and 0.0 < b["frac"] < 1.0

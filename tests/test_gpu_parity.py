@@ -438,6 +438,26 @@ def test_seeded_search_never_settles_on_a_target_with_a_nan_coordinate():
     assert np.array_equal(T.as_array(), oT.as_array())
 
 
+def test_finite_queries_beyond_the_f32_screen_keep_their_exact_neighbour():
+    """a finite query farther than ~1.8e19 from every target overflows the f32 screen of the seeded first
+    search (every screened distance is +inf), which used to leave it without a seed -- "NaN query", index 0 -- for the
+    rest of the call, while the f64 distance the contract is defined on is finite.  70 000 queries (the one-lane path)
+    with a few at 1e20 and 1e30."""
+    rng = np.random.default_rng(31)
+    m, n = 30_000, 70_000
+    dst = rng.normal(size=(m, 3)) * 5
+    src = dst[rng.integers(0, m, size=n)] + rng.normal(size=(n, 3)) * 0.05
+    far = rng.choice(n, size=12, replace=False)
+    src[far[:6]] = rng.normal(size=(6, 3)) * 1e20
+    src[far[6:]] = rng.normal(size=(6, 3)) * 1e30
+    icp = I.Icp3d(dst)
+    T, idx, inner = icp.estimate(src, I.Transform(), 3, return_info=True)
+    rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, dst, src, O.transform_identity(), 3, use_kdtree=False)
+    assert rc == O.OK
+    assert np.array_equal(idx, oidx), np.nonzero(idx != oidx)[0][:10]
+    assert np.array_equal(inner, oinner) and np.array_equal(T.as_array(), oT.as_array())
+
+
 def test_warm_search_with_four_lanes_per_query_tracks_the_oracle_over_a_large_motion():
     """the pose moves a lot in the first iterations: boxes of many rows, dealt to the four lanes"""
     pk = synth.synthetic_scan3d_packets(150)

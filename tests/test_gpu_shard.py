@@ -145,6 +145,34 @@ def test_icp_create_multi_with_virtual_ranks_equals_one_handle(world, n, m, dim)
     multi.close()
 
 
+def test_grown_multi_equals_fresh_multi_equals_one_handle():
+    """BASELINE configs[4] across ranks (EXTENSION, include/icp_mi355x.h section 6): every rank appends the registered
+    scan to its replica of the target cloud; the grown object must answer like a fresh one on the concatenated cloud
+    and like ONE handle on it -- pose, indices, inner counts, bit for bit (frame loop: /root/reference/examples/scan3d.rs:113-133)."""
+    world = synth.box_cloud(synth.SEED + 11, 90_000, synth.ROOM_LO, synth.ROOM_HI)
+    first, rest = world[:50_000], world[50_000:]
+    rng = np.random.default_rng(3)
+    scan = world[rng.choice(len(world), 70_000, replace=False)] + rng.normal(size=(70_000, 3)) * 0.01
+    T0 = I.Transform([0.04, -0.03, 0.008])
+    moved = I.Transform([0.01, 0.02, -0.003])
+    grown = I.IcpMulti(first, [0] * 4)
+    Tg0 = grown.estimate(scan, T0, 3)  # (a registration before the append: snapshots, predictions, matches exist)
+    grown.append(rest, moved)
+    assert grown.target_count == len(world)
+    one = I.Icp3d(first)
+    one.append(rest, moved)
+    cat = one.read_targets(0, len(world))
+    fresh = I.IcpMulti(cat, [0] * 4)
+    a = grown.estimate(scan, T0, 4, return_info=True)
+    b = fresh.estimate(scan, T0, 4, return_info=True)
+    c = one.estimate(scan, T0, 4, return_info=True)
+    for x in (b, c):
+        assert np.array_equal(a[0].as_array(), x[0].as_array())
+        assert np.array_equal(a[1], x[1]) and np.array_equal(a[2], x[2])
+    grown.close()
+    fresh.close()
+
+
 def test_icp_create_multi_argument_checks():
     _, dst = synth.synthetic_pair(1, 5000)
     with pytest.raises(I.IcpError):
