@@ -1,11 +1,3 @@
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/m1; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 profiles/multi_one.py 1 > $O/out.txt 2>&1
-cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv; rm -rf $O/kt
-grep "W=" $O/out.txt
-python3 - <<'PY'
-import csv
-rows=list(csv.DictReader(open('gpurun_out/m1/kernel_stats.csv')))
-for r in rows[:14]:
-    print("%-60s n=%5s avg=%9.1f us  %5.1f%%"%(r['Name'][:60], r['Calls'], float(r['AverageNs'])/1e3, float(r['Percentage'])))
-PY
+cd $GRAFT_REPO_ROOT
+timeout -k 10 300 python -m pytest tests/test_full_config.py tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -3 || exit 1
+for cfg in "1 0.45" "2 0.45" "2 0.3" "2 0.6" "2 0.8" "3 0.45" "3 0.7" "4 0.6"; do set -- $cfg; ICP_GRID2=$1 ICP_GRID2_R=$2 timeout -k 10 120 python3 profiles/tile_probe.py 2>&1 | grep "ms/step" | sed "s/^/grid2=$1 r=$2 /"; done
