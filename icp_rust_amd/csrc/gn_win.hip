@@ -1000,7 +1000,10 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
   // on the evaluation stream this runs beside a speculative search: the variant whose every
   // workgroup fits next to three search waves per SIMD (one extra tiny launch; latency is hidden)
   static const bool no_co = getenv("ICP_WIN_NO_CORESIDENT") != nullptr;
-  const bool coresident = !no_co && h->stream == w.spec_stream;
+  // (round 3: the 4-launch form everywhere -- 0.1645 against 0.1660 ms per step on the 1M pair, 0.626 against 0.635 on
+  // the converging pair, the 28k frame unchanged: every workgroup of the inline-selecting accumulate kernel repeats
+  // 7.5 us of candidate loads and selections that the two-workgroup launch does once)
+  const bool coresident = !no_co;
   hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(kWinThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
                      w.d_wstate, w.d_scal);
   hipLaunchKernelGGL(k_win_compact<false>, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,

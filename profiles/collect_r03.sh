@@ -6,7 +6,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03
 mkdir -p $O
-B="--brute-steps 0 --cpu-iters 0 --gn-points 0"
+B="--brute-steps 0 --cpu-iters 0 --gn-points 0 --converging-calls 0"
 echo "== default bench"; python3 bench.py > $O/bench_default_1M.json 2> $O/bench_default.err
 echo "== kernel stats (grid)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py $B > $O/bench_grid_1M_under_rocprof.json 2> /dev/null
