@@ -89,7 +89,10 @@ def main():
         "ms_per_frame": frame_ms,
         "estimate_ms": {"mean": float(np.mean(est_ms)), "min": float(np.min(est_ms)), "max": float(np.max(est_ms))},
         "append_ms": {"mean": float(np.mean(app_ms)), "min": float(np.min(app_ms)), "max": float(np.max(app_ms)),
-                      "note": "transform + append + rebuild of the search grid over the whole map"},
+                      "note": "transform + append + search-grid update: the sorted records move up by their cells' shifts and the new ones "
+                              "fill the gaps (icp_grid_append_counters: incremental / rebuilt appends below); a full rebuild "
+                              "only for points beyond half a cell outside the grid's box or once the map has grown by half"},
+        "appends_incremental_rebuilt": list(world.append_counters()),
         "map_build_ms": 1e3 * t_build,
         "inner_updates_per_frame": inner_all,
         "pose_abs_err_vs_truth_last_frame": err[-1],

@@ -129,6 +129,7 @@ SIGNATURES = {
     "icp_gn_path_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_trim_pool": (None, []),
     "icp_append_targets": (C.c_int, [_vp, _vp, _sz, _pp]),
+    "icp_grid_append_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_append_targets_device": (C.c_int, [_vp, _vp, _sz, _pp]),
     "icp_reserve_targets": (C.c_int, [_vp, _sz]),
     "icp_target_count": (_sz, [_vp]),

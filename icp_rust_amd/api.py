@@ -485,6 +485,12 @@ class _Icp:
         self._keep = None  # the cloud now lives in the handle's own storage
         self.m = self.target_count
 
+    def append_counters(self):
+        """(appends served by moving the search grid's sorted records, appends that rebuilt the grid)"""
+        out = (C.c_uint64 * 2)()
+        check(lib().icp_grid_append_counters(self._h, out), "icp_grid_append_counters")
+        return int(out[0]), int(out[1])
+
     def reserve(self, capacity):
         check(lib().icp_reserve_targets(self._h, int(capacity)), "icp_reserve_targets")
         self._keep = None if capacity > self.m else self._keep

@@ -331,6 +331,13 @@ void free_handle(icp_handle *h) {  // really release everything
   (void)hipFree(h->grid.t_cnt);
   (void)hipFree(h->grid.t_btot);
   (void)hipFree(h->grid.t_part);
+  (void)hipFree(h->grid.d_rcell);
+  (void)hipFree(h->grid.d_rcell2);
+  (void)hipFree(h->grid.d_start2);
+  (void)hipFree(h->grid.d_pts2);
+  (void)hipFree(h->grid.t_shift);
+  (void)hipFree(h->grid.t_cell_new);
+  (void)hipFree(h->grid.d_flag);
   (void)hipFree(h->qsort.d_cell_of);
   (void)hipFree(h->qsort.d_cell);
   (void)hipFree(h->qsort.d_tmp);
@@ -402,6 +409,7 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->profile = 0;
     h->prof_seen = 0;
     h->grid.built = false;
+    h->grid.appends_moved = h->grid.appends_rebuilt = 0;
     h->qsort.valid = false;
     h->qsort.have_prev = false;
     h->qsort.slot_order = false;
@@ -1248,7 +1256,10 @@ int append_common(icp_handle *h, const double *pts, size_t k, const icp_pose *T,
   h->brute_valid = h->screen_valid = false;
   // the grid is what a map-sized cloud is searched with; the sweep's structures (SoA + f32 screen,
   // 36 B per target) are rebuilt right away only where the sweep is the engine in use
-  hipError_t e = build_grid(h);
+  bool appended = false;
+  hipError_t e = append_grid(h, m_before, k, &appended);  // (the sorted records move, nothing is re-sorted: nn_grid.hip)
+  if (e == hipSuccess && !appended) e = build_grid(h);
+  if (e == hipSuccess) ++(appended ? h->grid.appends_moved : h->grid.appends_rebuilt);
   if (e == hipSuccess && resolved_nn_mode(h) == ICP_NN_BRUTE) {
     if ((e = build_target_soa(h)) == hipSuccess) e = build_target_screen(h);
   }
@@ -1280,6 +1291,13 @@ extern "C" int icp_reserve_targets(icp_handle *h, size_t capacity) {
   return own_targets(h, capacity);
 }
 extern "C" size_t icp_target_count(const icp_handle *h) { return h ? h->m : 0; }
+// Observability: out[0] = appends served by moving the sorted records (append_grid), out[1] = appends that rebuilt the grid
+extern "C" int icp_grid_append_counters(const icp_handle *h, uint64_t out[2]) {
+  if (!h || !out) return ICP_BAD_ARGUMENT;
+  out[0] = h->grid.appends_moved;
+  out[1] = h->grid.appends_rebuilt;
+  return ICP_OK;
+}
 extern "C" int icp_read_targets(icp_handle *h, size_t first, size_t k, double *out) {
   if (!h || first > h->m || k > h->m - first || (k > 0 && !out)) return ICP_BAD_ARGUMENT;
   if (k == 0) return ICP_OK;

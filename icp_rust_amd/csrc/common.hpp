@@ -206,6 +206,15 @@ struct Grid {
   uint32_t *t_cell_of = nullptr, *t_cnt = nullptr, *t_btot = nullptr;
   size_t cap_tcell = 0, cap_tcnt = 0, cap_tbtot = 0;
   double *t_part = nullptr;     // bounding-box partials
+  // incremental append (append_grid): the cell of the record at every sorted position, and a second set of the
+  // sorted arrays (records move out of place by their cell's shift, then the sets swap)
+  uint32_t *d_rcell = nullptr, *d_rcell2 = nullptr, *d_start2 = nullptr, *t_shift = nullptr, *t_cell_new = nullptr;
+  GridPoint *d_pts2 = nullptr;
+  size_t cap_rcell = 0, cap_rcell2 = 0, cap_start2 = 0, cap_pts2 = 0, cap_shift = 0, cap_cell_new = 0;
+  size_t m_full = 0;            // targets at the last full build (the cell size was chosen for that many)
+  bool rcell_valid = false;     // d_rcell describes the current records
+  unsigned long long appends_moved = 0, appends_rebuilt = 0;  // observability (icp_grid_append_counters)
+  uint32_t *d_flag = nullptr;   // one word: a new point outside the grid's box (or not finite)
 };
 
 constexpr int kShardStatusWords = 4;  // behind the 2 x kWinBins histogram words of a sharded evaluation
@@ -323,6 +332,10 @@ hipError_t launch_materialize(icp_handle *h, const double *d_src, size_t n, cons
                               double *d_a, double *d_b);
 // exact uniform-grid NN: same outputs, same results as launch_nn_brute
 hipError_t build_grid(icp_handle *h);
+// the grid after k targets were appended behind the first m_old: moves the sorted records by their cells' shifts and
+// inserts the new ones (*done = false: not applicable -- no grid, a point outside its box, the cloud outgrew its cell
+// size -- and the caller rebuilds)
+hipError_t append_grid(icp_handle *h, size_t m_old, size_t k, bool *done);
 hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n, const Pose &T);
 long grid_coop_max();
 hipError_t launch_nn_tile(icp_handle *h, const double *q_src, const uint32_t *q_perm, unsigned n, const Pose &T,

@@ -351,6 +351,11 @@ void icp_trim_pool(void);
  * icp_reserve_targets sizes that storage ahead of time; icp_target_count reports m. */
 int icp_append_targets(icp_handle *h, const double *pts, size_t k, const icp_pose *T);
 int icp_append_targets_device(icp_handle *h, const double *d_pts, size_t k, const icp_pose *T);
+/* Observability: out[0] = appends served incrementally (the sorted records of the search grid move up by their cells'
+ * shifts and the new ones fill the gaps: possible while every new point lies within half a cell of the grid's box and
+ * the cloud has grown by less than half since the grid's cell size was chosen), out[1] = appends that rebuilt the grid.
+ * Either way the handle afterwards answers like a fresh handle on the concatenated cloud. */
+int icp_grid_append_counters(const icp_handle *h, uint64_t out[2]);
 int icp_reserve_targets(icp_handle *h, size_t capacity);
 size_t icp_target_count(const icp_handle *h);
 /* copy target points [first, first + k) back to the host (AoS), e.g. to save the map */

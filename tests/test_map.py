@@ -212,3 +212,39 @@ def test_scan_to_map_trajectory_on_gpu_matches_the_oracle_bit_for_bit():
     Rs, _, _ = harness.run_scan_to_map(pk, step=30, max_iter=5, icp_factory=OracleMap())
     for a, b in zip(Ts, Rs):
         assert np.max(np.abs(a.as_array() - b.as_array())) <= 1e-5 * max(1.0, np.max(np.abs(b.as_array())))
+
+
+@gpu
+def test_incremental_and_rebuilding_appends_both_equal_a_fresh_handle():
+    """The append moves the grid's sorted records instead of re-sorting the cloud while every new point lies within
+    half a cell of the grid's box (include/icp_mi355x.h: icp_grid_append_counters); points farther out, or a cloud
+    that has outgrown its cell size, rebuild.  Whatever path an append took, the handle must answer like a fresh one
+    on the concatenated cloud: nearest neighbours of a query set, and a registration, bit for bit."""
+    rng = np.random.default_rng(41)
+    base = synth.box_cloud(synth.SEED + 21, 60_000, synth.ROOM_LO, synth.ROOM_HI)
+    grown = I.Icp3d(base)
+    cloud = base
+    q = synth.box_cloud(synth.SEED + 22, 30_000, synth.ROOM_LO, synth.ROOM_HI) + rng.normal(size=(30_000, 3)) * 0.02
+    scan = base[rng.choice(len(base), 20_000, replace=False)] + rng.normal(size=(20_000, 3)) * 0.01
+    parts = [
+        synth.box_cloud(synth.SEED + 23, 5_000, synth.ROOM_LO, synth.ROOM_HI),                 # inside: moved
+        synth.box_cloud(synth.SEED + 24, 5_000, synth.ROOM_LO, synth.ROOM_HI) + rng.normal(size=(5_000, 3)) * 0.002,  # a hair outside (well within half a cell of 0.035): moved
+        synth.box_cloud(synth.SEED + 25, 300, synth.ROOM_LO, synth.ROOM_HI) + np.array([4.0, 0.0, 0.0]),              # far outside: rebuilt
+        synth.box_cloud(synth.SEED + 26, 7_000, synth.ROOM_LO, synth.ROOM_HI),                 # inside the new box: moved
+        synth.box_cloud(synth.SEED + 27, 60_000, synth.ROOM_LO, synth.ROOM_HI),                # outgrows the cell size: rebuilt
+    ]
+    T0 = I.Transform([0.02, -0.01, 0.004])
+    for part in parts:
+        grown.append(part)
+        cloud = np.concatenate([cloud, part])
+        fresh = I.Icp3d(cloud, nn_mode=I.NN_GRID)
+        assert I.lib().icp_get_nn_mode(grown._h) == I.NN_GRID
+        assert np.array_equal(grown.nn_search(q), fresh.nn_search(q))
+        a = grown.estimate(scan, T0, 3, return_info=True)
+        b = fresh.estimate(scan, T0, 3, return_info=True)
+        assert np.array_equal(a[0].as_array(), b[0].as_array()) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        fresh.close()
+    rc, want = O.nn_brute(cloud, q[:3000])
+    assert rc == O.OK and np.array_equal(grown.nn_search(q[:3000]), want)
+    moved, rebuilt = grown.append_counters()
+    assert moved >= 3 and rebuilt >= 2, (moved, rebuilt)
