@@ -100,7 +100,7 @@ hipError_t alloc_ctx(GnCtx &c, hipStream_t s) {
   if ((e = hipMemsetAsync(c.d_ctl, 0, sizeof(SelCtl), s)) != hipSuccess) return e;
   if ((e = hipMalloc(&c.d_sel, 2 * kSelProblems * sizeof(SelState))) != hipSuccess) return e;
   if ((e = hipMalloc(&c.d_scal, sizeof(GnScalars))) != hipSuccess) return e;
-  if ((e = hipMalloc(&c.d_partials, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_partials, (size_t)kReduceMaxBlocks * (kNSum + 1) * sizeof(double))) != hipSuccess) return e;
   const size_t whist_bytes = ((size_t)2 * kWinBins + kShardStatusWords) * sizeof(uint32_t);  // (+ the sharded status words)
   if ((e = hipMalloc(&c.d_whist, whist_bytes)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(c.d_whist, 0, whist_bytes, s)) != hipSuccess) return e;
@@ -1559,7 +1559,7 @@ static int shard_eval_hist_impl(icp_handle *h, const double *d_a, const double *
   }
   S.attempt_refined = refined != 0;
   S.refined_ready = false;
-  if (!S.d_ordered) HIP_TRY(hipMalloc(&S.d_ordered, (size_t)kReduceMaxBlocks * (kNAcc + 1) * sizeof(double)));
+  if (!S.d_ordered) HIP_TRY(hipMalloc(&S.d_ordered, (size_t)kReduceMaxBlocks * (kNSum + 1) * sizeof(double)));
   if (!w.h_whist) HIP_TRY(hipHostMalloc(&w.h_whist, (size_t)2 * kWinBins * sizeof(uint32_t), hipHostMallocDefault));
   if (w.gn_dirty) {
     HIP_TRY(launch_sel_init(h, S.n_local));

@@ -13,7 +13,16 @@ namespace icp {
 
 constexpr int kReduceThreads = 512;   // threads per block of the GN reduction tree
 constexpr int kReduceMaxBlocks = 256;
-constexpr int kNAcc = 13;             // jtj[9], jtr[3], huber error
+constexpr int kNAcc = 13;             // what a weighted evaluation hands the host: jtj[9], jtr[3], huber error
+// Round 3: the device folds the weighted normal equations PER DIMENSION j, WITHOUT the factor g_j = 1 / sigma_j, and
+// only the upper triangle of J^T W J:
+//   S_j[u(p,q)] = sum_i (w_ij J_ij[p]) J_ij[q]   (p <= q; u = 0..5 for 00 01 02 11 12 22)
+//   S_j[6 + k]  = sum_i (w_ij J_ij[k]) r_ij
+// and applies g to the folded totals: jtj[p][q] = g_x S_x[u] + g_y S_y[u], mirrored (combine_sum).  The reference
+// multiplies every term by w g first and evaluates all nine products (src/lib.rs:246-254); the two differ by rounding
+// only.  Without sigma in the terms the sums no longer have to wait for the four exact medians:
+// they ride in the pass that computes the residuals (gn_win.hip: k_win_hist_sums).
+constexpr int kNSum = 19;             // S_x[9] | S_y[9] | huber error
 constexpr int kSelProblems = 4;       // {x, y} x {lower, upper middle order statistic}
 constexpr int kSelBins = 4096;        // 12-bit radix digits
 constexpr int kSelPasses = 6;         // 12+12+12+12+12+4 bits
@@ -118,7 +127,7 @@ struct GnCtx {
   SelCtl *d_ctl = nullptr;
   SelState *d_sel = nullptr;    // 2 x kSelProblems (gn_pull.hip ping-pongs between the halves)
   GnScalars *d_scal = nullptr;
-  double *d_partials = nullptr; // kReduceMaxBlocks x (kNAcc+1)
+  double *d_partials = nullptr; // kReduceMaxBlocks x (kNSum+1)
   GnResult *h_res = nullptr;    // pinned coherent host memory, written by the last workgroup
   unsigned seq = 0;             // sequence number of the last fast evaluation launched
   bool gn_dirty = true;         // selection scratch is not in its all-zero rest state: k_sel_init first
@@ -283,7 +292,7 @@ struct icp_handle {
     size_t n_local = 0, n_total = 0;
     const double *d_a = nullptr;
     icp::Pose T;
-    double *d_ordered = nullptr;  // kReduceMaxBlocks x (kNAcc + 1): the block sums of all ranks in block order
+    double *d_ordered = nullptr;  // kReduceMaxBlocks x (kNSum + 1): the block sums of all ranks in block order
     bool active = false;
     icp::WinParams P2;            // the window refined from a missed attempt's global counts
     bool refined_ready = false, attempt_refined = false;

@@ -192,38 +192,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_wgn_accumulate(const double2
                                                         const double *__restrict__ ry, unsigned n,
                                                         Pose T, const GnScalars *__restrict__ scal,
                                                         double *__restrict__ partials) {
-  const double sig[2] = {scal->sigma[0], scal->sigma[1]};
-  double g[2];
-  g[0] = 1. / sig[0];
-  g[1] = 1. / sig[1];
-  double acc[kNAcc];
+  double acc[kNSum];
 #pragma unroll
-  for (int k = 0; k < kNAcc; ++k) acc[k] = 0.;
+  for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
   const unsigned G = gridDim.x * kReduceThreads;
-  for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x; i < n; i += G) {
-    const double2 s = a[i];
-    const double r[2] = {rx[i], ry[i]};
-    // jacobian(), src/lib.rs:176-184
-    const double a0 = -s.y, a1 = s.x;
-    const double b0 = T.r00 * a0 + T.r01 * a1;
-    const double b1 = T.r10 * a0 + T.r11 * a1;
-    const double J[2][3] = {{T.r00, T.r01, b0}, {T.r10, T.r11, b1}};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (sig[j] == 0.) continue;  // src/lib.rs:243-245
-      const double r_ij = r[j];
-      const double w_ij = huber_drho(r_ij * r_ij);
-      const double wg = w_ij * g[j];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) acc[9 + k] = acc[9 + k] + (wg * J[j][k]) * r_ij;
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) acc[3 * p + q] = acc[3 * p + q] + (wg * J[j][p]) * J[j][q];
-    }
-    acc[12] = acc[12] + huber_rho(r[0] * r[0] + r[1] * r[1]);
-  }
-  block_reduce_store<kNAcc>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
+  for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x; i < n; i += G) accumulate_pair<false>(a[i], rx[i], ry[i], T, acc);
+  block_reduce_store<kNSum>(acc, partials + (size_t)blockIdx.x * (kNSum + 1));
 }
 
 // gauss_newton_update (src/lib.rs:191-216), error (:38-43), huber_error (:45-50)
@@ -270,6 +244,29 @@ __global__ __launch_bounds__(kReduceThreads) void k_final_reduce(const double *_
   if (threadIdx.x == 0) {
     res->sigma[0] = scal->sigma[0];
     res->sigma[1] = scal->sigma[1];
+    res->nan_flag = scal->nan_flag;
+    res->overflow = 0;
+  }
+}
+
+// second stage of a WEIGHTED evaluation: fold the per-dimension sums, then jtj = g_x S_x + g_y S_y (combine_sum)
+__global__ __launch_bounds__(kReduceThreads) void k_final_reduce_weighted(const double *__restrict__ partials, int blocks,
+                                                                          const GnScalars *__restrict__ scal,
+                                                                          GnResult *__restrict__ res) {
+  __shared__ double s_tot[kNSum + 1];
+  double acc[kNSum + 1];
+#pragma unroll
+  for (int k = 0; k < kNSum + 1; ++k) acc[k] = 0.;
+  for (int i = threadIdx.x; i < blocks; i += kReduceThreads)
+#pragma unroll
+    for (int k = 0; k < kNSum; ++k) acc[k] = acc[k] + partials[(size_t)i * (kNSum + 1) + k];
+  block_reduce_store<kNSum + 1>(acc, s_tot);
+  __syncthreads();
+  const double sig[2] = {scal->sigma[0], scal->sigma[1]};
+  if (threadIdx.x < kNAcc + 1) res->acc[threadIdx.x] = threadIdx.x < kNAcc ? combine_sum(s_tot, (int)threadIdx.x, sig) : 0.;
+  if (threadIdx.x == 0) {
+    res->sigma[0] = sig[0];
+    res->sigma[1] = sig[1];
     res->nan_flag = scal->nan_flag;
     res->overflow = 0;
   }
@@ -322,7 +319,7 @@ hipError_t launch_weighted_gn(icp_handle *h, const double *d_a, const double *d_
   reduce_geometry(n_, &blocks, &threads);
   hipLaunchKernelGGL(k_wgn_accumulate, dim3(blocks), dim3(threads), 0, h->stream, (const double2 *)d_a,
                      w.d_rx, w.d_ry, n, T, w.d_scal, w.d_partials);
-  hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(kReduceThreads), 0, h->stream, w.d_partials, blocks, kNAcc, w.d_scal,
+  hipLaunchKernelGGL(k_final_reduce_weighted, dim3(1), dim3(kReduceThreads), 0, h->stream, w.d_partials, blocks, w.d_scal,
                      w.h_res);
   return hipGetLastError();
 }

@@ -121,16 +121,75 @@ __device__ __forceinline__ bool last_block_arrives(TicketSet *t) {
   return s_last != 0;
 }
 
+// One point's terms of the weighted normal equations (src/lib.rs:241-254) and of the Huber error (:45-50), added
+// into the kNSum running sums (common.hpp: per dimension, without 1 / sigma, upper triangle).  UNIFORM: called with
+// every lane of the wave active -- the square root / division of the Huber weight then runs only where some lane
+// needs it.
+template <bool UNIFORM>
+__device__ __forceinline__ void accumulate_pair(const double2 &s, double r0, double r1, const Pose &T, double *acc) {
+  const double k2 = ICP_HUBER_K * ICP_HUBER_K;
+  const double r[2] = {r0, r1};
+  const double a0 = -s.y, a1 = s.x;  // jacobian(), src/lib.rs:176-184
+  const double b0 = T.r00 * a0 + T.r01 * a1;
+  const double b1 = T.r10 * a0 + T.r11 * a1;
+  const double J[2][3] = {{T.r00, T.r01, b0}, {T.r10, T.r11, b1}};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const double r_ij = r[j];
+    const double e = r_ij * r_ij;
+    double w_ij = 1.;  // huber::drho, src/huber.rs:17-26
+    if (UNIFORM) {
+      if (__ballot(e > k2)) w_ij = huber_drho(e);
+    } else {
+      w_ij = huber_drho(e);
+    }
+    double *S = acc + 9 * j;
+    const double t0 = w_ij * J[j][0], t1 = w_ij * J[j][1], t2 = w_ij * J[j][2];
+    S[0] = S[0] + t0 * J[j][0];
+    S[1] = S[1] + t0 * J[j][1];
+    S[2] = S[2] + t0 * J[j][2];
+    S[3] = S[3] + t1 * J[j][1];
+    S[4] = S[4] + t1 * J[j][2];
+    S[5] = S[5] + t2 * J[j][2];
+    S[6] = S[6] + t0 * r_ij;
+    S[7] = S[7] + t1 * r_ij;
+    S[8] = S[8] + t2 * r_ij;
+  }
+  const double e2 = r[0] * r[0] + r[1] * r[1];
+  double rho = e2;  // huber::rho, src/huber.rs:6-15
+  if (UNIFORM) {
+    if (__ballot(e2 > k2)) rho = huber_rho(e2);
+  } else {
+    rho = huber_rho(e2);
+  }
+  acc[18] = acc[18] + rho;
+}
+
+// Entry k of what the host solves with -- jtj[9] (k = 3 p + q), jtr[3] (k = 9 ..), the Huber error (k = 12) -- from
+// the folded sums: g_x S_x + g_y S_y, a dimension whose sigma is 0 left out (src/lib.rs:243-245).  Host and device,
+// one definition (the oracle restates it).
+__host__ __device__ __forceinline__ double combine_sum(const double *S, int k, const double *sig) {
+  if (k >= 12) return S[18];
+  int u;
+  if (k >= 9) {
+    u = 6 + (k - 9);
+  } else {
+    const int p = k / 3, q = k % 3;
+    const int lo = p < q ? p : q, hi = p < q ? q : p;
+    u = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);  // 00 01 02 11 12 22 -> 0 .. 5
+  }
+  double v = 0.;
+  if (sig[0] != 0.) v = v + (1. / sig[0]) * S[u];
+  if (sig[1] != 0.) v = v + (1. / sig[1]) * S[9 + u];
+  return v;
+}
+
 // src/lib.rs:238-255 (+ :45-50) over this thread's points g, g + G, ... in index order (the
 // first level of the fixed reduction tree); residuals come from the arrays the first launch wrote
 template <int kAccBatch = 4>
 __device__ __forceinline__ void accumulate_points(const double2 *__restrict__ a, const double *__restrict__ rx,
                                                   const double *__restrict__ ry, unsigned n, const Pose &T,
-                                                  const double (&sig)[2], double (&acc)[kNAcc]) {
-  double g[2];
-  g[0] = 1. / sig[0];
-  g[1] = 1. / sig[1];
-  const double k2 = ICP_HUBER_K * ICP_HUBER_K;
+                                                  double (&acc)[kNSum]) {
   const unsigned G = gridDim.x * kReduceThreads;
   for (unsigned base = blockIdx.x * kReduceThreads + threadIdx.x; base < n; base += G * kAccBatch) {
     double2 s[kAccBatch];
@@ -148,30 +207,7 @@ __device__ __forceinline__ void accumulate_points(const double2 *__restrict__ a,
     for (int u = 0; u < kAccBatch; ++u) {
       const unsigned i = base + u * G;
       if (i >= n) continue;
-      const double r[2] = {r0[u], r1[u]};
-      const double a0 = -s[u].y, a1 = s[u].x;  // jacobian(), src/lib.rs:176-184
-      const double b0 = T.r00 * a0 + T.r01 * a1;
-      const double b1 = T.r10 * a0 + T.r11 * a1;
-      const double J[2][3] = {{T.r00, T.r01, b0}, {T.r10, T.r11, b1}};
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (sig[j] == 0.) continue;  // src/lib.rs:243-245
-        const double r_ij = r[j];
-        const double e = r_ij * r_ij;
-        double w_ij = 1.;  // huber::drho, src/huber.rs:17-26; sqrt+divide only where a lane needs it
-        if (__ballot(e > k2)) w_ij = huber_drho(e);
-        const double wg = w_ij * g[j];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) acc[9 + k] = acc[9 + k] + (wg * J[j][k]) * r_ij;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int q = 0; q < 3; ++q) acc[3 * p + q] = acc[3 * p + q] + (wg * J[j][p]) * J[j][q];
-      }
-      const double e2 = r[0] * r[0] + r[1] * r[1];
-      double rho = e2;  // huber::rho, src/huber.rs:6-15
-      if (__ballot(e2 > k2)) rho = huber_rho(e2);
-      acc[12] = acc[12] + rho;
+      accumulate_pair<true>(s[u], r0[u], r1[u], T, acc);
     }
   }
 }
@@ -181,20 +217,24 @@ __device__ __forceinline__ void accumulate_points(const double2 *__restrict__ a,
 __device__ __forceinline__ void publish_result(const double *partials, GnResult *res, unsigned seq,
                                                const double (&sig)[2], const double (&med)[2], int nan_flag,
                                                int overflow, int blocks_override = 0) {
-  double tot[kNAcc + 1];
+  double tot[kNSum + 1];
 #pragma unroll
-  for (int k = 0; k < kNAcc + 1; ++k) tot[k] = 0.;
+  for (int k = 0; k < kNSum + 1; ++k) tot[k] = 0.;
   // (a sharded evaluation folds the block sums of ALL ranks from a one-workgroup launch)
   const int blocks = blocks_override > 0 ? blocks_override : (int)gridDim.x;
   for (int i = threadIdx.x; i < blocks; i += kReduceThreads) {
-    double v[kNAcc];
+    double v[kNSum];
 #pragma unroll
-    for (int k = 0; k < kNAcc; ++k)
-      v[k] = __hip_atomic_load(&partials[(size_t)i * (kNAcc + 1) + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < kNSum; ++k)
+      v[k] = __hip_atomic_load(&partials[(size_t)i * (kNSum + 1) + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int k = 0; k < kNAcc; ++k) tot[k] = tot[k] + v[k];
+    for (int k = 0; k < kNSum; ++k) tot[k] = tot[k] + v[k];
   }
-  block_reduce_store<kNAcc + 1>(tot, res->acc);  // (its stores come from lanes of wave 0)
+  __shared__ double s_tot[kNSum + 1];
+  block_reduce_store<kNSum + 1>(tot, s_tot);  // (stored by lanes of wave 0)
+  __syncthreads();
+  if (threadIdx.x < kNAcc + 1)
+    res->acc[threadIdx.x] = threadIdx.x < kNAcc ? combine_sum(s_tot, (int)threadIdx.x, sig) : 0.;
   // everything the host reads is stored by lanes of wave 0: that wave's fence orders it before the
   // sequence number; the other waves have nothing to publish
   if (threadIdx.x < 64) {

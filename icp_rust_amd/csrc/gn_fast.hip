@@ -124,8 +124,9 @@ __global__ __launch_bounds__(1024) void k_tiny_eval(const double2 *__restrict__ 
                                                     unsigned n, Pose T, int blocks, GnResult *res,
                                                     unsigned seq) {
   __shared__ unsigned long long buf[2][2][1024];  // [buffer][x | y][slot]; buffer 0 ends up holding the sorted keys
-  __shared__ double sm[16][kNAcc + 1];
-  __shared__ double part[2][kNAcc + 1];
+  __shared__ double sm[16][kNSum + 1];
+  __shared__ double part[2][kNSum + 1];
+  __shared__ double s_tot[kNSum + 1];
   __shared__ double s_mad[2][2];
   __shared__ int s_nan;
   const unsigned tid = threadIdx.x;
@@ -177,42 +178,21 @@ __global__ __launch_bounds__(1024) void k_tiny_eval(const double2 *__restrict__ 
   sig[0] = ICP_PPF34 * ((n & 1) ? s_mad[0][0] : (s_mad[0][0] + s_mad[0][1]) / 2.);
   sig[1] = ICP_PPF34 * ((n & 1) ? s_mad[1][0] : (s_mad[1][0] + s_mad[1][1]) / 2.);
   // weighted normal equations + Huber error (src/lib.rs:238-255, 45-50), one point per thread
-  double acc[kNAcc + 1];
+  double acc[kNSum + 1];
 #pragma unroll
-  for (int k = 0; k < kNAcc + 1; ++k) acc[k] = 0.;
-  if (has) {
-    const double g[2] = {1. / sig[0], 1. / sig[1]};
-    const double r[2] = {r0, r1};
-    const double a0 = -s.y, a1 = s.x;
-    const double b0 = T.r00 * a0 + T.r01 * a1;
-    const double b1 = T.r10 * a0 + T.r11 * a1;
-    const double J[2][3] = {{T.r00, T.r01, b0}, {T.r10, T.r11, b1}};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (sig[j] == 0.) continue;
-      const double r_ij = r[j];
-      const double w_ij = huber_drho(r_ij * r_ij);
-      const double wg = w_ij * g[j];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) acc[9 + k] = acc[9 + k] + (wg * J[j][k]) * r_ij;
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) acc[3 * p + q] = acc[3 * p + q] + (wg * J[j][p]) * J[j][q];
-    }
-    acc[12] = acc[12] + huber_rho(r[0] * r[0] + r[1] * r[1]);
-  }
+  for (int k = 0; k < kNSum + 1; ++k) acc[k] = 0.;
+  if (has) accumulate_pair<false>(s, r0, r1, T, acc);
   TSTAMP();
   // stage 1: virtual blocks of 512 threads (8 waves each); a wave without points sums to +0.0
   if ((unsigned)wave * 64u < n) {
-    group_reduce<kNAcc + 1>(acc, sm, wave);
+    group_reduce<kNSum + 1>(acc, sm, wave);
   } else if ((tid & 63) == 0) {
 #pragma unroll
-    for (int k = 0; k < kNAcc + 1; ++k) sm[wave][k] = 0.;
+    for (int k = 0; k < kNSum + 1; ++k) sm[wave][k] = 0.;
   }
   __syncthreads();
-  if (tid < 2 * (kNAcc + 1)) {
-    const int vb = tid / (kNAcc + 1), k = tid % (kNAcc + 1);
+  if (tid < 2 * (kNSum + 1)) {
+    const int vb = tid / (kNSum + 1), k = tid % (kNSum + 1);
     double v = sm[8 * vb][k];
     for (int w = 1; w < 8; ++w) v = v + sm[8 * vb + w][k];
     part[vb][k] = v;
@@ -223,11 +203,13 @@ __global__ __launch_bounds__(1024) void k_tiny_eval(const double2 *__restrict__ 
   // sums is +0.0, and x + 0.0 is x (a -0.0 becomes +0.0, once and for all).  So lane 0 of wave 0
   // ends with (p0 + 0.0) + (p1 + 0.0) -- lane 1 joins at the last step -- and the fold adds zeros:
   // the same bits as the general path without its 84 shuffles.
-  if (tid < kNAcc + 1) {
+  if (tid < kNSum + 1) {
     const double p0 = (0. + part[0][tid]) + 0.;
     const double p1 = blocks > 1 ? (0. + part[1][tid]) + 0. : 0.;
-    res->acc[tid] = tid < kNAcc ? (p0 + p1) + 0. : 0.;
+    s_tot[tid] = tid < kNSum ? (p0 + p1) + 0. : 0.;
   }
+  __syncthreads();
+  if (tid < kNAcc + 1) res->acc[tid] = tid < kNAcc ? combine_sum(s_tot, (int)tid, sig) : 0.;  // g_x S_x + g_y S_y
   TSTAMP();
   // everything the host reads is stored by lanes of wave 0, so one wave's fence orders it before
   // the sequence number (a system-scope fence in all sixteen waves cost 2 us)
@@ -465,10 +447,10 @@ __global__ __launch_bounds__(B) void k_tiny_estimate(const double *__restrict__ 
   p += sizeof(unsigned long long) * 2 * 2 * 1024;
   TinySel *S = reinterpret_cast<TinySel *>(p);
   p += (sizeof(TinySel) + 15) & ~size_t(15);
-  double(*sm)[kNAcc + 1] = reinterpret_cast<double(*)[kNAcc + 1]>(p);
-  p += sizeof(double) * 16 * (kNAcc + 1);
-  double(*part)[kNAcc + 1] = reinterpret_cast<double(*)[kNAcc + 1]>(p);
-  p += sizeof(double) * 2 * (kNAcc + 1);
+  double(*sm)[kNSum + 1] = reinterpret_cast<double(*)[kNSum + 1]>(p);
+  p += sizeof(double) * 16 * (kNSum + 1);
+  double(*part)[kNSum + 1] = reinterpret_cast<double(*)[kNSum + 1]>(p);
+  p += sizeof(double) * 2 * (kNSum + 1);
   struct Ctl {
     Pose Ti, T;
     double s_mad[2][2];
@@ -552,7 +534,7 @@ __global__ __launch_bounds__(B) void k_tiny_estimate(const double *__restrict__ 
   }
   if (tid >= B / 64 && tid < 16) {  // the wave sums of the waves a smaller workgroup does not have
 #pragma unroll
-    for (int q = 0; q < kNAcc + 1; ++q) sm[tid][q] = 0.;
+    for (int q = 0; q < kNSum + 1; ++q) sm[tid][q] = 0.;
   }
 
   __syncthreads();
@@ -712,40 +694,20 @@ __global__ __launch_bounds__(B) void k_tiny_estimate(const double *__restrict__ 
       }
       TINY_STAMP(2);
       // weighted normal equations + Huber error (src/lib.rs:238-255, 45-50), one point per thread
-      double acc[kNAcc + 1];
+      double acc[kNSum + 1];
 #pragma unroll
-      for (int q = 0; q < kNAcc + 1; ++q) acc[q] = 0.;
-      if (has) {
-        const double g[2] = {1. / sig[0], 1. / sig[1]};
-        const double r[2] = {r0, r1};
-        const double a0 = -ay, a1 = ax;  // jacobian(), src/lib.rs:176-184
-        const double b0 = Ti.r00 * a0 + Ti.r01 * a1;
-        const double b1 = Ti.r10 * a0 + Ti.r11 * a1;
-        const double J[2][3] = {{Ti.r00, Ti.r01, b0}, {Ti.r10, Ti.r11, b1}};
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (sig[j] == 0.) continue;
-          const double r_ij = r[j];
-          const double wg = huber_drho(r_ij * r_ij) * g[j];
-#pragma unroll
-          for (int q = 0; q < 3; ++q) acc[9 + q] = acc[9 + q] + (wg * J[j][q]) * r_ij;
-#pragma unroll
-          for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) acc[3 * pp + q] = acc[3 * pp + q] + (wg * J[j][pp]) * J[j][q];
-        }
-        acc[12] = acc[12] + huber_rho(r[0] * r[0] + r[1] * r[1]);
-      }
+      for (int q = 0; q < kNSum + 1; ++q) acc[q] = 0.;
+      if (has) accumulate_pair<false>(make_double2(ax, ay), r0, r1, Ti, acc);
       // the tree of reduce_geometry(n), exactly as k_tiny_eval folds it
       if ((unsigned)wave * 64u < n) {
-        group_reduce<kNAcc + 1>(acc, sm, wave);
+        group_reduce<kNSum + 1>(acc, sm, wave);
       } else if ((tid & 63) == 0) {
 #pragma unroll
-        for (int q = 0; q < kNAcc + 1; ++q) sm[wave][q] = 0.;
+        for (int q = 0; q < kNSum + 1; ++q) sm[wave][q] = 0.;
       }
       __syncthreads();
-      if (tid < 2 * (kNAcc + 1)) {
-        const int vb = tid / (kNAcc + 1), q = tid % (kNAcc + 1);
+      if (tid < 2 * (kNSum + 1)) {
+        const int vb = tid / (kNSum + 1), q = tid % (kNSum + 1);
         double v = sm[8 * vb][q];
         for (int w = 1; w < 8; ++w) v = v + sm[8 * vb + w][q];
         part[vb][q] = v;
@@ -753,12 +715,13 @@ __global__ __launch_bounds__(B) void k_tiny_estimate(const double *__restrict__ 
       __syncthreads();
       TINY_STAMP(3);
       if (tid == 0) {
-        double tot[kNAcc];
-        for (int q = 0; q < kNAcc; ++q) {
+        double sum[kNSum], tot[kNAcc];
+        for (int q = 0; q < kNSum; ++q) {
           const double p0 = (0. + part[0][q]) + 0.;
           const double p1 = blocks > 1 ? (0. + part[1][q]) + 0. : 0.;
-          tot[q] = (p0 + p1) + 0.;
+          sum[q] = (p0 + p1) + 0.;
         }
+        for (int q = 0; q < kNAcc; ++q) tot[q] = combine_sum(sum, q, sig);  // g_x S_x + g_y S_y
         ++C->evals;
         double delta[3];
         if (C->nan | C->bail) {
@@ -810,7 +773,7 @@ static size_t tiny_lds_bytes(int dim, unsigned m) {
   size_t b = mp * (size_t)dim * sizeof(double) + (mp + 4) * sizeof(float4) + 16;
   b += sizeof(unsigned long long) * 2 * 2 * 1024;
   b += (sizeof(TinySel) + 15) & ~size_t(15);
-  b += sizeof(double) * 18 * (kNAcc + 1);
+  b += sizeof(double) * 18 * (kNSum + 1);
   b += 512;  // Ctl
   return b;
 }

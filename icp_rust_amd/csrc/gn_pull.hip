@@ -360,11 +360,11 @@ __global__ __launch_bounds__(kReduceThreads) void k_pull_accumulate(const double
   resolve_cand(keys, cand, ctl->cand_cnt_pull[1], st, key, over);
   const double sig[2] = {ICP_PPF34 * middle(n, key[0], key[1]),  // src/stats.rs:42-46
                          ICP_PPF34 * middle(n, key[2], key[3])};
-  double acc[kNAcc];
+  double acc[kNSum];
 #pragma unroll
-  for (int k = 0; k < kNAcc; ++k) acc[k] = 0.;
-  accumulate_points(a, rx, ry, n, T, sig, acc);
-  block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
+  for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
+  accumulate_points(a, rx, ry, n, T, acc);
+  block_reduce_store<kNSum, true>(acc, partials + (size_t)blockIdx.x * (kNSum + 1));
   // clear what the next evaluation accumulates into (nobody reads these in this launch)
   const unsigned G = gridDim.x * kReduceThreads;
   // (write-through: the next evaluation may run on the handle's other stream before this

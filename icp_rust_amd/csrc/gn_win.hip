@@ -832,11 +832,11 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
     const bool failed = st->fail != 0;
     const double med0[2] = {scal->median[0], scal->median[1]};
     const double sig0[2] = {scal->sigma[0], scal->sigma[1]};
-    double acc[kNAcc];
+    double acc[kNSum];
 #pragma unroll
-    for (int k = 0; k < kNAcc; ++k) acc[k] = 0.;
-    if (!failed) accumulate_points<2>(a, rx, ry, n, T, sig0, acc);
-    block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
+    for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
+    if (!failed) accumulate_points<2>(a, rx, ry, n, T, acc);
+    block_reduce_store<kNSum, true>(acc, partials + (size_t)blockIdx.x * (kNSum + 1));
     const unsigned G0 = gridDim.x * kReduceThreads;  // (write-through, see below)
     for (unsigned i = blockIdx.x * kReduceThreads + threadIdx.x; i < 2u * kWinBins; i += G0)
       __hip_atomic_store(&whist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -901,12 +901,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
       }
     }
   }
-  double acc[kNAcc];
+  double acc[kNSum];
 #pragma unroll
-  for (int k = 0; k < kNAcc; ++k) acc[k] = 0.;
-  if (!fail) accumulate_points<kWinAccBatch>(a, rx, ry, n, T, sig, acc);
+  for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
+  if (!fail) accumulate_points<kWinAccBatch>(a, rx, ry, n, T, acc);
   STAMP();
-  block_reduce_store<kNAcc, true>(acc, partials + (size_t)blockIdx.x * (kNAcc + 1));
+  block_reduce_store<kNSum, true>(acc, partials + (size_t)blockIdx.x * (kNSum + 1));
   // the histograms of the next evaluation start from zero (nobody reads them in this launch).
   // Write-through stores: the next evaluation may run on the handle's other stream, handed over
   // by the host as soon as it sees this kernel's result -- i.e. possibly before this kernel's

@@ -100,10 +100,10 @@ struct ShardCandHeader {
   unsigned pad[11];
 };
 size_t shard_cand_bytes() { return sizeof(ShardCandHeader) + (size_t)(2 * kWinCapMed + 2 * kWinCapRing) * sizeof(double); }
-// block sums: rows of (kNAcc + 1) doubles, `shard_part_rows(world)` rows per rank: its blocks first (unused
+// block sums: rows of (kNSum + 1) doubles, `shard_part_rows(world)` rows per rank: its blocks first (unused
 // rows zero), the last row = {nan flag, overflow, median x, median y, sigma x, sigma y}
 int shard_part_rows(int world) { return (kReduceMaxBlocks + world - 1) / world + 1; }
-size_t shard_part_bytes(int world) { return (size_t)shard_part_rows(world) * (kNAcc + 1) * sizeof(double); }
+size_t shard_part_bytes(int world) { return (size_t)shard_part_rows(world) * (kNSum + 1) * sizeof(double); }
 
 __global__ void k_shard_pack_candidates(const WinState *__restrict__ st, const double *__restrict__ wmed,
                                         const double *__restrict__ wring, unsigned char *__restrict__ out) {
@@ -169,11 +169,11 @@ __global__ void k_shard_merge_candidates(ShardPtrs srcs, int world, WinState *st
 __global__ void k_shard_pack_partials(const double *__restrict__ partials, int blocks_local, int rows,
                                       GnScalars *__restrict__ scal, double *__restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int W = kNAcc + 1;
+  const int W = kNSum + 1;
   if (t >= rows * W) return;
   const int row = t / W, k = t % W;
   double v = 0.;
-  if (row < blocks_local) v = k < kNAcc ? partials[(size_t)row * W + k] : 0.;
+  if (row < blocks_local) v = k < kNSum ? partials[(size_t)row * W + k] : 0.;
   else if (row == rows - 1) {
     if (k == 0) v = (double)scal->nan_flag;
     else if (k == 1) {
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_shard_fold(ShardPtrs srcs, i
                                                                int blocks_total, double *__restrict__ ordered,
                                                                GnResult *res, unsigned seq,
                                                                const uint32_t *__restrict__ status) {
-  const int W = kNAcc + 1;
+  const int W = kNSum + 1;
   if (threadIdx.x < kShardStatusWords) res->status[threadIdx.x] = status[threadIdx.x];  // (ahead of the fence + seq below)
   // gather the rows into block order (rank r owns blocks [B r / world, B (r + 1) / world))
   for (int b = threadIdx.x; b < blocks_total; b += kReduceThreads) {
@@ -272,7 +272,7 @@ static hipError_t accumulate_from(icp_handle *h, const double *d_a, size_t n_loc
                        (unsigned)n_total, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
                        (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, 0u);
   const int rows = shard_part_rows(world);
-  hipLaunchKernelGGL(k_shard_pack_partials, dim3((rows * (kNAcc + 1) + 255) / 256), dim3(256), 0, h->stream,
+  hipLaunchKernelGGL(k_shard_pack_partials, dim3((rows * (kNSum + 1) + 255) / 256), dim3(256), 0, h->stream,
                      (const double *)w.d_partials, blocks_local, rows, w.d_scal, (double *)d_out);
   return hipGetLastError();
 }

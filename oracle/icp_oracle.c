@@ -419,9 +419,16 @@ int orc_weighted_gauss_newton_update(const orc_pose *T, const double *a, const d
  * points g, g+G, g+2G, ... (G = blocks*threads) left to right from 0; a 64-lane wave
  * combines with v[l] += v[l+off] for off = 32,16,8,4,2,1; thread 0 left-folds the wave
  * sums of its block starting from wave 0's; a second stage applies the same scheme with
- * one block of `threads` threads over the `blocks` block sums.  13 accumulators:
- * jtj[9], jtr[3], huber error. */
-#define NACC 13
+ * one block of `threads` threads over the `blocks` block sums.
+ * What is summed (round 3; icp_rust_amd/csrc/common.hpp: kNSum): PER DIMENSION j, WITHOUT the factor
+ * g_j = 1 / sigma_j, and only the upper triangle of J^T W J --
+ *   S_j[u(p,q)] = sum_i (w_ij J_ij[p]) J_ij[q]   (p <= q; u = 0..5 for 00 01 02 11 12 22)
+ *   S_j[6 + k]  = sum_i (w_ij J_ij[k]) r_ij
+ * plus the Huber error: 19 sums; jtj[p][q] = g_x S_x[u] + g_y S_y[u] (mirrored), jtr likewise, are formed
+ * from the folded totals (tree_combine).  The reference multiplies every term by w g first and evaluates
+ * all nine products (lib.rs:246-254; orc_weighted_gauss_newton_update above restates THAT): the two differ
+ * by rounding only. */
+#define NACC 19
 static void tree_block_reduce(double (*v)[NACC], int threads, double out[NACC]) {
   /* v: per-thread accumulators of one block */
   int waves = (threads + 63) / 64;
@@ -435,6 +442,41 @@ static void tree_block_reduce(double (*v)[NACC], int threads, double out[NACC]) 
     double s = v[0][k];
     for (int w = 1; w < waves; ++w) s = s + v[64 * w][k];
     out[k] = s;
+  }
+}
+
+/* one point's terms, added into the 19 running sums */
+static inline void tree_accumulate_point(const orc_pose *T, const double s[2], const double r[2], double acc[NACC]) {
+  double J[2][3];
+  jacobian(T, s, J);
+  for (int j = 0; j < 2; ++j) {
+    double r_ij = r[j];
+    double w_ij = orc_huber_drho(r_ij * r_ij, ORC_HUBER_K);
+    double *S = acc + 9 * j;
+    double t0 = w_ij * J[j][0], t1 = w_ij * J[j][1], t2 = w_ij * J[j][2];
+    S[0] = S[0] + t0 * J[j][0];
+    S[1] = S[1] + t0 * J[j][1];
+    S[2] = S[2] + t0 * J[j][2];
+    S[3] = S[3] + t1 * J[j][1];
+    S[4] = S[4] + t1 * J[j][2];
+    S[5] = S[5] + t2 * J[j][2];
+    S[6] = S[6] + t0 * r_ij;
+    S[7] = S[7] + t1 * r_ij;
+    S[8] = S[8] + t2 * r_ij;
+  }
+  acc[18] = acc[18] + orc_huber_rho(r[0] * r[0] + r[1] * r[1], ORC_HUBER_K);
+}
+
+/* jtj[9], jtr[3] from the folded sums: g_x S_x + g_y S_y, a dimension whose sigma is 0 left out (lib.rs:243-245) */
+static void tree_combine(const double S[NACC], const double stddevs[2], double jtj[9], double jtr[3]) {
+  static const int upper[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  for (int k = 0; k < 12; ++k) {
+    int u = k >= 9 ? 6 + (k - 9) : upper[k / 3][k % 3];
+    double v = 0.;
+    if (stddevs[0] != 0.) v = v + (1. / stddevs[0]) * S[u];
+    if (stddevs[1] != 0.) v = v + (1. / stddevs[1]) * S[9 + u];
+    if (k >= 9) jtr[k - 9] = v;
+    else jtj[k] = v;
   }
 }
 
@@ -460,11 +502,7 @@ int orc_weighted_gauss_newton_update_tree(const orc_pose *T, const double *a, co
     for (int t = 0; t < threads; ++t) {
       double acc[NACC];
       for (int k = 0; k < NACC; ++k) acc[k] = 0.;
-      for (size_t i = (size_t)blk * threads + t; i < n; i += G) {
-        wgn_accumulate_point(T, a + 2 * i, res + 2 * i, stddevs, acc + 9, acc);
-        const double *r = res + 2 * i;
-        acc[12] = acc[12] + orc_huber_rho(r[0] * r[0] + r[1] * r[1], ORC_HUBER_K);
-      }
+      for (size_t i = (size_t)blk * threads + t; i < n; i += G) tree_accumulate_point(T, a + 2 * i, res + 2 * i, acc);
       memcpy(thr[t], acc, sizeof(acc));
     }
     tree_block_reduce(thr, threads, part[blk]);
@@ -480,17 +518,20 @@ int orc_weighted_gauss_newton_update_tree(const orc_pose *T, const double *a, co
   free(thr);
   free(part);
   free(res);
-  if (huber_err) *huber_err = total[12];
-  return solve_update(total, total + 9, delta);
+  if (huber_err) *huber_err = total[18];
+  double jtj[9], jtr[3];
+  tree_combine(total, stddevs, jtj, jtr);
+  return solve_update(jtj, jtr, delta);
 }
 
 /* The two halves of orc_weighted_gauss_newton_update_tree, for checking a SHARDED evaluation
  * (tests/test_dist_gloo.py): a rank that owns `blocks_local` of the tree's blocks holds exactly the
  * points they fold, compacted in fold order (chunk `it` of the local arrays is the part of global row
  * `it` its blocks cover), so running stage 1 over the local arrays with G = blocks_local * threads
- * reproduces those blocks' sums; stage 2 folds the block sums of all ranks in block order. */
+ * reproduces those blocks' sums; stage 2 folds the block sums of all ranks in block order and applies
+ * 1 / stddevs (the global statistics every rank selected). */
 int orc_wgn_tree_partials(const orc_pose *T, const double *a, const double *b, size_t n_local, int blocks_local,
-                          int threads, const double stddevs[2], double *out /* blocks_local x 13 */) {
+                          int threads, double *out /* blocks_local x 19 */) {
   if (threads % 64 != 0 || blocks_local < 0) return -1;
   size_t G = (size_t)blocks_local * (size_t)threads;
   double(*thr)[NACC] = (double(*)[NACC])malloc((size_t)threads * sizeof(*thr));
@@ -501,8 +542,7 @@ int orc_wgn_tree_partials(const orc_pose *T, const double *a, const double *b, s
       for (size_t i = (size_t)blk * threads + t; i < n_local; i += G) {
         double r[2];
         orc_residual(T, a + 2 * i, b + 2 * i, r);
-        wgn_accumulate_point(T, a + 2 * i, r, stddevs, acc + 9, acc);
-        acc[12] = acc[12] + orc_huber_rho(r[0] * r[0] + r[1] * r[1], ORC_HUBER_K);
+        tree_accumulate_point(T, a + 2 * i, r, acc);
       }
       memcpy(thr[t], acc, sizeof(acc));
     }
@@ -512,8 +552,8 @@ int orc_wgn_tree_partials(const orc_pose *T, const double *a, const double *b, s
   return ORC_OK;
 }
 
-int orc_wgn_tree_fold(const double *partials /* blocks x 13, block order */, int blocks, int threads, double delta[3],
-                      double *huber_err) {
+int orc_wgn_tree_fold(const double *partials /* blocks x 19, block order */, int blocks, int threads,
+                      const double stddevs[2], double delta[3], double *huber_err) {
   if (threads % 64 != 0 || blocks < 1) return -1;
   double(*thr)[NACC] = (double(*)[NACC])malloc((size_t)threads * sizeof(*thr));
   double total[NACC];
@@ -524,8 +564,10 @@ int orc_wgn_tree_fold(const double *partials /* blocks x 13, block order */, int
   }
   tree_block_reduce(thr, threads, total);
   free(thr);
-  if (huber_err) *huber_err = total[12];
-  return solve_update(total, total + 9, delta);
+  if (huber_err) *huber_err = total[18];
+  double jtj[9], jtr[3];
+  tree_combine(total, stddevs, jtj, jtr);
+  return solve_update(jtj, jtr, delta);
 }
 
 /* lib.rs:59-84, generic over the summation order */

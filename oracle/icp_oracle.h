@@ -120,8 +120,9 @@ int orc_icp_estimate_tree(const orc_kdtree *t, const double *dst, size_t m, cons
 
 /* halves of orc_weighted_gauss_newton_update_tree for checking a sharded evaluation (see icp_oracle.c) */
 int orc_wgn_tree_partials(const orc_pose *T, const double *a, const double *b, size_t n_local, int blocks_local,
-                          int threads, const double stddevs[2], double *out_blocks_x_13);
-int orc_wgn_tree_fold(const double *partials_blocks_x_13, int blocks, int threads, double delta[3], double *huber_err);
+                          int threads, double *out_blocks_x_19);
+int orc_wgn_tree_fold(const double *partials_blocks_x_19, int blocks, int threads, const double stddevs[2],
+                      double delta[3], double *huber_err);
 
 /* EXTENSION CHECKER (no reference counterpart, no parity claim): point-to-plane residuals as
  * include/icp_mi355x.h section 7 defines them; see the block comment in icp_oracle.c */

@@ -100,8 +100,8 @@ def lib():
         u32p)
     sig("orc_icp_estimate_tree", C.c_int, C.c_void_p, dp, sz, dp, sz, pp, sz, C.POINTER(IcpOpts), pp,
         u32p, u32p)
-    sig("orc_wgn_tree_partials", C.c_int, pp, dp, dp, sz, C.c_int, C.c_int, dp, dp)
-    sig("orc_wgn_tree_fold", C.c_int, dp, C.c_int, C.c_int, dp, dp)
+    sig("orc_wgn_tree_partials", C.c_int, pp, dp, dp, sz, C.c_int, C.c_int, dp)
+    sig("orc_wgn_tree_fold", C.c_int, dp, C.c_int, C.c_int, dp, dp, dp)
     sig("orc_p2pl_normals", C.c_int, dp, sz, C.c_int, dp)
     sig("orc_p2pl_normals_range", C.c_int, dp, sz, sz, C.c_int, dp)
     sig("orc_p2pl_estimate", C.c_int, C.c_void_p, dp, sz, dp, dp, sz, pp, sz, pp, u32p, u32p)
@@ -352,20 +352,23 @@ def p2pl_estimate(tree, normals, src, init, max_iter):
 
 
 # ---- halves of the tree-order evaluation (checking sharded evaluations) -------------------------
-def wgn_tree_partials(T, a, b, blocks_local, threads, stddevs):
+TREE_SUMS = 19  # per dimension 6 + 3 sums without 1 / sigma, + the Huber error (icp_oracle.c: NACC)
+
+
+def wgn_tree_partials(T, a, b, blocks_local, threads):
     a, ap = _d(a)
     b, bp = _d(b)
-    sd, sp = _d(stddevs)
-    out = np.zeros((max(blocks_local, 1), 13))
-    rc = lib().orc_wgn_tree_partials(C.byref(T), ap, bp, a.size // 2, blocks_local, threads, sp,
+    out = np.zeros((max(blocks_local, 1), TREE_SUMS))
+    rc = lib().orc_wgn_tree_partials(C.byref(T), ap, bp, a.size // 2, blocks_local, threads,
                                      out.ctypes.data_as(C.POINTER(C.c_double)))
     assert rc == OK
     return out[:blocks_local]
 
 
-def wgn_tree_fold(partials, threads):
+def wgn_tree_fold(partials, threads, stddevs):
     p, pp_ = _d(partials)
+    sd, sp = _d(stddevs)
     delta = np.zeros(3)
     err = C.c_double(0.0)
-    rc = lib().orc_wgn_tree_fold(pp_, p.shape[0], threads, delta.ctypes.data_as(C.POINTER(C.c_double)), C.byref(err))
+    rc = lib().orc_wgn_tree_fold(pp_, p.shape[0], threads, sp, delta.ctypes.data_as(C.POINTER(C.c_double)), C.byref(err))
     return rc, delta, err.value

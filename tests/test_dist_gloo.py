@@ -155,7 +155,7 @@ class OracleBlockStages:
         self.prepared = 0
 
     def part_bytes(self, world):
-        return 8 * 13 * (256 // world + 2)
+        return 8 * (O.TREE_SUMS * (256 // world + 2) + 4)
 
     def empty(self, nbytes, like):
         return torch.zeros(nbytes, dtype=torch.uint8)
@@ -219,17 +219,20 @@ class OracleBlockStages:
         rc, sd = O.calc_stddevs(res)
         assert rc == O.OK
         b0, b1, blocks, nl = block_shard(self.n_total, rank, world)
-        parts = O.wgn_tree_partials(_opose(T), a, b, b1 - b0, 512, sd)
+        parts = O.wgn_tree_partials(_opose(T), a, b, b1 - b0, 512)  # (sums without 1 / sigma: applied after the fold)
         out = part_out.view(torch.float64)
         out.zero_()
         out[0] = float(b1 - b0)
-        out[1:1 + parts.size] = torch.from_numpy(parts.reshape(-1).copy())
+        out[1:3] = torch.from_numpy(np.asarray(sd, dtype=np.float64))  # every rank selected the same statistics
+        out[3:3 + parts.size] = torch.from_numpy(parts.reshape(-1).copy())
         return _lib.OK
 
     def eval_finish(self, part_all):
         world = self.cur[3]
         allv = part_all.view(torch.float64).numpy().reshape(world, -1)
-        parts = np.concatenate([allv[q, 1:1 + 13 * int(allv[q, 0])].reshape(-1, 13) for q in range(world)])
+        K = O.TREE_SUMS
+        parts = np.concatenate([allv[q, 3:3 + K * int(allv[q, 0])].reshape(-1, K) for q in range(world)])
+        sd = allv[0, 1:3].copy()
         if not self.refined:
             self.evals += 1
         if self.miss_every and self.evals % self.miss_every == 0:  # "the predicted window missed"
@@ -237,7 +240,7 @@ class OracleBlockStages:
                 return _lib.RETRY_SHARDED, None, 0.0      # its counts place a refined window: again, sharded
             if self.evals % (2 * self.miss_every) == 0:
                 return _lib.RETRY_REPLICATED, None, 0.0   # every other time the refined attempt misses too
-        rc, delta, err = O.wgn_tree_fold(parts, 512)
+        rc, delta, err = O.wgn_tree_fold(parts, 512, sd)
         return (_lib.OK if rc == O.OK else _lib.NONE), delta, err
 
     def gn_step(self, a_full, b_full, T, kind):

@@ -570,6 +570,10 @@ def test_stage_calls_on_the_default_stream_are_ordered_and_shards_equal_the_whol
     src, dst = synth.synthetic_pair(n, m)
     d_src, d_dst = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
     whole = I.Icp3d(d_dst)
+    ref = I.Icp3d(d_dst).estimate(d_src, I.Transform(), 4)
+    # (the whole-call path folds its sums over the cell-sorted cloud, icp_last_fold_order; the stage calls fold over
+    # the cloud they are handed: hand them the sorted one)
+    d_src, _ = whole.sort_source_device(d_src, I.Transform())
     T1, inner1 = ShardedIcp(HipStages(whole), n).estimate(d_src, I.Transform(), 4)
     shards = [shard_range(n, r, 2) for r in range(2)]
     srcs = [d_src[lo:hi].contiguous() for lo, hi in shards]
@@ -589,7 +593,6 @@ def test_stage_calls_on_the_default_stream_are_ordered_and_shards_equal_the_whol
         inner2.append(k)
     assert np.array_equal(T1.as_array(), T.as_array())
     assert inner1.tolist() == inner2
-    ref = I.Icp3d(d_dst).estimate(d_src, I.Transform(), 4)
     assert np.array_equal(ref.as_array(), T.as_array())
 
 
