@@ -107,7 +107,16 @@ __device__ __forceinline__ bool last_block_arrives(TicketSet *t) {
     const unsigned nb = gridDim.x, sh = blockIdx.x & 15u;
     const unsigned in_shard = (nb - sh + 15u) >> 4;  // workgroups with this shard id
     int last = 0;
-    if (__hip_atomic_fetch_add(&t->shard[sh][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+#ifdef ICP_AB_TICKET2
+    if (false) {
+#else
+    if (nb <= 32u) {  // few enough arrivals for one word: one round trip instead of two
+#endif
+      if (__hip_atomic_fetch_add(&t->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1) {
+        __hip_atomic_store(&t->top[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
+    } else if (__hip_atomic_fetch_add(&t->shard[sh][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
       __hip_atomic_store(&t->shard[sh][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned nshards = nb < 16u ? nb : 16u;
       if (__hip_atomic_fetch_add(&t->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1) {
@@ -125,44 +134,51 @@ __device__ __forceinline__ bool last_block_arrives(TicketSet *t) {
 // into the kNSum running sums (common.hpp: per dimension, without 1 / sigma, upper triangle).  UNIFORM: called with
 // every lane of the wave active -- the square root / division of the Huber weight then runs only where some lane
 // needs it.
+// the nine sums of dimension j (upper triangle of w J^T J, then w J^T r), r_j the residual in that dimension
 template <bool UNIFORM>
-__device__ __forceinline__ void accumulate_pair(const double2 &s, double r0, double r1, const Pose &T, double *acc) {
+__device__ __forceinline__ void accumulate_dim(int j, const double2 &s, double r_j, const Pose &T, double *S) {
   const double k2 = ICP_HUBER_K * ICP_HUBER_K;
-  const double r[2] = {r0, r1};
   const double a0 = -s.y, a1 = s.x;  // jacobian(), src/lib.rs:176-184
-  const double b0 = T.r00 * a0 + T.r01 * a1;
-  const double b1 = T.r10 * a0 + T.r11 * a1;
-  const double J[2][3] = {{T.r00, T.r01, b0}, {T.r10, T.r11, b1}};
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const double r_ij = r[j];
-    const double e = r_ij * r_ij;
-    double w_ij = 1.;  // huber::drho, src/huber.rs:17-26
-    if (UNIFORM) {
-      if (__ballot(e > k2)) w_ij = huber_drho(e);
-    } else {
-      w_ij = huber_drho(e);
-    }
-    double *S = acc + 9 * j;
-    const double t0 = w_ij * J[j][0], t1 = w_ij * J[j][1], t2 = w_ij * J[j][2];
-    S[0] = S[0] + t0 * J[j][0];
-    S[1] = S[1] + t0 * J[j][1];
-    S[2] = S[2] + t0 * J[j][2];
-    S[3] = S[3] + t1 * J[j][1];
-    S[4] = S[4] + t1 * J[j][2];
-    S[5] = S[5] + t2 * J[j][2];
-    S[6] = S[6] + t0 * r_ij;
-    S[7] = S[7] + t1 * r_ij;
-    S[8] = S[8] + t2 * r_ij;
+  const double J0 = j ? T.r10 : T.r00, J1 = j ? T.r11 : T.r01;
+  const double J2 = J0 * a0 + J1 * a1;
+  const double e = r_j * r_j;
+  double w = 1.;  // huber::drho, src/huber.rs:17-26
+  if (UNIFORM) {
+    if (__ballot(e > k2)) w = huber_drho(e);
+  } else {
+    w = huber_drho(e);
   }
-  const double e2 = r[0] * r[0] + r[1] * r[1];
-  double rho = e2;  // huber::rho, src/huber.rs:6-15
+  const double t0 = w * J0, t1 = w * J1, t2 = w * J2;
+  S[0] = S[0] + t0 * J0;
+  S[1] = S[1] + t0 * J1;
+  S[2] = S[2] + t0 * J2;
+  S[3] = S[3] + t1 * J1;
+  S[4] = S[4] + t1 * J2;
+  S[5] = S[5] + t2 * J2;
+  S[6] = S[6] + t0 * r_j;
+  S[7] = S[7] + t1 * r_j;
+  S[8] = S[8] + t2 * r_j;
+}
+
+// huber::rho of the squared residual norm (src/huber.rs:6-15, src/lib.rs:45-50)
+template <bool UNIFORM>
+__device__ __forceinline__ void accumulate_rho(double r0, double r1, double *err) {
+  const double k2 = ICP_HUBER_K * ICP_HUBER_K;
+  const double e2 = r0 * r0 + r1 * r1;
+  double rho = e2;
   if (UNIFORM) {
     if (__ballot(e2 > k2)) rho = huber_rho(e2);
   } else {
     rho = huber_rho(e2);
   }
-  acc[18] = acc[18] + rho;
+  *err = *err + rho;
+}
+
+template <bool UNIFORM>
+__device__ __forceinline__ void accumulate_pair(const double2 &s, double r0, double r1, const Pose &T, double *acc) {
+  accumulate_dim<UNIFORM>(0, s, r0, T, acc);
+  accumulate_dim<UNIFORM>(1, s, r1, T, acc + 9);
+  accumulate_rho<UNIFORM>(r0, r1, acc + 18);
 }
 
 // Entry k of what the host solves with -- jtj[9] (k = 3 p + q), jtr[3] (k = 9 ..), the Huber error (k = 12) -- from
@@ -212,16 +228,13 @@ __device__ __forceinline__ void accumulate_points(const double2 *__restrict__ a,
   }
 }
 
-// Executed by the last workgroup: fold the block sums (block order, same tree) and release the
-// result to the host, which polls `seq` in pinned memory.
-__device__ __forceinline__ void publish_result(const double *partials, GnResult *res, unsigned seq,
-                                               const double (&sig)[2], const double (&med)[2], int nan_flag,
-                                               int overflow, int blocks_override = 0) {
+// Executed by the last workgroup: fold the block sums (block order, same tree) into s_tot[kNSum + 1] (LDS; valid
+// after the next barrier).  The sums do not depend on the order statistics, so a kernel that still has to select
+// those folds first -- the loads of the block sums then share a round trip with the loads of its candidates.
+__device__ __forceinline__ void fold_block_sums(const double *partials, int blocks, double *s_tot) {
   double tot[kNSum + 1];
 #pragma unroll
   for (int k = 0; k < kNSum + 1; ++k) tot[k] = 0.;
-  // (a sharded evaluation folds the block sums of ALL ranks from a one-workgroup launch)
-  const int blocks = blocks_override > 0 ? blocks_override : (int)gridDim.x;
   for (int i = threadIdx.x; i < blocks; i += kReduceThreads) {
     double v[kNSum];
 #pragma unroll
@@ -230,14 +243,54 @@ __device__ __forceinline__ void publish_result(const double *partials, GnResult 
 #pragma unroll
     for (int k = 0; k < kNSum; ++k) tot[k] = tot[k] + v[k];
   }
-  __shared__ double s_tot[kNSum + 1];
   block_reduce_store<kNSum + 1>(tot, s_tot);  // (stored by lanes of wave 0)
+}
+
+// The same fold (bit for bit) for at most 256 block sums -- what reduce_geometry yields -- in half the registers:
+// thread t takes sums [10 h, 10 h + 10) of row t % 256, h = t / 256, so waves 0-3 and 4-7 each see the rows in the
+// lanes fold_block_sums has them in; the wave sums are left-folded per half, plus the one `+ 0.` that stands for
+// the four all-zero waves of the general form (it only matters for a sum that is -0.).
+__device__ __forceinline__ void fold_block_sums_256(const double *partials, int blocks, double *s_tot) {
+  static_assert(kReduceThreads == 512 && (kNSum + 1) == 20 && kReduceMaxBlocks <= 256, "two halves of ten sums, one row per thread");
+  constexpr int H = (kNSum + 1) / 2;
+  __shared__ double sm[8][H];
+  const int t = threadIdx.x, row = t & 255, half = t >> 8, lane = t & 63, wave = t >> 6;
+  double v[H];
+#pragma unroll
+  for (int k = 0; k < H; ++k) v[k] = 0.;
+  if (row < blocks) {
+    double x[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k)
+      x[k] = (half * H + k < kNSum) ? __hip_atomic_load(&partials[(size_t)row * (kNSum + 1) + half * H + k],
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : 0.;
+#pragma unroll
+    for (int k = 0; k < H; ++k) v[k] = v[k] + x[k];
+  }
+  wave_tree<H>(v);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < H; ++k) sm[wave][k] = v[k];
+  }
   __syncthreads();
-  if (threadIdx.x < kNAcc + 1)
-    res->acc[threadIdx.x] = threadIdx.x < kNAcc ? combine_sum(s_tot, (int)threadIdx.x, sig) : 0.;
-  // everything the host reads is stored by lanes of wave 0: that wave's fence orders it before the
-  // sequence number; the other waves have nothing to publish
+  if (t < kNSum + 1) {
+    const int h = t / H, k = t % H;
+    double s = sm[4 * h][k];
+    for (int w = 1; w < 4; ++w) s = s + sm[4 * h + w][k];
+    s_tot[t] = s + 0.;
+  }
+}
+
+// ... and release the result to the host, which polls `seq` in pinned memory.
+__device__ __forceinline__ void publish_folded(const double *s_tot, GnResult *res, unsigned seq, const double (&sig)[2],
+                                               const double (&med)[2], int nan_flag, int overflow) {
+  // everything the host reads is stored by lanes of wave 0, and the sequence number by its lane 0 with release
+  // semantics at system scope: the write-back and the wait that implement the release are wave-wide, so they
+  // order every lane's stores before it (an extra __threadfence_system() in front cost ~1 us, measured)
   if (threadIdx.x < 64) {
+    if (threadIdx.x < kNAcc + 1)
+      res->acc[threadIdx.x] = threadIdx.x < kNAcc ? combine_sum(s_tot, (int)threadIdx.x, sig) : 0.;
     if (threadIdx.x == kNAcc + 1) {
       res->sigma[0] = sig[0];
       res->sigma[1] = sig[1];
@@ -248,9 +301,23 @@ __device__ __forceinline__ void publish_result(const double *partials, GnResult 
       res->nan_flag = nan_flag;
       res->overflow = overflow;
     }
+#ifdef ICP_AB_FENCE2
     __threadfence_system();
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     if (threadIdx.x == 0) __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+__device__ __forceinline__ void publish_result(const double *partials, GnResult *res, unsigned seq,
+                                               const double (&sig)[2], const double (&med)[2], int nan_flag,
+                                               int overflow, int blocks_override = 0) {
+  __shared__ double s_tot[kNSum + 1];
+  // (a sharded evaluation folds the block sums of ALL ranks from a one-workgroup launch)
+  fold_block_sums(partials, blocks_override > 0 ? blocks_override : (int)gridDim.x, s_tot);
+  __syncthreads();
+  publish_folded(s_tot, res, seq, sig, med, nan_flag, overflow);
 }
 
 }  // namespace icp

@@ -694,13 +694,26 @@ __global__ __launch_bounds__(B) void k_tiny_estimate(const double *__restrict__ 
       }
       TINY_STAMP(2);
       // weighted normal equations + Huber error (src/lib.rs:238-255, 45-50), one point per thread
-      double acc[kNSum + 1];
-#pragma unroll
-      for (int q = 0; q < kNSum + 1; ++q) acc[q] = 0.;
-      if (has) accumulate_pair<false>(make_double2(ax, ay), r0, r1, Ti, acc);
-      // the tree of reduce_geometry(n), exactly as k_tiny_eval folds it
+      // the tree of reduce_geometry(n), exactly as k_tiny_eval folds it -- one dimension's sums at a time (half
+      // the registers of all nineteen at once; the wave trees of different sums are independent)
       if ((unsigned)wave * 64u < n) {
-        group_reduce<kNSum + 1>(acc, sm, wave);
+        static_assert(kNSum == 19, "9 + 9 + 1");
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          double half[10];
+#pragma unroll
+          for (int q = 0; q < 10; ++q) half[q] = 0.;
+          if (has) {
+            accumulate_dim<false>(j, make_double2(ax, ay), j ? r1 : r0, Ti, half);
+            if (j == 0) accumulate_rho<false>(r0, r1, &half[9]);
+          }
+          wave_tree<10>(half);
+          if ((tid & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) sm[wave][9 * j + q] = half[q];
+            sm[wave][18 + j] = half[9];  // (the error; the pad sums to +0.0)
+          }
+        }
       } else if ((tid & 63) == 0) {
 #pragma unroll
         for (int q = 0; q < kNSum + 1; ++q) sm[wave][q] = 0.;
@@ -714,14 +727,18 @@ __global__ __launch_bounds__(B) void k_tiny_estimate(const double *__restrict__ 
       }
       __syncthreads();
       TINY_STAMP(3);
+      // the last level of the tree and g_x S_x + g_y S_y, one thread per entry (rows 0 and 1 of `sm` are free until
+      // the next evaluation's wave sums; thread 0 alone with arrays in scratch memory cost 2.7 us per evaluation)
+      if (tid < kNSum) {
+        const double p0 = (0. + part[0][tid]) + 0.;
+        const double p1 = blocks > 1 ? (0. + part[1][tid]) + 0. : 0.;
+        sm[0][tid] = (p0 + p1) + 0.;
+      }
+      __syncthreads();
+      if (tid < kNAcc) sm[1][tid] = combine_sum(sm[0], (int)tid, sig);
+      __syncthreads();
       if (tid == 0) {
-        double sum[kNSum], tot[kNAcc];
-        for (int q = 0; q < kNSum; ++q) {
-          const double p0 = (0. + part[0][q]) + 0.;
-          const double p1 = blocks > 1 ? (0. + part[1][q]) + 0. : 0.;
-          sum[q] = (p0 + p1) + 0.;
-        }
-        for (int q = 0; q < kNAcc; ++q) tot[q] = combine_sum(sum, q, sig);  // g_x S_x + g_y S_y
+        const double *tot = sm[1];
         ++C->evals;
         double delta[3];
         if (C->nan | C->bail) {

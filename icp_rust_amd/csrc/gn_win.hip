@@ -61,23 +61,45 @@ __device__ __forceinline__ unsigned wbin(double r, const WinDim &w) {
   return region_bin(r - w.x[4], w.sf, kF2, kWinFine);
 }
 
+// The same function (same operations on the same operands, hence the same bins) as selects of the region's
+// origin / scale / first bin followed by ONE region_bin: a fifth of the code, for the places that run once per
+// launch -- cold code is fetched while everybody waits ("code size is latency"); the
+// streaming loops keep the branches above, whose compares read the window from scalar registers (this form
+// copies it into 32 vector registers).
+__device__ __forceinline__ unsigned wbin_cold(double r, const WinDim &w) {
+  const bool g1 = r >= w.x[1], g2 = r >= w.x[2], g3 = r >= w.x[3], g4 = r >= w.x[4];
+  const double base = g4 ? w.x[4] : (g3 ? w.x[3] : (g2 ? w.x[2] : (g1 ? w.x[1] : w.x[0])));
+  const bool coarse = g1 != g2 || g3 != g4;  // regions 1 and 3
+  const int first = g4 ? kF2 : (g3 ? kC1 : (g2 ? kF1 : (g1 ? kC0 : kF0)));
+  const bool inside = r >= w.x[0] && !(r >= w.x[5]);
+  const double off = inside ? r - base : 0.;
+  const unsigned j = region_bin(off, coarse ? w.sc : w.sf, first, coarse ? kWinCoarse : kWinFine);
+  if (!(r >= w.x[0])) return 0u;
+  return r >= w.x[5] ? (unsigned)(kWinBins - 1) : j;
+}
+
 // lower edge of regular bin j (1 <= j <= kWinBins-1; the upper edge of j is the lower edge of j+1)
 __device__ __forceinline__ double wedge(int j, const WinDim &w) {
   if (j >= kWinBins - 1) return w.x[5];
-  if (j >= kF2) return w.x[4] + (double)(j - kF2) / w.sf;
-  if (j >= kC1) return w.x[3] + (double)(j - kC1) / w.sc;
-  if (j >= kF1) return w.x[2] + (double)(j - kF1) / w.sf;
-  if (j >= kC0) return w.x[1] + (double)(j - kC0) / w.sc;
-  return w.x[0] + (double)(j - kF0) / w.sf;
+  const bool g1 = j >= kC0, g2 = j >= kF1, g3 = j >= kC1, g4 = j >= kF2;
+  const double base = g4 ? w.x[4] : (g3 ? w.x[3] : (g2 ? w.x[2] : (g1 ? w.x[1] : w.x[0])));
+  const int first = g4 ? kF2 : (g3 ? kC1 : (g2 ? kF1 : (g1 ? kC0 : kF0)));
+  const bool coarse = g1 != g2 || g3 != g4;
+  return base + (double)(j - first) / (coarse ? w.sc : w.sf);
 }
 
 // ---- W ------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWinThreads) void k_win_hist(const double2 *__restrict__ a,
-                                                          const double2 *__restrict__ b, Pose T,
-                                                          double *__restrict__ rx, double *__restrict__ ry,
-                                                          unsigned n, WinParams P, uint32_t *whist, WinState *st,
-                                                          GnScalars *scal) {
+// SUMS: the running sums of the normal equations ride along (they do not depend on the order statistics any more,
+// common.hpp: kNSum); the launch then has the geometry of the reduction tree and leaves one block sum per workgroup.
+template <bool SUMS>
+__device__ __forceinline__ void win_hist_body(const double2 *__restrict__ a, const double2 *__restrict__ b,
+                                              const Pose &T, double *__restrict__ rx, double *__restrict__ ry,
+                                              unsigned n, const WinParams &P, uint32_t *whist, WinState *st,
+                                              GnScalars *scal, double *partials) {
   __shared__ uint32_t lh[2 * kWinBins];
+  double acc[SUMS ? kNSum : 1];
+#pragma unroll
+  for (int k = 0; k < (SUMS ? kNSum : 1); ++k) acc[k] = 0.;
 #ifdef ICP_WIN_DEBUG
   long long wst[6];
   wst[0] = wall_clock64();
@@ -117,6 +139,7 @@ __global__ __launch_bounds__(kWinThreads) void k_win_hist(const double2 *__restr
       if (j1 == 0u) ++edge[2];
       else if (j1 == (unsigned)(kWinBins - 1)) ++edge[3];
       else atomicAdd(&lh[kWinBins + j1], 1u);
+      if (SUMS) accumulate_pair<true>(s[u], v0, v1, T, acc);  // (this thread's points in index order: the tree's first level)
     }
   }
 #pragma unroll
@@ -146,6 +169,24 @@ __global__ __launch_bounds__(kWinThreads) void k_win_hist(const double2 *__restr
     printf("[W blk %d] zero %lld stream %lld barrier %lld flush %lld (x10ns)\n", blockIdx.x, wst[1] - wst[0],
            wst[2] - wst[1], wst[3] - wst[2], wst[4] - wst[3]);
 #endif
+  if (SUMS) block_reduce_store<SUMS ? kNSum : 1, true>(acc, partials + (size_t)blockIdx.x * (kNSum + 1));
+}
+
+__global__ __launch_bounds__(kWinThreads) void k_win_hist(const double2 *__restrict__ a,
+                                                          const double2 *__restrict__ b, Pose T,
+                                                          double *__restrict__ rx, double *__restrict__ ry,
+                                                          unsigned n, WinParams P, uint32_t *whist, WinState *st,
+                                                          GnScalars *scal) {
+  win_hist_body<false>(a, b, T, rx, ry, n, P, whist, st, scal, nullptr);
+}
+
+// launched with reduce_geometry(n): workgroup i leaves block sum i of the fixed reduction tree in `partials`
+__global__ __launch_bounds__(kWinThreads) void k_win_hist_sums(const double2 *__restrict__ a,
+                                                               const double2 *__restrict__ b, Pose T,
+                                                               double *__restrict__ rx, double *__restrict__ ry,
+                                                               unsigned n, WinParams P, uint32_t *whist, WinState *st,
+                                                               GnScalars *scal, double *partials) {
+  win_hist_body<true>(a, b, T, rx, ry, n, P, whist, st, scal, partials);
 }
 
 // ---- W' (refined windows, n > 4M): the histograms again for new windows, from the stored residuals
@@ -304,12 +345,12 @@ __device__ __forceinline__ WinGeom window_geometry(const uint32_t *c, unsigned n
 }
 
 __device__ __forceinline__ void inside_bins(const WinGeom &g, const WinDim &w, double d, int &s, int &e) {
-  s = (int)wbin(g.mU - d + g.q, w) + 1;  // [s, e): regular bins only
-  e = (int)wbin(g.mL + d - g.q, w);
+  s = (int)wbin_cold(g.mU - d + g.q, w) + 1;  // [s, e): regular bins only
+  e = (int)wbin_cold(g.mL + d - g.q, w);
 }
 __device__ __forceinline__ void possible_bins(const WinGeom &g, const WinDim &w, double d, int &s, int &e) {
-  s = (int)wbin(g.mL - d - g.q, w);      // [s, e): may include the catch-all bins
-  e = (int)wbin(g.mU + d + g.q, w) + 1;
+  s = (int)wbin_cold(g.mL - d - g.q, w);      // [s, e): may include the catch-all bins
+  e = (int)wbin_cold(g.mU + d + g.q, w) + 1;
 }
 
 // one half of the bracket: role 0 -> t1 = max{t: #possible(d_t) <= klo}, role 1 -> t2 = min{t: #inside(d_t) > khi}
@@ -372,14 +413,27 @@ __device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, co
 // n_local: the residuals THIS launch streams; n: the points the histogram counts.  They differ only in a
 // sharded evaluation (api.hip, "sharded evaluation"), where whist holds the sum over all ranks and every
 // rank resolves the same bins but appends only its own candidates.
-template <bool LISTS>
-__global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__restrict__ rx,
-                                                             const double *__restrict__ ry, unsigned n_local,
-                                                             unsigned n, WinParams P,
-                                                             const uint32_t *__restrict__ whist, WinState *st,
-                                                             double *wmed, double *wring,
-                                                             const unsigned *__restrict__ llen, unsigned lcap) {
+// FINISH: the launch goes on to select the order statistics itself (k_win_finish below) -- the candidates are
+// stored write-through for the workgroup that arrives last, a missed window does not end the workgroup early, and
+// what the histogram says about the candidate lists is handed back in `sel` (every workgroup derives the same).
+struct WinSel {
+  unsigned med_base[2], med_cnt[2], inner[2], ring_cnt[2];
+  double range[2][4];
+};
+
+template <bool LISTS, bool FINISH>
+__device__ __forceinline__ bool win_compact_body(const double *__restrict__ rx, const double *__restrict__ ry,
+                                                 unsigned n_local, unsigned n, const WinParams &P,
+                                                 const uint32_t *__restrict__ whist, WinState *st, double *wmed,
+                                                 double *wring, const unsigned *__restrict__ llen, unsigned lcap,
+                                                 WinSel &sel) {
   __shared__ uint32_t cum[2 * kWinBins];  // points in lower bins
+  __shared__ unsigned s_selu[2][4];
+  __shared__ double s_seld[2][4];
+  auto put = [](double *p, double v) {
+    if (FINISH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+  };
   __shared__ unsigned s_wtot[2][16];
   __shared__ int s_rng[2][8];
   __shared__ double s_med[2][kWinBlkMed], s_ring[2][kWinBlkRing];
@@ -392,6 +446,24 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
   cst[0] = wall_clock64();
 #endif
   if (tid < 4) s_cnt[tid] = 0;
+  // the first batch of residuals does not wait for the bins to be resolved: its loads travel with the histogram's
+  const unsigned G = gridDim.x * kWinThreads;
+  double pre[2][kWinBatch];
+#ifdef ICP_AB_PREFETCH
+  constexpr bool kPrefetch = !LISTS;
+#else
+  constexpr bool kPrefetch = false;  // (measured: no gain on the 28k frame, and 37 more registers in the kernel)
+#endif
+  if (kPrefetch) {
+#pragma unroll
+    for (int u = 0; u < kWinBatch; ++u) {
+      const unsigned i = blockIdx.x * kWinThreads + tid + u * G;
+      if (i < n_local) {
+        pre[0][u] = rx[i];
+        pre[1][u] = ry[i];
+      }
+    }
+  }
   unsigned v[2][PER], inc[2], tot[2];
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
@@ -486,6 +558,14 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
       s_rng[d][4] = R.i0;
       s_rng[d][5] = R.i1;
       s_rng[d][6] = ok ? 0 : 1;
+      if (FINISH) {
+        s_selu[d][0] = med_base;
+        s_selu[d][1] = med_cnt;
+        s_selu[d][2] = inner;
+        s_selu[d][3] = ring_cnt;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_seld[d][k] = range[k];
+      }
       if (blockIdx.x == 0) {
         st->med_base[d] = med_base;
         st->med_cnt[d] = med_cnt;
@@ -504,14 +584,26 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
   __syncthreads();
 #ifdef ICP_WIN_DEBUG
   cst[2] = wall_clock64();
-  if (tid == 0 && blockIdx.x == 100)
+  if (tid == 0 && blockIdx.x == 0 && (clock64() & 15) == 0)
     printf("[C resolve] start->geo %lld geometry %lld bracket %lld (wave 3: %lld %lld) barrier1 %lld resolve_window %lld barrier2 %lld (x10ns)\n",
            s_rst[0][0] - cst[1], s_rst[0][1] - s_rst[0][0], s_rst[0][2] - s_rst[0][1], s_rst[3][1] - s_rst[3][0],
            s_rst[3][2] - s_rst[3][1], t_b1 - s_rst[0][2], t_b2 - t_b1, cst[2] - t_b2);
 #endif
   const bool fail = (s_rng[0][6] | s_rng[1][6]) != 0;
   if (blockIdx.x == 0 && tid == 0) st->fail = fail ? 1u : 0u;
-  if (fail) return;
+  if (FINISH) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      sel.med_base[d] = s_selu[d][0];
+      sel.med_cnt[d] = s_selu[d][1];
+      sel.inner[d] = s_selu[d][2];
+      sel.ring_cnt[d] = s_selu[d][3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sel.range[d][k] = s_seld[d][k];
+    }
+  } else if (fail) {
+    return true;
+  }
   unsigned mlo[2], mhi[2], a0[2], b1[2], i0[2], i1[2];
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
@@ -522,16 +614,24 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
     i0[d] = (unsigned)s_rng[d][4];
     i1[d] = (unsigned)s_rng[d][5];
   }
-  const unsigned G = gridDim.x * kWinThreads;
   const unsigned lim[2] = {LISTS ? llen[0] : n_local, LISTS ? llen[1] : n_local};
-  const unsigned nmax = lim[0] > lim[1] ? lim[0] : lim[1];
-  for (unsigned base = blockIdx.x * kWinThreads + tid; base < nmax; base += G * kWinBatch) {
+  const unsigned nmax = fail ? 0u : (lim[0] > lim[1] ? lim[0] : lim[1]);  // (a missed window: nothing to collect)
+  const unsigned base0 = blockIdx.x * kWinThreads + tid;
+  for (unsigned base = base0; base < nmax; base += G * kWinBatch) {
     double v[2][kWinBatch];
+    if (kPrefetch && base == base0) {
 #pragma unroll
-    for (int u = 0; u < kWinBatch; ++u) {
-      const unsigned i = base + u * G;
-      if (i < lim[0]) v[0][u] = rx[i];
-      if (i < lim[1]) v[1][u] = ry[i];
+      for (int u = 0; u < kWinBatch; ++u) {
+        v[0][u] = pre[0][u];
+        v[1][u] = pre[1][u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kWinBatch; ++u) {
+        const unsigned i = base + u * G;
+        if (i < lim[0]) v[0][u] = rx[i];
+        if (i < lim[1]) v[1][u] = ry[i];
+      }
     }
 #pragma unroll
     for (int u = 0; u < kWinBatch; ++u) {
@@ -550,7 +650,7 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
             s_med[d][pos] = r;
           } else {
             const unsigned g = atomicAdd(&st->list_cnt[d][0], 1u);
-            if (g < (unsigned)kWinCapMed) wmed[(size_t)d * kWinCapMed + g] = r;
+            if (g < (unsigned)kWinCapMed) put(&wmed[(size_t)d * kWinCapMed + g], r);
           }
         }
         if (j >= a0[d] && j <= b1[d] && !(j >= i0[d] && j <= i1[d])) {
@@ -559,7 +659,7 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
             s_ring[d][pos] = r;
           } else {
             const unsigned g = atomicAdd(&st->list_cnt[2 + d][0], 1u);
-            if (g < (unsigned)kWinCapRing) wring[(size_t)d * kWinCapRing + g] = r;
+            if (g < (unsigned)kWinCapRing) put(&wring[(size_t)d * kWinCapRing + g], r);
           }
         }
       }
@@ -581,19 +681,31 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
   if (tid < 2 * kWinBlkMed) {
     const int d = tid / kWinBlkMed, e = tid % kWinBlkMed;
     const unsigned pos = s_base[d] + e;
-    if ((unsigned)e < s_cnt[d] && pos < (unsigned)kWinCapMed) wmed[(size_t)d * kWinCapMed + pos] = s_med[d][e];
+    if ((unsigned)e < s_cnt[d] && pos < (unsigned)kWinCapMed) put(&wmed[(size_t)d * kWinCapMed + pos], s_med[d][e]);
   } else if (tid < 2 * kWinBlkMed + 2 * kWinBlkRing) {
     const int q = tid - 2 * kWinBlkMed, d = q / kWinBlkRing, e = q % kWinBlkRing;
     const unsigned pos = s_base[2 + d] + e;
-    if ((unsigned)e < s_cnt[2 + d] && pos < (unsigned)kWinCapRing) wring[(size_t)d * kWinCapRing + pos] = s_ring[d][e];
+    if ((unsigned)e < s_cnt[2 + d] && pos < (unsigned)kWinCapRing) put(&wring[(size_t)d * kWinCapRing + pos], s_ring[d][e]);
   }
 #ifdef ICP_WIN_DEBUG
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   cst[4] = wall_clock64();
-  if (tid == 0 && blockIdx.x == 100)
+  if (tid == 0 && blockIdx.x == 0 && (clock64() & 15) == 0)
     printf("[C blk %d] scan %lld resolve %lld stream %lld append %lld (x10ns)\n", blockIdx.x, cst[1] - cst[0],
            cst[2] - cst[1], cst[3] - cst[2], cst[4] - cst[3]);
 #endif
+  return fail;
+}
+
+template <bool LISTS>
+__global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__restrict__ rx,
+                                                             const double *__restrict__ ry, unsigned n_local,
+                                                             unsigned n, WinParams P,
+                                                             const uint32_t *__restrict__ whist, WinState *st,
+                                                             double *wmed, double *wring,
+                                                             const unsigned *__restrict__ llen, unsigned lcap) {
+  WinSel sel;
+  win_compact_body<LISTS, false>(rx, ry, n_local, n, P, whist, st, wmed, wring, llen, lcap, sel);
 }
 
 // ---- A ------------------------------------------------------------------------------
@@ -771,6 +883,110 @@ __device__ __forceinline__ void select_n(const double (&v)[ND][NV], const unsign
 __device__ __forceinline__ double middle_of(unsigned n, unsigned long long klo, unsigned long long khi) {
   const double lo = k2f(klo), hi = k2f(khi);
   return (n & 1) ? lo : (lo + hi) / 2.;  // src/stats.rs:18-27
+}
+
+// C + the rest of the evaluation, for sums that were accumulated beside the histograms (k_win_hist_sums): the
+// workgroup that arrives last has every candidate of the launch in reach (write-through stores, sc1 loads), ranks
+// them, folds the block sums of the earlier launch and releases the result -- two launches per evaluation.
+static_assert(kWinThreads == kReduceThreads, "the launches of an evaluation share the reduction tree's geometry");
+__global__ __launch_bounds__(kWinThreads) void k_win_finish(const double *__restrict__ rx,
+                                                            const double *__restrict__ ry, unsigned n, WinParams P,
+                                                            uint32_t *whist, WinState *st, double *wmed, double *wring,
+                                                            GnScalars *scal, const double *partials, int sum_blocks,
+                                                            SelCtl *ctl, GnResult *res, unsigned seq) {
+  constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
+  WinSel sel;
+#ifdef ICP_WIN_DEBUG
+  long long fst[10];
+  fst[0] = wall_clock64();
+#endif
+  bool fail = win_compact_body<false, true>(rx, ry, n, n, P, whist, st, wmed, wring, nullptr, 0u, sel);
+#ifdef ICP_WIN_DEBUG
+  fst[1] = wall_clock64();
+#endif
+  if (!last_block_arrives(&ctl->t[2])) return;
+#ifdef ICP_WIN_DEBUG
+  fst[2] = wall_clock64();
+#endif
+  const unsigned tid = threadIdx.x;
+  double med[2] = {0., 0.}, sig[2] = {0., 0.};
+  __shared__ double s_tot[kNSum + 1];
+  const int nan_flag = __hip_atomic_load(&scal->nan_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {
+    // one round trip for everything the rest of the kernel reads: candidates, their counts, the block sums
+    double vm[2][PM], vr[2][PR];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+      for (int u = 0; u < PM; ++u)
+        vm[d][u] = __hip_atomic_load(&wmed[(size_t)d * kWinCapMed + tid + u * kReduceThreads], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < PR; ++u)
+        vr[d][u] = __hip_atomic_load(&wring[(size_t)d * kWinCapRing + tid + u * kReduceThreads], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned got[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      got[k] = __hip_atomic_load(&st->list_cnt[k][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fold_block_sums_256(partials, sum_blocks, s_tot);  // (they do not depend on the statistics selected below)
+    // the histograms of the next evaluation start from zero (every workgroup has read them); write-through, and
+    // drained before the barriers in front of the release below: the host may hand the next evaluation to the
+    // handle's other stream as soon as it sees this result
+    for (unsigned i = tid; i < 2u * kWinBins; i += kWinThreads)
+      __hip_atomic_store(&whist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the appended counts are cross-checked against the histogram: a mismatch is a miss)
+    fail = fail || got[0] != sel.med_cnt[0] || got[1] != sel.med_cnt[1] || got[2] != sel.ring_cnt[0] ||
+           got[3] != sel.ring_cnt[1];
+    const unsigned klo = (n - 1) / 2, khi = n / 2;
+    if (!fail) {
+      unsigned long long key[2][2];
+      const double m_lo[2] = {sel.range[0][0], sel.range[1][0]}, m_hi[2] = {sel.range[0][1], sel.range[1][1]};
+      const long long mlo[2] = {(long long)klo - sel.med_base[0], (long long)klo - sel.med_base[1]};
+      const long long mhi[2] = {(long long)khi - sel.med_base[0], (long long)khi - sel.med_base[1]};
+#ifdef ICP_WIN_DEBUG
+      fst[3] = wall_clock64();
+#endif
+      select_n<2, PM>(vm, sel.med_cnt, m_lo, m_hi, mlo, mhi, key, fail);
+#ifdef ICP_WIN_DEBUG
+      fst[4] = wall_clock64();
+#endif
+      if (!fail) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          med[d] = middle_of(n, key[d][0], key[d][1]);
+#pragma unroll
+          for (int u = 0; u < PR; ++u) vr[d][u] = fabs(vr[d][u] - med[d]);  // src/stats.rs:35
+        }
+        const double r_lo[2] = {sel.range[0][2], sel.range[1][2]}, r_hi[2] = {sel.range[0][3], sel.range[1][3]};
+        const long long dlo[2] = {(long long)klo - sel.inner[0], (long long)klo - sel.inner[1]};
+        const long long dhi[2] = {(long long)khi - sel.inner[0], (long long)khi - sel.inner[1]};
+        select_n<2, PR>(vr, sel.ring_cnt, r_lo, r_hi, dlo, dhi, key, fail);
+        if (!fail) {
+          sig[0] = ICP_PPF34 * middle_of(n, key[0][0], key[0][1]);  // src/stats.rs:42-46
+          sig[1] = ICP_PPF34 * middle_of(n, key[1][0], key[1][1]);
+        } else {
+          med[0] = med[1] = 0.;
+        }
+      }
+    }
+  }
+  if (tid == 0 && fail) st->fail = 1u;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#ifdef ICP_WIN_DEBUG
+  fst[5] = wall_clock64();
+#endif
+  publish_folded(s_tot, res, seq, sig, med, nan_flag, fail ? 2 : 0);
+#ifdef ICP_WIN_DEBUG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  fst[6] = wall_clock64();
+  if (tid == 0 && seq % 16 == 5)
+    printf("[F last blk %d of %d] compact %lld ticket %lld loads %lld sel1 %lld sel2 %lld publish %lld (x10ns) cnt %u %u %u %u\n", blockIdx.x,
+           gridDim.x, fst[1] - fst[0], fst[2] - fst[1], fst[3] - fst[2], fst[4] - fst[3], fst[5] - fst[4], fst[6] - fst[5],
+           sel.med_cnt[0], sel.med_cnt[1], sel.ring_cnt[0], sel.ring_cnt[1]);
+#endif
 }
 
 // The order statistics of one evaluation from its candidate lists, one workgroup per dimension
@@ -1004,6 +1220,19 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
   // the converging pair, the 28k frame unchanged: every workgroup of the inline-selecting accumulate kernel repeats
   // 7.5 us of candidate loads and selections that the two-workgroup launch does once)
   const bool coresident = !no_co;
+  static const bool no_fuse = getenv("ICP_WIN_NO_FUSE") != nullptr;
+  static const int fuse_mode = getenv("ICP_WIN_FUSE_MODE") ? atoi(getenv("ICP_WIN_FUSE_MODE")) : 2;  // 1: everywhere, 2: search stream only, 3: evaluation stream only
+  const bool on_eval_stream = w.spec_stream && s == w.spec_stream;
+  if (!no_fuse && (fuse_mode == 1 || (fuse_mode == 2 && !on_eval_stream) || (fuse_mode == 3 && on_eval_stream))) {  // two launches: residuals + histograms + sums, then candidates + selection + fold
+    int blocks, threads;
+    reduce_geometry(n_, &blocks, &threads);
+    hipLaunchKernelGGL(k_win_hist_sums, dim3(blocks), dim3(threads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
+                       w.d_wstate, w.d_scal, w.d_partials);
+    hipLaunchKernelGGL(k_win_finish, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
+                       (const double *)w.d_ry, n, P, w.d_whist, w.d_wstate, w.d_wmed, w.d_wring, w.d_scal,
+                       (const double *)w.d_partials, blocks, w.d_ctl, w.h_res, ++w.seq);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(kWinThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
                      w.d_wstate, w.d_scal);
   hipLaunchKernelGGL(k_win_compact<false>, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
