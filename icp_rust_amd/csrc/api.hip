@@ -962,9 +962,11 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     uint32_t inner = 0;
     // two streams: the search is enqueued first; the evaluation's workgroups arrive on the
     // high-priority stream and are placed as soon as a CU has room
+    w.search_beside_eval = speculate;
     const int rc = estimate_transform_loop(h, A[cur], B[cur], n, &dT, &inner, hook,
                                            two_streams ? w.spec_stream : nullptr, two_streams && nn_first,
                                            first_pre_launched, it == 0 ? 3 : 0, it == 0 ? 4 : 1);
+    w.search_beside_eval = false;
     if (rc != ICP_OK) return rc;
     if (inner_iters) inner_iters[it] = inner;
     prev_inner = inner;

@@ -150,6 +150,7 @@ struct Workspace : GnCtx {
   unsigned long long spec_hits = 0, spec_misses = 0, pre_evals = 0;
   uint32_t last_inner = 0xffffffffu;  // updates the inner loop applied in the last outer iteration of the previous call
   hipStream_t spec_stream = nullptr;  // later evaluations of an inner loop run beside the speculative search
+  bool search_beside_eval = false;    // this outer iteration bets on a speculative search: its deciding evaluation shares the CUs with it
   uint32_t *d_idx = nullptr;
   uint32_t *d_idx_slot = nullptr;  // the last search's indices in slot order (icp_estimate_device, QuerySort::slot_order)
   // refined windows (n > 4M, gn_win.hip): a strided sample of the pairs and a host copy of the histograms

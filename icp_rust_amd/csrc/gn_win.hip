@@ -1221,9 +1221,15 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
   // 7.5 us of candidate loads and selections that the two-workgroup launch does once)
   const bool coresident = !no_co;
   static const bool no_fuse = getenv("ICP_WIN_NO_FUSE") != nullptr;
-  static const int fuse_mode = getenv("ICP_WIN_FUSE_MODE") ? atoi(getenv("ICP_WIN_FUSE_MODE")) : 2;  // 1: everywhere, 2: search stream only, 3: evaluation stream only
+  // Two launches (residuals + histograms + sums, then candidates + selection + fold) unless the evaluation shares
+  // the CUs with a speculative search: beside three search waves per SIMD the four small launches below fit better
+  // (1M pair: 0.154 ms per step against 0.157 fused everywhere and 0.158 never; profiles/r03_eval_fusion_ab.txt).
+  // ICP_WIN_FUSE_MODE: 1 = everywhere, 2 = as described (default), 3 = only beside a search, 4 = search stream only.
+  static const int fuse_mode = getenv("ICP_WIN_FUSE_MODE") ? atoi(getenv("ICP_WIN_FUSE_MODE")) : 2;
   const bool on_eval_stream = w.spec_stream && s == w.spec_stream;
-  if (!no_fuse && (fuse_mode == 1 || (fuse_mode == 2 && !on_eval_stream) || (fuse_mode == 3 && on_eval_stream))) {  // two launches: residuals + histograms + sums, then candidates + selection + fold
+  const bool beside_search = on_eval_stream && w.search_beside_eval;
+  if (!no_fuse && (fuse_mode == 1 || (fuse_mode == 2 && !beside_search) || (fuse_mode == 3 && beside_search) ||
+                   (fuse_mode == 4 && !on_eval_stream))) {
     int blocks, threads;
     reduce_geometry(n_, &blocks, &threads);
     hipLaunchKernelGGL(k_win_hist_sums, dim3(blocks), dim3(threads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,

@@ -49,4 +49,19 @@ if what in ("both", "pair"):
     slope = (t40[len(t40) // 2] - 20 * ts[len(ts) // 2]) / 20
     out.append(f"pair1M min {1e3 * ts[0]:.4f} med {1e3 * ts[len(ts) // 2]:.4f} ms/step; marginal step {1e3 * slope:.4f} ms, "
                f"per-call {1e3 * (20 * ts[len(ts) // 2] - 20 * slope):.3f} ms")
+if what in ("both", "conv"):
+    src, dst, _ = synth.converging_pair(1_000_000, 1_000_000)
+    d_src, d_dst = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+    icp = I.Icp3d(d_dst)
+    icp.estimate(d_src, I.Transform(), 20)
+    ts = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        T, idx, inner = icp.estimate(d_src, I.Transform(), 20, return_info=True)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    ev = int(np.sum(inner)) + 20
+    out.append(f"converging med {1e3 * ts[len(ts) // 2]:.2f} ms/call, {ev} evaluations -> {1e6 * ts[len(ts) // 2] / ev:.1f} us each")
 print(" | ".join(out), flush=True)
