@@ -288,6 +288,13 @@ def nn_tile_counters(icp):
     return int(out[0]), int(out[1])
 
 
+def nn_cert_counters(icp):
+    """(searches that checked certificates so far, queries whose certificate failed in the last of them)"""
+    out = (C.c_uint64 * 2)()
+    check(lib().icp_nn_cert_counters(icp._h, out), "icp_nn_cert_counters")
+    return int(out[0]), int(out[1])
+
+
 class _Icp:
     DIM = 0
 

@@ -342,6 +342,8 @@ void free_handle(icp_handle *h) {  // really release everything
   (void)hipFree(h->qsort.d_cell);
   (void)hipFree(h->qsort.d_tmp);
   (void)hipFree(h->qsort.d_list);
+  (void)hipFree(h->qsort.d_cert_lists);
+  (void)hipFree(h->qsort.d_cert_ctr);
   (void)hipFree(h->qsort.d_perm);
   (void)hipFree(h->qsort.d_sorted);
   (void)hipFree(h->qsort.d_prev);
@@ -1012,6 +1014,22 @@ extern "C" int icp_nn_tile_counters(icp_handle *h, uint64_t out[2]) {
   HIP_TRY(hipMemcpy(flags.data(), h->qsort.d_list, flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   out[0] = h->qsort.last_waves;
   for (uint32_t f : flags) out[1] += f != 0;
+  return ICP_OK;
+}
+
+// Observability: the certified searches of `h` (nn_grid.hip, k_nn_cert) -- out[0] = searches that checked
+// certificates since the handle was created, out[1] = queries whose certificate failed in the last of them (they
+// were searched as before).
+extern "C" int icp_nn_cert_counters(icp_handle *h, uint64_t out[2]) {
+  if (!h || !out) return ICP_BAD_ARGUMENT;
+  out[0] = h->qsort.cert_searches;
+  out[1] = 0;
+  if (!h->qsort.last_cert_ctr) return ICP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  unsigned ctr[16 * 32];
+  HIP_TRY(hipMemcpy(ctr, h->qsort.last_cert_ctr, sizeof(ctr), hipMemcpyDeviceToHost));
+  for (int l = 0; l < 16; ++l) out[1] += ctr[l * 32];
   return ICP_OK;
 }
 

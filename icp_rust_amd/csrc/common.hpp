@@ -258,6 +258,16 @@ struct QuerySort {
   bool have_prev = false;      // d_prev holds the matches of an earlier search of this snapshot
   PrevMatch *d_prev = nullptr; // per sorted slot: the last match (idx = ~0u: none)
   double *d_sorted = nullptr;
+  // certified matches (nn_grid.hip: k_nn_cert): how far the searches of this snapshot have moved the queries so far
+  // (per unit of |s_xy| and flat; upper bounds, accumulated in launch order), the previous search's pose, the work
+  // lists of the queries whose certificate failed and their counters (two sets, alternating between searches)
+  bool have_certs = false, have_pose = false, have_pose_before = false;
+  double decay_r = 0., decay_t = 0.;
+  Pose last_pose;
+  uint32_t *d_cert_lists = nullptr;
+  unsigned *d_cert_ctr = nullptr, *last_cert_ctr = nullptr;
+  unsigned cert_seq = 0;
+  unsigned long long cert_searches = 0;
 };
 
 // stable LSD radix sort of (cell, index) pairs by cell (qsort.hip); values in = 0 .. n-1

@@ -857,17 +857,30 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid(const double *__restri
 #ifndef ICP_WARM_QUADS
 #define ICP_WARM_QUADS 2  // aligned quads (of four records) in flight per lane
 #endif
-template <int DIM>
+// CERT: the walk also leaves a CERTIFICATE in the slot's record (PrevMatch::pad, see k_nn_cert below): a lower
+// bound on the distance from this query to every target other than its match, from what the walk saw anyway --
+// the second smallest screened distance among the records it visited, and the distance to everything it skipped
+// (rows beyond the radius, cells clipped off a row, the cells outside its box), each bound rounded down by the
+// margins that already make the pruning conservative.
+struct CertDecay {  // how far a query can have moved since the snapshot was taken, per unit of |s_xy| and flat:
+  float r_lo, t_lo;  // lower bounds (a certificate is stored relative to the snapshot: + decay at creation)
+  float r_hi, t_hi;  // upper bounds (... and checked against the decay at the time of the check)
+};
+
+template <int DIM, bool CERT = false>
 __device__ __forceinline__ void warm_query(const unsigned k, const double *__restrict__ src,
                                            const uint32_t *__restrict__ perm, Pose T, const GridParams &g,
                                            const uint32_t *__restrict__ start, const GridPoint *__restrict__ pts,
                                            const double *__restrict__ dst, uint32_t *__restrict__ idx,
-                                           double2 *__restrict__ a, double2 *__restrict__ b, PrevMatch *prev) {
+                                           double2 *__restrict__ a, double2 *__restrict__ b, PrevMatch *prev,
+                                           CertDecay cd = CertDecay{0.f, 0.f, 0.f, 0.f}) {
   const unsigned i = perm ? perm[k] : k;  // null: outputs in slot order
   double q[3];
   q[0] = src[(size_t)k * DIM + 0];
   q[1] = src[(size_t)k * DIM + 1];
   q[2] = DIM == 3 ? src[(size_t)k * DIM + 2] : 0.;
+  float s_norm_lo = 0.f;  // CERT: a lower bound of |s_xy|
+  if (CERT) s_norm_lo = __builtin_amdgcn_sqrtf(fmaxf((float)(q[0] * q[0] + q[1] * q[1]) * 0.9999997f, 0.f)) * 0.9999997f;
   {  // Transform::transform, src/transform.rs:22-24
     const double nx = (T.r00 * q[0] + T.r01 * q[1]) + T.tx;
     const double ny = (T.r10 * q[0] + T.r11 * q[1]) + T.ty;
@@ -958,11 +971,28 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
     const float v = fmaxf(fmaxf(below, above) - mgf, 0.f);
     return v * v * 0.9999997f;
   };
+  // CERT: m2 = the smallest screened squared distance among the visited records other than the match (a match that
+  // is replaced joins with its exact distance); skip2 = the smallest squared distance bound of anything not visited
+  float m2 = __builtin_huge_valf(), skip2 = __builtin_huge_valf();
+  if (CERT && !wide) {
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {  // targets in cells outside the box [lo_c, hi_c] (slab2's argument, for whole half-spaces)
+      if (lo_c[d] > 0) {
+        const float gq = fmaxf(qf[d] - (float)lo_c[d] * hf[d] - mgf, 0.f);
+        skip2 = fminf(skip2, gq * gq * 0.9999997f);
+      }
+      if (hi_c[d] < g.n[d] - 1) {
+        const float gq = fmaxf((float)(hi_c[d] + 1) * hf[d] - qf[d] - mgf, 0.f);
+        skip2 = fminf(skip2, gq * gq * 0.9999997f);
+      }
+    }
+  }
   auto consider = [&](uint32_t ti) {
     const double tx = dst[(size_t)ti * DIM + 0], ty = dst[(size_t)ti * DIM + 1];
     const double tz = DIM == 3 ? dst[(size_t)ti * DIM + 2] : 0.;
     const double dd = dist2(tx, ty, tz);
     if (dd < best || (dd == best && ti < bi)) {
+      if (CERT && bi != 0xffffffffu) m2 = fminf(m2, (float)best * 0.9999997f);  // the match it replaces is "another target" now
       best = dd;
       bi = ti;
       bx = tx;
@@ -989,14 +1019,24 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
       int xl = lo_c[0], xh = hi_c[0];
       if (!wide) {
         const float dyz = slab2(1, cy) + dz2;
-        if (dyz > bf) continue;  // every target of the row is strictly farther than the best so far
+        if (dyz > bf) {  // every target of the row is strictly farther than the best so far
+          if (CERT) skip2 = fminf(skip2, dyz);
+          continue;
+        }
         // a target of this row that can still win or tie has |x - qx| <= sqrt(best - dy^2 - dz^2)
         // (v_sqrt_f32 returns 0 for a denormal argument: sqrt of it is < 1.1e-19 <= mgf, build_grid's f32_ok)
 #ifndef ICP_WARM_NOCLIP
         const float hw = __builtin_amdgcn_sqrtf(bf - dyz) * 1.000001f + mgf;
         xl = max(xl, cell_lo(qf[0] - hw, em[0], 0));
         xh = min(xh, cell_hi(qf[0] + hw, em[0], 0));
-        if (xl > xh) continue;
+        if (xl > xh) {
+          if (CERT) skip2 = 0.f;  // (cannot happen: the query's own cell is in both ranges; no certificate if it does)
+          continue;
+        }
+        if (CERT) {  // the cells of the row on either side of [xl, xh]
+          if (xl > lo_c[0]) skip2 = fminf(skip2, slab2(0, xl - 1) + dyz);
+          if (xh < hi_c[0]) skip2 = fminf(skip2, slab2(0, xh + 1) + dyz);
+        }
 #endif
       }
       const uint32_t rb = ((uint32_t)iz * g.n[1] + cy) * g.n[0];
@@ -1078,7 +1118,21 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
       for (uint32_t u = 0; u < kR; ++u)
         if (!(sc[u] > thr32) && t[u].idx != bi) consider(t[u].idx);
 #endif
+      if (CERT) {
+#pragma unroll
+        for (uint32_t u = 0; u < kR; ++u) m2 = fminf(m2, t[u].idx != bi ? sc[u] : __builtin_huge_valf());
+      }
     }
+  }
+  uint32_t cert_bits = 0;
+  if (CERT && !wide && bi != 0xffffffffu) {
+    // distances from squared bounds: a screened square is within 4e-7 relative of |qf - pf|^2, and |q - p| is
+    // within ecf of |qf - pf| (the screen's own error budget above); the skip bounds are lower bounds already
+    const float seen = __builtin_amdgcn_sqrtf(m2) * 0.9999994f - ecf;
+    const float skipped = __builtin_amdgcn_sqrtf(skip2) * 0.9999997f;
+    const float cert = fminf(seen, skipped);
+    const float abs_lo = (cert + (cd.r_lo * s_norm_lo + cd.t_lo) * 0.9999997f) * 0.9999997f;
+    if (cert > 0.f && abs_lo > 0.f && abs_lo < __builtin_huge_valf()) cert_bits = __float_as_uint(abs_lo);
   }
   if (bi == 0xffffffffu) {  // no finite distance at all: index 0, as a scan from 0 would (k_nn_grid does the same)
     bi = 0;
@@ -1087,13 +1141,13 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
     bz = DIM == 3 ? dst[2] : 0.;
   }
   // a slot whose match did not change already holds this record
-  if (bi != pm.idx) {
+  if (CERT || bi != pm.idx) {
     PrevMatch out;
     out.x = bx;
     out.y = by;
     out.z = bz;
     out.idx = bi;
-    out.pad = 0;
+    out.pad = cert_bits;
     prev[k] = out;
   }
   if (idx) idx[i] = bi;
@@ -1101,17 +1155,123 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
   if (b) b[i] = make_double2(bx, by);
 }
 
-template <int DIM>
+template <int DIM, bool CERT>
 __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(const double *__restrict__ src,
                                                                const uint32_t *__restrict__ perm, unsigned n, Pose T,
                                                                GridParams g, const uint32_t *__restrict__ start,
                                                                const GridPoint *__restrict__ pts,
                                                                const double *__restrict__ dst, uint32_t *__restrict__ idx,
                                                                double2 *__restrict__ a, double2 *__restrict__ b,
-                                                               PrevMatch *prev) {
+                                                               PrevMatch *prev, CertDecay cd) {
   const unsigned k = blockIdx.x * kGridThreads + threadIdx.x;
   if (k >= n) return;
-  warm_query<DIM>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev);
+  warm_query<DIM, CERT>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev, cd);
+}
+
+// ------------------------------------------------------ certified matches ----
+// From one outer iteration to the next the pose moves a query by a fraction of the point spacing, and nine matches
+// in ten stay what they were (profiles/r03_nn_stability.txt).  A walk that re-derives them costs as much as one that
+// finds a new match; a CERTIFICATE does not: if every target other than the previous match p was farther than c
+// from the query when the certificate was made, and the query has moved by at most e since, then every other
+// target is still farther than c - e -- so |q' - p| < c - e proves p is the unique nearest neighbour of q', in
+// exact arithmetic and therefore (the margins below are ~1e-6 relative, the contract's f64 distances round at
+// 1e-16) in the contract's (d^2, index) order too.  No neighbour is visited: the slot's record holds p's
+// coordinates.  c comes out of the last walk for free (warm_query<CERT>); e is bounded per query by
+//     |T' s - T s| <= ||R' - R||_F |s_xy| + |t' - t|,
+// summed by the host over the searches of the snapshot in launch order (QuerySort::decay_r / decay_t: searches of
+// one snapshot run on one stream), so the record stores c + decay(at creation) and a check subtracts decay(now):
+// nothing is written for a query that passes.  Queries that fail go to work lists (one reservation per workgroup,
+// sixteen lists: a single counter serialises at ~90 reservations per microsecond), which k_nn_walk_lists walks
+// with dense waves.  Results cannot depend on any of it: a certificate only ever skips a walk whose result it proves.
+constexpr int kCertLists = 16;
+constexpr int kCertCtrStride = 32;  // words between the lists' counters (a 128-byte line each)
+constexpr int kCertThreads = 256;   // queries per reservation
+
+template <int DIM>
+__global__ __launch_bounds__(kCertThreads) void k_nn_cert(const double *__restrict__ src,
+                                                          const uint32_t *__restrict__ perm, unsigned n, Pose T,
+                                                          const double *__restrict__ dst, uint32_t *__restrict__ idx,
+                                                          double2 *__restrict__ a, double2 *__restrict__ b,
+                                                          const PrevMatch *__restrict__ prev, CertDecay cd,
+                                                          uint32_t *__restrict__ lists, unsigned list_cap,
+                                                          unsigned *ctr, unsigned *ctr_next) {
+  __shared__ unsigned s_cnt[kCertThreads / 64], s_base;
+  const unsigned k = blockIdx.x * kCertThreads + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x < kCertLists) ctr_next[threadIdx.x * kCertCtrStride] = 0;  // (the next search's counters)
+  bool fail = false;
+  if (k < n) {
+    const unsigned i = perm ? perm[k] : k;
+    double q[3];
+    q[0] = src[(size_t)k * DIM + 0];
+    q[1] = src[(size_t)k * DIM + 1];
+    q[2] = DIM == 3 ? src[(size_t)k * DIM + 2] : 0.;
+    const PrevMatch pm = prev[k];
+    // an upper bound of |s_xy|
+    const float s_norm = __builtin_amdgcn_sqrtf((float)(q[0] * q[0] + q[1] * q[1]) * 1.0000003f) * 1.0000003f;
+    {  // Transform::transform, src/transform.rs:22-24
+      const double nx = (T.r00 * q[0] + T.r01 * q[1]) + T.tx;
+      const double ny = (T.r10 * q[0] + T.r11 * q[1]) + T.ty;
+      q[0] = nx;
+      q[1] = ny;
+    }
+    if (pm.idx == 0xffffffffu) {  // no finite distance was ever found (NaN query): index 0, as a scan from 0 would
+      if (idx) idx[i] = 0;
+      if (a) a[i] = make_double2(q[0], q[1]);
+      if (b) b[i] = make_double2(dst[0], dst[1]);
+    } else {
+      const double ddx = q[0] - pm.x, ddy = q[1] - pm.y;
+      double best = ddx * ddx + ddy * ddy;
+      if (DIM == 3) {
+        const double ddz = q[2] - pm.z;
+        best = best + ddz * ddz;
+      }
+      const float bf = fmaxf((float)best * 1.0000003f, 1e-37f);   // >= best
+      const float rs = __builtin_amdgcn_sqrtf(bf) * 1.0000003f;   // >= sqrt(best)
+      const float moved = (cd.r_hi * s_norm + cd.t_hi) * 1.000001f;  // >= the decay now
+      const float c_abs = __uint_as_float(pm.pad);
+      // (NaN or infinite anything: the comparison is false and the query is searched)
+      const bool pass = pm.pad != 0u && (rs + moved) * 1.000001f < c_abs;
+      if (pass) {
+        if (idx) idx[i] = pm.idx;
+        if (a) a[i] = make_double2(q[0], q[1]);
+        if (b) b[i] = make_double2(pm.x, pm.y);
+      } else {
+        fail = true;
+      }
+    }
+  }
+  const unsigned long long mask = __ballot(fail);
+  if (lane == 0) s_cnt[wave] = (unsigned)__popcll(mask);
+  __syncthreads();
+  const int list = blockIdx.x % kCertLists;
+  if (threadIdx.x == 0) {
+    unsigned tot = 0;
+#pragma unroll
+    for (int w = 0; w < kCertThreads / 64; ++w) tot += s_cnt[w];
+    s_base = tot ? atomicAdd(&ctr[list * kCertCtrStride], tot) : 0u;
+  }
+  __syncthreads();
+  if (fail) {
+    unsigned pos = s_base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+#pragma unroll
+    for (int w = 0; w < kCertThreads / 64; ++w) pos += w < wave ? s_cnt[w] : 0u;
+    if (pos < list_cap) lists[(size_t)list * list_cap + pos] = k;  // (list_cap covers every query of the list's workgroups)
+  }
+}
+
+// the walk proper (with a fresh certificate) for the listed queries: blockIdx.y = list
+template <int DIM>
+__global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_walk_lists(
+    const double *__restrict__ src, const uint32_t *__restrict__ perm, Pose T, GridParams g,
+    const uint32_t *__restrict__ start, const GridPoint *__restrict__ pts, const double *__restrict__ dst,
+    uint32_t *__restrict__ idx, double2 *__restrict__ a, double2 *__restrict__ b, PrevMatch *prev, CertDecay cd,
+    const uint32_t *__restrict__ lists, unsigned list_cap, const unsigned *__restrict__ ctr) {
+  const unsigned cnt = min(ctr[blockIdx.y * kCertCtrStride], list_cap);
+  const unsigned j = blockIdx.x * kGridThreads + threadIdx.x;
+  if (j >= cnt) return;
+  const unsigned k = lists[(size_t)blockIdx.y * list_cap + j];
+  warm_query<DIM, true>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev, cd);
 }
 
 // The same search for the waves the tile kernel (nn_tile.hip) handed back (a flag per wave): one workgroup
@@ -1304,8 +1464,12 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     (void)hipFree(Q.d_sorted);
     (void)hipFree(Q.d_prev);
     (void)hipFree(Q.d_list);
+    (void)hipFree(Q.d_cert_lists);
+    (void)hipFree(Q.d_cert_ctr);
     Q.d_prev = nullptr;
     Q.d_list = nullptr;
+    Q.d_cert_lists = nullptr;
+    Q.d_cert_ctr = nullptr;
     Q.d_cell_of = Q.d_cell = Q.d_perm = nullptr;
     Q.d_sorted = nullptr;
     Q.cap = 0;
@@ -1318,6 +1482,11 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     if ((e = hipMalloc(&Q.d_sorted, n_ * 3 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_prev, n_ * sizeof(PrevMatch))) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_list, (n_ / 64 + 1) * sizeof(uint32_t))) != hipSuccess) return e;
+    // work lists of the certified search: every list can take all the queries of its workgroups
+    if ((e = hipMalloc(&Q.d_cert_lists, (n_ + (size_t)(kCertLists + 1) * kCertThreads) * sizeof(uint32_t))) != hipSuccess) return e;
+    if ((e = hipMalloc(&Q.d_cert_ctr, (size_t)2 * kCertLists * kCertCtrStride * sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(Q.d_cert_ctr, 0, (size_t)2 * kCertLists * kCertCtrStride * sizeof(unsigned), s)) != hipSuccess) return e;
+    Q.cert_seq = 0;
     Q.cap = n_;
   }
   // ICP_QSORT_BLOCK: log2 of the row bundle's side (0: row after row); the key must fit 32 bits
@@ -1343,6 +1512,9 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
                        (const uint32_t *)Q.d_perm, Q.d_sorted);
   }
   Q.have_prev = false;  // the first search of this snapshot reads no previous matches, it only records them
+  Q.have_certs = false;
+  Q.have_pose = Q.have_pose_before = false;
+  Q.decay_r = Q.decay_t = 0.;
   if ((e = hipGetLastError()) != hipSuccess) return e;
   Q.src = d_src;
   Q.n = n_;
@@ -1407,12 +1579,87 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
     return we;
   }
   if ((q_prev || seeded) && !coop && xform && G.p.f32_ok && !old_warm) {
-    if (h->dim == 3)
-      hipLaunchKernelGGL(k_nn_grid_warm<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
-                         G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev);
-    else
-      hipLaunchKernelGGL(k_nn_grid_warm<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
-                         G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev);
+    // certificates (k_nn_cert above): ICP_NN_NO_CERT=1 searches every query every time, as rounds 1-2 did
+    static const bool no_cert = getenv("ICP_NN_NO_CERT") != nullptr;
+    // a step so long that too few certificates survive it: skip the check (in smallest cell sides; at 0.006 a third
+    // of the certificates fail, at 0.2 six in seven, and the break-even is about one half)
+    static const double cert_max_step = getenv("ICP_NN_CERT_MAX_STEP") ? atof(getenv("ICP_NN_CERT_MAX_STEP")) : 0.01;
+    QuerySort &QW = h->qsort;
+    double step = 0.;
+    QW.have_pose_before = QW.have_pose;
+    if (QW.have_pose) {  // how far this search's pose is from the previous search's, per unit of |s_xy| and flat
+      const double dr = sqrt((T.r00 - QW.last_pose.r00) * (T.r00 - QW.last_pose.r00) +
+                             (T.r01 - QW.last_pose.r01) * (T.r01 - QW.last_pose.r01) +
+                             (T.r10 - QW.last_pose.r10) * (T.r10 - QW.last_pose.r10) +
+                             (T.r11 - QW.last_pose.r11) * (T.r11 - QW.last_pose.r11));
+      const double dt = sqrt((T.tx - QW.last_pose.tx) * (T.tx - QW.last_pose.tx) +
+                             (T.ty - QW.last_pose.ty) * (T.ty - QW.last_pose.ty));
+      QW.decay_r += dr * (1. + 1e-12);
+      QW.decay_t += dt * (1. + 1e-12);
+      // (|s_xy| of a source cloud that registers against these targets: about the reach of their bounding box)
+      double reach = 0.;
+      for (int d = 0; d < 2; ++d) {
+        const double lo = fabs(G.p.lo[d]), hi = fabs(G.p.lo[d] + G.p.h[d] * G.p.n[d]);
+        reach += (lo > hi ? lo : hi) * (lo > hi ? lo : hi);
+      }
+      step = dr * sqrt(reach) + dt;
+    }
+    QW.last_pose = T;
+    QW.have_pose = true;
+    CertDecay cd;
+    cd.r_lo = (float)(QW.decay_r * (1. - 1e-7));
+    cd.t_lo = (float)(QW.decay_t * (1. - 1e-7));
+    cd.r_hi = (float)(QW.decay_r * (1. + 1e-7));
+    cd.t_hi = (float)(QW.decay_t * (1. + 1e-7));
+    const bool decay_ok = std::isfinite(QW.decay_r) && std::isfinite(QW.decay_t);
+    double hmin = G.p.h[0];
+    for (int d = 1; d < h->dim; ++d) hmin = G.p.h[d] < hmin ? G.p.h[d] : hmin;
+    // Certificates pay once a registration has settled (converging pair: 0.05-3 % of them fail from the tenth outer
+    // iteration on, 33 % at the fourth); while the pose still moves by a tenth of a cell per iteration they do not
+    // (benchmark pair: 85 % fail, and a walk that leaves certificates costs 30 % more than one that does not): such
+    // searches run as rounds 1-2 had them.  Certificates already in the records stay valid either way.
+    const bool certs = !no_cert && decay_ok && QW.d_cert_lists != nullptr && QW.have_pose_before && step <= cert_max_step * hmin;
+    const bool check = certs && q_prev && QW.have_certs;
+    if (check) {
+      const unsigned cblocks = (n + kCertThreads - 1) / kCertThreads;
+      const unsigned list_cap = ((cblocks + kCertLists - 1) / kCertLists) * kCertThreads;
+      unsigned *ctr = QW.d_cert_ctr + (size_t)(QW.cert_seq & 1u) * kCertLists * kCertCtrStride;
+      unsigned *ctr_next = QW.d_cert_ctr + (size_t)((QW.cert_seq + 1u) & 1u) * kCertLists * kCertCtrStride;
+      ++QW.cert_seq;
+      ++QW.cert_searches;
+      QW.last_cert_ctr = ctr;
+      const dim3 wgrid((list_cap + kGridThreads - 1) / kGridThreads, kCertLists);
+      if (h->dim == 3) {
+        hipLaunchKernelGGL(k_nn_cert<3>, dim3(cblocks), dim3(kCertThreads), 0, h->stream, q_src, q_perm, n, T, h->d_dst,
+                           d_idx, (double2 *)d_a, (double2 *)d_b, (const PrevMatch *)Q.d_prev, cd, QW.d_cert_lists,
+                           list_cap, ctr, ctr_next);
+        hipLaunchKernelGGL(k_nn_walk_lists<3>, wgrid, dim3(kGridThreads), 0, h->stream, q_src, q_perm, T, G.p, G.d_start,
+                           G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd,
+                           (const uint32_t *)QW.d_cert_lists, list_cap, (const unsigned *)ctr);
+      } else {
+        hipLaunchKernelGGL(k_nn_cert<2>, dim3(cblocks), dim3(kCertThreads), 0, h->stream, q_src, q_perm, n, T, h->d_dst,
+                           d_idx, (double2 *)d_a, (double2 *)d_b, (const PrevMatch *)Q.d_prev, cd, QW.d_cert_lists,
+                           list_cap, ctr, ctr_next);
+        hipLaunchKernelGGL(k_nn_walk_lists<2>, wgrid, dim3(kGridThreads), 0, h->stream, q_src, q_perm, T, G.p, G.d_start,
+                           G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd,
+                           (const uint32_t *)QW.d_cert_lists, list_cap, (const unsigned *)ctr);
+      }
+    } else if (certs) {
+      QW.have_certs = true;
+      if (h->dim == 3)
+        hipLaunchKernelGGL((k_nn_grid_warm<3, true>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd);
+      else
+        hipLaunchKernelGGL((k_nn_grid_warm<2, true>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd);
+    } else {
+      if (h->dim == 3)
+        hipLaunchKernelGGL((k_nn_grid_warm<3, false>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd);
+      else
+        hipLaunchKernelGGL((k_nn_grid_warm<2, false>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd);
+    }
     hipError_t we = hipGetLastError();
     if (ev0 && ev1) {
       (void)hipEventRecord(ev1, h->stream);

@@ -314,6 +314,12 @@ int icp_sort_source_device(icp_handle *h, const double *d_src, size_t n, const i
 /* Observability: the last LDS-tile search of `h` (the warm grid search beyond 65 536 source points): out[0] = waves
  * launched, out[1] = waves handed to the per-lane gather walk because their unions exceeded the LDS budget. */
 int icp_nn_tile_counters(icp_handle *h, uint64_t out[2]);
+/* Observability: certified matches (the searches of an estimate call after the first, beyond 65 536 source points:
+ * a query whose previous match is provably still its nearest neighbour -- it has moved less than the margin the
+ * last walk left it -- is not searched again).  out[0] = searches that checked certificates
+ * since the handle was created, out[1] = queries whose certificate failed in the last of them (searched as ever).
+ * ICP_NN_NO_CERT=1 in the environment searches every query every time. */
+int icp_nn_cert_counters(icp_handle *h, uint64_t out[2]);
 
 /* Observability for tests: which pipeline served the weighted Gauss-Newton evaluations of
  * this handle (NULL: the scratch handle behind the free functions) since it was created.

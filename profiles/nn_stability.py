@@ -21,6 +21,8 @@ for name, (src, dst) in (("bench pair", synth.synthetic_pair(1_000_000, 1_000_00
         A = T.as_array() if hasattr(T, "as_array") else np.asarray(T)
         if prev_T is not None:
             changed = float((idx != prev_idx).mean())
-            print(f"  iters {prev_k}->{k}: pose change {np.abs(A - prev_T).max():.3e}, indices changed {100 * changed:.3f} %, inner {inner[-1]}")
+            cs = I.nn_cert_counters(icp)
+            print(f"  iters {prev_k}->{k}: pose change {np.abs(A - prev_T).max():.3e}, indices changed {100 * changed:.3f} %, inner {inner[-1]}; "
+                  f"certificates failed in the last search: {100 * cs[1] / len(src):.2f} % ({cs[0]} certified searches so far)")
         prev_T, prev_idx, prev_k = A, idx, k
     icp.close()

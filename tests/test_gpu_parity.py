@@ -416,6 +416,64 @@ def test_seeded_first_search_and_the_warm_search_after_it_on_hostile_clouds(name
         assert np.array_equal(b.cpu().numpy(), np.tile(dst[want][:, :2], (reps, 1)))
 
 
+@pytest.mark.parametrize("dim,kind", [(3, "uniform"), (3, "lattice"), (2, "uniform"), (3, "mm")])
+def test_certified_matches_equal_the_kdtree_along_a_chain_of_small_steps(dim, kind):
+    """once a registration has settled, a search proves most previous matches still nearest instead of walking the
+    grid again (nn_grid.hip: k_nn_cert): along a chain of poses -- tiny steps, a repeated pose, one long jump, tiny
+    steps again -- every index of every search must equal the kd-tree oracle's, whatever the certificates skipped."""
+    import torch
+
+    rng = np.random.default_rng(77 + dim + len(kind))
+    m, n = 150_000, 200_000
+    scale = 1000.0 if kind == "mm" else 1.0
+    if kind == "lattice":  # ties everywhere: a certificate may only pass where the match is the unique nearest
+        side = int(round(m ** (1.0 / dim)))
+        axes = [np.arange(side, dtype=np.float64)] * dim
+        dst = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, dim) * 0.5
+        src = dst[rng.integers(0, len(dst), size=n)] + np.round(rng.normal(size=(n, dim)) * 2) * 0.125
+    else:
+        box = np.array([40.0, 40.0, 4.0][:dim]) * scale
+        dst = rng.uniform(-1, 1, size=(m, dim)) * box
+        src = dst[rng.integers(0, m, size=n)] + rng.normal(size=(n, dim)) * 0.05 * scale
+    spacing = float(np.prod(2 * (dst.max(0) - dst.min(0)) / 2 + 1e-9) / len(dst)) ** (1.0 / dim)
+    icp = (I.Icp3d if dim == 3 else I.Icp2d)(dst, nn_mode=I.NN_GRID)
+    d_q = torch.from_numpy(np.ascontiguousarray(src)).cuda()
+    idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    a = torch.empty((n, 2), dtype=torch.float64, device="cuda")
+    b = torch.empty_like(a)
+    tree = O.KdTree(dst)
+    reach = float(np.abs(src[:, :2]).max())
+    params = [np.zeros(3)]
+    steps = [1e-4, 1e-3, 0.0, 2e-3, 1e-2, 1e-4, 30.0, 1e-3, 1e-4, 0.0, 5e-4]  # in NN spacings
+    for st in steps:
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        step = st * spacing * d
+        step[2] = step[2] / max(reach, 1.0)  # the rotation moves the farthest query by about as much
+        params.append(params[-1] + step)
+    icp.prepare_source_device(d_q, I.Transform(params[0]))
+    failed = []
+    for prm in params:
+        T = I.Transform(prm)
+        icp.correspond_device(d_q, T, a, b, idx)
+        icp.synchronize()
+        failed.append(I.nn_cert_counters(icp))
+        p = T.pose
+        moved = src.copy()
+        moved[:, 0] = (p.r00 * src[:, 0] + p.r01 * src[:, 1]) + p.tx  # Transform::transform, src/transform.rs:22-24
+        moved[:, 1] = (p.r10 * src[:, 0] + p.r11 * src[:, 1]) + p.ty
+        rc, want = tree.search(moved)
+        assert rc == O.OK
+        got = idx.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), (prm, int((got != want).sum()))
+        assert np.array_equal(a.cpu().numpy(), moved[:, :2])
+        assert np.array_equal(b.cpu().numpy(), dst[want][:, :2])
+    searches = failed[-1][0]
+    assert searches >= 5, failed  # the small steps were checked (the long jump and the search after it were not)
+    if kind != "lattice":
+        assert min(f[1] for f in failed[2:] if f[0] > 0) < 0.2 * n, failed  # ... and mostly passed
+
+
 def test_seeded_search_never_settles_on_a_target_with_a_nan_coordinate():
     """regression (profiles/extended_fuzz.py, seeds 10154 / 10654): the seed pass took the first record it saw,
     even one at a NaN distance, and a match at a NaN distance is never displaced (every comparison with it is
