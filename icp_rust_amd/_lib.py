@@ -104,12 +104,12 @@ SIGNATURES = {
     "icp_shard_histogram_words": (_sz, []),
     "icp_shard_candidates_bytes": (_sz, []),
     "icp_shard_partials_bytes": (_sz, [C.c_int]),
+    "icp_shard_exchange_bytes": (_sz, [C.c_int]),
     "icp_shard_take_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _sz]),
     "icp_shard_put_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _sz]),
     "icp_shard_eval_hist_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _pp, C.c_int, C.c_int,
                                              C.POINTER(_vp)]),
     "icp_shard_eval_compact_device": (C.c_int, [_vp, _vp]),
-    "icp_shard_eval_accumulate_device": (C.c_int, [_vp, _vp, _vp]),
     "icp_shard_eval_finish_device": (C.c_int, [_vp, _vp, _dp, _dp]),
     "icp_create_multi": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _sz, C.POINTER(C.c_int), C.c_int]),
     "icp_multi_estimate": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),

@@ -1474,8 +1474,8 @@ extern "C" int icp_estimate_point_to_plane(icp_handle *h, const double *src, siz
 }
 
 // ------------------------------------------------ sharded evaluation (stage calls) -----
-// shard.hip has the design.  One evaluation = hist -> [sum the histograms over ranks] -> compact ->
-// [gather the candidates] -> accumulate -> [gather the block sums] -> finish.  ICP_RETRY_REPLICATED
+// shard.hip has the design.  One evaluation = hist (residuals, histograms, block sums) -> [sum the histograms over
+// ranks] -> compact -> [gather every rank's candidates + block sums] -> finish.  ICP_RETRY_REPLICATED
 // from hist (no prediction yet) or finish (the window missed) means: gather the pairs of all ranks in
 // global order and call icp_weighted_gn_step_device on them -- same bits, and it seeds the prediction.
 extern "C" int icp_shard_geometry(size_t n_total, int rank, int world, int *b0, int *b1, int *blocks, size_t *n_local) {
@@ -1486,6 +1486,7 @@ extern "C" int icp_shard_geometry(size_t n_total, int rank, int world, int *b0, 
 extern "C" size_t icp_shard_histogram_words(void) { return (size_t)2 * kWinBins + kShardStatusWords; }
 extern "C" size_t icp_shard_candidates_bytes(void) { return shard_cand_bytes(); }
 extern "C" size_t icp_shard_partials_bytes(int world) { return world >= 1 ? shard_part_bytes(world) : 0; }
+extern "C" size_t icp_shard_exchange_bytes(int world) { return world >= 1 ? shard_exchange_bytes(world) : 0; }
 
 static int shard_copy(icp_handle *h, const void *src, void *dst, size_t n_total, int rank, int world, size_t elem_bytes,
                       bool take) {
@@ -1592,28 +1593,20 @@ static int shard_eval_hist_impl(icp_handle *h, const double *d_a, const double *
   S.d_a = d_a;
   S.T = *T;
   ++w.win_tried;
-  HIP_TRY(shard_launch_hist(h, d_a, d_b, S.n_local, S.T, S.P));
+  HIP_TRY(shard_launch_hist(h, d_a, d_b, S.n_local, S.T, S.P, S.b1 - S.b0));
   *d_hist = w.d_whist;
   S.active = true;
   return ICP_OK;
 }
 
-extern "C" int icp_shard_eval_compact_device(icp_handle *h, void *d_candidates_out) {
-  if (!h || !h->shard.active || !d_candidates_out) return ICP_BAD_ARGUMENT;
+extern "C" int icp_shard_eval_compact_device(icp_handle *h, void *d_exchange_out) {
+  if (!h || !h->shard.active || !d_exchange_out) return ICP_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
   // the global counts also go to the host: if this window misses, they place the next attempt's
   HIP_TRY(hipMemcpyAsync(h->ws.h_whist, h->ws.d_whist, (size_t)2 * kWinBins * sizeof(uint32_t), hipMemcpyDeviceToHost,
                          h->stream));
-  HIP_TRY(shard_launch_compact(h, h->shard.n_local, h->shard.n_total, h->shard.P, d_candidates_out));
-  return ICP_OK;
-}
-
-extern "C" int icp_shard_eval_accumulate_device(icp_handle *h, const void *d_candidates_all, void *d_partials_out) {
-  if (!h || !h->shard.active || !d_candidates_all || !d_partials_out) return ICP_BAD_ARGUMENT;
   const icp_handle::ShardEval &S = h->shard;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(shard_launch_accumulate(h, S.d_a, S.n_local, S.n_total, S.T, d_candidates_all, S.world, S.b1 - S.b0,
-                                  d_partials_out));
+  HIP_TRY(shard_launch_compact(h, S.n_local, S.n_total, S.P, S.world, S.b1 - S.b0, d_exchange_out));
   return ICP_OK;
 }
 
@@ -1658,18 +1651,18 @@ static int shard_finish_common(icp_handle *h, double delta[3], double *huber_err
   return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
 }
 
-extern "C" int icp_shard_eval_finish_device(icp_handle *h, const void *d_partials_all, double delta[3], double *huber_err) {
-  if (!h || !h->shard.active || !d_partials_all || !delta) return ICP_BAD_ARGUMENT;
+extern "C" int icp_shard_eval_finish_device(icp_handle *h, const void *d_exchange_all, double delta[3], double *huber_err) {
+  if (!h || !h->shard.active || !d_exchange_all || !delta) return ICP_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(shard_launch_fold(h, d_partials_all, h->shard.world, h->shard.blocks, h->shard.d_ordered));
+  HIP_TRY(shard_launch_finish(h, d_exchange_all, h->shard.world, h->shard.n_total, h->shard.blocks, h->shard.d_ordered));
   return shard_finish_common(h, delta, huber_err);
 }
 
-// (multi.hip) the same with the block sums of every rank read where they lie: one pointer per rank
-int icp_shard_eval_finish_ptrs(icp_handle *h, const void *const *part_ptrs, double delta[3], double *huber_err) {
-  if (!h || !h->shard.active || !part_ptrs || !delta) return ICP_BAD_ARGUMENT;
+// (multi.hip) the same with the block of every rank read where it lies: one pointer per rank
+int icp_shard_eval_finish_ptrs(icp_handle *h, const void *const *exch_ptrs, double delta[3], double *huber_err) {
+  if (!h || !h->shard.active || !exch_ptrs || !delta) return ICP_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(shard_launch_fold_ptrs(h, part_ptrs, h->shard.world, h->shard.blocks, h->shard.d_ordered));
+  HIP_TRY(shard_launch_finish_ptrs(h, exch_ptrs, h->shard.world, h->shard.n_total, h->shard.blocks, h->shard.d_ordered));
   return shard_finish_common(h, delta, huber_err);
 }
 

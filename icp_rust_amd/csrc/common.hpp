@@ -231,6 +231,16 @@ constexpr int kShardStatusWords = 4;  // behind the 2 x kWinBins histogram words
 constexpr int kShardMaxWorld = 16;  // ranks of one sharded evaluation (a node has 8 GPUs)
 constexpr unsigned kGridPad = 8;  // records past the last target that a quad-aligned read may touch
 
+// sharded evaluation (shard.hip): the head of the block a rank hands to the others, and one pointer per rank
+struct ShardCandHeader {
+  unsigned cnt[4];  // appended {med x, med y, ring x, ring y}
+  unsigned fail;    // this rank's compaction missed (identical on every rank: same histogram)
+  unsigned pad[11];
+};
+struct ShardPtrs {
+  const unsigned char *p[kShardMaxWorld];
+};
+
 struct PrevMatch {  // a query's previous nearest neighbour, stored per sorted slot (coalesced)
   double x, y, z;
   uint32_t idx, pad;
@@ -400,18 +410,17 @@ hipError_t launch_shard_copy(icp_handle *h, const void *src, void *dst, size_t n
 size_t shard_cand_bytes();
 int shard_part_rows(int world);
 size_t shard_part_bytes(int world);
+size_t shard_exchange_bytes(int world);  // what a rank hands to the others: candidates + block sums
 hipError_t shard_launch_hist(icp_handle *h, const double *d_a, const double *d_b, size_t n_local, const Pose &T,
-                             const WinParams &P);
-hipError_t shard_launch_compact(icp_handle *h, size_t n_local, size_t n_total, const WinParams &P, void *d_out);
-hipError_t shard_launch_accumulate(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
-                                   const void *d_cand_all, int world, int blocks_local, void *d_out);
-hipError_t shard_launch_fold(icp_handle *h, const void *d_part_all, int world, int blocks_total, double *d_ordered);
+                             const WinParams &P, int blocks_local);
+hipError_t shard_launch_compact(icp_handle *h, size_t n_local, size_t n_total, const WinParams &P, int world,
+                                int blocks_local, void *d_out);
+hipError_t shard_launch_finish(icp_handle *h, const void *d_exch_all, int world, size_t n_total, int blocks_total,
+                               double *d_ordered);
 hipError_t shard_launch_status(icp_handle *h, int rc);
 // ... the same from one pointer per rank (peer memory read in place), and the flag exchange of icp_create_multi
-hipError_t shard_launch_accumulate_ptrs(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
-                                        const void *const *cand_ptrs, int world, int blocks_local, void *d_out);
-hipError_t shard_launch_fold_ptrs(icp_handle *h, const void *const *part_ptrs, int world, int blocks_total,
-                                  double *d_ordered);
+hipError_t shard_launch_finish_ptrs(icp_handle *h, const void *const *exch_ptrs, int world, size_t n_total,
+                                    int blocks_total, double *d_ordered);
 }  // namespace icp
 int icp_shard_eval_finish_ptrs(icp_handle *h, const void *const *part_ptrs, double delta[3], double *huber_err);
 namespace icp {

@@ -1151,15 +1151,155 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
   publish_result(partials, res, seq, sig, med, scal->nan_flag, fail ? 2 : 0);
 }
 
-// the sharded evaluation (shard.hip) launches this variant from another translation unit
-template __global__ void k_win_accumulate<true, false>(const double2 *__restrict__, const double *__restrict__,
-                                                       const double *__restrict__, unsigned, unsigned, Pose,
-                                                       const WinState *__restrict__, const double *__restrict__,
-                                                       const double *__restrict__, GnScalars *, double *, uint32_t *,
-                                                       SelCtl *, GnResult *, unsigned);
+// the sharded evaluation (shard.hip) launches this one from another translation unit
 template __global__ void k_win_compact<false>(const double *__restrict__, const double *__restrict__, unsigned, unsigned,
                                               WinParams, const uint32_t *__restrict__, WinState *, double *, double *,
                                               const unsigned *__restrict__, unsigned);
+
+// ---- the last stage of a sharded evaluation (shard.hip has the design) ---------------------------------
+// One workgroup: the candidates of every rank, read where the exchange left them (thread t takes elements t,
+// t + 512, ... of the concatenation in rank order -- any order would do), the exact statistics from them, the
+// block sums of every rank placed in block order and folded like one GPU's, the result released to the host.
+__global__ __launch_bounds__(kReduceThreads) void k_shard_finish(ShardPtrs srcs, int world, unsigned n_total,
+                                                                 int blocks_total, const WinState *st,
+                                                                 double *ordered, uint32_t *whist, GnResult *res,
+                                                                 unsigned seq) {
+  constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
+  constexpr int W = kNSum + 1;
+  __shared__ unsigned s_base[kShardMaxWorld + 1][4];
+  __shared__ unsigned s_fail;
+  const unsigned tid = threadIdx.x;
+#ifdef ICP_WIN_DEBUG
+  long long sst[8];
+  sst[0] = wall_clock64();
+#endif
+  const uint32_t *status = whist + 2 * kWinBins;
+  if (tid < (unsigned)kShardStatusWords) res->status[tid] = status[tid];  // (ahead of the release of seq below)
+  if (tid == 0) {
+    unsigned base[4] = {0, 0, 0, 0}, fail = 0;
+    for (int q = 0; q < world; ++q) {
+      const ShardCandHeader *hq = reinterpret_cast<const ShardCandHeader *>(srcs.p[q]);
+      fail |= hq->fail;
+      for (int k = 0; k < 4; ++k) {
+        s_base[q][k] = base[k];
+        base[k] += hq->cnt[k];
+      }
+    }
+    for (int k = 0; k < 4; ++k) s_base[world][k] = base[k];
+    s_fail = fail;
+  }
+  // the block sums into block order (rank r owns blocks [B r / world, B (r + 1) / world)), the flags of every rank
+  const int rows = (kReduceMaxBlocks + world - 1) / world + 1;
+  const size_t part_off = sizeof(ShardCandHeader) + (size_t)(2 * kWinCapMed + 2 * kWinCapRing) * sizeof(double);
+  for (int b = tid; b < blocks_total; b += kReduceThreads) {
+    // the rank whose range holds b (32-bit arithmetic: blocks_total <= 256, world <= 16)
+    unsigned r = ((unsigned)(b + 1) * (unsigned)world - 1u) / (unsigned)blocks_total;
+    while ((unsigned)blocks_total * r / (unsigned)world > (unsigned)b) --r;
+    while ((unsigned)blocks_total * (r + 1u) / (unsigned)world <= (unsigned)b) ++r;
+    const int b0 = (int)((unsigned)blocks_total * r / (unsigned)world);
+    const double *pr = reinterpret_cast<const double *>(srcs.p[r] + part_off) + (size_t)(b - b0) * W;
+    double v[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) v[k] = pr[k];  // (every load in flight before the first store)
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+      __hip_atomic_store(&ordered[(size_t)b * W + k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  int nan_flag = 0;
+  for (int r = 0; r < world; ++r)
+    nan_flag |= reinterpret_cast<const double *>(srcs.p[r] + part_off)[(size_t)(rows - 1) * W] != 0.;
+  __syncthreads();
+#ifdef ICP_WIN_DEBUG
+  sst[1] = wall_clock64();
+#endif
+  bool fail = s_fail != 0;
+  const unsigned got[4] = {s_base[world][0], s_base[world][1], s_base[world][2], s_base[world][3]};
+  // (the appended counts are cross-checked against the histogram: a mismatch is a miss)
+  fail = fail || got[0] != st->med_cnt[0] || got[1] != st->med_cnt[1] || got[2] != st->ring_cnt[0] ||
+         got[3] != st->ring_cnt[1] || got[0] > (unsigned)kWinCapMed || got[1] > (unsigned)kWinCapMed ||
+         got[2] > (unsigned)kWinCapRing || got[3] > (unsigned)kWinCapRing;
+  double med[2] = {0., 0.}, sig[2] = {0., 0.};
+  if (!fail) {
+    // where element e of list k (0, 1: median candidates x, y; 2, 3: ring x, y) of the concatenation lies; every
+    // address first, then every load: one round trip instead of twenty
+    auto where = [&](int k, unsigned e) -> const double * {
+      const double *body0 = reinterpret_cast<const double *>(srcs.p[0] + sizeof(ShardCandHeader));
+      if (e >= got[k]) return body0;  // (not a candidate: any readable address)
+      int q = 0;
+      while (q + 1 < world && s_base[q + 1][k] <= e) ++q;
+      const double *body = reinterpret_cast<const double *>(srcs.p[q] + sizeof(ShardCandHeader));
+      const size_t off = k < 2 ? (size_t)k * kWinCapMed : (size_t)2 * kWinCapMed + (size_t)(k - 2) * kWinCapRing;
+      return body + off + (e - s_base[q][k]);
+    };
+    const double *pm[2][PM], *pr[2][PR];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+      for (int u = 0; u < PM; ++u) pm[d][u] = where(d, tid + u * kReduceThreads);
+#pragma unroll
+      for (int u = 0; u < PR; ++u) pr[d][u] = where(2 + d, tid + u * kReduceThreads);
+    }
+    double vm[2][PM], vr[2][PR];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+      for (int u = 0; u < PM; ++u) vm[d][u] = *pm[d][u];
+#pragma unroll
+      for (int u = 0; u < PR; ++u) vr[d][u] = *pr[d][u];
+    }
+    const unsigned klo = (n_total - 1) / 2, khi = n_total / 2;
+    const unsigned em[2] = {got[0], got[1]}, er[2] = {got[2], got[3]};
+    const double m_lo[2] = {st->med_lo[0], st->med_lo[1]}, m_hi[2] = {st->med_hi[0], st->med_hi[1]};
+    const double r_lo[2] = {st->ring_lo[0], st->ring_lo[1]}, r_hi[2] = {st->ring_hi[0], st->ring_hi[1]};
+    const long long mlo[2] = {(long long)klo - st->med_base[0], (long long)klo - st->med_base[1]};
+    const long long mhi[2] = {(long long)khi - st->med_base[0], (long long)khi - st->med_base[1]};
+    unsigned long long key[2][2];
+#ifdef ICP_WIN_DEBUG
+    sst[2] = wall_clock64();
+#endif
+    select_n<2, PM>(vm, em, m_lo, m_hi, mlo, mhi, key, fail);
+#ifdef ICP_WIN_DEBUG
+    sst[3] = wall_clock64();
+#endif
+    if (!fail) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        med[d] = middle_of(n_total, key[d][0], key[d][1]);
+#pragma unroll
+        for (int u = 0; u < PR; ++u) vr[d][u] = fabs(vr[d][u] - med[d]);  // src/stats.rs:35
+      }
+      const long long dlo[2] = {(long long)klo - st->ring_inner[0], (long long)klo - st->ring_inner[1]};
+      const long long dhi[2] = {(long long)khi - st->ring_inner[0], (long long)khi - st->ring_inner[1]};
+      select_n<2, PR>(vr, er, r_lo, r_hi, dlo, dhi, key, fail);
+      if (!fail) {
+        sig[0] = ICP_PPF34 * middle_of(n_total, key[0][0], key[0][1]);  // src/stats.rs:42-46
+        sig[1] = ICP_PPF34 * middle_of(n_total, key[1][0], key[1][1]);
+      } else {
+        med[0] = med[1] = 0.;
+      }
+    }
+  }
+  // the histograms of the next evaluation start from zero (this rank's copy of the ranks' sum; the status words
+  // behind them are rewritten by every hist stage)
+  for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads)
+    __hip_atomic_store(&whist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef ICP_WIN_DEBUG
+  sst[4] = wall_clock64();
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#ifdef ICP_WIN_DEBUG
+  sst[5] = wall_clock64();
+#endif
+  publish_result(ordered, res, seq, sig, med, nan_flag, fail ? 2 : 0, blocks_total);
+#ifdef ICP_WIN_DEBUG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  sst[6] = wall_clock64();
+  if (tid == 0 && seq % 16 == 3)
+    printf("[SF] gather %lld fetch %lld sel1 %lld sel2+zero %lld drain %lld publish %lld (x10ns)\n", sst[1] - sst[0], sst[2] - sst[1],
+           sst[3] - sst[2], sst[4] - sst[3], sst[5] - sst[4], sst[6] - sst[5]);
+#endif
+}
 
 // ---- host ---------------------------------------------------------------------------
 bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind, bool any_n, double f_override) {

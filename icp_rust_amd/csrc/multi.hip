@@ -41,7 +41,7 @@ struct icp_multi {
     uint32_t *d_idx = nullptr;
     double *d_a_full = nullptr, *d_b_full = nullptr;  // replicated fallback
     // exports (peer-visible) and this rank's flag words {hist, candidates, partials, pairs}
-    unsigned char *x_hist = nullptr, *x_cand = nullptr, *x_part = nullptr;
+    unsigned char *x_hist = nullptr, *x_exch = nullptr;  // exported: histograms; candidates + block sums
     unsigned *x_flags = nullptr;
     unsigned *d_err = nullptr;
   };
@@ -120,7 +120,7 @@ int ensure_rank_buffers(icp_multi *M, icp_multi::Rank &R, size_t n_local, size_t
   return ICP_OK;
 }
 
-enum { kFlagHist = 0, kFlagCand = 1, kFlagPart = 2, kFlagPairs = 3 };
+enum { kFlagHist = 0, kFlagCand = 1, kFlagPairs = 3 };
 
 // every rank bumps flag `which` to `value` behind what it has enqueued so far
 int signal_all(icp_multi *M, int which, unsigned value) {
@@ -168,32 +168,22 @@ int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta
       ICP_TRY(wait_all(M, R, kFlagHist, gen));
       for (int p = 0; p < W; ++p) ptrs[p] = M->r[p].x_hist;
       HIP_TRY(multi_sum_hist(R.h->stream, ptrs, W, hist[q]));
-      // 2. candidates
-      ICP_TRY(icp_shard_eval_compact_device(R.h, R.x_cand));
+      // 2. candidates + block sums
+      ICP_TRY(icp_shard_eval_compact_device(R.h, R.x_exch));
     }
     ICP_TRY(signal_all(M, kFlagCand, gen));
     for (int q = 0; q < W; ++q) {
       auto &R = M->r[q];
       HIP_TRY(hipSetDevice(R.device));
       ICP_TRY(wait_all(M, R, kFlagCand, gen));
-      for (int p = 0; p < W; ++p) ptrs[p] = M->r[p].x_cand;
-      const icp_handle::ShardEval &S = R.h->shard;
-      HIP_TRY(shard_launch_accumulate_ptrs(R.h, S.d_a, S.n_local, S.n_total, S.T, ptrs, W, S.b1 - S.b0, R.x_part));
-    }
-    // 3. block sums
-    ICP_TRY(signal_all(M, kFlagPart, gen));
-    for (int q = 0; q < W; ++q) {
-      auto &R = M->r[q];
-      HIP_TRY(hipSetDevice(R.device));
-      ICP_TRY(wait_all(M, R, kFlagPart, gen));
     }
     int rcf = ICP_OK;
     for (int q = 0; q < W; ++q) {
       auto &R = M->r[q];
       double dq[3], eq = 0.;
-      // (finish = fold from the peers' exports + wait + bookkeeping; the contiguous-buffer entry point
-      // of the ABI is not used here: the block sums are read in place)
-      for (int p = 0; p < W; ++p) ptrs[p] = M->r[p].x_part;
+      // (finish = selection + fold from the peers' exports + wait + bookkeeping; the contiguous-buffer entry
+      // point of the ABI is not used here: the peers' blocks are read in place)
+      for (int p = 0; p < W; ++p) ptrs[p] = M->r[p].x_exch;
       const int rc = icp_shard_eval_finish_ptrs(R.h, ptrs, dq, &eq);
       if (q == 0) {
         rcf = rc;
@@ -263,8 +253,7 @@ extern "C" void icp_destroy_multi(icp_multi *M) {
     (void)hipFree(R.d_a_full);
     (void)hipFree(R.d_b_full);
     (void)hipFree(R.x_hist);
-    (void)hipFree(R.x_cand);
-    (void)hipFree(R.x_part);
+    (void)hipFree(R.x_exch);
     (void)hipFree(R.x_flags);
     if (R.d_err) (void)hipHostFree(R.d_err);
   }
@@ -317,8 +306,7 @@ extern "C" int icp_create_multi(icp_multi **out, int dim, const double *dst, siz
     if (rc != ICP_OK) break;
     const bool peers = !M->one_device;
     if ((e = alloc_export((void **)&R.x_hist, icp_shard_histogram_words() * 4, peers)) != hipSuccess ||
-        (e = alloc_export((void **)&R.x_cand, icp_shard_candidates_bytes(), peers)) != hipSuccess ||
-        (e = alloc_export((void **)&R.x_part, icp_shard_partials_bytes(n_devices), peers)) != hipSuccess ||
+        (e = alloc_export((void **)&R.x_exch, icp_shard_exchange_bytes(n_devices), peers)) != hipSuccess ||
         (e = alloc_export((void **)&R.x_flags, 4 * 32 * sizeof(unsigned), peers)) != hipSuccess ||
         (e = hipHostMalloc((void **)&R.d_err, sizeof(unsigned), hipHostMallocCoherent)) != hipSuccess ||
         (e = hipMemset(R.x_flags, 0, 4 * 32 * sizeof(unsigned))) != hipSuccess) {

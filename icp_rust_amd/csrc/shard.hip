@@ -9,12 +9,14 @@
 // is the global range [it G + b0 512, it G + b1 512)), searches their nearest neighbours and produces
 // their block sums with the SAME kernels the one-GPU path runs -- launched over its own blocks, on its
 // local arrays, every per-thread and per-block sum is the one the global launch would have produced.
-// What crosses ranks is small and exact:
+// What crosses ranks is small and exact, in TWO exchanges per evaluation (three until round 3: the block sums
+// used to depend on sigma and so could only be made after the candidates had been exchanged; since the sums are
+// kept per dimension without 1 / sigma -- common.hpp, kNSum -- they ride with the residual pass):
 //   1. the window histograms (2 x 2048 u32): integer sums, order-free;
-//   2. the candidate lists around the median and the MAD ring (a few hundred doubles per rank): order
-//      statistics do not depend on the order of the list;
-//   3. the block sums (14 doubles per block), placed in block order -- the second stage then folds the
-//      same numbers in the same order as on one GPU.
+//   2. one block per rank (ShardCandHeader ...): the candidate lists around the median and the MAD ring (a few
+//      hundred doubles: order statistics do not depend on the order of the list) and the rank's block sums
+//      (19 doubles per block), which the last stage places in block order -- it then folds the same numbers in
+//      the same order as one GPU does.
 // The exchange itself is the caller's (RCCL through torch.distributed in icp_rust_amd/dist.py, peer
 // copies inside icp_create_multi); these are the stage-level calls between the exchanges.
 #include "common.hpp"
@@ -23,19 +25,17 @@
 namespace icp {
 
 hipError_t launch_sel_init(icp_handle *h, size_t n);
-__global__ void k_win_hist(const double2 *__restrict__ a, const double2 *__restrict__ b, Pose T, double *__restrict__ rx,
-                           double *__restrict__ ry, unsigned n, WinParams P, uint32_t *whist, WinState *st,
-                           GnScalars *scal);
+__global__ void k_win_hist_sums(const double2 *__restrict__ a, const double2 *__restrict__ b, Pose T,
+                                double *__restrict__ rx, double *__restrict__ ry, unsigned n, WinParams P, uint32_t *whist,
+                                WinState *st, GnScalars *scal, double *partials);
 template <bool LISTS>
 __global__ void k_win_compact(const double *__restrict__ rx, const double *__restrict__ ry, unsigned n_local, unsigned n,
                               WinParams P, const uint32_t *__restrict__ whist, WinState *st, double *wmed, double *wring,
                               const unsigned *__restrict__ llen, unsigned lcap);
-template <bool INLINE_SELECT, bool PUBLISH>
-__global__ void k_win_accumulate(const double2 *__restrict__ a, const double *__restrict__ rx,
-                                 const double *__restrict__ ry, unsigned n, unsigned n_total, Pose T,
-                                 const WinState *__restrict__ st, const double *__restrict__ wmed,
-                                 const double *__restrict__ wring, GnScalars *scal, double *partials, uint32_t *whist,
-                                 SelCtl *ctl, GnResult *res, unsigned seq);
+// (gn_win.hip, beside the selection code it shares with the one-GPU pipelines) the last stage: candidates of every
+// rank -> exact statistics; block sums of every rank, in block order -> the result
+__global__ void k_shard_finish(ShardPtrs srcs, int world, unsigned n_total, int blocks_total, const WinState *st,
+                               double *ordered, uint32_t *whist, GnResult *res, unsigned seq);
 
 void shard_geometry(size_t n_total, int rank, int world, int *b0, int *b1, int *blocks, size_t *n_local) {
   int B, threads;
@@ -93,22 +93,21 @@ hipError_t launch_shard_copy(icp_handle *h, const void *src, void *dst, size_t n
 }
 
 // ---- what a rank hands to the others ---------------------------------------------------
-// candidates: [ShardCandHeader][med x: kWinCapMed][med y][ring x: kWinCapRing][ring y] doubles
-struct ShardCandHeader {
-  unsigned cnt[4];  // appended {med x, med y, ring x, ring y}
-  unsigned fail;    // this rank's compaction missed (identical on every rank: same histogram)
-  unsigned pad[11];
-};
+// one block per rank and evaluation (common.hpp: ShardCandHeader has the layout):
+//   [ShardCandHeader][med x: kWinCapMed][med y][ring x: kWinCapRing][ring y] doubles,
+//   then shard_part_rows(world) rows of (kNSum + 1) doubles: the rank's block sums first (unused rows zero), the
+//   last row = {nan flag}
 size_t shard_cand_bytes() { return sizeof(ShardCandHeader) + (size_t)(2 * kWinCapMed + 2 * kWinCapRing) * sizeof(double); }
-// block sums: rows of (kNSum + 1) doubles, `shard_part_rows(world)` rows per rank: its blocks first (unused
-// rows zero), the last row = {nan flag, overflow, median x, median y, sigma x, sigma y}
 int shard_part_rows(int world) { return (kReduceMaxBlocks + world - 1) / world + 1; }
 size_t shard_part_bytes(int world) { return (size_t)shard_part_rows(world) * (kNSum + 1) * sizeof(double); }
+size_t shard_exchange_bytes(int world) { return shard_cand_bytes() + shard_part_bytes(world); }
 
-__global__ void k_shard_pack_candidates(const WinState *__restrict__ st, const double *__restrict__ wmed,
-                                        const double *__restrict__ wring, unsigned char *__restrict__ out) {
+__global__ void k_shard_pack(const WinState *__restrict__ st, const double *__restrict__ wmed,
+                             const double *__restrict__ wring, const double *__restrict__ partials, int blocks_local,
+                             int rows, const GnScalars *__restrict__ scal, unsigned char *__restrict__ out) {
   ShardCandHeader *hd = reinterpret_cast<ShardCandHeader *>(out);
   double *body = reinterpret_cast<double *>(out + sizeof(ShardCandHeader));
+  double *prow = body + (size_t)(2 * kWinCapMed + 2 * kWinCapRing);
   const unsigned cm[2] = {min(st->list_cnt[0][0], (unsigned)kWinCapMed), min(st->list_cnt[1][0], (unsigned)kWinCapMed)};
   const unsigned cr[2] = {min(st->list_cnt[2][0], (unsigned)kWinCapRing), min(st->list_cnt[3][0], (unsigned)kWinCapRing)};
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -124,118 +123,31 @@ __global__ void k_shard_pack_candidates(const WinState *__restrict__ st, const d
     for (unsigned e = t; e < cr[d]; e += G)
       body[(size_t)2 * kWinCapMed + (size_t)d * kWinCapRing + e] = wring[(size_t)d * kWinCapRing + e];
   }
-}
-
-// the candidates of every rank, concatenated in rank order into this rank's dense lists (any order would do)
-// (`srcs`: one pointer per rank -- slices of an all-gathered buffer, or the ranks' own export buffers
-// read in place over xGMI, icp_create_multi)
-struct ShardPtrs {
-  const unsigned char *p[kShardMaxWorld];
-};
-__global__ void k_shard_merge_candidates(ShardPtrs srcs, int world, WinState *st, double *__restrict__ wmed,
-                                         double *__restrict__ wring) {
-  __shared__ unsigned s_base[4];
-  __shared__ unsigned s_fail;
-  const int r = blockIdx.x;  // one workgroup per source rank
-  if (threadIdx.x == 0) {
-    unsigned base[4] = {0, 0, 0, 0}, fail = 0;
-    for (int q = 0; q < world; ++q) {
-      const ShardCandHeader *hq = reinterpret_cast<const ShardCandHeader *>(srcs.p[q]);
-      fail |= hq->fail;
-      if (q < r)
-        for (int k = 0; k < 4; ++k) base[k] += hq->cnt[k];
-    }
-    for (int k = 0; k < 4; ++k) s_base[k] = base[k];
-    s_fail = fail;
-    if (r == world - 1) {  // totals: what k_win_accumulate cross-checks against the histogram's counts
-      const ShardCandHeader *hl = reinterpret_cast<const ShardCandHeader *>(srcs.p[r]);
-      for (int k = 0; k < 4; ++k) st->list_cnt[k][0] = base[k] + hl->cnt[k];
-      st->fail = fail ? 1u : 0u;
-    }
-  }
-  __syncthreads();
-  if (s_fail) return;
-  const ShardCandHeader *hd = reinterpret_cast<const ShardCandHeader *>(srcs.p[r]);
-  const double *body = reinterpret_cast<const double *>(srcs.p[r] + sizeof(ShardCandHeader));
-  for (int d = 0; d < 2; ++d) {
-    for (unsigned e = threadIdx.x; e < hd->cnt[d]; e += blockDim.x)
-      if (s_base[d] + e < (unsigned)kWinCapMed) wmed[(size_t)d * kWinCapMed + s_base[d] + e] = body[(size_t)d * kWinCapMed + e];
-    for (unsigned e = threadIdx.x; e < hd->cnt[2 + d]; e += blockDim.x)
-      if (s_base[2 + d] + e < (unsigned)kWinCapRing)
-        wring[(size_t)d * kWinCapRing + s_base[2 + d] + e] = body[(size_t)2 * kWinCapMed + (size_t)d * kWinCapRing + e];
-  }
-}
-
-__global__ void k_shard_pack_partials(const double *__restrict__ partials, int blocks_local, int rows,
-                                      GnScalars *__restrict__ scal, double *__restrict__ out) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int W = kNSum + 1;
-  if (t >= rows * W) return;
-  const int row = t / W, k = t % W;
-  double v = 0.;
-  if (row < blocks_local) v = k < kNSum ? partials[(size_t)row * W + k] : 0.;
-  else if (row == rows - 1) {
-    if (k == 0) v = (double)scal->nan_flag;
-    else if (k == 1) {
-      v = (double)scal->overflow;
-      // consumed: k_win_accumulate<true, false> parks a missed window here, and the one-GPU pipelines OR
-      // whatever they find in this word into their own verdict (a stale 2 sent the next un-sharded
-      // evaluation of this handle to the radix pipeline -- and left the ranks of a later sharded run with
-      // different prediction states; found by profiles/multi_fuzz.py)
-      scal->overflow = 0;
-    }
-    else if (k == 2) v = scal->median[0];
-    else if (k == 3) v = scal->median[1];
-    else if (k == 4) v = scal->sigma[0];
-    else if (k == 5) v = scal->sigma[1];
+  for (unsigned e = t; e < (unsigned)(rows * W); e += G) {
+    const int row = (int)e / W, k = (int)e % W;
+    double v = 0.;
+    if (row < blocks_local) v = k < kNSum ? partials[(size_t)row * W + k] : 0.;
+    else if (row == rows - 1 && k == 0) v = (double)scal->nan_flag;
+    prow[e] = v;
   }
-  out[t] = v;
-}
-
-// second stage of the tree over the block sums of every rank, in block order; one workgroup
-__global__ __launch_bounds__(kReduceThreads) void k_shard_fold(ShardPtrs srcs, int rows, int world,
-                                                               int blocks_total, double *__restrict__ ordered,
-                                                               GnResult *res, unsigned seq,
-                                                               const uint32_t *__restrict__ status) {
-  const int W = kNSum + 1;
-  if (threadIdx.x < kShardStatusWords) res->status[threadIdx.x] = status[threadIdx.x];  // (ahead of the fence + seq below)
-  // gather the rows into block order (rank r owns blocks [B r / world, B (r + 1) / world))
-  for (int b = threadIdx.x; b < blocks_total; b += kReduceThreads) {
-    int r = (int)(((long long)(b + 1) * world - 1) / blocks_total);  // the rank whose range holds b
-    while ((long long)blocks_total * r / world > b) --r;
-    while ((long long)blocks_total * (r + 1) / world <= b) ++r;
-    const int b0 = (int)((long long)blocks_total * r / world);
-    const double *pr = reinterpret_cast<const double *>(srcs.p[r]);
-    for (int k = 0; k < W; ++k) ordered[(size_t)b * W + k] = pr[(size_t)(b - b0) * W + k];
-  }
-  int nan_flag = 0, overflow = 0;
-  for (int r = 0; r < world; ++r) {
-    const double *fl = reinterpret_cast<const double *>(srcs.p[r]) + (size_t)(rows - 1) * W;
-    nan_flag |= fl[0] != 0.;
-    overflow |= (int)fl[1];
-  }
-  const double *f0 = reinterpret_cast<const double *>(srcs.p[0]) + (size_t)(rows - 1) * W;  // every rank selected the same statistics
-  const double med[2] = {f0[2], f0[3]}, sig[2] = {f0[4], f0[5]};
-  __syncthreads();
-  __threadfence();
-  publish_result(ordered, res, seq, sig, med, nan_flag, overflow, blocks_total);
 }
 
 // ---- stage launchers (api.hip drives them; each enqueues on h->stream) ---------------------------
+// residuals + histograms + the block sums of this rank's blocks: the launch of the one-GPU pipeline over the
+// rank's own blocks, on its local arrays
 hipError_t shard_launch_hist(icp_handle *h, const double *d_a, const double *d_b, size_t n_local, const Pose &T,
-                             const WinParams &P) {
+                             const WinParams &P, int blocks_local) {
   Workspace &w = h->ws;
-  const unsigned n = (unsigned)n_local;
-  const unsigned per = 512 * 4;
-  unsigned hb = (n + per - 1) / per;
-  if (hb > (unsigned)kWinBlocks) hb = kWinBlocks;
-  if (hb < 1) hb = 1;
-  hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(512), 0, h->stream, (const double2 *)d_a, (const double2 *)d_b, T, w.d_rx,
-                     w.d_ry, n, P, w.d_whist, w.d_wstate, w.d_scal);
+  if (blocks_local < 1) return hipSuccess;
+  hipLaunchKernelGGL(k_win_hist_sums, dim3(blocks_local), dim3(kReduceThreads), 0, h->stream, (const double2 *)d_a,
+                     (const double2 *)d_b, T, w.d_rx, w.d_ry, (unsigned)n_local, P, w.d_whist, w.d_wstate, w.d_scal,
+                     w.d_partials);
   return hipGetLastError();
 }
 
-hipError_t shard_launch_compact(icp_handle *h, size_t n_local, size_t n_total, const WinParams &P, void *d_out) {
+hipError_t shard_launch_compact(icp_handle *h, size_t n_local, size_t n_total, const WinParams &P, int world,
+                                int blocks_local, void *d_out) {
   Workspace &w = h->ws;
   const unsigned n = (unsigned)n_local;
   const unsigned per = 512 * 4;
@@ -245,8 +157,9 @@ hipError_t shard_launch_compact(icp_handle *h, size_t n_local, size_t n_total, c
   hipLaunchKernelGGL(k_win_compact<false>, dim3(hb), dim3(512), 0, h->stream, (const double *)w.d_rx,
                      (const double *)w.d_ry, n, (unsigned)n_total, P, (const uint32_t *)w.d_whist, w.d_wstate, w.d_wmed,
                      w.d_wring, (const unsigned *)nullptr, 0u);
-  hipLaunchKernelGGL(k_shard_pack_candidates, dim3(8), dim3(256), 0, h->stream, (const WinState *)w.d_wstate,
-                     (const double *)w.d_wmed, (const double *)w.d_wring, (unsigned char *)d_out);
+  hipLaunchKernelGGL(k_shard_pack, dim3(16), dim3(256), 0, h->stream, (const WinState *)w.d_wstate,
+                     (const double *)w.d_wmed, (const double *)w.d_wring, (const double *)w.d_partials, blocks_local,
+                     shard_part_rows(world), (const GnScalars *)w.d_scal, (unsigned char *)d_out);
   return hipGetLastError();
 }
 
@@ -261,45 +174,20 @@ static ShardPtrs table(const void *const *ptrs, int world) {
   return t;
 }
 
-static hipError_t accumulate_from(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
-                                  const ShardPtrs &cands, int world, int blocks_local, void *d_out) {
+static hipError_t finish_from(icp_handle *h, const ShardPtrs &blocks_of, int world, size_t n_total, int blocks_total,
+                              double *d_ordered) {
   Workspace &w = h->ws;
-  hipLaunchKernelGGL(k_shard_merge_candidates, dim3(world), dim3(256), 0, h->stream, cands, world, w.d_wstate, w.d_wmed,
-                     w.d_wring);
-  if (blocks_local > 0)
-    hipLaunchKernelGGL((k_win_accumulate<true, false>), dim3(blocks_local), dim3(kReduceThreads), 0, h->stream,
-                       (const double2 *)d_a, (const double *)w.d_rx, (const double *)w.d_ry, (unsigned)n_local,
-                       (unsigned)n_total, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
-                       (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, 0u);
-  const int rows = shard_part_rows(world);
-  hipLaunchKernelGGL(k_shard_pack_partials, dim3((rows * (kNSum + 1) + 255) / 256), dim3(256), 0, h->stream,
-                     (const double *)w.d_partials, blocks_local, rows, w.d_scal, (double *)d_out);
+  hipLaunchKernelGGL(k_shard_finish, dim3(1), dim3(kReduceThreads), 0, h->stream, blocks_of, world, (unsigned)n_total,
+                     blocks_total, (const WinState *)w.d_wstate, d_ordered, w.d_whist, w.h_res, ++w.seq);
   return hipGetLastError();
 }
-hipError_t shard_launch_accumulate(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
-                                   const void *d_cand_all, int world, int blocks_local, void *d_out) {
-  return accumulate_from(h, d_a, n_local, n_total, T, slices(d_cand_all, shard_cand_bytes(), world), world, blocks_local,
-                         d_out);
+hipError_t shard_launch_finish(icp_handle *h, const void *d_exch_all, int world, size_t n_total, int blocks_total,
+                               double *d_ordered) {
+  return finish_from(h, slices(d_exch_all, shard_exchange_bytes(world), world), world, n_total, blocks_total, d_ordered);
 }
-hipError_t shard_launch_accumulate_ptrs(icp_handle *h, const double *d_a, size_t n_local, size_t n_total, const Pose &T,
-                                        const void *const *cand_ptrs, int world, int blocks_local, void *d_out) {
-  return accumulate_from(h, d_a, n_local, n_total, T, table(cand_ptrs, world), world, blocks_local, d_out);
-}
-
-hipError_t shard_launch_fold(icp_handle *h, const void *d_part_all, int world, int blocks_total, double *d_ordered) {
-  Workspace &w = h->ws;
-  hipLaunchKernelGGL(k_shard_fold, dim3(1), dim3(kReduceThreads), 0, h->stream,
-                     slices(d_part_all, shard_part_bytes(world), world), shard_part_rows(world), world, blocks_total,
-                     d_ordered, w.h_res, ++w.seq, (const uint32_t *)(w.d_whist + 2 * kWinBins));
-  return hipGetLastError();
-}
-hipError_t shard_launch_fold_ptrs(icp_handle *h, const void *const *part_ptrs, int world, int blocks_total,
-                                  double *d_ordered) {
-  Workspace &w = h->ws;
-  hipLaunchKernelGGL(k_shard_fold, dim3(1), dim3(kReduceThreads), 0, h->stream, table(part_ptrs, world),
-                     shard_part_rows(world), world, blocks_total, d_ordered, w.h_res, ++w.seq,
-                     (const uint32_t *)(w.d_whist + 2 * kWinBins));
-  return hipGetLastError();
+hipError_t shard_launch_finish_ptrs(icp_handle *h, const void *const *exch_ptrs, int world, size_t n_total,
+                                    int blocks_total, double *d_ordered) {
+  return finish_from(h, table(exch_ptrs, world), world, n_total, blocks_total, d_ordered);
 }
 
 // The status words behind the histograms: one-hot by what this rank's hist stage answered.  They travel with the

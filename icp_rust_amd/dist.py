@@ -117,10 +117,10 @@ class HipStages:
         self.torch = torch
         icp.set_stream(torch.cuda.current_stream().cuda_stream)
         self.hist_words = int(lib().icp_shard_histogram_words())
-        self.cand_bytes = int(lib().icp_shard_candidates_bytes())
 
-    def part_bytes(self, world):
-        return int(lib().icp_shard_partials_bytes(world))
+    def exch_bytes(self, world):
+        """what a rank hands to the others between compact and finish: its candidates + its block sums"""
+        return int(lib().icp_shard_exchange_bytes(world))
 
     def empty(self, nbytes, like):
         return self.torch.empty(nbytes, dtype=self.torch.uint8, device=like.device)
@@ -197,17 +197,13 @@ class HipStages:
             cache[key] = torch.as_tensor(raw, device=device)
         return cache[key]
 
-    def eval_compact(self, cand_out):
-        return lib().icp_shard_eval_compact_device(self.icp._h, C.c_void_p(cand_out.data_ptr()))
+    def eval_compact(self, exch_out):
+        return lib().icp_shard_eval_compact_device(self.icp._h, C.c_void_p(exch_out.data_ptr()))
 
-    def eval_accumulate(self, cand_all, part_out):
-        return lib().icp_shard_eval_accumulate_device(self.icp._h, C.c_void_p(cand_all.data_ptr()),
-                                                      C.c_void_p(part_out.data_ptr()))
-
-    def eval_finish(self, part_all):
+    def eval_finish(self, exch_all):
         delta = np.zeros(3)
         err = C.c_double(0.0)
-        rc = lib().icp_shard_eval_finish_device(self.icp._h, C.c_void_p(part_all.data_ptr()),
+        rc = lib().icp_shard_eval_finish_device(self.icp._h, C.c_void_p(exch_all.data_ptr()),
                                                 delta.ctypes.data_as(C.POINTER(C.c_double)), C.byref(err))
         return rc, delta, err.value
 
@@ -284,8 +280,7 @@ class BlockShardedIcp:
             nl = max(self.geom[rk.rank][3], 1)
             rk.bufs = dict(
                 a=st.empty_points(nl, 2, like), b=st.empty_points(nl, 2, like), idx=st.empty_index(nl, like),
-                cand=st.empty(st.cand_bytes, like), cand_all=st.empty(W * st.cand_bytes, like),
-                part=st.empty(st.part_bytes(W), like), part_all=st.empty(W * st.part_bytes(W), like),
+                exch=st.empty(st.exch_bytes(W), like), exch_all=st.empty(W * st.exch_bytes(W), like),
                 # replicated fallback: every rank's pairs, padded to the largest shard, and the full arrays
                 pair_send=st.empty_points(self.n_local_max, 4, like),
                 pair_recv=st.empty_points(W * self.n_local_max, 4, like),
@@ -300,7 +295,7 @@ class BlockShardedIcp:
                                    rk.rank, self.world, T, kind, refined) for rk in rks]
         rcs = {rc for rc, _ in res}
         if all(hasattr(rk.stages, "eval_status") for rk in rks):
-            # Every rank takes part in the SAME three exchanges whatever its own hist stage answered; the answers travel
+            # Every rank takes part in the SAME two exchanges whatever its own hist stage answered; the answers travel
             # as four status counters behind the histograms, so after the sum all ranks know all answers and branch
             # alike.  Each rank decides its answer from state that is replicated by construction (the window
             # prediction comes from global statistics), but a rank-local condition -- a HIP error, a handle with
@@ -312,20 +307,13 @@ class BlockShardedIcp:
             ok = [rc == _lib.OK for rc, _ in res]
             for rk, o in zip(rks, ok):
                 if o:
-                    _lib.check(rk.stages.eval_compact(rk.bufs["cand"]), "icp_shard_eval_compact_device")
+                    _lib.check(rk.stages.eval_compact(rk.bufs["exch"]), "icp_shard_eval_compact_device")
                 else:
-                    rk.bufs["cand"].zero_()
-            self.comm.gather([rk.bufs["cand"] for rk in rks], [rk.bufs["cand_all"] for rk in rks])
-            for rk, o in zip(rks, ok):
-                if o:
-                    _lib.check(rk.stages.eval_accumulate(rk.bufs["cand_all"], rk.bufs["part"]),
-                               "icp_shard_eval_accumulate_device")
-                else:
-                    rk.bufs["part"].zero_()
-            self.comm.gather([rk.bufs["part"] for rk in rks], [rk.bufs["part_all"] for rk in rks])
+                    rk.bufs["exch"].zero_()
+            self.comm.gather([rk.bufs["exch"] for rk in rks], [rk.bufs["exch_all"] for rk in rks])
             outs, sts = [], []
             for rk, o in zip(rks, ok):
-                outs.append(rk.stages.eval_finish(rk.bufs["part_all"]) if o else None)
+                outs.append(rk.stages.eval_finish(rk.bufs["exch_all"]) if o else None)
                 sts.append(rk.stages.eval_status(not o))
             st = sts[0]
             assert all(s == st for s in sts)
@@ -349,13 +337,9 @@ class BlockShardedIcp:
         elif rcs == {_lib.OK}:
             self.comm.sum_([h for _, h in res])
             for rk in rks:
-                _lib.check(rk.stages.eval_compact(rk.bufs["cand"]), "icp_shard_eval_compact_device")
-            self.comm.gather([rk.bufs["cand"] for rk in rks], [rk.bufs["cand_all"] for rk in rks])
-            for rk in rks:
-                _lib.check(rk.stages.eval_accumulate(rk.bufs["cand_all"], rk.bufs["part"]),
-                           "icp_shard_eval_accumulate_device")
-            self.comm.gather([rk.bufs["part"] for rk in rks], [rk.bufs["part_all"] for rk in rks])
-            outs = [rk.stages.eval_finish(rk.bufs["part_all"]) for rk in rks]
+                _lib.check(rk.stages.eval_compact(rk.bufs["exch"]), "icp_shard_eval_compact_device")
+            self.comm.gather([rk.bufs["exch"] for rk in rks], [rk.bufs["exch_all"] for rk in rks])
+            outs = [rk.stages.eval_finish(rk.bufs["exch_all"]) for rk in rks]
             rc = outs[0][0]
             assert all(o[0] == rc for o in outs)  # every rank folds the same numbers
             if rc == _lib.RETRY_SHARDED:  # the window missed; its counts place one that will not

@@ -40,7 +40,12 @@ extern "C" {
 /* 3: additions only (icp_last_fold_order; icp_sort_source_device).  Behavioural note: icp_estimate[_device] on the grid
  * engine now folds its sums over the source cloud in FOLD ORDER (a deterministic sort by target-grid cell, section 9a)
  * instead of the caller's order -- same correspondences, pose equal within the rounding of a re-ordered sum (~1e-12) */
-#define ICP_ABI_VERSION 3
+/* 4: the sharded evaluation has TWO exchanges: icp_shard_eval_accumulate_device is gone, icp_shard_eval_compact_device
+ * hands out one block per rank (candidates + block sums, icp_shard_exchange_bytes) and icp_shard_eval_finish_device
+ * takes the gathered blocks.  Additions: icp_shard_exchange_bytes, icp_nn_cert_counters, icp_multi_append_targets,
+ * icp_grid_append_counters.  Behavioural note: the sums of the weighted normal equations are kept per dimension and
+ * scaled by 1 / sigma after the fold (g_x S_x + g_y S_y) instead of per term -- pose equal within rounding (~1e-13) */
+#define ICP_ABI_VERSION 4
 
 typedef enum icp_status {
   ICP_OK = 0,
@@ -219,16 +224,19 @@ int icp_weighted_gn_step_device(icp_handle *h, const double *d_a_xy, const doubl
  * them out of a full array in fold order, icp_shard_put_device is the inverse).  It searches their
  * nearest neighbours (icp_correspond_device on its compact source cloud) and evaluates them with
  *   icp_shard_eval_hist_device        residuals + window histograms of its points   -> *d_hist
+ *                                     (+ the running sums of its blocks, kept in the handle: since ABI 4 they
+ *                                     carry no 1 / sigma and so need not wait for the statistics)
  *      [host: SUM the icp_shard_histogram_words() u32 at *d_hist over all ranks, in place -- EVERY rank, whatever
  *       its hist call answered (short of ICP_BAD_ARGUMENT): the last four words are status counters, one-hot per
  *       rank {OK, RETRY_REPLICATED, NONE, other}; after the sum every rank reads the same four counts
  *       (icp_shard_eval_status) and takes the same branch, also when a rank-local condition made one rank answer
  *       differently from its peers -- the ranks must never enter different collectives]
- *   icp_shard_eval_compact_device     its candidates around the median / the MAD    -> d_candidates_out
- *      [host: ALL-GATHER icp_shard_candidates_bytes() bytes per rank, rank order]
- *   icp_shard_eval_accumulate_device  exact statistics + the sums of its blocks     -> d_partials_out
- *      [host: ALL-GATHER icp_shard_partials_bytes(world) bytes per rank, rank order]
- *   icp_shard_eval_finish_device      second stage over all block sums, 3x3 solve   -> delta, Huber error
+ *   icp_shard_eval_compact_device     its candidates around the median / the MAD
+ *                                     and its block sums                             -> d_exchange_out
+ *      [host: ALL-GATHER icp_shard_exchange_bytes(world) bytes per rank, rank order]
+ *   icp_shard_eval_finish_device      exact statistics from all candidates, second stage over all block
+ *                                     sums, 3x3 solve                                -> delta, Huber error
+ * Two exchanges per evaluation (ABI 3 had a third: icp_shard_eval_accumulate_device between compact and finish).
  * What crosses ranks is integer counts, order statistics candidates and per-block sums placed in block
  * order, so every rank ends with the bits one GPU computes.  The exchange is the host's: RCCL
  * (icp_rust_amd/dist.py drives these calls through torch.distributed), or the peer copies of
@@ -236,22 +244,22 @@ int icp_weighted_gn_step_device(icp_handle *h, const double *d_a_xy, const doubl
  * yet / fewer blocks than ranks; from finish: the predicted window missed) means: gather the pairs of
  * all ranks in global order and call icp_weighted_gn_step_device on them instead -- same result, and
  * it provides the prediction.  ICP_RETRY_SHARDED from finish: the window missed, but its (exact,
- * global) counts place a narrower one that will not -- run the four stages again with refined = 1.
+ * global) counts place a narrower one that will not -- run the three stages again with refined = 1.
  * All calls are asynchronous on the handle's stream except finish. */
 int icp_shard_geometry(size_t n_total, int rank, int world, int *block_first, int *block_end, int *blocks,
                        size_t *n_local);
 size_t icp_shard_histogram_words(void);
-size_t icp_shard_candidates_bytes(void);
-size_t icp_shard_partials_bytes(int world);
+size_t icp_shard_candidates_bytes(void);     /* layout of the exchanged block: the candidates ... */
+size_t icp_shard_partials_bytes(int world);  /* ... then the block sums */
+size_t icp_shard_exchange_bytes(int world);  /* = the two together */
 int icp_shard_take_device(icp_handle *h, const void *d_full, void *d_local, size_t n_total, int rank, int world,
                           size_t elem_bytes);
 int icp_shard_put_device(icp_handle *h, const void *d_local, void *d_full, size_t n_total, int rank, int world,
                          size_t elem_bytes);
 int icp_shard_eval_hist_device(icp_handle *h, const double *d_a_xy_local, const double *d_b_xy_local, size_t n_total,
                                int rank, int world, const icp_pose *T, int kind, int refined, uint32_t **d_hist);
-int icp_shard_eval_compact_device(icp_handle *h, void *d_candidates_out);
-int icp_shard_eval_accumulate_device(icp_handle *h, const void *d_candidates_all, void *d_partials_out);
-int icp_shard_eval_finish_device(icp_handle *h, const void *d_partials_all, double delta[3], double *huber_err);
+int icp_shard_eval_compact_device(icp_handle *h, void *d_exchange_out);
+int icp_shard_eval_finish_device(icp_handle *h, const void *d_exchange_all, double delta[3], double *huber_err);
 /* the four status counts of the evaluation in flight.  from_device = 0: as finish left them in host memory (valid once
  * finish has returned, no wait); 1: read from the summed buffer behind the stream (a rank whose own hist call was not
  * ICP_OK and which ran no finish).  icp_shard_eval_abort_device: after an evaluation the ranks did not ALL answer with

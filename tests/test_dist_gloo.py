@@ -148,14 +148,14 @@ class OracleBlockStages:
         self.dst, self.tree = dst, O.KdTree(dst)
         self.n_total, self.world = n_total, world
         self.nl_max = max(block_shard(n_total, r, world)[3] for r in range(world))
-        self.cand_bytes = 8 * (1 + 2 * self.nl_max)
         self.seen_kind = set()
         self.evals = 0
         self.miss_every = miss_every
         self.prepared = 0
 
-    def part_bytes(self, world):
-        return 8 * (O.TREE_SUMS * (256 // world + 2) + 4)
+    def exch_bytes(self, world):
+        """what a rank hands to the others between compact and finish: [count, its residuals][blocks, its block sums]"""
+        return 8 * (1 + 2 * self.nl_max) + 8 * (O.TREE_SUMS * (256 // world + 2) + 4)
 
     def empty(self, nbytes, like):
         return torch.zeros(nbytes, dtype=torch.uint8)
@@ -204,35 +204,32 @@ class OracleBlockStages:
         self.hist = h
         return _lib.OK, h
 
-    def eval_compact(self, cand_out):
+    def eval_compact(self, exch_out):
         assert int(self.hist[0]) == self.n_total  # the histogram now holds the sum over ranks
-        v = cand_out.view(torch.float64)
+        a, b, rank, world, T = self.cur
+        v = exch_out.view(torch.float64)
+        v.zero_()
         v[0] = float(len(self.res))
         v[1:1 + 2 * len(self.res)] = torch.from_numpy(self.res.reshape(-1).copy())
+        # the sums of this rank's blocks do not wait for the statistics (no 1 / sigma in them: applied after the fold)
+        b0, b1, blocks, nl = block_shard(self.n_total, rank, world)
+        parts = O.wgn_tree_partials(_opose(T), a, b, b1 - b0, 512)
+        off = 1 + 2 * self.nl_max
+        v[off] = float(b1 - b0)
+        v[off + 1:off + 1 + parts.size] = torch.from_numpy(parts.reshape(-1).copy())
         return _lib.OK
 
-    def eval_accumulate(self, cand_all, part_out):
-        a, b, rank, world, T = self.cur
-        allv = cand_all.view(torch.float64).numpy().reshape(world, -1)
+    def eval_finish(self, exch_all):
+        world = self.cur[3]
+        allv = exch_all.view(torch.float64).numpy().reshape(world, -1)
         res = np.concatenate([allv[q, 1:1 + 2 * int(allv[q, 0])].reshape(-1, 2) for q in range(world)])
         assert len(res) == self.n_total
-        rc, sd = O.calc_stddevs(res)
+        rc, sd = O.calc_stddevs(res)  # every rank selects the same statistics from the same candidates
         assert rc == O.OK
-        b0, b1, blocks, nl = block_shard(self.n_total, rank, world)
-        parts = O.wgn_tree_partials(_opose(T), a, b, b1 - b0, 512)  # (sums without 1 / sigma: applied after the fold)
-        out = part_out.view(torch.float64)
-        out.zero_()
-        out[0] = float(b1 - b0)
-        out[1:3] = torch.from_numpy(np.asarray(sd, dtype=np.float64))  # every rank selected the same statistics
-        out[3:3 + parts.size] = torch.from_numpy(parts.reshape(-1).copy())
-        return _lib.OK
-
-    def eval_finish(self, part_all):
-        world = self.cur[3]
-        allv = part_all.view(torch.float64).numpy().reshape(world, -1)
         K = O.TREE_SUMS
-        parts = np.concatenate([allv[q, 3:3 + K * int(allv[q, 0])].reshape(-1, K) for q in range(world)])
-        sd = allv[0, 1:3].copy()
+        off = 1 + 2 * self.nl_max
+        parts = np.concatenate([allv[q, off + 1:off + 1 + K * int(allv[q, off])].reshape(-1, K) for q in range(world)])
+        sd = np.asarray(sd, dtype=np.float64)
         if not self.refined:
             self.evals += 1
         if self.miss_every and self.evals % self.miss_every == 0:  # "the predicted window missed"
