@@ -1489,6 +1489,22 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     Q.cert_seq = 0;
     Q.cap = n_;
   }
+  // Clouds that get four lanes per query (frames of a few tens of thousands of points) keep the caller's order: the
+  // snapshot exists for the per-slot previous matches, and the sort (a cell pass, eight rocprim launches, a gather:
+  // 50 us of a 1.26 ms registration of a 28k-point frame) buys such a search nothing measurable -- the targets it
+  // walks fit the L2 whatever order the queries come in.  ICP_QSORT_SMALL=1 sorts them all the same.
+  static const bool sort_small = getenv("ICP_QSORT_SMALL") != nullptr;
+  Q.identity = (long)n <= grid_coop_max() && !sort_small;
+  if (Q.identity) {
+    Q.have_prev = false;
+    Q.have_certs = false;
+    Q.have_pose = Q.have_pose_before = false;
+    Q.decay_r = Q.decay_t = 0.;
+    Q.src = d_src;
+    Q.n = n_;
+    Q.valid = true;
+    return hipSuccess;
+  }
   // ICP_QSORT_BLOCK: log2 of the row bundle's side (0: row after row); the key must fit 32 bits
   // (row after row serves the gather walk best: 84.1 / 86.3 / 90.4 / 94.3 us per search for 0 / 1 / 2 / 3; the
   // LDS-tile search wants 1: 5 100 -> 700 of 15 625 waves beyond its LDS budget)
@@ -1537,9 +1553,9 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   const Grid &G = h->grid;
   const QuerySort &Q = h->qsort;
   const bool sorted = xform && Q.valid && Q.src == d_src && Q.n == n_;
-  const double *q_src = sorted ? Q.d_sorted : d_src;
+  const double *q_src = (sorted && !Q.identity) ? Q.d_sorted : d_src;
   // slot order (icp_estimate_device): outputs stay in the snapshot's order -- k-th pair = k-th sorted point
-  const uint32_t *q_perm = (sorted && !Q.slot_order) ? Q.d_perm : nullptr;
+  const uint32_t *q_perm = (sorted && !Q.slot_order && !Q.identity) ? Q.d_perm : nullptr;
   PrevMatch *q_prev_out = sorted ? Q.d_prev : nullptr;
   const PrevMatch *q_prev = (sorted && Q.have_prev) ? Q.d_prev : nullptr;
   if (sorted) h->qsort.have_prev = true;

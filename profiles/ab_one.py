@@ -23,6 +23,16 @@ if what in ("both", "frame"):
         ts.append(time.perf_counter() - t0)
     ts.sort()
     out.append(f"frame28k min {1e3 * ts[0]:.3f} med {1e3 * ts[len(ts) // 2]:.3f} ms")
+    sh = np.ascontiguousarray(s3[np.random.default_rng(5).permutation(len(s3))])  # the same frame in random order
+    for _ in range(3):
+        icp.estimate(sh, I.Transform(), 20)
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        icp.estimate(sh, I.Transform(), 20)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    out.append(f"shuffled med {1e3 * ts[len(ts) // 2]:.3f} ms")
     icp.close()
 if what in ("both", "pair"):
     src, dst = synth.synthetic_pair(1_000_000, 1_000_000)
