@@ -33,5 +33,14 @@ echo "== two ranks sharing this GPU over gloo (functional rehearsal of bench --g
 ICP_BENCH_SHARE_GPU=1 timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 40 --warmup 2 --brute-steps 0 --weak-steps 20 2> $O/bench_2rank.err | grep '^{' > $O/bench_2rank_shared_gloo.json
 echo "== virtual ranks: cost of the exchanges"; python3 profiles/multi_virtual_timing.py > $O/multi_virtual_timing.txt 2>&1
 echo "== map"; python3 bench_map.py > $O/bench_map_10M.json 2> /dev/null
+echo "== timelines: steady state of the 1M pair, one 28k-point frame"
+rocprofv3 --kernel-trace --output-format csv -d $O/ks -- python3 bench.py $B --steps 60 > /dev/null 2>&1
+python3 profiles/steady_state_timeline.py $O/ks > $O/timeline_steady_state.txt; rm -rf $O/ks
+rocprofv3 --kernel-trace --output-format csv -d $O/kf -- python3 profiles/frame28k_trace.py > $O/frame28k_run.txt 2>&1
+TAIL=75 python3 profiles/frame28k_trace.py --analyze $O/kf > $O/frame28k_timeline.txt; rm -rf $O/kf
+echo "== evaluation pipelines side by side (profiles/ab_libs.py: fused everywhere / default / search stream only / never)"
+python3 profiles/ab_libs.py 2 icp_rust_amd/lib/libicp_mi355x.so:ICP_WIN_FUSE_MODE=1 icp_rust_amd/lib/libicp_mi355x.so icp_rust_amd/lib/libicp_mi355x.so:ICP_WIN_FUSE_MODE=4 icp_rust_amd/lib/libicp_mi355x.so:ICP_WIN_NO_FUSE=1 > $O/eval_fusion_ab.txt 2>&1
+echo "== matches that survive an outer iteration, certificates"; python3 profiles/nn_stability.py > $O/nn_stability.txt 2>&1
+python3 profiles/settled_phase.py > $O/settled_phase.txt 2>&1; ICP_NN_NO_CERT=1 python3 profiles/settled_phase.py >> $O/settled_phase.txt 2>&1
 fi
 ls -la $O

@@ -11,14 +11,12 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
 rows.sort()
 warm = [i for i, r in enumerate(rows) if r[2].startswith("icp::k_nn_grid<3, true, false") or r[2].startswith("icp::k_nn_grid_warm<3")]
 start = warm[len(warm) * 2 // 3]  # well inside a 20-iteration call
-while not rows[start][2].startswith("icp::k_win_compact"):
-    start -= 1
 t0 = rows[start][0]
 print("rocprofv3 --kernel-trace of `python3 bench.py --brute-steps 0 --cpu-iters 0 --gn-points 0`: consecutive kernels of the "
       "steady state of the timed region (us).")
 print("q = HW queue: one is the handle's stream (search + first evaluation of every outer iteration), the other the "
       "evaluation stream (the evaluation that decides the speculated pose).\n")
 qs = {}
-for s, e, n, q in rows[start:start + 34]:
+for s, e, n, q in rows[start:start + 30]:
     qn = qs.setdefault(q, f"q{len(qs) + 1}")
     print(f"{n[:44]:44s} {qn} start {(s - t0) / 1e3:8.1f} end {(e - t0) / 1e3:8.1f} dur {(e - s) / 1e3:6.1f}")
