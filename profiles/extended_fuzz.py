@@ -11,6 +11,7 @@ import numpy as np
 import icp_rust_amd as I
 import oracle_ffi as O
 import test_gpu_fuzz as F
+from parity_util import oracle_in_device_order  # (the sums of a call are folded in that call's fold order)
 
 LOG = open(os.path.join(ROOT, "gpurun_out", "extended_fuzz_progress.log"), "w") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else sys.stderr
 
@@ -63,10 +64,8 @@ for seed in range(first, first + count):
     note("registration seed", seed, "dim", dim, "n", n, "m", m, "iters", iters)
     icp = (I.Icp3d if dim == 3 else I.Icp2d)(dst)
     T, idx, inner = icp.estimate(src, I.Transform(), iters, return_info=True)
+    rc, oT, oidx, oinner = oracle_in_device_order(icp, dim, dst, src, O.transform_identity(), iters)
     icp.close()
-    b, t = I.reduce_geometry(n)
-    rc, oT, oidx, oinner = O.icp_estimate(dim, dst, src, O.transform_identity(), iters, use_kdtree=True, sum_mode=1,
-                                          reduce_blocks=b, reduce_threads=t)
     if rc != O.OK or not (np.array_equal(idx, oidx) and np.array_equal(inner, oinner) and np.array_equal(T.as_array(), oT.as_array())):
         bad += 1
         print("REGISTRATION MISMATCH seed", seed, "dim", dim, "n", n, "m", m, "iters", iters, "rc", rc,
@@ -110,9 +109,7 @@ for seed in range(first, first + max(count // 4, 1)):
             Tn, idx, inner = icp.estimate(src, T, iters, return_info=True)
         else:
             Tn, idx, inner = icp.estimate(torch.from_numpy(src).cuda(), T, iters, return_info=True)
-        b, t = I.reduce_geometry(n)
-        rc, oT, oidx, oinner = O.icp_estimate(dim, dst, src, O.Pose(*T.pose.as_tuple()), iters, use_kdtree=True, sum_mode=1,
-                                              reduce_blocks=b, reduce_threads=t)
+        rc, oT, oidx, oinner = oracle_in_device_order(icp, dim, dst, src, O.Pose(*T.pose.as_tuple()), iters)
         same = rc == O.OK and np.array_equal(Tn.as_array(), oT.as_array()) and np.array_equal(inner, oinner[:len(inner)]) \
             and (iters == 0 or np.array_equal(idx, oidx))
         if not same:
@@ -189,9 +186,12 @@ for seed in range(first, first + max(count // 16, 1)):
             got = ("ok", Tn.as_array(), idx, inner)
         except I._lib.IcpError as e:
             got = ("err", e.status)
-        b, t = I.reduce_geometry(n)
-        rc, oT, oidx, oinner = O.icp_estimate(dim, dst, src, O.Pose(*T.pose.as_tuple()), iters, use_kdtree=True, sum_mode=1,
-                                              reduce_blocks=b, reduce_threads=t)
+        if got[0] == "ok":
+            rc, oT, oidx, oinner = oracle_in_device_order(icp, dim, dst, src, O.Pose(*T.pose.as_tuple()), iters)
+        else:
+            b, t = I.reduce_geometry(n)
+            rc, oT, oidx, oinner = O.icp_estimate(dim, dst, src, O.Pose(*T.pose.as_tuple()), iters, use_kdtree=True, sum_mode=1,
+                                                  reduce_blocks=b, reduce_threads=t)
         if rc == O.OK:
             same = got[0] == "ok" and np.array_equal(got[1], oT.as_array()) and np.array_equal(got[2], oidx) and \
                 np.array_equal(got[3], oinner)
