@@ -328,9 +328,9 @@ def main():
                 T, _ = driver.step(d_src, T)
         # HIP events around every search launch of a short run (<= 40 steps: the cold first search of
         # each 20-step estimate call then weighs exactly its 1-in-20 share, as in a rocprofv3 trace of
-        # the same command); on longer runs around every 3rd launch (an event pair costs a few us of
-        # stream time; 3 is coprime with the 20-step cycle, so cold searches are sampled at their share)
-        icp.profile_enable(1 if steps <= 40 else 3)
+        # the same command); on longer runs around every 7th launch (an event pair costs a few us of
+        # stream time; 7 is coprime with the 20-step cycle, so cold searches are sampled at their share)
+        icp.profile_enable(1 if steps <= 40 else 7)
         icp.profile_read()
         barrier()
         t0 = time.perf_counter()

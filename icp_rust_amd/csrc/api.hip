@@ -386,11 +386,13 @@ extern "C" void icp_destroy(icp_handle *h) {
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   if (h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);  // work enqueued on a caller's stream
   if (h->ws.spec_stream) (void)hipStreamSynchronize(h->ws.spec_stream);
-  for (auto &ev : h->prof_events) {
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
+  for (auto *v : {&h->prof_events, &h->prof_free}) {
+    for (auto &ev : *v) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    v->clear();
   }
-  h->prof_events.clear();
   if (getenv("ICP_DBG_WIN") && h->ws.win_tried)
     fprintf(stderr,
             "[icp] window evaluations: %llu tried, %llu missed; speculative searches: %llu hit, %llu missed; "
@@ -508,6 +510,14 @@ extern "C" int icp_profile_enable(icp_handle *h, int enable) {
   if (!h) return ICP_BAD_ARGUMENT;
   h->profile = enable < 0 ? 0 : enable;
   h->prof_seen = 0;
+  if (h->profile > 0) {  // event pairs ahead of the region they will time (creating one costs tens of microseconds)
+    HIP_TRY(hipSetDevice(h->device));
+    while (h->prof_free.size() < 32) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) break;
+      h->prof_free.emplace_back(a, b);
+    }
+  }
   return ICP_OK;
 }
 extern "C" int icp_profile_read(icp_handle *h, double *ms, uint64_t *launches) {
@@ -518,8 +528,7 @@ extern "C" int icp_profile_read(icp_handle *h, double *ms, uint64_t *launches) {
   for (auto &ev : h->prof_events) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) total += t;
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
+    h->prof_free.push_back(ev);  // (creating an event pair costs more host time than recording it: reused)
   }
   if (ms) *ms = total;
   if (launches) *launches = h->prof_events.size();

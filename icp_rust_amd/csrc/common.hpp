@@ -331,6 +331,7 @@ struct icp_handle {
   int profile = 0;         // 0: off; k: event pairs around every k-th search launch
   unsigned prof_seen = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;  // event pairs read out, kept for the next samples
 };
 
 namespace icp {

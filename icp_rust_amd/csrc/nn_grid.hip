@@ -1561,7 +1561,12 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   if (sorted) h->qsort.have_prev = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (h->profile > 0 && (h->prof_seen++ % (unsigned)h->profile) == 0) {
-    if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
+    if (!h->prof_free.empty()) {
+      ev0 = h->prof_free.back().first;
+      ev1 = h->prof_free.back().second;
+      h->prof_free.pop_back();
+      (void)hipEventRecord(ev0, h->stream);
+    } else if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
       (void)hipEventRecord(ev0, h->stream);
   }
   // four lanes per query while one lane per query cannot fill the chip (8 lanes measured the same, 16
