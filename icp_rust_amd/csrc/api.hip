@@ -1533,7 +1533,8 @@ extern "C" int icp_shard_eval_hist_device(icp_handle *h, const double *d_a, cons
   const int rc = shard_eval_hist_impl(h, d_a, d_b, n_total, rank, world, T, kind, refined, d_hist);
   if (rc == ICP_BAD_ARGUMENT) return rc;
   *d_hist = h->ws.d_whist;
-  if (shard_launch_status(h, rc) != hipSuccess) return ICP_HIP_ERROR;
+  // the status words: written by the hist launch itself when this rank answers OK and owns blocks, else by a launch of their own
+  if (!(rc == ICP_OK && h->shard.b1 - h->shard.b0 >= 1) && shard_launch_status(h, rc) != hipSuccess) return ICP_HIP_ERROR;
   return rc;
 }
 
@@ -1611,9 +1612,7 @@ static int shard_eval_hist_impl(icp_handle *h, const double *d_a, const double *
 extern "C" int icp_shard_eval_compact_device(icp_handle *h, void *d_exchange_out) {
   if (!h || !h->shard.active || !d_exchange_out) return ICP_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
-  // the global counts also go to the host: if this window misses, they place the next attempt's
-  HIP_TRY(hipMemcpyAsync(h->ws.h_whist, h->ws.d_whist, (size_t)2 * kWinBins * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                         h->stream));
+  // (the global counts go to the host only if this window misses -- they place the next attempt's: k_shard_finish)
   const icp_handle::ShardEval &S = h->shard;
   HIP_TRY(shard_launch_compact(h, S.n_local, S.n_total, S.P, S.world, S.b1 - S.b0, d_exchange_out));
   return ICP_OK;

@@ -95,8 +95,11 @@ template <bool SUMS>
 __device__ __forceinline__ void win_hist_body(const double2 *__restrict__ a, const double2 *__restrict__ b,
                                               const Pose &T, double *__restrict__ rx, double *__restrict__ ry,
                                               unsigned n, const WinParams &P, uint32_t *whist, WinState *st,
-                                              GnScalars *scal, double *partials) {
+                                              GnScalars *scal, double *partials, int status_cls = -1) {
   __shared__ uint32_t lh[2 * kWinBins];
+  // (a sharded hist stage that answers OK: the rank's one-hot status words behind the histograms, shard.hip)
+  if (SUMS && status_cls >= 0 && blockIdx.x == 0 && threadIdx.x < (unsigned)kShardStatusWords)
+    whist[2 * kWinBins + threadIdx.x] = (int)threadIdx.x == status_cls ? 1u : 0u;
   double acc[SUMS ? kNSum : 1];
 #pragma unroll
   for (int k = 0; k < (SUMS ? kNSum : 1); ++k) acc[k] = 0.;
@@ -185,8 +188,8 @@ __global__ __launch_bounds__(kWinThreads) void k_win_hist_sums(const double2 *__
                                                                const double2 *__restrict__ b, Pose T,
                                                                double *__restrict__ rx, double *__restrict__ ry,
                                                                unsigned n, WinParams P, uint32_t *whist, WinState *st,
-                                                               GnScalars *scal, double *partials) {
-  win_hist_body<true>(a, b, T, rx, ry, n, P, whist, st, scal, partials);
+                                                               GnScalars *scal, double *partials, int status_cls) {
+  win_hist_body<true>(a, b, T, rx, ry, n, P, whist, st, scal, partials, status_cls);
 }
 
 // ---- W' (refined windows, n > 4M): the histograms again for new windows, from the stored residuals
@@ -1163,7 +1166,7 @@ template __global__ void k_win_compact<false>(const double *__restrict__, const 
 __global__ __launch_bounds__(kReduceThreads) void k_shard_finish(ShardPtrs srcs, int world, unsigned n_total,
                                                                  int blocks_total, const WinState *st,
                                                                  double *ordered, uint32_t *whist, GnResult *res,
-                                                                 unsigned seq) {
+                                                                 unsigned seq, uint32_t *h_counts) {
   constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
   constexpr int W = kNSum + 1;
   __shared__ unsigned s_base[kShardMaxWorld + 1][4];
@@ -1279,6 +1282,11 @@ __global__ __launch_bounds__(kReduceThreads) void k_shard_finish(ShardPtrs srcs,
       }
     }
   }
+  // a window that missed: its (global, exact) counts place the next attempt's -- to the host, by the wave that
+  // releases the result (pinned memory; only on this path, so no copy per evaluation)
+  if (fail && h_counts && tid < 64)
+    for (unsigned i = tid; i < 2u * kWinBins; i += 64) h_counts[i] = whist[i];
+  __syncthreads();
   // the histograms of the next evaluation start from zero (this rank's copy of the ranks' sum; the status words
   // behind them are rewritten by every hist stage)
   for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads)
@@ -1373,7 +1381,7 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
     int blocks, threads;
     reduce_geometry(n_, &blocks, &threads);
     hipLaunchKernelGGL(k_win_hist_sums, dim3(blocks), dim3(threads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
-                       w.d_wstate, w.d_scal, w.d_partials);
+                       w.d_wstate, w.d_scal, w.d_partials, -1);
     hipLaunchKernelGGL(k_win_finish, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
                        (const double *)w.d_ry, n, P, w.d_whist, w.d_wstate, w.d_wmed, w.d_wring, w.d_scal,
                        (const double *)w.d_partials, blocks, w.d_ctl, w.h_res, ++w.seq);

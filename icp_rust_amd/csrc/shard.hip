@@ -27,7 +27,7 @@ namespace icp {
 hipError_t launch_sel_init(icp_handle *h, size_t n);
 __global__ void k_win_hist_sums(const double2 *__restrict__ a, const double2 *__restrict__ b, Pose T,
                                 double *__restrict__ rx, double *__restrict__ ry, unsigned n, WinParams P, uint32_t *whist,
-                                WinState *st, GnScalars *scal, double *partials);
+                                WinState *st, GnScalars *scal, double *partials, int status_cls);
 template <bool LISTS>
 __global__ void k_win_compact(const double *__restrict__ rx, const double *__restrict__ ry, unsigned n_local, unsigned n,
                               WinParams P, const uint32_t *__restrict__ whist, WinState *st, double *wmed, double *wring,
@@ -35,7 +35,7 @@ __global__ void k_win_compact(const double *__restrict__ rx, const double *__res
 // (gn_win.hip, beside the selection code it shares with the one-GPU pipelines) the last stage: candidates of every
 // rank -> exact statistics; block sums of every rank, in block order -> the result
 __global__ void k_shard_finish(ShardPtrs srcs, int world, unsigned n_total, int blocks_total, const WinState *st,
-                               double *ordered, uint32_t *whist, GnResult *res, unsigned seq);
+                               double *ordered, uint32_t *whist, GnResult *res, unsigned seq, uint32_t *h_counts);
 
 void shard_geometry(size_t n_total, int rank, int world, int *b0, int *b1, int *blocks, size_t *n_local) {
   int B, threads;
@@ -142,7 +142,7 @@ hipError_t shard_launch_hist(icp_handle *h, const double *d_a, const double *d_b
   if (blocks_local < 1) return hipSuccess;
   hipLaunchKernelGGL(k_win_hist_sums, dim3(blocks_local), dim3(kReduceThreads), 0, h->stream, (const double2 *)d_a,
                      (const double2 *)d_b, T, w.d_rx, w.d_ry, (unsigned)n_local, P, w.d_whist, w.d_wstate, w.d_scal,
-                     w.d_partials);
+                     w.d_partials, 0 /* this rank answers OK: the status words ride with the launch */);
   return hipGetLastError();
 }
 
@@ -178,7 +178,7 @@ static hipError_t finish_from(icp_handle *h, const ShardPtrs &blocks_of, int wor
                               double *d_ordered) {
   Workspace &w = h->ws;
   hipLaunchKernelGGL(k_shard_finish, dim3(1), dim3(kReduceThreads), 0, h->stream, blocks_of, world, (unsigned)n_total,
-                     blocks_total, (const WinState *)w.d_wstate, d_ordered, w.d_whist, w.h_res, ++w.seq);
+                     blocks_total, (const WinState *)w.d_wstate, d_ordered, w.d_whist, w.h_res, ++w.seq, w.h_whist);
   return hipGetLastError();
 }
 hipError_t shard_launch_finish(icp_handle *h, const void *d_exch_all, int world, size_t n_total, int blocks_total,
