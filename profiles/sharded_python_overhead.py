@@ -16,7 +16,8 @@ for _ in range(2):
     torch.cuda.synchronize(); t_lib = (time.perf_counter() - t0) / 20
 icp2 = I.Icp3d(d_dst)
 drv = BlockShardedIcp({0: HipStages(icp2)}, n, 1, LocalComm(1))
-local = drv.take_source(d_src)
+srt, perms = drv.sort_source(d_src, I.Transform())  # (the fold order of the library's call: same bits)
+local = drv.take_source(srt)
 for _ in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     T2, inner = drv.estimate(local, I.Transform(), 20)
