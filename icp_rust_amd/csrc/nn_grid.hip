@@ -1357,17 +1357,25 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__r
         for (int iy = y0; iy <= y1; ++iy) {
           const uint32_t rb = ((uint32_t)iz * g.n[1] + iy) * g.n[0];
           const uint32_t s0 = start[rb + x0], e0 = start[rb + x1 + 1];
-          for (uint32_t j = s0; j < e0; ++j) {
-            const uint4 w = reinterpret_cast<const uint4 *>(pts)[j];
-            const float fx = qf[0] - __uint_as_float(w.x), fy = qf[1] - __uint_as_float(w.y);
-            const float fz = DIM == 3 ? qf[2] - __uint_as_float(w.z) : 0.f;
-            const float s2 = fx * fx + fy * fy + fz * fz;
-            if (s2 < best) {  // (a target with a NaN or infinite coordinate never compares less: it cannot be a seed,
-              best = s2;      // and a seed at a NaN distance would never be displaced by the warm kernel)
-              bi = w.w;
-            } else if (s2 == __builtin_huge_valf() && any == 0xffffffffu && fabsf(__uint_as_float(w.x)) < __builtin_huge_valf() &&
-                       fabsf(__uint_as_float(w.y)) < __builtin_huge_valf() && fabsf(__uint_as_float(w.z)) < __builtin_huge_valf()) {
-              any = w.w;  // a finite query beyond ~1.8e19 of every target: the f32 screen overflows, the f64 distance does not
+          // four records in flight (a run is a handful of records; one by one each load waited out the one before:
+          // 113 us per 1M queries); a slot past the run repeats its last record, which changes nothing
+          for (uint32_t j0 = s0; j0 < e0; j0 += 4) {
+            uint4 wv[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) wv[u] = reinterpret_cast<const uint4 *>(pts)[min(j0 + u, e0 - 1)];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+              const uint4 w = wv[u];
+              const float fx = qf[0] - __uint_as_float(w.x), fy = qf[1] - __uint_as_float(w.y);
+              const float fz = DIM == 3 ? qf[2] - __uint_as_float(w.z) : 0.f;
+              const float s2 = fx * fx + fy * fy + fz * fz;
+              if (s2 < best) {  // (a target with a NaN or infinite coordinate never compares less: it cannot be a seed,
+                best = s2;      // and a seed at a NaN distance would never be displaced by the warm kernel)
+                bi = w.w;
+              } else if (s2 == __builtin_huge_valf() && any == 0xffffffffu && fabsf(__uint_as_float(w.x)) < __builtin_huge_valf() &&
+                         fabsf(__uint_as_float(w.y)) < __builtin_huge_valf() && fabsf(__uint_as_float(w.z)) < __builtin_huge_valf()) {
+                any = w.w;  // a finite query beyond ~1.8e19 of every target: the f32 screen overflows, the f64 distance does not
+              }
             }
           }
         }
