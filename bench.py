@@ -134,19 +134,20 @@ def gn_large(npts):
     gbs = 96.0 * npts / per_eval / 1e9
     window = c1[0] > c0[0]
     digits = 2 if npts <= (4 << 20) else 3
-    # bytes the launches really stream per point: residual pass 32 in + 16 out, every further selection
-    # pass 16 in, accumulate 32 in.  Beyond 4M points the windows are refined in two passes: the second
-    # histogram pass re-reads the residuals (16), the compaction then reads only the short lists of
-    # residuals inside the fine windows (~1 % of the points).
+    # bytes the launches really stream per point: residual pass 32 in + 16 out (the running sums ride with it since
+    # round 3: no accumulate pass), every further selection pass 16 in.  Beyond 4M points the windows are refined in
+    # two passes: the second histogram pass re-reads the residuals (16), the candidate pass then reads only the short
+    # lists of residuals inside the fine windows (~1 % of the points).  The radix pipeline still accumulates last (32).
     refined = window and npts > (4 << 20)
-    streamed = (48 + 16 + 32) if window else (48 + 16 * (2 * (digits + 1) - 1) + 32)
+    streamed = (48 + 16) if window else (48 + 16 * (2 * (digits + 1) - 1) + 32)
     return {"points": npts, "evaluations": int(evals), "inner_iterations": int(applied),
             "ms_per_evaluation": 1e3 * per_eval, "algorithmic_bytes_per_evaluation": 96 * npts,
             "achieved_GBs": gbs, "peak_GBs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
             "streamed_bytes_per_point": streamed, "streamed_GBs": streamed * npts / per_eval / 1e9,
             "streamed_frac": streamed * npts / per_eval / 1e9 / HBM_PEAK_GBS,
-            "pipeline": ("refined windows (statistics of a 256k-pair sample, two histogram passes, compaction of the "
-                         "fine-window lists, accumulate)" if refined else "window (3 launches)") if window
+            "pipeline": ("refined windows (statistics of a 256k-pair sample; residuals + histograms + block sums; second "
+                         "histogram pass over the residuals; candidates from the fine-window lists, selection, fold)"
+                         if refined else "window (2 launches)") if window
                         else f"radix digits ({2 * (digits + 1) + 1} launches)",
             "note": "reduce kernels alone on pairs past the 256 MiB Infinity Cache (SURVEY 8(d)(i)); bytes as SURVEY "
                     "prices them, selection passes not counted"}

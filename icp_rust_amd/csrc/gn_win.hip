@@ -91,7 +91,7 @@ __device__ __forceinline__ double wedge(int j, const WinDim &w) {
 // ---- W ------------------------------------------------------------------------------
 // SUMS: the running sums of the normal equations ride along (they do not depend on the order statistics any more,
 // common.hpp: kNSum); the launch then has the geometry of the reduction tree and leaves one block sum per workgroup.
-template <bool SUMS>
+template <bool SUMS, int BATCH = kWinBatch>
 __device__ __forceinline__ void win_hist_body(const double2 *__restrict__ a, const double2 *__restrict__ b,
                                               const Pose &T, double *__restrict__ rx, double *__restrict__ ry,
                                               unsigned n, const WinParams &P, uint32_t *whist, WinState *st,
@@ -115,10 +115,10 @@ __device__ __forceinline__ void win_hist_body(const double2 *__restrict__ a, con
   unsigned edge[4] = {0u, 0u, 0u, 0u};  // {below, above} x {x, y}: one word each, kept out of the LDS atomics
   bool saw_nan = false;
   const unsigned G = gridDim.x * kWinThreads;
-  for (unsigned base = blockIdx.x * kWinThreads + threadIdx.x; base < n; base += G * kWinBatch) {
-    double2 s[kWinBatch], d[kWinBatch];
+  for (unsigned base = blockIdx.x * kWinThreads + threadIdx.x; base < n; base += G * BATCH) {
+    double2 s[BATCH], d[BATCH];
 #pragma unroll
-    for (int u = 0; u < kWinBatch; ++u) {
+    for (int u = 0; u < BATCH; ++u) {
       const unsigned i = base + u * G;
       if (i < n) {
         s[u] = a[i];
@@ -126,7 +126,7 @@ __device__ __forceinline__ void win_hist_body(const double2 *__restrict__ a, con
       }
     }
 #pragma unroll
-    for (int u = 0; u < kWinBatch; ++u) {
+    for (int u = 0; u < BATCH; ++u) {
       const unsigned i = base + u * G;
       if (i >= n) continue;
       // residual(), src/lib.rs:34-36
@@ -190,6 +190,19 @@ __global__ __launch_bounds__(kWinThreads) void k_win_hist_sums(const double2 *__
                                                                unsigned n, WinParams P, uint32_t *whist, WinState *st,
                                                                GnScalars *scal, double *partials, int status_cls) {
   win_hist_body<true>(a, b, T, rx, ry, n, P, whist, st, scal, partials, status_cls);
+}
+
+#ifndef ICP_DEEP_BATCH
+#define ICP_DEEP_BATCH 8
+#endif
+// beyond 4M points the same launch runs against HBM bandwidth: eight pairs in flight per lane (the geometry of the
+// reduction tree allows one workgroup per CU only; 8 x 32 B x 512 lanes = 128 KB in flight per CU)
+__global__ __launch_bounds__(kWinThreads) void k_win_hist_sums_deep(const double2 *__restrict__ a,
+                                                                    const double2 *__restrict__ b, Pose T,
+                                                                    double *__restrict__ rx, double *__restrict__ ry,
+                                                                    unsigned n, WinParams P, uint32_t *whist,
+                                                                    WinState *st, GnScalars *scal, double *partials) {
+  win_hist_body<true, ICP_DEEP_BATCH>(a, b, T, rx, ry, n, P, whist, st, scal, partials, -1);
 }
 
 // ---- W' (refined windows, n > 4M): the histograms again for new windows, from the stored residuals
@@ -892,18 +905,21 @@ __device__ __forceinline__ double middle_of(unsigned n, unsigned long long klo, 
 // workgroup that arrives last has every candidate of the launch in reach (write-through stores, sc1 loads), ranks
 // them, folds the block sums of the earlier launch and releases the result -- two launches per evaluation.
 static_assert(kWinThreads == kReduceThreads, "the launches of an evaluation share the reduction tree's geometry");
+// LISTS (second pass of the refined windows): rx / ry are the lists k_win_rehist made (llen entries, at most lcap).
+template <bool LISTS>
 __global__ __launch_bounds__(kWinThreads) void k_win_finish(const double *__restrict__ rx,
                                                             const double *__restrict__ ry, unsigned n, WinParams P,
                                                             uint32_t *whist, WinState *st, double *wmed, double *wring,
                                                             GnScalars *scal, const double *partials, int sum_blocks,
-                                                            SelCtl *ctl, GnResult *res, unsigned seq) {
+                                                            SelCtl *ctl, GnResult *res, unsigned seq,
+                                                            const unsigned *__restrict__ llen, unsigned lcap) {
   constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
   WinSel sel;
 #ifdef ICP_WIN_DEBUG
   long long fst[10];
   fst[0] = wall_clock64();
 #endif
-  bool fail = win_compact_body<false, true>(rx, ry, n, n, P, whist, st, wmed, wring, nullptr, 0u, sel);
+  bool fail = win_compact_body<LISTS, true>(rx, ry, n, n, P, whist, st, wmed, wring, llen, lcap, sel);
 #ifdef ICP_WIN_DEBUG
   fst[1] = wall_clock64();
 #endif
@@ -1382,9 +1398,9 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
     reduce_geometry(n_, &blocks, &threads);
     hipLaunchKernelGGL(k_win_hist_sums, dim3(blocks), dim3(threads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
                        w.d_wstate, w.d_scal, w.d_partials, -1);
-    hipLaunchKernelGGL(k_win_finish, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
+    hipLaunchKernelGGL(k_win_finish<false>, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
                        (const double *)w.d_ry, n, P, w.d_whist, w.d_wstate, w.d_wmed, w.d_wring, w.d_scal,
-                       (const double *)w.d_partials, blocks, w.d_ctl, w.h_res, ++w.seq);
+                       (const double *)w.d_partials, blocks, w.d_ctl, w.h_res, ++w.seq, (const unsigned *)nullptr, 0u);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(kWinThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
@@ -1451,8 +1467,12 @@ hipError_t launch_win_first_pass(icp_handle *h, const double *d_a, const double 
                                  const WinParams &P1) {
   Workspace &w = h->ws;
   const unsigned n = (unsigned)n_;
-  hipLaunchKernelGGL(k_win_hist, dim3(win_hist_blocks(n)), dim3(kWinThreads), 0, h->stream, (const double2 *)d_a,
-                     (const double2 *)d_b, T, w.d_rx, w.d_ry, n, P1, w.d_whist, w.d_wstate, w.d_scal);
+  // residuals + histograms + the block sums of the reduction tree (they do not depend on the statistics: the pairs
+  // are streamed ONCE per evaluation; until round 3 an accumulate pass read them again after the second pass)
+  int blocks, threads;
+  reduce_geometry(n_, &blocks, &threads);
+  hipLaunchKernelGGL(k_win_hist_sums_deep, dim3(blocks), dim3(threads), 0, h->stream, (const double2 *)d_a,
+                     (const double2 *)d_b, T, w.d_rx, w.d_ry, n, P1, w.d_whist, w.d_wstate, w.d_scal, w.d_partials);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   e = hipMemcpyAsync(w.h_whist, w.d_whist, (size_t)2 * kWinBins * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
@@ -1538,15 +1558,12 @@ hipError_t launch_win_second_pass(icp_handle *h, const double *d_a, size_t n_, c
   hipLaunchKernelGGL(k_win_rehist, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx, (const double *)w.d_ry, n,
                      P2, w.d_whist, w.d_wstate, lx, ly, (unsigned)kRefineListCap, w.d_rlist_len);
   const unsigned cb = hb < (unsigned)kWinBlocks ? hb : (unsigned)kWinBlocks;  // a few hundred thousand values: one workgroup per CU
-  hipLaunchKernelGGL(k_win_compact<true>, dim3(cb), dim3(kWinThreads), 0, s, (const double *)lx, (const double *)ly, n, n,
-                     P2, (const uint32_t *)w.d_whist, w.d_wstate, w.d_wmed, w.d_wring, (const unsigned *)w.d_rlist_len,
-                     (unsigned)kRefineListCap);
   int blocks, threads;
   reduce_geometry(n_, &blocks, &threads);
-  hipLaunchKernelGGL(k_win_accumulate<true>, dim3(blocks), dim3(threads), 0, s, (const double2 *)d_a,
-                     (const double *)w.d_rx, (const double *)w.d_ry, n, n, T, (const WinState *)w.d_wstate,
-                     (const double *)w.d_wmed, (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl,
-                     w.h_res, ++w.seq);
+  // candidates out of the lists; the last workgroup selects the statistics and folds the first pass' block sums
+  hipLaunchKernelGGL(k_win_finish<true>, dim3(cb), dim3(kWinThreads), 0, s, (const double *)lx, (const double *)ly, n, P2,
+                     w.d_whist, w.d_wstate, w.d_wmed, w.d_wring, w.d_scal, (const double *)w.d_partials, blocks, w.d_ctl,
+                     w.h_res, ++w.seq, (const unsigned *)w.d_rlist_len, (unsigned)kRefineListCap);
   return hipGetLastError();
 }
 
