@@ -25,7 +25,7 @@ BUDGET = {  # demangled-name fragment -> max VGPRs
     "k_win_compactILb0E": 72,            # (the list variant of the refined windows runs alone)
     "k_win_select": 72,
     "k_win_accumulateILb0E": 88,         # ... (19 running sums since round 3)
-    "k_win_hist_sums": 104,              # the two launches of the evaluation behind the search
+    "k_win_hist_sumsE": 112,             # the two launches of the evaluation behind the search (not the deep-batch variant beyond 4M points, which runs alone)
     "k_win_finish": 120,
 }
 
@@ -64,7 +64,7 @@ def test_kernels_that_share_a_simd_stay_within_their_register_budget():
     assert seen == set(BUDGET), sorted(set(BUDGET) - seen)
     up8 = lambda x: (x + 7) // 8 * 8
     # 3 search waves + 2 waves (one workgroup of 512 threads) of any launch of the deciding evaluation, per SIMD
-    for k in ("k_win_histE", "k_win_compactILb0E", "k_win_select", "k_win_accumulateILb0E", "k_win_hist_sums"):
+    for k in ("k_win_histE", "k_win_compactILb0E", "k_win_select", "k_win_accumulateILb0E", "k_win_hist_sumsE"):
         assert 3 * up8(BUDGET["k_nn_grid_warmILi3ELb0E"]) + 2 * up8(BUDGET[k]) <= 512, k
     for k in ("k_win_histE", "k_win_compactILb0E", "k_win_select"):
         assert 3 * up8(BUDGET["k_nn_gridILi3ELb1ELb0E"]) + 2 * up8(BUDGET[k]) <= 512, k
