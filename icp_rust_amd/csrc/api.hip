@@ -422,6 +422,12 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->shard.refined_ready = h->shard.attempt_refined = false;
     h->normals_m = 0;
     h->normals_k = 0;
+    static const bool no_hints = getenv("ICP_NO_POOL_HINTS") != nullptr;
+    for (int k = 0; k < 5; ++k) {  // what the next owner may start from (common.hpp: hint_kind)
+      w.hint_kind[k] = no_hints ? Workspace::WinPred() : w.win_kind[k];
+      w.hint_kind[k].wide = false;
+    }
+    w.hint_last_inner = no_hints ? 0xffffffffu : w.last_inner;
     w.win_valid = w.win_wide = false;
     for (auto &wk : w.win_kind) wk = Workspace::WinPred();
     // whatever the previous owner's last evaluations left in the selection scratch (a parked flag, a
@@ -667,6 +673,17 @@ static void record_statistics(Workspace &w, int kind, bool has_median, const GnR
     }
 }
 
+// A handle fresh from the pool: the previous owner's prediction for this kind of evaluation, adopted once.  Only the
+// library's own loops call this (estimate_transform_loop): a handle that serves as a rank of a sharded evaluation goes
+// through the stage calls, where a rank-local prediction (and the `wide` flag a miss leaves behind) would give the
+// ranks different windows for the same histogram sum.
+static void adopt_pool_hint(Workspace &w, int kind) {
+  if (Workspace::kind_has_slot(kind) && !w.win_kind[kind].valid && !w.win_valid && w.hint_kind[kind].valid) {
+    w.win_kind[kind] = w.hint_kind[kind];
+    w.hint_kind[kind].valid = false;
+  }
+}
+
 // weighted_gauss_newton_update on device pairs (src/lib.rs:218-261); also yields the
 // Huber error of the same T (src/lib.rs:75), which shares the pass.
 // `after_launch` (optional) runs once, right after the first attempt's kernels have been enqueued
@@ -815,6 +832,10 @@ static int estimate_transform_loop(icp_handle *h, const double *d_a, const doubl
           return map_hip(he);
         }
       }
+      {
+        const int kind_now = it == 0 ? first_kind : (it == 1 ? second_kind : 2);
+        if (!(it == 0 && first_pre_launched)) adopt_pool_hint(h->ws, kind_now);
+      }
       const int rc = (it == 1 && !hook_first)
                          ? wgn_step(h, d_a, d_b, n, T, delta, &err, [&] { return second_eval_hook(T); }, false, second_kind)
                          : wgn_step(h, d_a, d_b, n, T, delta, &err, it == 0 && first_pre_launched,
@@ -922,7 +943,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   Pose spec_pose = T;
   // the bet needs "the inner loop took exactly one update last time"; across calls the handle
   // remembers how its previous call ended (a new frame usually behaves like the last one)
-  uint32_t prev_inner = w.last_inner;
+  uint32_t prev_inner = w.last_inner != 0xffffffffu ? w.last_inner : w.hint_last_inner;  // (a pooled handle: its previous owner's)
   hipStream_t search_stream = h->stream;
   for (size_t it = 0; it < max_iter; ++it) {
     if (spec_valid && memcmp(&spec_pose, &T, sizeof(Pose)) == 0) {

@@ -184,6 +184,12 @@ struct Workspace : GnCtx {
   // say nothing about, but it usually resembles the start of the previous call.  Their statistics also
   // seed kinds 0 and 1 for the call's second iteration.
   WinPred win_kind[5];
+  // HINTS from the previous owner of a pooled handle (examples/scan3d.rs creates an Icp3d per frame, and the next frame
+  // resembles the last): its per-kind predictions and how its last inner loop ended.  Adopted once, by the one-GPU
+  // evaluation of that kind (api.hip: wgn_step) -- a prediction can cost a repeated evaluation, never change a result
+  // -- and never by the sharded stages, whose branch decisions may only depend on replicated state.
+  WinPred hint_kind[5];
+  uint32_t hint_last_inner = 0xffffffffu;
   static bool kind_has_slot(int kind) { return kind == 0 || kind == 1 || kind == 3 || kind == 4; }
   unsigned long long win_tried = 0, win_missed = 0, short_evals = 0, radix_evals = 0;
 };
