@@ -289,6 +289,29 @@ def test_pooled_handles_start_clean():
     check3d(50_000, 50_000, 4, 3)
 
 
+def test_a_pooled_handle_starts_from_its_previous_owners_predictions_and_changes_nothing():
+    """examples/scan3d.rs builds an Icp3d per frame: a handle taken from the pool adopts the window predictions of its
+    previous owner for its first evaluations (common.hpp: hint_kind) -- fewer evaluations through the 7-launch
+    pipeline, the same bits (a window is verified by exact counts whatever it was centred on)."""
+    from icp_rust_amd import synth
+
+    I.lib().icp_trim_pool()
+    pk = synth.synthetic_scan3d_packets(75 * 4)
+    frames = [synth.remove_invalid_values(pk[75 * k:75 * (k + 1)]) for k in range(4)]
+    pulls = []
+    for k in range(3):
+        icp = I.Icp3d(frames[k])
+        T, idx, inner = icp.estimate(frames[k + 1], I.Transform(), 6, return_info=True)
+        rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, frames[k], frames[k + 1], O.transform_identity(), 6)
+        pulls.append(I.gn_path_counters(icp)[2])
+        icp.close()
+        assert rc == O.OK
+        assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
+        assert np.array_equal(T.as_array(), oT.as_array())
+    assert pulls[0] >= 2            # a handle without history: the first two kinds of evaluation have no prediction
+    assert max(pulls[1:]) < pulls[0]  # its successors from the pool start from its predictions
+
+
 def test_a_pooled_handle_changes_dimension():
     """regression (found by profiles/extended_fuzz.py as a device memory fault): the cell-sorted copy
     of the source cloud was sized n * dim doubles but its capacity remembered as n points, so a 3-D
