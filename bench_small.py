@@ -17,8 +17,9 @@ for _ in range(20): T, idx, inner = icp.estimate(src, I.Transform(), 20, return_
 t = (time.perf_counter() - t0) / 20
 print(f"2D scan ({len(src)}x{len(dst)}): GPU estimate(20 it) {t*1e3:.3f} ms, inner {inner.tolist()}")
 t0 = time.perf_counter()
-for _ in range(20): I.Icp2d(dst)
-print(f"   Icp2d::new {1e3*(time.perf_counter()-t0)/20:.3f} ms")
+for _ in range(20):
+    tmp = I.Icp2d(dst); tmp.synchronize(); tmp.close()  # (dropping a handle whose upload is still in flight waits 5x longer)
+print(f"   Icp2d::new + drop {1e3*(time.perf_counter()-t0)/20:.3f} ms")
 tree = O.KdTree(dst)
 t0 = time.perf_counter()
 for _ in range(20): rc, oT, _, oin = tree.estimate(src, O.transform_identity(), 20)
@@ -31,8 +32,9 @@ t0 = time.perf_counter()
 for _ in range(10): T3, idx, inner = icp3.estimate(s3, I.Transform(), 20, return_info=True)
 print(f"3D scan ({len(s3)}x{len(d3)}): GPU estimate(20 it) {1e3*(time.perf_counter()-t0)/10:.3f} ms, inner {inner.tolist()}")
 t0 = time.perf_counter()
-for _ in range(10): I.Icp3d(d3)
-print(f"   Icp3d::new {1e3*(time.perf_counter()-t0)/10:.3f} ms")
+for _ in range(10):
+    tmp = I.Icp3d(d3); tmp.synchronize(); tmp.close()
+print(f"   Icp3d::new + drop {1e3*(time.perf_counter()-t0)/10:.3f} ms")
 t0=time.perf_counter(); tree3 = O.KdTree(d3); tb=time.perf_counter()-t0
 t0 = time.perf_counter()
 for _ in range(3): rc, oT, _, oin = tree3.estimate(s3, O.transform_identity(), 20)
