@@ -302,7 +302,7 @@ def main():
     def measure(mode, steps, warmup, want_parity=False, weak=False):
         """K timed outer iterations = one Icp3d::estimate(src, T, K) call on resident data.
         N ranks: the grid engine runs block-sharded (dist.BlockShardedIcp: every rank searches and
-        evaluates the points of its reduction-tree blocks, three small exchanges per evaluation, same
+        evaluates the points of its reduction-tree blocks, two small exchanges per evaluation, same
         bits as one GPU); the sweep, whose search is 99.8 % of the step, keeps contiguous shards and a
         replicated inner loop (dist.ShardedIcp).  weak: N x n source points instead of n."""
         icp = I.Icp3d(d_dst, device=local_rank, nn_mode=mode)

@@ -273,7 +273,7 @@ int icp_shard_eval_abort_device(icp_handle *h);
  * that repeat only some devices, e.g. {0, 0, 1, 1}, are refused.)
  * The same from ONE host process over the GPUs of a node (SURVEY.md 8(b) sketch: device_ids /
  * n_devices): rank r is a handle on device_ids[r], the target cloud is replicated, the source cloud
- * sharded by reduction-tree block, and the three exchanges are peer reads over xGMI behind flags (no
+ * sharded by reduction-tree block, and the two exchanges are peer reads over xGMI behind flags (no
  * collective library: there is no ICP_RCCL_ERROR).  The result equals icp_estimate's on one GPU bit
  * for bit.  device_ids may repeat a device ("virtual ranks": how the N-rank path is tested on a
  * one-GPU box; ranks on one device share a stream).  icp_multi_counters: out[0] evaluations that ran
