@@ -23,3 +23,15 @@ print("new+drop", t(new_drop), "new+sync+drop", t(new_sync_drop), "frame (new+es
 def nogc():
     return I.Icp2d(dst)
 print("new without close (as bench_small)", t(nogc))
+tn, ts, tc = [], [], []
+for _ in range(30):
+    t0 = time.perf_counter(); h = I.Icp2d(dst); t1 = time.perf_counter(); h.synchronize(); t2 = time.perf_counter(); h.close(); t3 = time.perf_counter()
+    tn.append(t1 - t0); ts.append(t2 - t1); tc.append(t3 - t2)
+med = lambda v: 1e3 * sorted(v)[len(v) // 2]
+print("pieces: new", med(tn), "sync", med(ts), "close", med(tc))
+import torch
+tn, ts, tc = [], [], []
+for _ in range(30):
+    t0 = time.perf_counter(); h = I.Icp2d(dst); t1 = time.perf_counter(); h.close(); t3 = time.perf_counter()
+    tn.append(t1 - t0); tc.append(t3 - t1)
+print("pieces without sync: new", med(tn), "close", med(tc))
