@@ -151,5 +151,6 @@ def synthetic_scan3d_packets(n_packets, seed=SEED + 100, motion=(0.004, -0.002, 
 def remove_invalid_values(points):
     """examples/scan3d.rs:63-69: keep p with norm(p) > 0.2 (norm as src/norm.rs:8-21)."""
     p = np.asarray(points, dtype=np.float64).reshape(-1, 3)
-    nrm = np.sqrt((p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]) + p[:, 2] * p[:, 2])
-    return np.ascontiguousarray(p[nrm > 0.2])
+    sq = p * p  # (the same products, one contiguous pass)
+    nrm = np.sqrt((sq[:, 0] + sq[:, 1]) + sq[:, 2])
+    return np.compress(nrm > 0.2, p, axis=0)  # (half the time of boolean-mask indexing; contiguous)
