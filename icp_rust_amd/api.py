@@ -281,6 +281,13 @@ def gn_path_counters(icp=None):
     return tuple(int(x) for x in out)
 
 
+def gn_loop_counters(icp=None):
+    """(launches, evaluations served, launches that handed an evaluation back) of the one-launch inner loop"""
+    out = (C.c_uint64 * 3)()
+    check(lib().icp_gn_loop_counters(icp._h if icp is not None else None, out), "icp_gn_loop_counters")
+    return tuple(int(x) for x in out)
+
+
 def nn_tile_counters(icp):
     """(waves launched, waves handed to the per-lane gather walk) of the handle's last LDS-tile search"""
     out = (C.c_uint64 * 2)()

@@ -11,6 +11,7 @@
 #include <new>
 
 #include "common.hpp"
+#include "gn_loop.hpp"
 
 using namespace icp;
 
@@ -81,6 +82,10 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_rlist_len);
   (void)hipFree(w.d_part_d);
   (void)hipFree(w.d_part_i);
+  (void)hipFree(w.d_loop_ctl);
+  (void)hipFree(w.d_loop_hist);
+  (void)hipFree(w.d_loop_part);
+  if (w.h_loop_res) (void)hipHostFree(w.h_loop_res);
   free_ctx(w);
   free_ctx(w.alt);
   if (w.spec_stream) {
@@ -632,10 +637,8 @@ static inline void cpu_relax() {
   __asm__ __volatile__("" ::: "memory");
 #endif
 }
-static hipError_t wait_result(icp_handle *h) {
+static hipError_t wait_seq(icp_handle *h, volatile unsigned *seq, unsigned want) {
   static const bool no_poll = getenv("ICP_NO_POLL") != nullptr;
-  const unsigned want = h->ws.seq;
-  volatile unsigned *seq = &h->ws.h_res->seq;
   if (!no_poll) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -648,6 +651,7 @@ static hipError_t wait_result(icp_handle *h) {
   }
   return hipStreamSynchronize(h->stream);
 }
+static hipError_t wait_result(icp_handle *h) { return wait_seq(h, &h->ws.h_res->seq, h->ws.seq); }
 
 // check_input_size, src/lib.rs:186-189
 static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
@@ -798,7 +802,139 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   return wgn_step(h, d_a, d_b, n, T, delta, huber_err, [] { return hipSuccess; }, pre_launched, kind);
 }
 
-// estimate_transform (src/lib.rs:59-84) on device pairs.  `second_eval_hook(T1)` (optional) is
+// ---- the inner loop in one launch (gn_loop.hip) --------------------------------------------------------------
+static std::mutex g_loop_mu;  // one resident loop launch per process at a time: two of them, each waiting at its grid
+                              // barrier for workgroups the other one keeps off the CUs, would only end by timeout
+
+static hipError_t ensure_loop(icp_handle *h) {
+  Workspace &w = h->ws;
+  if (w.d_loop_ctl) return hipSuccess;
+  hipError_t e;
+  const size_t hist_bytes = (size_t)4 * kWinBins * sizeof(uint32_t);
+  if ((e = hipMalloc(&w.d_loop_ctl, sizeof(LoopCtl))) != hipSuccess) return e;
+  if ((e = hipMalloc(&w.d_loop_hist, hist_bytes)) != hipSuccess) return e;
+  if ((e = hipMalloc(&w.d_loop_part, gn_loop_partials_doubles() * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipHostMalloc(&w.h_loop_res, sizeof(LoopResult), hipHostMallocCoherent)) != hipSuccess) return e;
+  memset(w.h_loop_res, 0, sizeof(LoopResult));
+  if ((e = hipMemsetAsync(w.d_loop_ctl, 0, sizeof(LoopCtl), h->stream)) != hipSuccess) return e;
+  return hipMemsetAsync(w.d_loop_hist, 0, hist_bytes, h->stream);
+}
+
+static void record_values(Workspace &w, int kind, const double med[2], const double sigma[2]) {
+  GnResult r = {};
+  for (int d = 0; d < 2; ++d) {
+    r.median[d] = med[d];
+    r.sigma[d] = sigma[d];
+  }
+  record_statistics(w, kind, true, r);
+}
+
+// From evaluation *it on, as far as the device gets by itself.  *served = false: nothing was launched (no window
+// prediction for evaluation *it) -- the caller steps once from the host.  Otherwise the loop's state is the launch's:
+// *finished, or evaluation *it is the caller's to serve (a window missed, a rotation beyond the restated sin / cos).
+static int gn_loop_run(icp_handle *h, const double *d_a, const double *d_b, size_t n, int first_kind, int second_kind,
+                       Pose *T, double *prev_error, uint32_t *applied, int *it, bool *finished, bool *served) {
+  Workspace &w = h->ws;
+  *served = *finished = false;
+  auto kind_of = [&](int i) { return i == 0 ? first_kind : (i == 1 ? second_kind : 2); };
+  const int kind0 = kind_of(*it), kind1 = kind_of(*it + 1);
+  adopt_pool_hint(w, kind0);
+  LoopArgs A = {};
+  if (!window_usable(h, n, &A.PA, kind0)) return ICP_OK;
+  const bool own0 = Workspace::kind_has_slot(kind0) && w.win_kind[kind0].valid;
+  double p_med[2][2], p_sigma[2][2];
+  for (int d = 0; d < 2; ++d) {
+    p_med[0][d] = own0 ? w.win_kind[kind0].med[d] : w.win_med[d];
+    p_sigma[0][d] = own0 ? w.win_kind[kind0].sigma[d] : w.win_sigma[d];
+  }
+  // the second evaluation of the launch: the host's own prediction for that KIND of evaluation if it has one (the
+  // population after the first update differs from the first one's, common.hpp: Workspace::win_kind), else the launch
+  // centres it on its first evaluation like every later one
+  adopt_pool_hint(w, kind1);
+  const bool own1 = kind1 != 2 && Workspace::kind_has_slot(kind1) && w.win_kind[kind1].valid;
+  A.pb_valid = own1 && window_usable(h, n, &A.PB, kind1) ? 1 : 0;
+  if (A.pb_valid)
+    for (int d = 0; d < 2; ++d) {
+      p_med[1][d] = w.win_kind[kind1].med[d];
+      p_sigma[1][d] = w.win_kind[kind1].sigma[d];
+    }
+  A.f_next = window_half_width(n, w.win_wide);
+  HIP_TRY(ensure_loop(h));
+  if (w.gn_dirty) {  // (the host-driven pipelines' rest state; the launch itself does not touch it)
+    HIP_TRY(launch_sel_init(h, n));
+    w.gn_dirty = false;
+  }
+  A.a = (const double2 *)d_a;
+  A.b = (const double2 *)d_b;
+  A.n = (unsigned)n;
+  A.it0 = (unsigned)*it;
+  A.applied0 = *applied;
+  A.T0 = *T;
+  A.prev_error0 = *prev_error;
+  A.whist = w.d_loop_hist;
+  A.wmed = w.d_wmed;
+  A.wring = w.d_wring;
+  A.partials = w.d_loop_part;
+  A.ctl = reinterpret_cast<LoopCtl *>(w.d_loop_ctl);
+  LoopResult *res = reinterpret_cast<LoopResult *>(w.h_loop_res);
+  A.res = res;
+  A.seq = ++w.loop_seq;
+  {
+    std::lock_guard<std::mutex> lk(g_loop_mu);
+    HIP_TRY(launch_gn_loop(h, A));
+    HIP_TRY(wait_seq(h, &res->seq, A.seq));
+  }
+  *served = true;
+  ++w.loop_launches;
+  w.loop_evals += res->evals;
+  w.win_tried += res->evals + (res->status == 1 ? 1u : 0u);
+  if (res->status == 5) {  // not resident: put the scratch back into its rest state and step from the host from now on
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemsetAsync(w.d_loop_ctl, 0, sizeof(LoopCtl), h->stream));
+    HIP_TRY(hipMemsetAsync(w.d_loop_hist, 0, (size_t)4 * kWinBins * sizeof(uint32_t), h->stream));
+    w.loop_off = true;
+  }
+  // the statistics the next predictions are made from, in the order the evaluations ran
+  for (unsigned e = 0; e < res->evals && e < 2u; ++e) {
+    const int kind = kind_of(*it + (int)e);
+    record_values(w, kind, res->med[e], res->sigma[e]);
+    if (e == 0 || A.pb_valid) {  // back to narrow windows once a kind's statistics have settled (wgn_step)
+      bool &wide = (e == 0 ? own0 : true) ? w.win_kind[kind].wide : w.win_wide;
+      double shift = 0.;
+      for (int d = 0; d < 2; ++d)
+        shift = fmax(shift, (fabs(res->med[e][d] - p_med[e][d]) + fabs(res->sigma[e][d] - p_sigma[e][d])) / p_sigma[e][d]);
+      if (wide && shift < 0.01) wide = false;
+    }
+  }
+  if (res->evals > 2u) {
+    record_values(w, 2, res->med[2], res->sigma[2]);
+    w.win_wide = false;
+  }
+  *T = res->Ti;
+  *prev_error = res->prev_error;
+  *applied = res->applied;
+  if (res->status == 3) {
+    w.gn_dirty = true;
+    return ICP_NAN_INPUT;
+  }
+  if (res->finished) {
+    *finished = true;
+    return ICP_OK;
+  }
+  ++w.loop_handbacks;
+  *it = (int)res->it;
+  if (res->status == 1) {  // evaluation *it missed its window: what a miss leaves behind (wgn_step)
+    ++w.win_missed;
+    const int kind = kind_of(*it);
+    const bool own = Workspace::kind_has_slot(kind) && w.win_kind[kind].valid;
+    (own ? w.win_kind[kind].wide : w.win_wide) = true;
+  }
+  return ICP_OK;
+}
+
+// estimate_transform (src/lib.rs:59-84) on device pairs.  Pair sets of up to 2^20 run the loop on the device
+// (gn_loop.hip: one launch, gn_loop_run above); the host steps only where that launch hands an evaluation back, and
+// for larger sets.  `second_eval_hook(T1)` (optional, host-stepped loops only) is
 // called when the evaluation at the once-updated pose T1 has been enqueued: if that evaluation
 // ends the loop -- the usual case once a registration has settled -- T1 is the result, so the
 // caller may start work for it while the device is still evaluating.
@@ -814,7 +950,17 @@ static int estimate_transform_loop(icp_handle *h, const double *d_a, const doubl
   uint32_t applied = 0;
   if (input_size_ok(n)) {
     double prev_error = DBL_MAX;  // f64::MAX, src/lib.rs:63
+    const bool device_loop = !eval_stream && !first_pre_launched && gn_loop_applies(n);
     for (int it = 0; it < ICP_INNER_MAX_ITER; ++it) {
+      if (device_loop && !h->ws.loop_off) {
+        bool finished = false, served = false;
+        const int rc = gn_loop_run(h, d_a, d_b, n, first_kind, second_kind, &T, &prev_error, &applied, &it, &finished,
+                                   &served);
+        if (rc != ICP_OK) return rc;
+        if (finished) break;
+        if (it >= ICP_INNER_MAX_ITER) break;
+        (void)served;  // either way evaluation `it` is stepped from the host now
+      }
       double delta[3], err = 0.;
       hipStream_t first_stream = h->stream;
       const bool on_eval_stream = it >= 1 && eval_stream;
@@ -919,8 +1065,11 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   static const bool one_stream_env = getenv("ICP_SPEC_SAME_STREAM") != nullptr;
   static const bool nn_first = getenv("ICP_SPEC_NN_LAST") == nullptr;
   Workspace &w = h->ws;
+  // Pair sets the one-launch inner loop serves (gn_loop.hip) need neither the bet nor the second stream: an outer
+  // iteration is search -> loop launch -> one host wait, whatever the inner loop does.
+  const bool device_loop = gn_loop_applies(n) && !w.loop_off;
   // with a caller-supplied stream everything stays on that stream
-  const bool two_streams = !no_spec && !one_stream_env && h->stream == h->own_stream;
+  const bool two_streams = !device_loop && !no_spec && !one_stream_env && h->stream == h->own_stream;
   Pose T = *init;
   if (max_iter > 0) {
     const int prc = icp_prepare_source_device(h, d_src, n, init);
@@ -959,7 +1108,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     }
     spec_valid = false;
     pre_valid = false;
-    const bool speculate = !no_spec && n > 0 && h->m > 0 && it + 1 < max_iter && prev_inner == 1;
+    const bool speculate = !device_loop && !no_spec && n > 0 && h->m > 0 && it + 1 < max_iter && prev_inner == 1;
     auto launch_spec = [&](const Pose &T1) -> hipError_t {
       spec_pose = transform_mul(T1, T);  // src/lib.rs:127, 170 -- what the outer loop will compute
       uint32_t *idx_out = (it + 2 == max_iter && d_last_idx) ? idx_target : nullptr;
@@ -1121,6 +1270,19 @@ extern "C" int icp_gn_path_counters(icp_handle *h, uint64_t out[6]) {
   out[3] = h->ws.radix_evals;
   out[4] = h->ws.spec_hits;
   out[5] = h->ws.spec_misses;
+  return ICP_OK;
+}
+
+extern "C" int icp_gn_loop_counters(icp_handle *h, uint64_t out[3]) {
+  if (!out) return ICP_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!h) {
+    const int rc = scratch_handle(&h);
+    if (rc != ICP_OK) return rc;
+  }
+  out[0] = h->ws.loop_launches;
+  out[1] = h->ws.loop_evals;
+  out[2] = h->ws.loop_handbacks;
   return ICP_OK;
 }
 

@@ -192,6 +192,13 @@ struct Workspace : GnCtx {
   uint32_t hint_last_inner = 0xffffffffu;
   static bool kind_has_slot(int kind) { return kind == 0 || kind == 1 || kind == 3 || kind == 4; }
   unsigned long long win_tried = 0, win_missed = 0, short_evals = 0, radix_evals = 0;
+  // one-launch inner loop (gn_loop.hip): control block, the two parity histograms / block-sum sets, the pinned result
+  void *d_loop_ctl = nullptr, *h_loop_res = nullptr;
+  uint32_t *d_loop_hist = nullptr;
+  double *d_loop_part = nullptr;
+  unsigned loop_seq = 0;
+  bool loop_off = false;  // a launch was not resident (its grid barrier timed out): this handle steps from the host
+  unsigned long long loop_launches = 0, loop_evals = 0, loop_handbacks = 0;
 };
 
 // ---- uniform grid over the target cloud (nn_grid.hip) ------------------------------
@@ -404,6 +411,7 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
 // orchestration (two waits) lives in api.hip:wgn_step
 constexpr size_t kRefineListCap = 1u << 21;  // expected: ~4e5 per dimension
 constexpr size_t kRefineSample = 1u << 18;  // standard error of its median: 0.0025 sigma (1M: 0.0012, 60 us more)
+double window_half_width(size_t n, bool wide);
 bool refine_applies(size_t n);
 bool make_window(const double med[2], const double sigma[2], double f, WinParams *P);
 hipError_t launch_sample_pairs(icp_handle *h, const double *d_a, const double *d_b, size_t n);

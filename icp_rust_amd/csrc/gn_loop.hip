@@ -1,0 +1,642 @@
+// The whole inner loop of estimate_transform (src/lib.rs:59-84) in ONE launch, for pair sets that fit the register
+// files of the chip (n <= 8 x 256 x 512 = 1 048 576).
+//
+// The pairs (a_i, b_i) of an outer iteration do not change while the inner loop runs -- only the pose does
+// (src/lib.rs:66-82) -- and 1M pairs are 32 MB against 128 MB of vector registers.  So the launch has the geometry of
+// the reduction tree (reduce_geometry(n) workgroups of 512), every thread LOADS ITS POINTS ONCE
+// (thread g of the tree folds points g, g + G, ...: at most eight) and the up-to-200 evaluations of
+// weighted_gauss_newton_update (src/lib.rs:218-261) + huber_error (:45-50) run out of registers:
+//
+//   A  residuals of the thread's points -> window histograms (LDS, flushed with integer atomics) + the thread's 19
+//      running sums -> block sum                                                       [grid barrier]
+//   B  every workgroup reads the global counts, derives the bins of the order statistics (gn_win_device.hpp: the same
+//      bracket as k_win_finish) and appends its candidates -- from registers again         [grid barrier]
+//   C  every workgroup loads the candidate lists and the block sums, selects the four exact order statistics
+//      (src/stats.rs:11-47), folds the block sums in the tree's order, applies 1 / sigma, solves the 3 x 3 system
+//      (src/linalg.rs:3-29), takes the reference's two break tests (src/lib.rs:71-78) and composes the pose (:81) --
+//      redundantly and deterministically, so all workgroups hold the same bits and nothing is broadcast.
+//
+// Two grid barriers per evaluation and no kernel boundary, no host round trip, no re-read of the pairs or of stored
+// residuals.  Every sum is folded in the order of the launch-per-stage pipelines (k_win_hist_sums / k_win_finish), the
+// order statistics are the exact ones: results are bit-identical to them and to the oracle's tree variant.
+//
+// What the kernel cannot do it hands back: a window that missed (status 1), a rotation beyond the restated range of
+// sin / cos (status 1 as well: the host repeats that evaluation with its own pipelines), a NaN residual (status 3),
+// a grid barrier that timed out because the launch was not fully resident (status 5; nothing else may occupy the CUs
+// for longer than kLoopTimeoutTicks).  The state handed back is the state BEFORE the evaluation that was not served.
+#include "common.hpp"
+#include "gn_device.hpp"
+#include "gn_win_device.hpp"
+#include "gn_loop.hpp"
+
+namespace icp {
+
+namespace {
+
+constexpr long long kLoopTimeoutTicks = 25000000;  // wall_clock64 runs at 100 MHz: 250 ms
+
+__device__ __forceinline__ double to_sgpr(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ Pose pose_sgpr(const Pose &T) {
+  Pose o;
+  o.r00 = to_sgpr(T.r00);
+  o.r10 = to_sgpr(T.r10);
+  o.r01 = to_sgpr(T.r01);
+  o.r11 = to_sgpr(T.r11);
+  o.tx = to_sgpr(T.tx);
+  o.ty = to_sgpr(T.ty);
+  return o;
+}
+__device__ __forceinline__ WinDim windim_sgpr(const WinDim &w) {
+  WinDim o;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) o.x[k] = to_sgpr(w.x[k]);
+  o.sf = to_sgpr(w.sf);
+  o.sc = to_sgpr(w.sc);
+  return o;
+}
+
+__device__ __forceinline__ unsigned ld_u32(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_u32(unsigned *p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_f64(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_f64(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// All workgroups of the launch meet here (generation `gen` = 1, 2, ... within the launch).  Arrivals are counted on
+// sixteen shard words + one top word (gn_device.hpp: last_block_arrives has the reasons), the last arriver resets the
+// counters and releases every shard's line; everybody else polls its own shard's line.  Stores and atomics issued
+// before the barrier are drained first (write-through stores + sc1 loads: the hand-off rules of gn_device.hpp).
+// Returns false when the wait timed out or another workgroup raised `abort` (uniform over the workgroup).
+__device__ __forceinline__ bool grid_barrier(LoopCtl *c, unsigned gen) {
+  __shared__ int s_ok;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const unsigned nb = gridDim.x, sh = blockIdx.x & 15u;
+    const unsigned nshards = nb < 16u ? nb : 16u;
+    int last = 0;
+    if (threadIdx.x == 0) {
+      if (nb <= 32u) {
+        if (__hip_atomic_fetch_add(&c->bar_top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1) {
+          st_u32(&c->bar_top[0], 0u);
+          last = 1;
+        }
+      } else {
+        const unsigned in_shard = (nb - sh + 15u) >> 4;
+        if (__hip_atomic_fetch_add(&c->bar_shard[sh][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+          st_u32(&c->bar_shard[sh][0], 0u);
+          if (__hip_atomic_fetch_add(&c->bar_top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1) {
+            st_u32(&c->bar_top[0], 0u);
+            last = 1;
+          }
+        }
+      }
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    int ok = 1;
+    if (last) {
+      if (threadIdx.x < nshards) st_u32(&c->bar_release[threadIdx.x][0], gen);
+    } else if (threadIdx.x == 0) {
+      const long long t0 = wall_clock64();
+      for (;;) {
+        if (ld_u32(&c->bar_release[sh][0]) >= gen) break;
+        if (ld_u32(&c->abort[0]) != 0u) {
+          ok = 0;
+          break;
+        }
+        if (wall_clock64() - t0 > kLoopTimeoutTicks) {
+          st_u32(&c->abort[0], 1u);
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    if (threadIdx.x == 0) s_ok = ok;
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+
+// The last workgroup to leave the launch puts the control block and both histograms back into their all-zero rest
+// state (nobody polls or reads them any more).
+__device__ __forceinline__ void leave_launch(LoopCtl *c, uint32_t *whist) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(&c->done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  for (unsigned i = threadIdx.x; i < 4u * kWinBins; i += blockDim.x) st_u32(&whist[i], 0u);
+  for (unsigned i = threadIdx.x; i < sizeof(LoopCtl) / sizeof(unsigned); i += blockDim.x)
+    st_u32(reinterpret_cast<unsigned *>(c) + i, 0u);
+}
+
+struct LoopBins {  // what phase B derives from the global counts (identical in every workgroup)
+  WinSel sel;
+  unsigned mlo[2], mhi[2], a0[2], b1[2], i0[2], i1[2];
+  bool fail;
+};
+
+// Phase B, first half: the global histogram (parity buffer `whist`) -> cumulative counts in LDS -> bins of the two
+// middle ranks, bracket of the MAD (gn_win_device.hpp), exactly as win_compact_body<false, true> resolves them.
+__device__ __forceinline__ void loop_resolve(const uint32_t *whist, unsigned n, const WinParams &P, uint32_t *cum,
+                                             LoopBins &R) {
+  __shared__ unsigned s_selu[2][4];
+  __shared__ double s_seld[2][4];
+  __shared__ unsigned s_wtot[2][16];
+  __shared__ int s_rng[2][8];
+  __shared__ int s_t[2][2];
+  constexpr int PER = kWinBins / kReduceThreads, NW = kReduceThreads / 64;
+  static_assert(PER == 4, "four bins per thread");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned v[2][PER], inc[2], tot[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(whist + d * kWinBins) + 2 * tid;
+    const unsigned long long x0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long x1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[d][0] = (unsigned)x0;
+    v[d][1] = (unsigned)(x0 >> 32);
+    v[d][2] = (unsigned)x1;
+    v[d][3] = (unsigned)(x1 >> 32);
+  }
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    tot[d] = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) tot[d] += v[d][i];
+    unsigned s = tot[d];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned t = __shfl_up(s, off);
+      if (lane >= off) s += t;
+    }
+    inc[d] = s;
+    if (lane == 63) s_wtot[d][wave] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    unsigned wbase = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) wbase += (w < wave) ? s_wtot[d][w] : 0u;
+    unsigned run = wbase + inc[d] - tot[d];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      cum[d * kWinBins + PER * tid + i] = run;
+      run += v[d][i];
+    }
+  }
+  __syncthreads();
+  WinGeom geo = {};
+  if (wave < 4) {  // waves 0,1: t1 of x,y; waves 2,3: t2 of x,y
+    const int d = wave & 1, role = wave >> 1;
+    geo = window_geometry(cum + d * kWinBins, n, P.d[d]);
+    const int t = geo.ok ? bracket_search(cum + d * kWinBins, n, P.d[d], geo, role) : -1;
+    if (lane == 0) s_t[role][d] = t;
+  }
+  __syncthreads();
+  if (wave < 2) {
+    const int d = wave;
+    WinRanges W = {};
+    unsigned med_base = 0, med_cnt = 0, inner = 0, ring_cnt = 0;
+    double range[4] = {0., 0., 0., 0.};
+    unsigned counted = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) counted += s_wtot[d][w];
+    const bool ok = counted == n && resolve_window(cum + d * kWinBins, n, P.d[d], geo, s_t[0][d], s_t[1][d], W, med_base,
+                                                   med_cnt, inner, ring_cnt, range);
+    if (lane == 0) {
+      s_rng[d][0] = W.mlo;
+      s_rng[d][1] = W.mhi;
+      s_rng[d][2] = W.a0;
+      s_rng[d][3] = W.b1;
+      s_rng[d][4] = W.i0;
+      s_rng[d][5] = W.i1;
+      s_rng[d][6] = ok ? 0 : 1;
+      s_selu[d][0] = med_base;
+      s_selu[d][1] = med_cnt;
+      s_selu[d][2] = inner;
+      s_selu[d][3] = ring_cnt;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_seld[d][k] = range[k];
+    }
+  }
+  __syncthreads();
+  R.fail = (s_rng[0][6] | s_rng[1][6]) != 0;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    R.sel.med_base[d] = s_selu[d][0];
+    R.sel.med_cnt[d] = s_selu[d][1];
+    R.sel.inner[d] = s_selu[d][2];
+    R.sel.ring_cnt[d] = s_selu[d][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) R.sel.range[d][k] = s_seld[d][k];
+    R.mlo[d] = (unsigned)s_rng[d][0];
+    R.mhi[d] = (unsigned)s_rng[d][1];
+    R.a0[d] = (unsigned)s_rng[d][2];
+    R.b1[d] = (unsigned)s_rng[d][3];
+    R.i0[d] = (unsigned)s_rng[d][4];
+    R.i1[d] = (unsigned)s_rng[d][5];
+  }
+}
+
+#ifdef ICP_LOOP_PROFILE
+#define LOOP_STAMP(slot)                                \
+  do {                                                  \
+    const long long now_ = wall_clock64();              \
+    prof[slot] += now_ - t_last;                        \
+    t_last = now_;                                      \
+  } while (0)
+#else
+#define LOOP_STAMP(slot) ((void)0)
+#endif
+
+struct LoopLocal {  // per workgroup, LDS: the loop's state, replicated
+  Pose Ti;
+  double prev_error;
+  double med[2], sig[2];
+  WinParams P;
+  unsigned applied;
+  int done, status;
+};
+
+}  // namespace
+
+// K = pairs per thread (at most kLoopMaxK): n <= K * gridDim.x * 512.  Dynamic LDS: K x 512 source points, then K x 512
+// matched targets (16 bytes each: a conflict-free ds_read_b128 per lane and point).  The loops over a thread's points
+// are ROLLED: unrolled eight-fold the kernel was 81 KB of code, more than the instruction cache two CUs share, and
+// every phase of every evaluation waited for its own instructions.
+__global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned K) {
+  extern __shared__ double2 s_pts[];
+  // phase A / B: histograms, cumulative counts; phase C: the selection's workspace
+  __shared__ __align__(16) unsigned char s_work[sizeof(SelectLds<2>) > 2 * kWinBins * sizeof(uint32_t) ? sizeof(SelectLds<2>)
+                                                                                                         : 2 * kWinBins * sizeof(uint32_t)];
+  uint32_t *const s_bins = reinterpret_cast<uint32_t *>(s_work);
+  SelectLds<2> &s_sel = *reinterpret_cast<SelectLds<2> *>(s_work);
+  __shared__ double s_med[2][kWinBlkMed], s_ring[2][kWinBlkRing];
+  __shared__ unsigned s_cnt[4], s_base[4];
+  __shared__ double s_tot[kNSum + 1], s_acc[kNAcc + 3];
+  __shared__ WinSel s_ws;
+  __shared__ LoopLocal L;
+  constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
+  const unsigned tid = threadIdx.x, n = A.n;
+  const unsigned G = gridDim.x * kReduceThreads, first = blockIdx.x * kReduceThreads + tid;
+  LoopCtl *const ctl = A.ctl;
+  double2 *const s_a = s_pts, *const s_b = s_pts + (size_t)K * kReduceThreads;
+  // this thread's points: first, first + G, ... (index order: the first level of the reduction tree)
+  const unsigned mine = first < n ? (n - 1u - first) / G + 1u : 0u;
+
+  // ---- the thread's points, once -------------------------------------------------------------------------------
+  for (unsigned k = 0; k < mine; ++k) {
+    const unsigned i = first + k * G;
+    s_a[k * kReduceThreads + tid] = A.a[i];
+    s_b[k * kReduceThreads + tid] = A.b[i];
+  }
+  if (tid < sizeof(WinParams) / sizeof(double))
+    reinterpret_cast<double *>(&L.P)[tid] = reinterpret_cast<const double *>(&A.PA)[tid];
+  if (tid == 0) {
+    L.Ti = A.T0;
+    L.prev_error = A.prev_error0;
+    L.applied = A.applied0;
+    L.done = 0;
+    L.status = 0;
+    L.med[0] = L.med[1] = L.sig[0] = L.sig[1] = 0.;
+  }
+  __syncthreads();
+#ifdef ICP_LOOP_PROFILE
+  long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
+  const long long t_begin = t_last;
+#endif
+  unsigned gen = 0, evals = 0;
+  unsigned it = A.it0;
+  LOOP_STAMP(0);
+  bool aborted = false;
+  for (; it < (unsigned)ICP_INNER_MAX_ITER; ++it, ++evals) {
+    const unsigned par = evals & 1u;
+    uint32_t *const whist = A.whist + (size_t)par * 2 * kWinBins;
+    double *const partials = A.partials + (size_t)par * kReduceMaxBlocks * (kNSum + 1);
+    double *const totals = A.partials + (size_t)2 * kReduceMaxBlocks * (kNSum + 1) + (size_t)par * (kNSum + 1);
+    unsigned *const lcnt = &ctl->list_cnt[par][0][0];
+    const Pose T = pose_sgpr(L.Ti);
+    WinParams P;
+    P.d[0] = windim_sgpr(L.P.d[0]);
+    P.d[1] = windim_sgpr(L.P.d[1]);
+
+    // ---- A: residuals -> histograms + running sums ----------------------------------------------------------------
+    for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads) s_bins[i] = 0;
+    __syncthreads();
+    {
+      double acc[kNSum];
+#pragma unroll
+      for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
+      unsigned edge[4] = {0u, 0u, 0u, 0u};
+      bool saw_nan = false;
+#pragma unroll 2
+      for (unsigned k = 0; k < mine; ++k) {
+        const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
+        // residual(), src/lib.rs:34-36
+        const double v0 = ((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x;
+        const double v1 = ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y;
+        saw_nan |= (v0 != v0) | (v1 != v1);
+        const unsigned j0 = wbin_cold(v0, P.d[0]), j1 = wbin_cold(v1, P.d[1]);
+        if (j0 == 0u) ++edge[0];
+        else if (j0 == (unsigned)(kWinBins - 1)) ++edge[1];
+        else atomicAdd(&s_bins[j0], 1u);
+        if (j1 == 0u) ++edge[2];
+        else if (j1 == (unsigned)(kWinBins - 1)) ++edge[3];
+        else atomicAdd(&s_bins[kWinBins + j1], 1u);
+        accumulate_pair<true>(ak, v0, v1, T, acc);  // (this thread's points in index order: the tree's first level)
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        unsigned v = edge[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
+        if ((tid & 63) == 0 && v) atomicAdd(&s_bins[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
+      }
+      if (saw_nan) atomicOr(&ctl->nan_flag[0], 1u);
+      __syncthreads();
+      LOOP_STAMP(1);
+      for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads) {  // dense flush: contiguous words
+        const uint32_t c = s_bins[i];
+        if (c) atomicAdd(&whist[i], c);
+      }
+      block_reduce_store<kNSum, true>(acc, partials + (size_t)blockIdx.x * (kNSum + 1));
+    }
+    LOOP_STAMP(2);
+    if (!grid_barrier(ctl, ++gen)) {
+      aborted = true;
+      break;
+    }
+    LOOP_STAMP(3);
+
+    // ---- B: bins of the order statistics from the global counts; this workgroup's candidates -----------------------
+    LoopBins R;
+    loop_resolve(whist, n, L.P, s_bins, R);  // (the window from LDS: the bracket indexes it by wave)
+    LOOP_STAMP(4);
+    if (tid < 4) s_cnt[tid] = 0;
+    // the buffers of the NEXT evaluation back to zero (read last before the previous evaluation's second barrier,
+    // written next behind this evaluation's second barrier)
+    {
+      uint32_t *const other = A.whist + (size_t)(par ^ 1u) * 2 * kWinBins;
+      for (unsigned i = first; i < 2u * kWinBins; i += G) st_u32(&other[i], 0u);
+      if (blockIdx.x == 0 && tid < 4) st_u32(&ctl->list_cnt[par ^ 1u][tid][0], 0u);
+    }
+    __syncthreads();
+    if (!R.fail) {
+#pragma unroll 2
+      for (unsigned k = 0; k < mine; ++k) {
+        const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
+        const double v[2] = {((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x, ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y};
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const double r = v[d];
+          const unsigned j = wbin_cold(r, P.d[d]);
+          if (j >= R.mlo[d] && j <= R.mhi[d]) {
+            const unsigned pos = atomicAdd(&s_cnt[d], 1u);
+            if (pos < (unsigned)kWinBlkMed) {
+              s_med[d][pos] = r;
+            } else {
+              const unsigned g = atomicAdd(&lcnt[d * 32], 1u);
+              if (g < (unsigned)kWinCapMed) st_f64(&A.wmed[(size_t)d * kWinCapMed + g], r);
+            }
+          }
+          if (j >= R.a0[d] && j <= R.b1[d] && !(j >= R.i0[d] && j <= R.i1[d])) {
+            const unsigned pos = atomicAdd(&s_cnt[2 + d], 1u);
+            if (pos < (unsigned)kWinBlkRing) {
+              s_ring[d][pos] = r;
+            } else {
+              const unsigned g = atomicAdd(&lcnt[(2 + d) * 32], 1u);
+              if (g < (unsigned)kWinCapRing) st_f64(&A.wring[(size_t)d * kWinCapRing + g], r);
+            }
+          }
+        }
+      }
+    }
+    if (tid == 0) s_ws = R.sel;  // (phase C reads it back: fewer registers live across the barrier)
+    __syncthreads();
+    if (tid < 4) {
+      const unsigned cap = tid < 2 ? kWinBlkMed : kWinBlkRing;
+      const unsigned c = s_cnt[tid] < cap ? s_cnt[tid] : cap;
+      s_base[tid] = c ? atomicAdd(&lcnt[tid * 32], c) : 0u;
+    }
+    __syncthreads();
+    if (tid < 2 * kWinBlkMed) {
+      const int d = tid / kWinBlkMed, e = tid % kWinBlkMed;
+      const unsigned pos = s_base[d] + e;
+      if ((unsigned)e < s_cnt[d] && pos < (unsigned)kWinCapMed) st_f64(&A.wmed[(size_t)d * kWinCapMed + pos], s_med[d][e]);
+    } else if (tid < 2 * kWinBlkMed + 2 * kWinBlkRing) {
+      const int q = tid - 2 * kWinBlkMed, d = q / kWinBlkRing, e = q % kWinBlkRing;
+      const unsigned pos = s_base[2 + d] + e;
+      if ((unsigned)e < s_cnt[2 + d] && pos < (unsigned)kWinCapRing)
+        st_f64(&A.wring[(size_t)d * kWinCapRing + pos], s_ring[d][e]);
+    }
+    // ONE workgroup folds the block sums (they have been complete since the first barrier) and leaves the twenty
+    // totals for everybody: 256 workgroups reading all 256 rows each was 10 MB of same-address traffic per evaluation
+    if (blockIdx.x == gridDim.x - 1) {
+      fold_block_sums_256(partials, (int)gridDim.x, s_tot);
+      __syncthreads();
+      if (tid < kNSum + 1) st_f64(&totals[tid], s_tot[tid]);
+    }
+    const bool b_fail = R.fail;
+    LOOP_STAMP(5);
+    if (!grid_barrier(ctl, ++gen)) {
+      aborted = true;
+      break;
+    }
+    LOOP_STAMP(6);
+
+    // ---- C: the exact statistics, the folded sums, the update -- the same in every workgroup ------------------------
+    bool fail = b_fail;
+    double med[2] = {0., 0.}, sig[2] = {0., 0.};
+    {
+      const unsigned cm[2] = {s_ws.med_cnt[0], s_ws.med_cnt[1]}, cr[2] = {s_ws.ring_cnt[0], s_ws.ring_cnt[1]};
+      double vm[2][PR], vr[2][PR];  // (one instantiation of the selection: both lists in the ring's shape)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+          const unsigned e = tid + u * kReduceThreads;
+          vm[d][u] = (u < PM && !fail && e < cm[d]) ? ld_f64(&A.wmed[(size_t)d * kWinCapMed + e]) : 0.;
+          vr[d][u] = (!fail && e < cr[d]) ? ld_f64(&A.wring[(size_t)d * kWinCapRing + e]) : 0.;
+        }
+      }
+      unsigned got[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) got[k] = ld_u32(&lcnt[k * 32]);
+      const unsigned nan_flag = ld_u32(&ctl->nan_flag[0]);
+      if (tid < kNSum + 1) s_tot[tid] = ld_f64(&totals[tid]);
+      LOOP_STAMP(7);
+      // (the appended counts are cross-checked against the histogram: a mismatch is a miss)
+      fail = fail || got[0] != cm[0] || got[1] != cm[1] || got[2] != cr[0] || got[3] != cr[1];
+      const unsigned klo = (n - 1) / 2, khi = n / 2;
+      if (!fail && !nan_flag) {
+        unsigned long long key[2][2];
+        const double m_lo[2] = {s_ws.range[0][0], s_ws.range[1][0]}, m_hi[2] = {s_ws.range[0][1], s_ws.range[1][1]};
+        const long long mlo[2] = {(long long)klo - s_ws.med_base[0], (long long)klo - s_ws.med_base[1]};
+        const long long mhi[2] = {(long long)khi - s_ws.med_base[0], (long long)khi - s_ws.med_base[1]};
+        select_n_lds<2, PR>(vm, cm, m_lo, m_hi, mlo, mhi, key, fail, s_sel);
+        if (!fail) {
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            med[d] = middle_of(n, key[d][0], key[d][1]);
+#pragma unroll
+            for (int u = 0; u < PR; ++u) vr[d][u] = fabs(vr[d][u] - med[d]);  // src/stats.rs:35
+          }
+          const double r_lo[2] = {s_ws.range[0][2], s_ws.range[1][2]}, r_hi[2] = {s_ws.range[0][3], s_ws.range[1][3]};
+          const long long dlo[2] = {(long long)klo - s_ws.inner[0], (long long)klo - s_ws.inner[1]};
+          const long long dhi[2] = {(long long)khi - s_ws.inner[0], (long long)khi - s_ws.inner[1]};
+          select_n_lds<2, PR>(vr, cr, r_lo, r_hi, dlo, dhi, key, fail, s_sel);
+          if (!fail) {
+            sig[0] = ICP_PPF34 * middle_of(n, key[0][0], key[0][1]);  // src/stats.rs:42-46
+            sig[1] = ICP_PPF34 * middle_of(n, key[1][0], key[1][1]);
+          }
+        }
+      }
+      __syncthreads();  // (s_tot)
+      LOOP_STAMP(8);
+      if (tid < kNAcc) s_acc[tid] = combine_sum(s_tot, (int)tid, sig);
+      __syncthreads();
+      if (tid == 0) {
+        double delta[3];
+        if (nan_flag) {
+          L.done = 1;
+          L.status = 3;
+        } else if (fail) {
+          L.done = 1;
+          L.status = 1;
+        } else {
+          L.med[0] = med[0];
+          L.med[1] = med[1];
+          L.sig[0] = sig[0];
+          L.sig[1] = sig[1];
+          const double err = s_acc[12];
+          if (!solve_update(s_acc, s_acc + 9, delta)) {
+            L.done = 1;  // None, src/lib.rs:67-69
+          } else if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD) {
+            L.done = 1;  // src/lib.rs:71-73
+          } else if (err > L.prev_error) {
+            L.done = 1;  // src/lib.rs:75-78
+          } else {
+            bool in_range;
+            const Pose D = transform_new_in_range(delta, &in_range);
+            if (!in_range) {  // the host repeats this evaluation and applies the update with the C library's sin / cos
+              L.done = 1;
+              L.status = 4;
+            } else {
+              L.prev_error = err;
+              L.Ti = transform_mul(D, L.Ti);  // src/lib.rs:81
+              ++L.applied;
+              L.done = 2;  // (applied: the next evaluation's window is made below)
+            }
+          }
+        }
+        // what the host records as this evaluation's statistics (first / second / most recent of the launch)
+        if (blockIdx.x == 0 && !nan_flag && !fail) {
+          const int slot = evals < 2u ? (int)evals : 2;
+          A.res->med[slot][0] = med[0];
+          A.res->med[slot][1] = med[1];
+          A.res->sigma[slot][0] = sig[0];
+          A.res->sigma[slot][1] = sig[1];
+          if (slot < 2) {
+            A.res->med[2][0] = med[0];
+            A.res->med[2][1] = med[1];
+            A.res->sigma[2][0] = sig[0];
+            A.res->sigma[2][1] = sig[1];
+          }
+        }
+      }
+      __syncthreads();
+      if (L.done == 2) {
+        // the next evaluation's window: the prediction the host made for the loop's second evaluation, else this
+        // evaluation's own statistics
+        if (evals == 0 && A.pb_valid) {
+          if (tid < sizeof(WinParams) / sizeof(double))
+            reinterpret_cast<double *>(&L.P)[tid] = reinterpret_cast<const double *>(&A.PB)[tid];
+          if (tid == 0) L.done = 0;
+        } else if (tid == 0) {
+          if (make_window_hd(L.med, L.sig, A.f_next, &L.P)) {
+            L.done = 0;
+          } else {  // (no usable prediction: the host's pipelines serve the next evaluation)
+            L.done = 1;
+            L.status = 2;
+          }
+        }
+        __syncthreads();
+      }
+      LOOP_STAMP(9);
+    }
+    if (L.done) {
+      // status 0: evaluation `it` ended the loop (it is not counted as applied); 1 / 4: evaluation `it` was not served;
+      // 2: evaluation `it` was served and applied, evaluation `it + 1` has no window
+      if (L.status == 0 || L.status == 2) ++evals;
+      if (L.status == 2) ++it;
+      break;
+    }
+  }
+  if (blockIdx.x == 0 && tid < 64) {
+    LoopResult *res = A.res;
+    if (tid == 0) {
+      res->Ti = L.Ti;
+      res->prev_error = L.prev_error;
+      res->applied = L.applied;
+      res->it = it;
+      res->evals = evals;
+      res->status = aborted ? 5 : L.status;
+      res->finished = (!aborted && L.status == 0) ? 1 : 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) __hip_atomic_store(&res->seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+#ifdef ICP_LOOP_PROFILE
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && (A.seq % 8) == 1)
+    printf("[loop blk %d/%d n %u K %u] evals %u; x10ns: load %lld | A %lld flush+reduce %lld bar1 %lld | resolve %lld cand %lld bar2 %lld | "
+           "loads %lld select %lld solve %lld | all %lld\n", blockIdx.x, gridDim.x, n, K, evals, prof[0], prof[1], prof[2], prof[3],
+           prof[4], prof[5], prof[6], prof[7], prof[8], prof[9], wall_clock64() - t_begin);
+#endif
+  if (!aborted) leave_launch(ctl, A.whist);
+}
+
+bool gn_loop_applies(size_t n) {
+  static const bool off = getenv("ICP_NO_GN_LOOP") != nullptr;
+  int blocks, threads;
+  reduce_geometry(n, &blocks, &threads);
+  return !off && n >= (size_t)(1u << 12) && n <= (size_t)kLoopMaxK * (size_t)blocks * (size_t)threads;
+}
+
+size_t gn_loop_partials_doubles() { return (size_t)2 * kReduceMaxBlocks * (kNSum + 1) + (size_t)2 * (kNSum + 1); }
+
+hipError_t launch_gn_loop(icp_handle *h, const LoopArgs &args) {
+  int blocks, threads;
+  reduce_geometry(args.n, &blocks, &threads);
+  const size_t G = (size_t)blocks * threads;
+  const unsigned K = (unsigned)((args.n + G - 1) / G);
+  // up to 128 KB of dynamic LDS beside ~31 KB of static: granted once per process
+  static int lds_granted = 0;  // 0 not asked yet, 1 yes, -1 refused
+  if (lds_granted == 0) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gn_loop), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             kLoopMaxK * kReduceThreads * 2 * (int)sizeof(double2));
+    lds_granted = e == hipSuccess ? 1 : -1;
+    if (e != hipSuccess) (void)hipGetLastError();
+  }
+  if (lds_granted < 0 || K > (unsigned)kLoopMaxK) return hipErrorInvalidValue;
+  const size_t lds = (size_t)K * kReduceThreads * 2 * sizeof(double2);
+  hipLaunchKernelGGL(k_gn_loop, dim3(blocks), dim3(threads), lds, h->stream, args, K);
+  return hipGetLastError();
+}
+
+}  // namespace icp

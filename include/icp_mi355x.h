@@ -338,6 +338,11 @@ int icp_nn_cert_counters(icp_handle *h, uint64_t out[2]);
  * path returns the same bits; the counters only show that a test exercised what it meant to. */
 int icp_gn_path_counters(icp_handle *h, uint64_t out[6]);
 
+/* ... and the one-launch inner loop (gn_loop.hip: the whole estimate_transform loop, src/lib.rs:59-84, of a pair set of
+ * up to 2^20 in one launch): out[0] launches, out[1] evaluations they served (counted in out[0] of
+ * icp_gn_path_counters as well), out[2] launches that handed an evaluation back to the host-stepped pipelines. */
+int icp_gn_loop_counters(icp_handle *h, uint64_t out[3]);
+
 /* The reference builds a new Icp per frame (examples/scan2d.rs:87, scan3d.rs:130), so icp_destroy
  * keeps the device buffers, streams and pinned memory of up to two handles per process for the
  * next icp_create on the same device (a create then costs its kernels, not its allocations).

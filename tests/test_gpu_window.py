@@ -141,7 +141,8 @@ def test_estimate_uses_the_window_pipeline_and_stays_bit_exact():
     T, idx, inner = icp.estimate(src, I.Transform(), 8, return_info=True)
     tried, missed, short, radix, spec_hit, spec_miss = I.gn_path_counters(icp)
     assert tried > 8 and missed <= tried // 2
-    assert spec_hit + spec_miss > 0  # the outer loop bet on at least one next pose
+    launches, served, _ = I.gn_loop_counters(icp)
+    assert launches >= 7 and served > 8  # the inner loops ran on the device (gn_loop.hip), one launch per outer iteration
     rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, dst, src, O.transform_identity(), 8)
     assert rc == O.OK
     assert np.array_equal(idx, oidx)
@@ -149,18 +150,16 @@ def test_estimate_uses_the_window_pipeline_and_stays_bit_exact():
     assert np.array_equal(T.as_array(), oT.as_array())
 
 
-def test_speculative_search_hits_and_misses_leave_the_result_alone():
-    """A small cloud whose inner loop needs a varying number of updates: the bet on the next pose is
-    sometimes wrong, the discarded search must not leak into the result (indices, inner counts and
-    pose equal the oracle's, bit for bit), and the same run with speculation disabled is identical."""
+def test_inner_loops_of_varying_length_on_the_device_leave_the_result_alone():
+    """A small cloud whose inner loop needs a varying number of updates: every inner loop is one launch
+    (gn_loop.hip) whatever its length; indices, inner counts and pose equal the oracle's, bit for bit."""
     from icp_rust_amd import synth
     n, m = 28_000, 28_000
     src, dst = synth.synthetic_pair(n, m)
     icp = I.Icp3d(dst)
     T, idx, inner = icp.estimate(src, I.Transform(), 12, return_info=True)
-    _, _, _, _, hit, miss = I.gn_path_counters(icp)
-    assert hit + miss > 0
-    assert len(set(int(x) for x in inner)) > 1 or hit > 0
+    launches, served, handbacks = I.gn_loop_counters(icp)
+    assert launches >= 11 and served >= int(np.sum(inner)) and handbacks <= 3
     rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, dst, src, O.transform_identity(), 12)
     assert rc == O.OK
     assert np.array_equal(idx, oidx)
@@ -169,10 +168,10 @@ def test_speculative_search_hits_and_misses_leave_the_result_alone():
 
 
 def test_two_stream_estimate_equals_single_stream_stage_calls_repeatedly():
-    """icp_estimate_device hands evaluations and searches back and forth between the handle's two
-    streams through host waits only; the stage calls run the same iteration on one stream.  Both
-    must agree bit for bit, every time (a hand-over that leaves state in an XCD's L2 shows up
-    here as an occasional mismatch)."""
+    """icp_estimate_device runs every inner loop as one launch whose workgroups hand histograms, candidates
+    and block sums to each other across grid barriers; the stage calls run the same iteration launch by
+    launch.  Both must agree bit for bit, every time (a hand-over that leaves state in an XCD's L2 shows
+    up here as an occasional mismatch)."""
     import torch
 
     from icp_rust_amd import synth
@@ -191,8 +190,7 @@ def test_two_stream_estimate_equals_single_stream_stage_calls_repeatedly():
         T, inner = fused.estimate(d_src, I.Transform(), 10, return_info="inner")
         assert np.array_equal(T.as_array(), T_ref.as_array()), rep
         assert inner.tolist() == inner_ref.tolist(), rep
-    hit, miss = I.gn_path_counters(fused)[4:]
-    assert hit > 0
+    assert I.gn_loop_counters(fused)[0] > 0
 
 
 def test_refined_windows_beyond_4m_points():
