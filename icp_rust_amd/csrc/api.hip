@@ -945,12 +945,13 @@ template <typename Hook>
 static int estimate_transform_loop(icp_handle *h, const double *d_a, const double *d_b, size_t n, Pose *out,
                                    uint32_t *inner_iters, Hook &&second_eval_hook,
                                    hipStream_t eval_stream = nullptr, bool hook_first = false,
-                                   bool first_pre_launched = false, int first_kind = 0, int second_kind = 1) {
+                                   bool first_pre_launched = false, int first_kind = 0, int second_kind = 1,
+                                   bool allow_device_loop = true) {
   Pose T = transform_identity();
   uint32_t applied = 0;
   if (input_size_ok(n)) {
     double prev_error = DBL_MAX;  // f64::MAX, src/lib.rs:63
-    const bool device_loop = !eval_stream && !first_pre_launched && gn_loop_applies(n);
+    const bool device_loop = allow_device_loop && !first_pre_launched && gn_loop_applies(n);
     for (int it = 0; it < ICP_INNER_MAX_ITER; ++it) {
       if (device_loop && !h->ws.loop_off) {
         bool finished = false, served = false;
@@ -1065,11 +1066,14 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   static const bool one_stream_env = getenv("ICP_SPEC_SAME_STREAM") != nullptr;
   static const bool nn_first = getenv("ICP_SPEC_NN_LAST") == nullptr;
   Workspace &w = h->ws;
-  // Pair sets the one-launch inner loop serves (gn_loop.hip) need neither the bet nor the second stream: an outer
-  // iteration is search -> loop launch -> one host wait, whatever the inner loop does.
-  const bool device_loop = gn_loop_applies(n) && !w.loop_off;
+  // Two ways through an outer iteration, chosen per iteration from how the previous inner loop went:
+  //  * it applied exactly ONE update (a settled registration; the benchmark pair): the host steps the two evaluations
+  //    and bets on the pose after the first update -- the search for it runs beside the second evaluation (below);
+  //  * anything else: the inner loop is ONE launch (gn_loop.hip), an iteration is search -> loop launch -> one host
+  //    wait, however many updates the loop applies; no bet.
+  const bool loop_ok = gn_loop_applies(n);
   // with a caller-supplied stream everything stays on that stream
-  const bool two_streams = !device_loop && !no_spec && !one_stream_env && h->stream == h->own_stream;
+  const bool two_streams = !no_spec && !one_stream_env && h->stream == h->own_stream;
   Pose T = *init;
   if (max_iter > 0) {
     const int prc = icp_prepare_source_device(h, d_src, n, init);
@@ -1108,6 +1112,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     }
     spec_valid = false;
     pre_valid = false;
+    const bool device_loop = loop_ok && !w.loop_off && !first_pre_launched && !(two_streams && prev_inner == 1);
     const bool speculate = !device_loop && !no_spec && n > 0 && h->m > 0 && it + 1 < max_iter && prev_inner == 1;
     auto launch_spec = [&](const Pose &T1) -> hipError_t {
       spec_pose = transform_mul(T1, T);  // src/lib.rs:127, 170 -- what the outer loop will compute
@@ -1145,8 +1150,9 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     // high-priority stream and are placed as soon as a CU has room
     w.search_beside_eval = speculate;
     const int rc = estimate_transform_loop(h, A[cur], B[cur], n, &dT, &inner, hook,
-                                           two_streams ? w.spec_stream : nullptr, two_streams && nn_first,
-                                           first_pre_launched, it == 0 ? 3 : 0, it == 0 ? 4 : 1);
+                                           two_streams && !device_loop ? w.spec_stream : nullptr,
+                                           two_streams && nn_first && !device_loop, first_pre_launched, it == 0 ? 3 : 0,
+                                           it == 0 ? 4 : 1, device_loop);
     w.search_beside_eval = false;
     if (rc != ICP_OK) return rc;
     if (inner_iters) inner_iters[it] = inner;

@@ -73,57 +73,60 @@ __device__ __forceinline__ double ld_f64(const double *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// All workgroups of the launch meet here (generation `gen` = 1, 2, ... within the launch).  Arrivals are counted on
-// sixteen shard words + one top word (gn_device.hpp: last_block_arrives has the reasons), the last arriver resets the
-// counters and releases every shard's line; everybody else polls its own shard's line.  Stores and atomics issued
-// before the barrier are drained first (write-through stores + sc1 loads: the hand-off rules of gn_device.hpp).
+__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Grid barriers WITHOUT read-modify-writes.  A counting barrier costs two dependent returning atomics (shard, top), a
+// release store and a poll: four trips to the memory side, 2.5 - 3 us measured.  Here every workgroup owns one 64-bit
+// FLAG WORD per barrier kind and stores (generation | payload) into it once its data is out (stores drained first);
+// wave 0 of every workgroup polls the flag words of all workgroups, four per lane: one store and one poll.  The words
+// a lane saw last are handed back -- the second barrier of an evaluation carries each workgroup's candidate counts in
+// its payload, so the poll that ends the barrier is also the gather of the counts.
 // Returns false when the wait timed out or another workgroup raised `abort` (uniform over the workgroup).
-__device__ __forceinline__ bool grid_barrier(LoopCtl *c, unsigned gen) {
+constexpr unsigned long long kFlagGenMask = 0xffffull;
+__device__ __forceinline__ bool flag_barrier(unsigned long long *flags, LoopCtl *c, unsigned gen, unsigned long long payload,
+                                             unsigned long long *s_seen /* LDS, kReduceMaxBlocks words, or null */) {
   __shared__ int s_ok;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x < 64) {
-    const unsigned nb = gridDim.x, sh = blockIdx.x & 15u;
-    const unsigned nshards = nb < 16u ? nb : 16u;
-    int last = 0;
-    if (threadIdx.x == 0) {
-      if (nb <= 32u) {
-        if (__hip_atomic_fetch_add(&c->bar_top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1) {
-          st_u32(&c->bar_top[0], 0u);
-          last = 1;
-        }
-      } else {
-        const unsigned in_shard = (nb - sh + 15u) >> 4;
-        if (__hip_atomic_fetch_add(&c->bar_shard[sh][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
-          st_u32(&c->bar_shard[sh][0], 0u);
-          if (__hip_atomic_fetch_add(&c->bar_top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1) {
-            st_u32(&c->bar_top[0], 0u);
-            last = 1;
-          }
-        }
-      }
-    }
-    last = __builtin_amdgcn_readfirstlane(last);
+    const unsigned nb = gridDim.x, lane = threadIdx.x;
+    if (lane == 0)
+      __hip_atomic_store(&flags[blockIdx.x], (unsigned long long)gen | (payload << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long seen[4] = {0, 0, 0, 0};
     int ok = 1;
-    if (last) {
-      if (threadIdx.x < nshards) st_u32(&c->bar_release[threadIdx.x][0], gen);
-    } else if (threadIdx.x == 0) {
-      const long long t0 = wall_clock64();
-      for (;;) {
-        if (ld_u32(&c->bar_release[sh][0]) >= gen) break;
-        if (ld_u32(&c->abort[0]) != 0u) {
-          ok = 0;
-          break;
+    const long long t0 = wall_clock64();
+    for (;;) {
+      bool all = true;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned b = lane + 64u * j;
+        if (b < nb) {
+          seen[j] = ld_u64(&flags[b]);
+          all = all && (seen[j] & kFlagGenMask) >= (unsigned long long)gen;
         }
-        if (wall_clock64() - t0 > kLoopTimeoutTicks) {
-          st_u32(&c->abort[0], 1u);
-          ok = 0;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
       }
+      if (__all(all)) break;
+      int stop = 0;
+      if (lane == 0) {
+        if (ld_u32(&c->abort[0]) != 0u) stop = 1;
+        else if (wall_clock64() - t0 > kLoopTimeoutTicks) {
+          st_u32(&c->abort[0], 1u);
+          stop = 1;
+        }
+      }
+      if (__builtin_amdgcn_readfirstlane(stop)) {
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
     }
-    if (threadIdx.x == 0) s_ok = ok;
+    if (s_seen) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s_seen[lane + 64u * j] = (lane + 64u * j < nb) ? seen[j] : 0ull;
+    }
+    if (lane == 0) s_ok = ok;
   }
   __syncthreads();
   return s_ok != 0;
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
   long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
   const long long t_begin = t_last;
 #endif
-  unsigned gen = 0, evals = 0;
+  unsigned evals = 0;
   unsigned it = A.it0;
   LOOP_STAMP(0);
   bool aborted = false;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
       double acc[kNSum];
 #pragma unroll
       for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
-      unsigned edge[4] = {0u, 0u, 0u, 0u};
+      unsigned edge[4] = {0u, 0u, 0u, 0u};  // wave-uniform: points of this WAVE in the catch-all bins {below, above} x {x, y}
       bool saw_nan = false;
 #pragma unroll 2
       for (unsigned k = 0; k < mine; ++k) {
@@ -353,20 +356,21 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
         const double v1 = ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y;
         saw_nan |= (v0 != v0) | (v1 != v1);
         const unsigned j0 = wbin_cold(v0, P.d[0]), j1 = wbin_cold(v1, P.d[1]);
-        if (j0 == 0u) ++edge[0];
-        else if (j0 == (unsigned)(kWinBins - 1)) ++edge[1];
-        else atomicAdd(&s_bins[j0], 1u);
-        if (j1 == 0u) ++edge[2];
-        else if (j1 == (unsigned)(kWinBins - 1)) ++edge[3];
-        else atomicAdd(&s_bins[kWinBins + j1], 1u);
+        // (the catch-all bins hold most of a far-off prediction's points: counted by ballot, not by 64 LDS atomics on
+        // one word -- and not by shuffles: four dependent six-step reductions were a microsecond per evaluation)
+        const bool lo0 = j0 == 0u, hi0 = j0 == (unsigned)(kWinBins - 1), lo1 = j1 == 0u, hi1 = j1 == (unsigned)(kWinBins - 1);
+        edge[0] += (unsigned)__popcll(__ballot(lo0));
+        edge[1] += (unsigned)__popcll(__ballot(hi0));
+        edge[2] += (unsigned)__popcll(__ballot(lo1));
+        edge[3] += (unsigned)__popcll(__ballot(hi1));
+        if (!lo0 && !hi0) atomicAdd(&s_bins[j0], 1u);
+        if (!lo1 && !hi1) atomicAdd(&s_bins[kWinBins + j1], 1u);
         accumulate_pair<true>(ak, v0, v1, T, acc);  // (this thread's points in index order: the tree's first level)
       }
+      if ((tid & 63) == 0) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        unsigned v = edge[k];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
-        if ((tid & 63) == 0 && v) atomicAdd(&s_bins[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
+        for (int k = 0; k < 4; ++k)
+          if (edge[k]) atomicAdd(&s_bins[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], edge[k]);
       }
       if (saw_nan) atomicOr(&ctl->nan_flag[0], 1u);
       __syncthreads();
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
       block_reduce_store<kNSum, true>(acc, partials + (size_t)blockIdx.x * (kNSum + 1));
     }
     LOOP_STAMP(2);
-    if (!grid_barrier(ctl, ++gen)) {
+    if (!flag_barrier(ctl->flag1, ctl, evals + 1u, 0ull, nullptr)) {
       aborted = true;
       break;
     }
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
     }
     const bool b_fail = R.fail;
     LOOP_STAMP(5);
-    if (!grid_barrier(ctl, ++gen)) {
+    if (!flag_barrier(ctl->flag2, ctl, evals + 1u, 0ull, nullptr)) {
       aborted = true;
       break;
     }

@@ -9,9 +9,10 @@ constexpr int kLoopMaxK = 8;  // pairs a thread of the reduction tree keeps in r
 // Device-resident control block of the launch; all zero between launches (the last workgroup to leave resets it).
 // One 128-byte line per word that is polled or hit by atomics.
 struct LoopCtl {
-  unsigned bar_shard[16][32];
-  unsigned bar_top[32];
-  unsigned bar_release[16][32];  // generation of the last completed grid barrier, one copy per shard
+  // one word per workgroup and barrier of an evaluation: (evaluation number | payload << 16), written once per
+  // evaluation by its owner, polled by everybody (gn_loop.hip: flag_barrier)
+  unsigned long long flag1[kReduceMaxBlocks];
+  unsigned long long flag2[kReduceMaxBlocks];
   unsigned abort[32];            // a grid barrier timed out: every workgroup leaves
   unsigned done[32];             // workgroups that have left the launch
   unsigned nan_flag[32];
