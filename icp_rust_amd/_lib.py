@@ -11,6 +11,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 # ICP_MI355X_LIB: load another build of the same library (e.g. the diagnostic one with counters)
+# Ranks that share a device ("virtual ranks", tests) run their one-launch inner loops side by side on streams of their
+# own and wait for each other inside the launches: each stream needs a hardware queue of its own.  The HIP runtime
+# reads this when it starts, so it is set before anything can have touched the GPU (a value of the caller's wins).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LIB_PATH = os.environ.get("ICP_MI355X_LIB") or os.path.join(_HERE, "lib", "libicp_mi355x.so")
 
 OK, NONE, EMPTY_DST, NAN_INPUT, BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, OUT_OF_MEMORY, RETRY_REPLICATED, RETRY_SHARDED = range(10)
@@ -114,6 +118,16 @@ SIGNATURES = {
     "icp_create_multi": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _sz, C.POINTER(C.c_int), C.c_int]),
     "icp_multi_estimate": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
     "icp_multi_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "icp_multi_loop_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "icp_loop_inbox_bytes": (_sz, []),
+    "icp_loop_inbox": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
+    "icp_loop_inbox_ipc_handle": (C.c_int, [_vp, C.c_char_p]),
+    "icp_loop_ipc_open": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "icp_loop_ipc_close": (C.c_int, [_vp]),
+    "icp_shard_loop_connect": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "icp_shard_loop_launch_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint, C.c_uint, C.c_int, C.c_uint32, _pp, C.c_double,
+                                               C.c_int, C.c_int]),
+    "icp_shard_loop_wait": (C.c_int, [_vp, _pp, C.POINTER(C.c_double), _u32p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p]),
     "icp_destroy_multi": (None, [_vp]),
     "icp_synchronize": (C.c_int, [_vp]),
     "icp_profile_enable": (C.c_int, [_vp, C.c_int]),

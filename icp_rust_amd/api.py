@@ -636,6 +636,12 @@ class IcpMulti:
         check(lib().icp_multi_counters(self._h, out), "icp_multi_counters")
         return int(out[0]), int(out[1])
 
+    def loop_counters(self):
+        """(launches per rank, evaluations served, launches that handed an evaluation back) of the one-launch inner loop"""
+        out = (C.c_uint64 * 3)()
+        check(lib().icp_multi_loop_counters(self._h, out), "icp_multi_loop_counters")
+        return tuple(int(x) for x in out)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             lib().icp_destroy_multi(self._h)

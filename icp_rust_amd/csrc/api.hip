@@ -20,6 +20,9 @@ hipError_t launch_sel_init(icp_handle *h, size_t n);
 hipError_t launch_stddevs(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T);
 }  // namespace icp
 
+struct LoopPlan;
+static void free_loop_plan(void *p);
+
 namespace {
 
 int map_hip(hipError_t e) {
@@ -82,6 +85,8 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_rlist_len);
   (void)hipFree(w.d_part_d);
   (void)hipFree(w.d_part_i);
+  (void)hipFree(w.d_loop_inbox);
+  free_loop_plan(w.loop_plan);
   (void)hipFree(w.d_loop_ctl);
   (void)hipFree(w.d_loop_hist);
   (void)hipFree(w.d_loop_part);
@@ -829,36 +834,104 @@ static void record_values(Workspace &w, int kind, const double med[2], const dou
   record_statistics(w, kind, true, r);
 }
 
-// From evaluation *it on, as far as the device gets by itself.  *served = false: nothing was launched (no window
-// prediction for evaluation *it) -- the caller steps once from the host.  Otherwise the loop's state is the launch's:
-// *finished, or evaluation *it is the caller's to serve (a window missed, a rotation beyond the restated sin / cos).
-static int gn_loop_run(icp_handle *h, const double *d_a, const double *d_b, size_t n, int first_kind, int second_kind,
-                       Pose *T, double *prev_error, uint32_t *applied, int *it, bool *finished, bool *served) {
-  Workspace &w = h->ws;
-  *served = *finished = false;
-  auto kind_of = [&](int i) { return i == 0 ? first_kind : (i == 1 ? second_kind : 2); };
-  const int kind0 = kind_of(*it), kind1 = kind_of(*it + 1);
-  adopt_pool_hint(w, kind0);
-  LoopArgs A = {};
-  if (!window_usable(h, n, &A.PA, kind0)) return ICP_OK;
-  const bool own0 = Workspace::kind_has_slot(kind0) && w.win_kind[kind0].valid;
+// What a launch of the device-resident loop is planned with, and what its result is read against: the window
+// predictions for its first two evaluations (taken from the handle's per-kind history, common.hpp: Workspace::win_kind).
+struct LoopPlan {
+  LoopArgs A;
+  int first_kind = 0, second_kind = 1, it0 = 0;
+  bool own0 = false;
   double p_med[2][2], p_sigma[2][2];
+  int kind_of(int i) const { return i == 0 ? first_kind : (i == 1 ? second_kind : 2); }
+};
+
+// false: the handle has no prediction for evaluation `it` (nothing is launched).  `hints`: a handle fresh from the pool
+// may adopt its previous owner's predictions -- never a rank of a sharded registration, whose windows must be the
+// other ranks' (DESIGN.md section 7).
+static bool loop_plan(icp_handle *h, size_t n, int it, int first_kind, int second_kind, bool hints, LoopPlan *pl) {
+  Workspace &w = h->ws;
+  pl->first_kind = first_kind;
+  pl->second_kind = second_kind;
+  pl->it0 = it;
+  pl->A = LoopArgs{};
+  const int kind0 = pl->kind_of(it), kind1 = pl->kind_of(it + 1);
+  if (hints) adopt_pool_hint(w, kind0);
+  if (!window_usable(h, n, &pl->A.PA, kind0, !hints)) return false;
+  pl->own0 = Workspace::kind_has_slot(kind0) && w.win_kind[kind0].valid;
   for (int d = 0; d < 2; ++d) {
-    p_med[0][d] = own0 ? w.win_kind[kind0].med[d] : w.win_med[d];
-    p_sigma[0][d] = own0 ? w.win_kind[kind0].sigma[d] : w.win_sigma[d];
+    pl->p_med[0][d] = pl->own0 ? w.win_kind[kind0].med[d] : w.win_med[d];
+    pl->p_sigma[0][d] = pl->own0 ? w.win_kind[kind0].sigma[d] : w.win_sigma[d];
   }
   // the second evaluation of the launch: the host's own prediction for that KIND of evaluation if it has one (the
   // population after the first update differs from the first one's, common.hpp: Workspace::win_kind), else the launch
   // centres it on its first evaluation like every later one
-  adopt_pool_hint(w, kind1);
+  if (hints) adopt_pool_hint(w, kind1);
   const bool own1 = kind1 != 2 && Workspace::kind_has_slot(kind1) && w.win_kind[kind1].valid;
-  A.pb_valid = own1 && window_usable(h, n, &A.PB, kind1) ? 1 : 0;
-  if (A.pb_valid)
+  pl->A.pb_valid = own1 && window_usable(h, n, &pl->A.PB, kind1, !hints) ? 1 : 0;
+  if (pl->A.pb_valid)
     for (int d = 0; d < 2; ++d) {
-      p_med[1][d] = w.win_kind[kind1].med[d];
-      p_sigma[1][d] = w.win_kind[kind1].sigma[d];
+      pl->p_med[1][d] = w.win_kind[kind1].med[d];
+      pl->p_sigma[1][d] = w.win_kind[kind1].sigma[d];
     }
-  A.f_next = window_half_width(n, w.win_wide);
+  pl->A.f_next = window_half_width(n, w.win_wide);
+  return true;
+}
+
+// The launch's result into the loop's state and the handle's prediction history.  *finished, or evaluation *it is the
+// caller's to serve (a window missed, a rotation beyond the restated sin / cos).
+static int loop_finish(icp_handle *h, const LoopPlan &pl, const LoopResult *res, Pose *T, double *prev_error,
+                       uint32_t *applied, int *it, bool *finished) {
+  Workspace &w = h->ws;
+  *finished = false;
+  ++w.loop_launches;
+  w.loop_evals += res->evals;
+  w.win_tried += res->evals + (res->status == 1 ? 1u : 0u);
+  // the statistics the next predictions are made from, in the order the evaluations ran
+  for (unsigned e = 0; e < res->evals && e < 2u; ++e) {
+    const int kind = pl.kind_of(pl.it0 + (int)e);
+    record_values(w, kind, res->med[e], res->sigma[e]);
+    if (e == 0 || pl.A.pb_valid) {  // back to narrow windows once a kind's statistics have settled (wgn_step)
+      bool &wide = (e == 0 ? pl.own0 : true) ? w.win_kind[kind].wide : w.win_wide;
+      double shift = 0.;
+      for (int d = 0; d < 2; ++d)
+        shift = fmax(shift, (fabs(res->med[e][d] - pl.p_med[e][d]) + fabs(res->sigma[e][d] - pl.p_sigma[e][d])) / pl.p_sigma[e][d]);
+      if (wide && shift < 0.01) wide = false;
+    }
+  }
+  if (res->evals > 2u) {
+    record_values(w, 2, res->med[2], res->sigma[2]);
+    w.win_wide = false;
+  }
+  *T = res->Ti;
+  *prev_error = res->prev_error;
+  *applied = res->applied;
+  if (res->status == 3) {
+    w.gn_dirty = true;
+    return ICP_NAN_INPUT;
+  }
+  if (res->finished) {
+    *finished = true;
+    return ICP_OK;
+  }
+  ++w.loop_handbacks;
+  *it = (int)res->it;
+  if (res->status == 1) {  // evaluation *it missed its window: what a miss leaves behind (wgn_step)
+    ++w.win_missed;
+    const int kind = pl.kind_of(*it);
+    const bool own = Workspace::kind_has_slot(kind) && w.win_kind[kind].valid;
+    (own ? w.win_kind[kind].wide : w.win_wide) = true;
+  }
+  return ICP_OK;
+}
+
+// From evaluation *it on, as far as the device gets by itself.  *served = false: nothing was launched (no window
+// prediction for evaluation *it) -- the caller steps once from the host.
+static int gn_loop_run(icp_handle *h, const double *d_a, const double *d_b, size_t n, int first_kind, int second_kind,
+                       Pose *T, double *prev_error, uint32_t *applied, int *it, bool *finished, bool *served) {
+  Workspace &w = h->ws;
+  *served = *finished = false;
+  LoopPlan pl;
+  if (!loop_plan(h, n, *it, first_kind, second_kind, true, &pl)) return ICP_OK;
+  LoopArgs &A = pl.A;
   HIP_TRY(ensure_loop(h));
   if (w.gn_dirty) {  // (the host-driven pipelines' rest state; the launch itself does not touch it)
     HIP_TRY(launch_sel_init(h, n));
@@ -885,51 +958,195 @@ static int gn_loop_run(icp_handle *h, const double *d_a, const double *d_b, size
     HIP_TRY(wait_seq(h, &res->seq, A.seq));
   }
   *served = true;
-  ++w.loop_launches;
-  w.loop_evals += res->evals;
-  w.win_tried += res->evals + (res->status == 1 ? 1u : 0u);
   if (res->status == 5) {  // not resident: put the scratch back into its rest state and step from the host from now on
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemsetAsync(w.d_loop_ctl, 0, sizeof(LoopCtl), h->stream));
     HIP_TRY(hipMemsetAsync(w.d_loop_hist, 0, (size_t)4 * kWinBins * sizeof(uint32_t), h->stream));
     w.loop_off = true;
   }
-  // the statistics the next predictions are made from, in the order the evaluations ran
-  for (unsigned e = 0; e < res->evals && e < 2u; ++e) {
-    const int kind = kind_of(*it + (int)e);
-    record_values(w, kind, res->med[e], res->sigma[e]);
-    if (e == 0 || A.pb_valid) {  // back to narrow windows once a kind's statistics have settled (wgn_step)
-      bool &wide = (e == 0 ? own0 : true) ? w.win_kind[kind].wide : w.win_wide;
-      double shift = 0.;
-      for (int d = 0; d < 2; ++d)
-        shift = fmax(shift, (fabs(res->med[e][d] - p_med[e][d]) + fabs(res->sigma[e][d] - p_sigma[e][d])) / p_sigma[e][d]);
-      if (wide && shift < 0.01) wide = false;
-    }
+  return loop_finish(h, pl, res, T, prev_error, applied, it, finished);
+}
+
+static void free_loop_plan(void *p) { delete reinterpret_cast<LoopPlan *>(p); }
+
+// ---- ... and over the ranks of a sharded registration (include/icp_mi355x.h section 5b) ---------------------------------
+extern "C" size_t icp_loop_inbox_bytes(void) { return sizeof(LoopInbox); }
+
+extern "C" int icp_loop_inbox(icp_handle *h, int fine_grained, void **d_inbox) {
+  if (!h || !d_inbox) return ICP_BAD_ARGUMENT;
+  Workspace &w = h->ws;
+  HIP_TRY(hipSetDevice(h->device));
+  if (w.d_loop_inbox && w.loop_inbox_fine != (fine_grained != 0)) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipFree(w.d_loop_inbox);
+    w.d_loop_inbox = nullptr;
   }
-  if (res->evals > 2u) {
-    record_values(w, 2, res->med[2], res->sigma[2]);
-    w.win_wide = false;
+  if (!w.d_loop_inbox) {
+    // memory a peer DEVICE writes while this device's kernels poll it must be fine-grained; ranks on one device
+    // (virtual ranks, or processes sharing a GPU through hipIpc) use ordinary device memory
+    if (fine_grained) HIP_TRY(hipExtMallocWithFlags(&w.d_loop_inbox, sizeof(LoopInbox), hipDeviceMallocFinegrained));
+    else HIP_TRY(hipMalloc(&w.d_loop_inbox, sizeof(LoopInbox)));
+    w.loop_inbox_fine = fine_grained != 0;
+    HIP_TRY(hipMemset(w.d_loop_inbox, 0, sizeof(LoopInbox)));
   }
-  *T = res->Ti;
-  *prev_error = res->prev_error;
-  *applied = res->applied;
-  if (res->status == 3) {
-    w.gn_dirty = true;
-    return ICP_NAN_INPUT;
-  }
-  if (res->finished) {
-    *finished = true;
-    return ICP_OK;
-  }
-  ++w.loop_handbacks;
-  *it = (int)res->it;
-  if (res->status == 1) {  // evaluation *it missed its window: what a miss leaves behind (wgn_step)
-    ++w.win_missed;
-    const int kind = kind_of(*it);
-    const bool own = Workspace::kind_has_slot(kind) && w.win_kind[kind].valid;
-    (own ? w.win_kind[kind].wide : w.win_wide) = true;
-  }
+  *d_inbox = w.d_loop_inbox;
   return ICP_OK;
+}
+
+extern "C" int icp_loop_inbox_ipc_handle(icp_handle *h, unsigned char out[64]) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI hands an IPC handle over as 64 bytes");
+  if (!h || !out || !h->ws.d_loop_inbox) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  hipIpcMemHandle_t mh;
+  HIP_TRY(hipIpcGetMemHandle(&mh, h->ws.d_loop_inbox));
+  memcpy(out, &mh, 64);
+  return ICP_OK;
+}
+extern "C" int icp_loop_ipc_open(int device, const unsigned char handle[64], void **d_ptr) {
+  if (!handle || !d_ptr) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(device));
+  hipIpcMemHandle_t mh;
+  memcpy(&mh, handle, 64);
+  HIP_TRY(hipIpcOpenMemHandle(d_ptr, mh, hipIpcMemLazyEnablePeerAccess));
+  return ICP_OK;
+}
+extern "C" int icp_loop_ipc_close(void *d_ptr) {
+  if (!d_ptr) return ICP_OK;
+  HIP_TRY(hipIpcCloseMemHandle(d_ptr));
+  return ICP_OK;
+}
+
+// every rank's inbox as mapped in this process, this rank's own among them; empties the own inbox: the ranks must meet
+// (a barrier of the driver) between their connects and the first launch
+extern "C" int icp_shard_loop_connect(icp_handle *h, int rank, int world, void *const *inboxes) {
+  if (!h || !inboxes || world < 1 || world > kShardMaxWorld || rank < 0 || rank >= world) return ICP_BAD_ARGUMENT;
+  Workspace &w = h->ws;
+  if (!w.d_loop_inbox || inboxes[rank] != w.d_loop_inbox) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemset(w.d_loop_inbox, 0, sizeof(LoopInbox)));
+  for (int q = 0; q < world; ++q) {
+    if (!inboxes[q]) return ICP_BAD_ARGUMENT;
+    w.loop_peers[q] = inboxes[q];
+  }
+  w.loop_rank = rank;
+  w.loop_world = world;
+  HIP_TRY(ensure_loop(h));  // (the pinned result block)
+  w.loop_seq = 0;           // launch numbers restart with the connection
+  memset(w.h_loop_res, 0, sizeof(LoopResult));
+  return ICP_OK;
+}
+
+// The inner loop of a sharded registration from evaluation `it0` on, in one launch per rank (gn_loop.hip:
+// k_gn_loop_shard).  d_a / d_b: this rank's pairs (icp_shard_geometry: compact, fold order); the state is the loop's
+// (src/lib.rs:62-82).  launch_no: 1, 2, ... -- the same number on every rank for the same launch, growing over the life
+// of the connection; eval_base: evaluations the earlier launches of the connection served (every rank's results say the
+// same).  ICP_RETRY_SHARDED: not launched -- no window prediction for evaluation it0, a pair set beyond the launch's
+// size, fewer tree blocks than ranks: the stage calls (icp_shard_eval_*) serve that evaluation; the answer depends on
+// replicated state only, so every rank gives it.
+// nh = 1: the rank of hs[0]; nh = world: ALL ranks (hs[q] = rank q, one device) in one launch on hs[0]'s stream.
+static int shard_loop_launch_common(icp_handle *const *hs, int nh, const double *const *d_a, const double *const *d_b,
+                                    size_t n_total, unsigned launch_no, unsigned eval_base, int it0, uint32_t applied0,
+                                    const icp_pose *Ti, double prev_error, int first_kind, int second_kind) {
+  icp_handle *h0 = hs[0];
+  Workspace &w0 = h0->ws;
+  if (w0.loop_rank < 0 || !w0.d_loop_inbox || (nh != 1 && nh != w0.loop_world)) return ICP_BAD_ARGUMENT;
+  const int world = w0.loop_world;
+  if (!gn_loop_shard_applies(n_total, world)) return ICP_RETRY_SHARDED;  // (before the pointers: a rank without points has none)
+  for (int q = 0; q < nh; ++q) {
+    Workspace &w = hs[q]->ws;
+    if (!d_a[q] || !d_b[q] || w.loop_world != world || (nh > 1 && w.loop_rank != q) || !w.d_loop_inbox) return ICP_BAD_ARGUMENT;
+    if (w.loop_off) return ICP_RETRY_SHARDED;
+  }
+  HIP_TRY(hipSetDevice(h0->device));
+  LoopRankPtrs ptrs = {};
+  for (int q = 0; q < nh; ++q) {
+    Workspace &w = hs[q]->ws;
+    if (!w.loop_plan) w.loop_plan = new (std::nothrow) LoopPlan();
+    if (!w.loop_plan) return ICP_OUT_OF_MEMORY;
+    LoopPlan &pl = *reinterpret_cast<LoopPlan *>(w.loop_plan);
+    if (!loop_plan(hs[q], n_total, it0, first_kind, second_kind, false, &pl)) {
+      if (q > 0) return ICP_HIP_ERROR;  // (the ranks' prediction state diverged: cannot happen)
+      return ICP_RETRY_SHARDED;
+    }
+    if (q > 0) {  // every rank must bin with the same windows
+      const LoopPlan &p0 = *reinterpret_cast<LoopPlan *>(w0.loop_plan);
+      if (memcmp(&pl.A.PA, &p0.A.PA, sizeof(WinParams)) != 0 || pl.A.pb_valid != p0.A.pb_valid ||
+          (pl.A.pb_valid && memcmp(&pl.A.PB, &p0.A.PB, sizeof(WinParams)) != 0) ||
+          memcmp(&pl.A.f_next, &p0.A.f_next, sizeof(double)) != 0)
+        return ICP_HIP_ERROR;
+    }
+    const int r = nh > 1 ? q : w.loop_rank;
+    ptrs.a[r] = (const double2 *)d_a[q];
+    ptrs.b[r] = (const double2 *)d_b[q];
+    ptrs.res[r] = reinterpret_cast<LoopResult *>(w.h_loop_res);
+    w.loop_seq = launch_no;
+  }
+  LoopPlan &pl = *reinterpret_cast<LoopPlan *>(w0.loop_plan);
+  LoopArgs A = pl.A;
+  LoopShardArgs S = {};
+  S.rank = nh > 1 ? 0 : w0.loop_rank;
+  S.world = world;
+  int B = 0;
+  for (int q = 0; q < world; ++q) {
+    int b0, b1;
+    size_t nl;
+    shard_geometry(n_total, q, world, &b0, &b1, &B, &nl);
+    S.first_block[q] = b0;
+    S.first_block[q + 1] = b1;
+    S.inbox[q] = reinterpret_cast<LoopInbox *>(w0.loop_peers[q]);
+  }
+  S.blocks_total = B;
+  S.gen_base = launch_no * 256u;
+  S.eval_base = eval_base;
+  A.n = (unsigned)n_total;
+  A.it0 = (unsigned)it0;
+  A.applied0 = applied0;
+  A.T0 = *Ti;
+  A.prev_error0 = prev_error;
+  A.seq = launch_no;
+  HIP_TRY(launch_gn_loop_shard(h0, A, S, ptrs, nh));
+  return ICP_OK;
+}
+
+extern "C" int icp_shard_loop_launch_device(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, unsigned launch_no,
+                                            unsigned eval_base, int it0, uint32_t applied0, const icp_pose *Ti, double prev_error,
+                                            int first_kind, int second_kind) {
+  if (!h || !Ti || n_total >= 0xffffffffull || it0 < 0 || launch_no == 0) return ICP_BAD_ARGUMENT;
+  return shard_loop_launch_common(&h, 1, &d_a, &d_b, n_total, launch_no, eval_base, it0, applied0, Ti, prev_error, first_kind,
+                                  second_kind);
+}
+
+// (multi.hip) all the ranks of one device in one launch on rank 0's stream
+int icp_shard_loop_launch_fused(icp_handle *const *hs, int world, const double *const *d_a, const double *const *d_b, size_t n_total,
+                                unsigned launch_no, unsigned eval_base, int it0, uint32_t applied0, const icp_pose *Ti,
+                                double prev_error, int first_kind, int second_kind) {
+  if (!hs || world < 1 || world > kShardMaxWorld || !Ti || !d_a || !d_b || n_total >= 0xffffffffull || it0 < 0 || launch_no == 0)
+    return ICP_BAD_ARGUMENT;
+  for (int q = 0; q < world; ++q)
+    if (!hs[q]) return ICP_BAD_ARGUMENT;
+  return shard_loop_launch_common(hs, world, d_a, d_b, n_total, launch_no, eval_base, it0, applied0, Ti, prev_error, first_kind,
+                                  second_kind);
+}
+
+// ... its result (blocks until this rank's launch has published it): the loop's state, *finished, or the evaluation
+// *it that the stage calls must serve before the next launch.  ICP_HIP_ERROR: the launch gave up waiting for a peer.
+extern "C" int icp_shard_loop_wait(icp_handle *h, icp_pose *Ti, double *prev_error, uint32_t *applied, int *it, int *finished,
+                                   uint32_t *evals) {
+  if (!h || !Ti || !prev_error || !applied || !it || !finished || !h->ws.loop_plan) return ICP_BAD_ARGUMENT;
+  Workspace &w = h->ws;
+  HIP_TRY(hipSetDevice(h->device));
+  LoopResult *res = reinterpret_cast<LoopResult *>(w.h_loop_res);
+  HIP_TRY(wait_seq(h, &res->seq, w.loop_seq));
+  if (evals) *evals = res->evals;
+  if (res->status == 5) {
+    w.loop_off = true;
+    return ICP_HIP_ERROR;
+  }
+  bool fin = false;
+  const int rc = loop_finish(h, *reinterpret_cast<LoopPlan *>(w.loop_plan), res, Ti, prev_error, applied, it, &fin);
+  *finished = fin ? 1 : 0;
+  return rc;
 }
 
 // estimate_transform (src/lib.rs:59-84) on device pairs.  Pair sets of up to 2^20 run the loop on the device

@@ -13,6 +13,7 @@ namespace icp {
 
 constexpr int kReduceThreads = 512;   // threads per block of the GN reduction tree
 constexpr int kReduceMaxBlocks = 256;
+constexpr int kShardMaxWorld = 16;  // ranks of one sharded evaluation (a node has 8 GPUs)
 constexpr int kNAcc = 13;             // what a weighted evaluation hands the host: jtj[9], jtr[3], huber error
 // Round 3: the device folds the weighted normal equations PER DIMENSION j, WITHOUT the factor g_j = 1 / sigma_j, and
 // only the upper triangle of J^T W J:
@@ -199,6 +200,13 @@ struct Workspace : GnCtx {
   unsigned loop_seq = 0;
   bool loop_off = false;  // a launch was not resident (its grid barrier timed out): this handle steps from the host
   unsigned long long loop_launches = 0, loop_evals = 0, loop_handbacks = 0;
+  // ... over the ranks of a sharded registration (gn_loop.hpp: LoopInbox): this rank's inbox, every rank's as mapped
+  // here, and the launch in flight (api.hip: icp_shard_loop_launch_device / icp_shard_loop_wait)
+  void *d_loop_inbox = nullptr;
+  bool loop_inbox_fine = false;
+  void *loop_peers[kShardMaxWorld] = {};
+  int loop_rank = -1, loop_world = 0;
+  void *loop_plan = nullptr;  // LoopPlan of the launch in flight (api.hip)
 };
 
 // ---- uniform grid over the target cloud (nn_grid.hip) ------------------------------
@@ -241,7 +249,6 @@ struct Grid {
 };
 
 constexpr int kShardStatusWords = 4;  // behind the 2 x kWinBins histogram words of a sharded evaluation
-constexpr int kShardMaxWorld = 16;  // ranks of one sharded evaluation (a node has 8 GPUs)
 constexpr unsigned kGridPad = 8;  // records past the last target that a quad-aligned read may touch
 
 // sharded evaluation (shard.hip): the head of the block a rank hands to the others, and one pointer per rank
@@ -440,6 +447,7 @@ hipError_t shard_launch_finish_ptrs(icp_handle *h, const void *const *exch_ptrs,
 }  // namespace icp
 int icp_shard_eval_finish_ptrs(icp_handle *h, const void *const *part_ptrs, double delta[3], double *huber_err);
 namespace icp {
+hipError_t multi_unpermute(hipStream_t s, const uint32_t *in, const uint32_t *perm, size_t n, uint32_t *out);
 hipError_t multi_signal(hipStream_t s, unsigned *flag, unsigned value);
 hipError_t multi_wait(hipStream_t s, const unsigned *const *flags, int world, unsigned value, unsigned *err);
 hipError_t multi_sum_hist(hipStream_t s, const void *const *hists, int world, uint32_t *out);

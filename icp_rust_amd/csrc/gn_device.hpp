@@ -250,6 +250,7 @@ __device__ __forceinline__ void fold_block_sums(const double *partials, int bloc
 // thread t takes sums [10 h, 10 h + 10) of row t % 256, h = t / 256, so waves 0-3 and 4-7 each see the rows in the
 // lanes fold_block_sums has them in; the wave sums are left-folded per half, plus the one `+ 0.` that stands for
 // the four all-zero waves of the general form (it only matters for a sum that is -0.).
+template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT>
 __device__ __forceinline__ void fold_block_sums_256(const double *partials, int blocks, double *s_tot) {
   static_assert(kReduceThreads == 512 && (kNSum + 1) == 20 && kReduceMaxBlocks <= 256, "two halves of ten sums, one row per thread");
   constexpr int H = (kNSum + 1) / 2;
@@ -263,7 +264,7 @@ __device__ __forceinline__ void fold_block_sums_256(const double *partials, int 
 #pragma unroll
     for (int k = 0; k < H; ++k)
       x[k] = (half * H + k < kNSum) ? __hip_atomic_load(&partials[(size_t)row * (kNSum + 1) + half * H + k],
-                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                          __ATOMIC_RELAXED, SCOPE)
                                     : 0.;
 #pragma unroll
     for (int k = 0; k < H; ++k) v[k] = v[k] + x[k];

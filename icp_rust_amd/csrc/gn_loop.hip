@@ -29,6 +29,8 @@
 #include "gn_win_device.hpp"
 #include "gn_loop.hpp"
 
+#include <algorithm>
+
 namespace icp {
 
 namespace {
@@ -155,8 +157,11 @@ struct LoopBins {  // what phase B derives from the global counts (identical in 
 
 // Phase B, first half: the global histogram (parity buffer `whist`) -> cumulative counts in LDS -> bins of the two
 // middle ranks, bracket of the MAD (gn_win_device.hpp), exactly as win_compact_body<false, true> resolves them.
+// SHARDED: the counts are the sum of `nsrc` histograms `stride` words apart (every rank's, pushed into this rank's
+// inbox: system-scope loads).
+template <bool SHARDED = false>
 __device__ __forceinline__ void loop_resolve(const uint32_t *whist, unsigned n, const WinParams &P, uint32_t *cum,
-                                             LoopBins &R) {
+                                             LoopBins &R, int nsrc = 1, size_t stride = 0) {
   __shared__ unsigned s_selu[2][4];
   __shared__ double s_seld[2][4];
   __shared__ unsigned s_wtot[2][16];
@@ -166,15 +171,35 @@ __device__ __forceinline__ void loop_resolve(const uint32_t *whist, unsigned n, 
   static_assert(PER == 4, "four bins per thread");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned v[2][PER], inc[2], tot[2];
+  if (!SHARDED) {
 #pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(whist + d * kWinBins) + 2 * tid;
-    const unsigned long long x0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long x1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v[d][0] = (unsigned)x0;
-    v[d][1] = (unsigned)(x0 >> 32);
-    v[d][2] = (unsigned)x1;
-    v[d][3] = (unsigned)(x1 >> 32);
+    for (int d = 0; d < 2; ++d) {
+      const unsigned long long *q = reinterpret_cast<const unsigned long long *>(whist + d * kWinBins) + 2 * tid;
+      const unsigned long long x0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long x1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v[d][0] = (unsigned)x0;
+      v[d][1] = (unsigned)(x0 >> 32);
+      v[d][2] = (unsigned)x1;
+      v[d][3] = (unsigned)(x1 >> 32);
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int i = 0; i < PER; ++i) v[d][i] = 0u;
+    for (int sidx = 0; sidx < nsrc; ++sidx) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const unsigned long long *q =
+            reinterpret_cast<const unsigned long long *>(whist + (size_t)sidx * stride + d * kWinBins) + 2 * tid;
+        const unsigned long long x0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long x1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        v[d][0] += (unsigned)x0;
+        v[d][1] += (unsigned)(x0 >> 32);
+        v[d][2] += (unsigned)x1;
+        v[d][3] += (unsigned)(x1 >> 32);
+      }
+    }
   }
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
@@ -615,6 +640,472 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
   if (!aborted) leave_launch(ctl, A.whist);
 }
 
+// ================================================================================================================
+// The same loop over the ranks of a sharded registration (gn_loop.hpp: LoopInbox has the protocol).  Per evaluation:
+//   A   as above, on this rank's tree blocks; the block sum goes straight into every rank's inbox (row = global block)
+//   L1  local barrier (this rank's workgroups)            -> the rank's histogram is complete
+//   X1  workgroup q pushes it into rank q's inbox, then the rank flag
+//   W1  wait for every rank's flag in the own inbox      -> the global counts = sum of the pushed histograms
+//   B   bins of the order statistics; this workgroup's candidates go into every rank's inbox, then its flag word
+//       (generation | counts)
+//   W2  wait for the flag words of ALL tree blocks in the own inbox -- the poll gathers the counts
+//   C   candidates gathered through the prefix of the counts, block sums folded in global block order, the update:
+//       the same bits on every rank, and the bits of one GPU.
+// Three waits per evaluation instead of two; the host is not involved.
+namespace {
+
+__device__ __forceinline__ unsigned long long ld_sys64(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double ld_sys_f64(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys_f64(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys_u32(unsigned *p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// wave 0 polls `count` (<= 256) flag words until each carries a generation >= gen; the words it saw last go to
+// s_seen (LDS, 256 words) when given.  Callers have drained their stores and stand behind a workgroup barrier.
+__device__ __forceinline__ bool poll_words(const unsigned long long *words, unsigned count, unsigned gen, unsigned *abort_word,
+                                           unsigned long long *s_seen) {
+  __shared__ int s_okw;
+  if (threadIdx.x < 64) {
+    const unsigned lane = threadIdx.x;
+    unsigned long long seen[4] = {0, 0, 0, 0};
+    int ok = 1;
+    const long long t0 = wall_clock64();
+    for (;;) {
+      bool all = true;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned b = lane + 64u * j;
+        if (b < count) {
+          seen[j] = ld_sys64(&words[b]);
+          all = all && (int)((unsigned)seen[j] - gen) >= 0;
+        }
+      }
+      if (__all(all)) break;
+      int stop = 0;
+      if (lane == 0) {
+        if (ld_u32(abort_word) != 0u) stop = 1;
+        else if (wall_clock64() - t0 > kLoopTimeoutTicks) {
+          st_u32(abort_word, 1u);
+          stop = 1;
+        }
+      }
+      if (__builtin_amdgcn_readfirstlane(stop)) {
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (s_seen) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s_seen[lane + 64u * j] = (lane + 64u * j < count) ? seen[j] : 0ull;
+    }
+    if (lane == 0) s_okw = ok;
+  }
+  __syncthreads();
+  return s_okw != 0;
+}
+
+// payload of a candidate flag word (its upper half)
+__device__ __forceinline__ unsigned cand_payload(unsigned mx, unsigned my, unsigned rx, unsigned ry, bool ovf, bool nan) {
+  return mx | (my << 6) | (rx << 12) | (ry << 19) | ((ovf ? 1u : 0u) << 26) | ((nan ? 1u : 0u) << 27);
+}
+__device__ __forceinline__ unsigned payload_count(unsigned p, int k) {
+  return k == 0 ? (p & 63u) : (k == 1 ? ((p >> 6) & 63u) : (k == 2 ? ((p >> 12) & 127u) : ((p >> 19) & 127u)));
+}
+
+}  // namespace
+
+// gridDim.y > 1: several ranks in ONE launch (ranks that share a device -- "virtual ranks": the launches of ranks wait
+// for each other, and more streams than hardware queues would queue one behind the other); blockIdx.y picks the rank,
+// R has each rank's pairs and result block.
+__global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, LoopShardArgs S, LoopRankPtrs R_, unsigned K) {
+  const int rank = S.rank + (int)blockIdx.y;
+  const unsigned nbl = (unsigned)(S.first_block[rank + 1] - S.first_block[rank]);  // this rank's workgroups
+  if (blockIdx.x >= nbl) return;
+  A.a = R_.a[rank];
+  A.b = R_.b[rank];
+  A.res = R_.res[rank];
+  S.b0 = S.first_block[rank];
+  extern __shared__ double2 s_pts[];
+  __shared__ __align__(16) unsigned char s_work[sizeof(SelectLds<2>) > 2 * kWinBins * sizeof(uint32_t) ? sizeof(SelectLds<2>)
+                                                                                                         : 2 * kWinBins * sizeof(uint32_t)];
+  uint32_t *const s_bins = reinterpret_cast<uint32_t *>(s_work);
+  SelectLds<2> &s_sel = *reinterpret_cast<SelectLds<2> *>(s_work);
+  __shared__ double s_med[2][kWinBlkMed], s_ring[2][kWinBlkRing];
+  __shared__ unsigned s_cnt[4];
+  __shared__ double s_tot[kNSum + 1], s_acc[kNAcc + 3], s_row[kNSum + 1];
+  // (the flag words of the second wait and the prefix of their counts overlay the same workspace: they live between
+  // phase B's last look at the cumulative counts and the first selection)
+  unsigned long long *const s_seen = reinterpret_cast<unsigned long long *>(s_work), *const s_incl = s_seen + kReduceMaxBlocks;
+  __shared__ unsigned long long s_wsum[4];
+  __shared__ unsigned s_flags;
+  __shared__ WinSel s_ws;
+  __shared__ LoopLocal L;
+  constexpr int PR = kWinCapRing / kReduceThreads, PM = kWinCapMed / kReduceThreads;
+  const unsigned tid = threadIdx.x, n = A.n;
+  const int W = S.world;
+  const unsigned gb = (unsigned)S.b0 + blockIdx.x, B = (unsigned)S.blocks_total;
+  const unsigned G = B * kReduceThreads, first = gb * kReduceThreads + tid;
+  const unsigned row_w = nbl * kReduceThreads, loc0 = blockIdx.x * kReduceThreads + tid;  // local layout (shard.hip)
+  LoopInbox *const me = S.inbox[rank];
+  double2 *const s_a = s_pts, *const s_b = s_pts + (size_t)K * kReduceThreads;
+  const unsigned mine = first < n ? (n - 1u - first) / G + 1u : 0u;
+  for (unsigned k = 0; k < mine; ++k) {
+    s_a[k * kReduceThreads + tid] = A.a[(size_t)k * row_w + loc0];
+    s_b[k * kReduceThreads + tid] = A.b[(size_t)k * row_w + loc0];
+  }
+  if (tid < sizeof(WinParams) / sizeof(double))
+    reinterpret_cast<double *>(&L.P)[tid] = reinterpret_cast<const double *>(&A.PA)[tid];
+  if (tid == 0) {
+    L.Ti = A.T0;
+    L.prev_error = A.prev_error0;
+    L.applied = A.applied0;
+    L.done = 0;
+    L.status = 0;
+    L.med[0] = L.med[1] = L.sig[0] = L.sig[1] = 0.;
+  }
+  __syncthreads();
+  unsigned evals = 0;
+  unsigned it = A.it0;
+  bool aborted = false;
+  for (; it < (unsigned)ICP_INNER_MAX_ITER; ++it, ++evals) {
+    const unsigned par = (S.eval_base + evals) & 1u;
+    const unsigned gen = S.gen_base + evals + 1u;
+    uint32_t *const whist = me->hist_local[par];
+    const Pose T = pose_sgpr(L.Ti);
+    WinParams P;
+    P.d[0] = windim_sgpr(L.P.d[0]);
+    P.d[1] = windim_sgpr(L.P.d[1]);
+
+    // ---- A ----------------------------------------------------------------------------------------------------------
+    for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads) s_bins[i] = 0;
+    if (tid == 0) s_flags = 0u;
+    __syncthreads();
+    {
+      double acc[kNSum];
+#pragma unroll
+      for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
+      unsigned edge[4] = {0u, 0u, 0u, 0u};
+      bool saw_nan = false;
+#pragma unroll 2
+      for (unsigned k = 0; k < mine; ++k) {
+        const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
+        const double v0 = ((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x;  // residual(), src/lib.rs:34-36
+        const double v1 = ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y;
+        saw_nan |= (v0 != v0) | (v1 != v1);
+        const unsigned j0 = wbin_cold(v0, P.d[0]), j1 = wbin_cold(v1, P.d[1]);
+        const bool lo0 = j0 == 0u, hi0 = j0 == (unsigned)(kWinBins - 1), lo1 = j1 == 0u, hi1 = j1 == (unsigned)(kWinBins - 1);
+        edge[0] += (unsigned)__popcll(__ballot(lo0));
+        edge[1] += (unsigned)__popcll(__ballot(hi0));
+        edge[2] += (unsigned)__popcll(__ballot(lo1));
+        edge[3] += (unsigned)__popcll(__ballot(hi1));
+        if (!lo0 && !hi0) atomicAdd(&s_bins[j0], 1u);
+        if (!lo1 && !hi1) atomicAdd(&s_bins[kWinBins + j1], 1u);
+        accumulate_pair<true>(ak, v0, v1, T, acc);
+      }
+      if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (edge[k]) atomicAdd(&s_bins[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], edge[k]);
+      }
+      if (saw_nan) atomicOr(&s_flags, 2u);
+      __syncthreads();
+      for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads) {
+        const uint32_t c = s_bins[i];
+        if (c) atomicAdd(&whist[i], c);
+      }
+      block_reduce_store<kNSum, false>(acc, s_row);  // (LDS; stored by lanes of wave 0)
+      __syncthreads();
+      // the block sum into every rank's inbox, row = global block: the fold of phase C reads them in block order
+      for (unsigned j = tid; j < (unsigned)W * (kNSum + 1); j += kReduceThreads) {
+        const unsigned q = j / (kNSum + 1), k = j % (kNSum + 1);
+        st_sys_f64(&S.inbox[q]->partials[par][gb][k], k < (unsigned)kNSum ? s_row[k] : 0.);
+      }
+    }
+    // ---- L1: this rank's workgroups ----------------------------------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&me->flag_block[gb], (unsigned long long)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!poll_words(&me->flag_block[S.b0], nbl, gen, &me->abort[0], nullptr)) {
+      aborted = true;
+      break;
+    }
+    // ---- X1: the rank's histogram into every inbox (workgroup q serves rank q) -------------------------------------
+    for (int q = (int)blockIdx.x; q < W; q += (int)nbl) {
+      uint32_t *dst = S.inbox[q]->hist_from[rank][par];
+      for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads) st_sys_u32(&dst[i], ld_u32(&whist[i]));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(&S.inbox[q]->flag_rank[rank], (unsigned long long)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // ---- W1 ----------------------------------------------------------------------------------------------------------
+    if (!poll_words(me->flag_rank, (unsigned)W, gen, &me->abort[0], nullptr)) {
+      aborted = true;
+      break;
+    }
+
+    // ---- B -----------------------------------------------------------------------------------------------------------
+    LoopBins R;
+    loop_resolve<true>(&me->hist_from[0][par][0], n, L.P, s_bins, R, W, (size_t)2 * 2 * kWinBins);
+    if (tid < 4) s_cnt[tid] = 0;
+    {
+      uint32_t *const other = me->hist_local[par ^ 1u];
+      for (unsigned i = loc0; i < 2u * kWinBins; i += row_w) st_u32(&other[i], 0u);
+    }
+    __syncthreads();
+    if (!R.fail) {
+#pragma unroll 2
+      for (unsigned k = 0; k < mine; ++k) {
+        const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
+        const double v[2] = {((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x, ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y};
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const double r = v[d];
+          const unsigned j = wbin_cold(r, P.d[d]);
+          if (j >= R.mlo[d] && j <= R.mhi[d]) {
+            const unsigned pos = atomicAdd(&s_cnt[d], 1u);
+            if (pos < (unsigned)kWinBlkMed) s_med[d][pos] = r;
+          }
+          if (j >= R.a0[d] && j <= R.b1[d] && !(j >= R.i0[d] && j <= R.i1[d])) {
+            const unsigned pos = atomicAdd(&s_cnt[2 + d], 1u);
+            if (pos < (unsigned)kWinBlkRing) s_ring[d][pos] = r;
+          }
+        }
+      }
+    }
+    if (tid == 0) s_ws = R.sel;
+    __syncthreads();
+    {
+      // (more candidates in one workgroup than it can stage -- a run of equal residuals among neighbouring points --
+      // is reported as a miss: the host's pipelines serve such an evaluation)
+      const bool ovf = s_cnt[0] > (unsigned)kWinBlkMed || s_cnt[1] > (unsigned)kWinBlkMed || s_cnt[2] > (unsigned)kWinBlkRing ||
+                       s_cnt[3] > (unsigned)kWinBlkRing;
+      const unsigned c[4] = {ovf ? 0u : s_cnt[0], ovf ? 0u : s_cnt[1], ovf ? 0u : s_cnt[2], ovf ? 0u : s_cnt[3]};
+      for (int q = 0; q < W; ++q) {
+        double *dst = S.inbox[q]->cand[gb];
+        if (tid < 2 * kWinBlkMed) {
+          const int d = tid / kWinBlkMed, e = tid % kWinBlkMed;
+          if ((unsigned)e < c[d]) st_sys_f64(&dst[d * kWinBlkMed + e], s_med[d][e]);
+        } else if (tid < 2 * kWinBlkMed + 2 * kWinBlkRing) {
+          const int x = tid - 2 * kWinBlkMed, d = x / kWinBlkRing, e = x % kWinBlkRing;
+          if ((unsigned)e < c[2 + d]) st_sys_f64(&dst[2 * kWinBlkMed + d * kWinBlkRing + e], s_ring[d][e]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid < (unsigned)W) {
+        const unsigned pay = cand_payload(c[0], c[1], c[2], c[3], ovf || R.fail, (s_flags & 2u) != 0u);
+        __hip_atomic_store(&S.inbox[tid]->flag_cand[gb], (unsigned long long)gen | ((unsigned long long)pay << 32), __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    // ---- W2 ----------------------------------------------------------------------------------------------------------
+    if (!poll_words(me->flag_cand, B, gen, &me->abort[0], s_seen)) {
+      aborted = true;
+      break;
+    }
+
+    // ---- C -----------------------------------------------------------------------------------------------------------
+    bool fail = false;
+    unsigned nan_flag = 0;
+    double med[2] = {0., 0.}, sig[2] = {0., 0.};
+    {
+      // inclusive prefix of the four counts over the tree blocks, 16 bits each in one word
+      unsigned long long v = 0;
+      unsigned pay = 0;
+      if (tid < kReduceMaxBlocks) {
+        pay = (unsigned)(s_seen[tid] >> 32);
+        if (tid < B)
+          v = (unsigned long long)payload_count(pay, 0) | ((unsigned long long)payload_count(pay, 1) << 16) |
+              ((unsigned long long)payload_count(pay, 2) << 32) | ((unsigned long long)payload_count(pay, 3) << 48);
+        else
+          pay = 0;
+      }
+      const int lane = tid & 63, wave = tid >> 6;
+      unsigned long long inc = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+      }
+      if (tid < kReduceMaxBlocks && lane == 63) s_wsum[wave] = inc;
+      const unsigned long long bad = __ballot((pay >> 26) & 1u), nanb = __ballot((pay >> 27) & 1u);
+      if (lane == 0 && tid < kReduceMaxBlocks && (bad | nanb)) atomicOr(&s_flags, (bad ? 4u : 0u) | (nanb ? 8u : 0u));
+      __syncthreads();
+      if (tid < kReduceMaxBlocks) {
+        unsigned long long base = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) base += (w < wave) ? s_wsum[w] : 0ull;
+        s_incl[tid] = base + inc;
+      }
+      __syncthreads();
+      const unsigned long long totals = s_incl[kReduceMaxBlocks - 1];
+      const unsigned tot[4] = {(unsigned)(totals & 0xffffu), (unsigned)((totals >> 16) & 0xffffu), (unsigned)((totals >> 32) & 0xffffu),
+                               (unsigned)(totals >> 48)};
+      fail = (s_flags & 4u) != 0u;
+      nan_flag = (s_flags & 8u) ? 1u : 0u;
+      const unsigned cm[2] = {s_ws.med_cnt[0], s_ws.med_cnt[1]}, cr[2] = {s_ws.ring_cnt[0], s_ws.ring_cnt[1]};
+      // (the gathered counts are cross-checked against the histogram: a mismatch is a miss)
+      fail = fail || tot[0] != cm[0] || tot[1] != cm[1] || tot[2] != cr[0] || tot[3] != cr[1];
+      // element e of list k lives in the block g whose inclusive count first exceeds e
+      auto fetch = [&](int k, unsigned e) -> double {
+        unsigned lo = 0, hi = B - 1;
+        while (lo < hi) {
+          const unsigned mid = (lo + hi) >> 1;
+          if ((unsigned)((s_incl[mid] >> (16 * k)) & 0xffffu) > e) hi = mid;
+          else lo = mid + 1;
+        }
+        const unsigned inc_g = (unsigned)((s_incl[lo] >> (16 * k)) & 0xffffu);
+        const unsigned cnt_g = payload_count((unsigned)(s_seen[lo] >> 32), k);
+        const unsigned off = e - (inc_g - cnt_g);
+        const unsigned basek = k < 2 ? (unsigned)k * kWinBlkMed : 2u * kWinBlkMed + (unsigned)(k - 2) * kWinBlkRing;
+        return ld_sys_f64(&me->cand[lo][basek + off]);
+      };
+      double vm[2][PR], vr[2][PR];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+          const unsigned e = tid + u * kReduceThreads;
+          vm[d][u] = (u < PM && !fail && e < cm[d]) ? fetch(d, e) : 0.;
+          vr[d][u] = (!fail && e < cr[d]) ? fetch(2 + d, e) : 0.;
+        }
+      }
+      fold_block_sums_256<__HIP_MEMORY_SCOPE_SYSTEM>(&me->partials[par][0][0], (int)B, s_tot);
+      __syncthreads();  // (every fetch has read the prefix: the selections may take the workspace)
+      const unsigned klo = (n - 1) / 2, khi = n / 2;
+      if (!fail && !nan_flag) {
+        unsigned long long key[2][2];
+        const double m_lo[2] = {s_ws.range[0][0], s_ws.range[1][0]}, m_hi[2] = {s_ws.range[0][1], s_ws.range[1][1]};
+        const long long mlo[2] = {(long long)klo - s_ws.med_base[0], (long long)klo - s_ws.med_base[1]};
+        const long long mhi[2] = {(long long)khi - s_ws.med_base[0], (long long)khi - s_ws.med_base[1]};
+        select_n_lds<2, PR>(vm, cm, m_lo, m_hi, mlo, mhi, key, fail, s_sel);
+        if (!fail) {
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            med[d] = middle_of(n, key[d][0], key[d][1]);
+#pragma unroll
+            for (int u = 0; u < PR; ++u) vr[d][u] = fabs(vr[d][u] - med[d]);  // src/stats.rs:35
+          }
+          const double r_lo[2] = {s_ws.range[0][2], s_ws.range[1][2]}, r_hi[2] = {s_ws.range[0][3], s_ws.range[1][3]};
+          const long long dlo[2] = {(long long)klo - s_ws.inner[0], (long long)klo - s_ws.inner[1]};
+          const long long dhi[2] = {(long long)khi - s_ws.inner[0], (long long)khi - s_ws.inner[1]};
+          select_n_lds<2, PR>(vr, cr, r_lo, r_hi, dlo, dhi, key, fail, s_sel);
+          if (!fail) {
+            sig[0] = ICP_PPF34 * middle_of(n, key[0][0], key[0][1]);  // src/stats.rs:42-46
+            sig[1] = ICP_PPF34 * middle_of(n, key[1][0], key[1][1]);
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < kNAcc) s_acc[tid] = combine_sum(s_tot, (int)tid, sig);
+      __syncthreads();
+      if (tid == 0) {
+        double delta[3];
+        if (nan_flag) {
+          L.done = 1;
+          L.status = 3;
+        } else if (fail) {
+          L.done = 1;
+          L.status = 1;
+        } else {
+          L.med[0] = med[0];
+          L.med[1] = med[1];
+          L.sig[0] = sig[0];
+          L.sig[1] = sig[1];
+          const double err = s_acc[12];
+          if (!solve_update(s_acc, s_acc + 9, delta)) {
+            L.done = 1;  // None, src/lib.rs:67-69
+          } else if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD) {
+            L.done = 1;  // src/lib.rs:71-73
+          } else if (err > L.prev_error) {
+            L.done = 1;  // src/lib.rs:75-78
+          } else {
+            bool in_range;
+            const Pose D = transform_new_in_range(delta, &in_range);
+            if (!in_range) {
+              L.done = 1;
+              L.status = 4;
+            } else {
+              L.prev_error = err;
+              L.Ti = transform_mul(D, L.Ti);  // src/lib.rs:81
+              ++L.applied;
+              L.done = 2;
+            }
+          }
+        }
+        if (blockIdx.x == 0 && !nan_flag && !fail) {
+          const int slot = evals < 2u ? (int)evals : 2;
+          A.res->med[slot][0] = med[0];
+          A.res->med[slot][1] = med[1];
+          A.res->sigma[slot][0] = sig[0];
+          A.res->sigma[slot][1] = sig[1];
+          if (slot < 2) {
+            A.res->med[2][0] = med[0];
+            A.res->med[2][1] = med[1];
+            A.res->sigma[2][0] = sig[0];
+            A.res->sigma[2][1] = sig[1];
+          }
+        }
+      }
+      __syncthreads();
+      if (L.done == 2) {
+        if (evals == 0 && A.pb_valid) {
+          if (tid < sizeof(WinParams) / sizeof(double))
+            reinterpret_cast<double *>(&L.P)[tid] = reinterpret_cast<const double *>(&A.PB)[tid];
+          if (tid == 0) L.done = 0;
+        } else if (tid == 0) {
+          if (make_window_hd(L.med, L.sig, A.f_next, &L.P)) {
+            L.done = 0;
+          } else {
+            L.done = 1;
+            L.status = 2;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (L.done) {
+      if (L.status == 0 || L.status == 2) ++evals;
+      if (L.status == 2) ++it;
+      break;
+    }
+  }
+  if (blockIdx.x == 0 && tid < 64) {
+    LoopResult *res = A.res;
+    if (tid == 0) {
+      res->Ti = L.Ti;
+      res->prev_error = L.prev_error;
+      res->applied = L.applied;
+      res->it = it;
+      res->evals = evals;
+      res->status = aborted ? 5 : L.status;
+      res->finished = (!aborted && L.status == 0) ? 1 : 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) __hip_atomic_store(&res->seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (!aborted) {  // the last workgroup of THIS rank: its own histograms back to zero (nobody else touches them)
+    __shared__ int s_lastw;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_lastw = __hip_atomic_fetch_add(&me->done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nbl - 1;
+    __syncthreads();
+    if (s_lastw) {
+      for (unsigned i = tid; i < 4u * kWinBins; i += kReduceThreads) st_u32(&me->hist_local[0][0] + i, 0u);
+      if (tid == 0) st_u32(&me->done[0], 0u);
+    }
+  }
+}
+
 bool gn_loop_applies(size_t n) {
   static const bool off = getenv("ICP_NO_GN_LOOP") != nullptr;
   int blocks, threads;
@@ -640,6 +1131,36 @@ hipError_t launch_gn_loop(icp_handle *h, const LoopArgs &args) {
   if (lds_granted < 0 || K > (unsigned)kLoopMaxK) return hipErrorInvalidValue;
   const size_t lds = (size_t)K * kReduceThreads * 2 * sizeof(double2);
   hipLaunchKernelGGL(k_gn_loop, dim3(blocks), dim3(threads), lds, h->stream, args, K);
+  return hipGetLastError();
+}
+
+bool gn_loop_shard_applies(size_t n_total, int world) {
+  static const bool off = getenv("ICP_NO_GN_LOOP") != nullptr;
+  int blocks, threads;
+  reduce_geometry(n_total, &blocks, &threads);
+  return !off && world >= 1 && world <= kShardMaxWorld && blocks >= world && n_total >= (size_t)(1u << 12) &&
+         n_total <= (size_t)kLoopMaxK * (size_t)blocks * (size_t)threads;
+}
+
+hipError_t launch_gn_loop_shard(icp_handle *h, const LoopArgs &args, const LoopShardArgs &sh, const LoopRankPtrs &ptrs, int ranks) {
+  int blocks, threads;
+  reduce_geometry(args.n, &blocks, &threads);
+  const size_t G = (size_t)blocks * threads;
+  const unsigned K = (unsigned)((args.n + G - 1) / G);
+  static int lds_granted = 0;
+  if (lds_granted == 0) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gn_loop_shard),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             kLoopMaxK * kReduceThreads * 2 * (int)sizeof(double2));
+    lds_granted = e == hipSuccess ? 1 : -1;
+    if (e != hipSuccess) (void)hipGetLastError();
+  }
+  int nb = 0;  // the widest of the ranks this launch carries
+  for (int q = sh.rank; q < sh.rank + ranks; ++q) nb = std::max(nb, sh.first_block[q + 1] - sh.first_block[q]);
+  if (lds_granted < 0 || K > (unsigned)kLoopMaxK || nb < 1 || ranks < 1 || sh.rank + ranks > sh.world || sh.blocks_total != blocks)
+    return hipErrorInvalidValue;
+  const size_t lds = (size_t)K * kReduceThreads * 2 * sizeof(double2);
+  hipLaunchKernelGGL(k_gn_loop_shard, dim3(nb, ranks), dim3(threads), lds, h->stream, args, sh, ptrs, K);
   return hipGetLastError();
 }
 

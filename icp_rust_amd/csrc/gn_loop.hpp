@@ -53,7 +53,47 @@ struct LoopArgs {
   unsigned seq;
 };
 
+// ---- the same loop over the ranks of a sharded registration ---------------------------------------------------
+// Rank r owns the reduction-tree blocks [b0, b1) (shard.hip) and launches one workgroup per block; what crosses the
+// ranks travels through INBOXES: one per rank, in that rank's memory, mapped by every peer (peer access between the
+// devices of one process, hipIpc between processes, plain pointers between virtual ranks on one device).  A producer
+// writes its bytes into every rank's inbox and then a flag word; a consumer only ever polls and reads ITS OWN inbox.
+// Flag words carry (generation | payload << 32); generations grow over the launches of a handle (launch number x 256 +
+// evaluation), so nothing has to be reset between launches and a rank that is one launch ahead cannot be mistaken.
+constexpr int kLoopCandPerBlock = 2 * kWinBlkMed + 2 * kWinBlkRing;  // doubles a workgroup may contribute per evaluation
+struct LoopInbox {
+  unsigned long long flag_block[kReduceMaxBlocks];  // own workgroups only: phase A of evaluation g is out (local barrier)
+  unsigned long long flag_rank[kShardMaxWorld];     // rank s has pushed its histogram of evaluation g
+  unsigned long long flag_cand[kReduceMaxBlocks];   // by global block: candidates + block sum of evaluation g are in; payload = counts
+  unsigned abort[32];
+  unsigned done[32];
+  uint32_t hist_local[2][2 * kWinBins];                   // this rank's counts (its workgroups' atomics), by parity
+  uint32_t hist_from[kShardMaxWorld][2][2 * kWinBins];    // ... and every rank's, pushed
+  double partials[2][kReduceMaxBlocks][kNSum + 1];        // block sums by global block, by parity
+  double cand[kReduceMaxBlocks][kLoopCandPerBlock];       // med x | med y | ring x | ring y of every workgroup
+};
+
+struct LoopShardArgs {
+  int rank, world;
+  int b0;                // (set by the kernel) first tree block of the workgroup's rank; its workgroup j is tree block b0 + j
+  int blocks_total;      // reduce_geometry(n_total)
+  int first_block[kShardMaxWorld + 1];  // tree blocks of rank s: [first_block[s], first_block[s + 1])
+  unsigned gen_base;     // launch number x 256
+  unsigned eval_base;    // evaluations the handle's earlier launches ran (parity of the double buffers continues)
+  LoopInbox *inbox[kShardMaxWorld];  // every rank's inbox as mapped here; inbox[rank] is this rank's own
+};
+
 bool gn_loop_applies(size_t n);
+bool gn_loop_shard_applies(size_t n_total, int world);
+// a.n = the points of the WHOLE registration; a.a / a.b = this rank's pairs (shard.hip: compact, fold order)
+// each rank's pairs and pinned result block (indexed by rank)
+struct LoopRankPtrs {
+  const double2 *a[kShardMaxWorld], *b[kShardMaxWorld];
+  LoopResult *res[kShardMaxWorld];
+};
+// `ranks` ranks, s.rank first, in one launch on h's stream (1 between devices and processes; all of them for ranks that
+// share a device)
+hipError_t launch_gn_loop_shard(icp_handle *h, const LoopArgs &a, const LoopShardArgs &s, const LoopRankPtrs &ptrs, int ranks);
 size_t gn_loop_partials_doubles();
 hipError_t launch_gn_loop(icp_handle *h, const LoopArgs &args);
 

@@ -27,6 +27,17 @@
 
 using namespace icp;
 
+extern "C" int icp_loop_inbox(icp_handle *h, int fine_grained, void **d_inbox);
+extern "C" int icp_shard_loop_connect(icp_handle *h, int rank, int world, void *const *inboxes);
+extern "C" int icp_shard_loop_launch_device(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, unsigned launch_no,
+                                            unsigned eval_base, int it0, uint32_t applied0, const icp_pose *Ti, double prev_error,
+                                            int first_kind, int second_kind);
+extern "C" int icp_shard_loop_wait(icp_handle *h, icp_pose *Ti, double *prev_error, uint32_t *applied, int *it, int *finished,
+                                   uint32_t *evals);
+int icp_shard_loop_launch_fused(icp_handle *const *hs, int world, const double *const *d_a, const double *const *d_b, size_t n_total,
+                                unsigned launch_no, unsigned eval_base, int it0, uint32_t applied0, const icp_pose *Ti,
+                                double prev_error, int first_kind, int second_kind);
+
 struct icp_multi {
   int world = 0, dim = 0;
   size_t m = 0;
@@ -49,9 +60,14 @@ struct icp_multi {
   // rank 0's device: the whole source cloud, its sorted copy and the permutation (the fold order of the call)
   double *d_sort_in = nullptr, *d_sort_out = nullptr;
   uint32_t *d_sort_perm = nullptr;
+  uint32_t *d_idx_full = nullptr, *d_idx_out = nullptr;  // the last search's indices: fold order / the caller's order
   size_t cap_sort = 0;
   unsigned seq = 0;  // generation of the exchanges
   uint64_t sharded = 0, replicated = 0;
+  // the inner loop as one launch per rank (gn_loop.hip: k_gn_loop_shard; api.hip: icp_shard_loop_*)
+  bool loop_ok = false;
+  unsigned loop_launch = 0, loop_evals = 0;
+  uint64_t loop_launches = 0, loop_served = 0, loop_handbacks = 0;
 };
 
 namespace {
@@ -230,6 +246,85 @@ int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta
   return rcr;
 }
 
+// The inner loop from evaluation *k on as ONE launch per rank: two enqueues per rank and OUTER iteration (search, loop),
+// no host wait inside the loop; the ranks exchange histograms, candidates and block sums through their inboxes from
+// inside the launches.  *served = false: nothing was launched (every rank said so: no window prediction yet, or the
+// pair set does not fit) -- evaluate() steps evaluation *k.
+int multi_loop(icp_multi *M, size_t n_total, Pose *Ti, double *prev_error, uint32_t *applied, int *k, bool *finished, bool *served) {
+  const int W = M->world;
+  *served = *finished = false;
+  const unsigned launch_no = M->loop_launch + 1;
+  int launched = 0;
+  if (M->one_device) {
+    // ranks that share a device: ALL of them in one launch on their shared stream, behind the searches (the launches of
+    // ranks wait for each other: as separate launches they would need a hardware queue each)
+    icp_handle *hs[kShardMaxWorld];
+    const double *as[kShardMaxWorld], *bs[kShardMaxWorld];
+    for (int q = 0; q < W; ++q) {
+      hs[q] = M->r[q].h;
+      as[q] = M->r[q].d_a;
+      bs[q] = M->r[q].d_b;
+    }
+    const int rc = icp_shard_loop_launch_fused(hs, W, as, bs, n_total, launch_no, M->loop_evals, *k, *applied, Ti, *prev_error, 0, 1);
+    if (rc == ICP_OK) launched = W;
+    else if (rc != ICP_RETRY_SHARDED) return rc;
+  } else {
+    for (int q = 0; q < W; ++q) {
+      auto &R = M->r[q];
+      const int rc = icp_shard_loop_launch_device(R.h, R.d_a, R.d_b, n_total, launch_no, M->loop_evals, *k, *applied, Ti, *prev_error, 0, 1);
+      if (rc == ICP_OK) ++launched;
+      else if (rc != ICP_RETRY_SHARDED) return rc;
+    }
+  }
+  if (launched == 0) return ICP_OK;
+  if (launched != W) {  // cannot happen: the answer depends on replicated state only
+    M->loop_ok = false;
+    MULTI_FAIL("the ranks disagreed about launching the inner loop");
+  }
+  M->loop_launch = launch_no;
+  ++M->loop_launches;
+  *served = true;
+  Pose T0 = *Ti;
+  double pe0 = *prev_error;
+  uint32_t ap0 = *applied, ev0 = 0;
+  int k0 = *k, fin0 = 0, rc0 = ICP_OK;
+  for (int q = 0; q < W; ++q) {
+    auto &R = M->r[q];
+    Pose Tq = *Ti;
+    double pe = *prev_error;
+    uint32_t ap = *applied, ev = 0;
+    int kq = *k, fin = 0;
+    const int rc = icp_shard_loop_wait(R.h, &Tq, &pe, &ap, &kq, &fin, &ev);
+    if (rc == ICP_HIP_ERROR) {
+      M->loop_ok = false;
+      MULTI_FAIL("an inner-loop launch gave up waiting for a peer");
+    }
+    if (q == 0) {
+      T0 = Tq;
+      pe0 = pe;
+      ap0 = ap;
+      ev0 = ev;
+      k0 = kq;
+      fin0 = fin;
+      rc0 = rc;
+    } else if (rc != rc0 || memcmp(&Tq, &T0, sizeof(Pose)) != 0 || memcmp(&pe, &pe0, sizeof(double)) != 0 || ap != ap0 || ev != ev0 ||
+               kq != k0 || fin != fin0) {
+      M->loop_ok = false;
+      MULTI_FAIL("the ranks finished an inner-loop launch differently");
+    }
+  }
+  M->loop_evals += ev0;
+  M->loop_served += ev0;
+  if (rc0 != ICP_OK) return rc0;
+  *Ti = T0;
+  *prev_error = pe0;
+  *applied = ap0;
+  *k = k0;
+  *finished = fin0 != 0;
+  if (!*finished) ++M->loop_handbacks;
+  return ICP_OK;
+}
+
 }  // namespace
 
 extern "C" void icp_destroy_multi(icp_multi *M) {
@@ -261,6 +356,8 @@ extern "C" void icp_destroy_multi(icp_multi *M) {
   (void)hipFree(M->d_sort_in);
   (void)hipFree(M->d_sort_out);
   (void)hipFree(M->d_sort_perm);
+  (void)hipFree(M->d_idx_full);
+  (void)hipFree(M->d_idx_out);
   delete M;
 }
 
@@ -317,6 +414,13 @@ extern "C" int icp_create_multi(icp_multi **out, int dim, const double *dst, siz
   }
   if (rc == ICP_OK && M->one_device)  // ranks on one device share one stream: lockstep order, no waiting
     for (int q = 1; q < n_devices; ++q) rc = rc == ICP_OK ? icp_set_stream(M->r[q].h, M->r[0].h->stream) : rc;
+  // the one-launch inner loop: every rank's inbox mapped on every rank (plain pointers: one process)
+  if (rc == ICP_OK && getenv("ICP_MULTI_NO_LOOP") == nullptr) {
+    void *boxes[kShardMaxWorld] = {};
+    for (int q = 0; q < n_devices && rc == ICP_OK; ++q) rc = icp_loop_inbox(M->r[q].h, M->one_device ? 0 : 1, &boxes[q]);
+    for (int q = 0; q < n_devices && rc == ICP_OK; ++q) rc = icp_shard_loop_connect(M->r[q].h, q, n_devices, boxes);
+    M->loop_ok = rc == ICP_OK;
+  }
   if (rc != ICP_OK) {
     icp_destroy_multi(M);
     return rc;
@@ -341,8 +445,15 @@ extern "C" size_t icp_multi_target_count(const icp_multi *M) { return M ? M->m :
 
 extern "C" int icp_multi_counters(const icp_multi *M, uint64_t out[2]) {
   if (!M || !out) return ICP_BAD_ARGUMENT;
-  out[0] = M->sharded;
+  out[0] = M->sharded + M->loop_served;  // evaluations that ran sharded: stepped from the host, or inside a loop launch
   out[1] = M->replicated;
+  return ICP_OK;
+}
+extern "C" int icp_multi_loop_counters(const icp_multi *M, uint64_t out[3]) {
+  if (!M || !out) return ICP_BAD_ARGUMENT;
+  out[0] = M->loop_launches;
+  out[1] = M->loop_served;
+  out[2] = M->loop_handbacks;
   return ICP_OK;
 }
 
@@ -376,7 +487,7 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
   // where one handle would keep the caller's order), and every rank compacts its blocks' points out of the
   // sorted copy on its own device -- a peer read over xGMI between devices; nothing returns to the host
   // (a first version dealt the shards on the host: two more 24 MB pageable transfers per call).
-  std::vector<uint32_t> perm_host;
+  bool sorted = false;
   std::vector<size_t> n_local(W);
   const double *d_full = nullptr;
   if (n > 0) {
@@ -386,13 +497,17 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
       (void)hipFree(M->d_sort_in);
       (void)hipFree(M->d_sort_out);
       (void)hipFree(M->d_sort_perm);
+      (void)hipFree(M->d_idx_full);
+      (void)hipFree(M->d_idx_out);
       M->d_sort_in = M->d_sort_out = nullptr;
-      M->d_sort_perm = nullptr;
+      M->d_sort_perm = M->d_idx_full = M->d_idx_out = nullptr;
       M->cap_sort = 0;
       const size_t cap = n + n / 8 + 1;
       HIP_TRY(hipMalloc(&M->d_sort_in, cap * 3 * sizeof(double)));
       HIP_TRY(hipMalloc(&M->d_sort_out, cap * 3 * sizeof(double)));
       HIP_TRY(hipMalloc(&M->d_sort_perm, cap * sizeof(uint32_t)));
+      HIP_TRY(alloc_export((void **)&M->d_idx_full, cap * sizeof(uint32_t), !M->one_device));
+      HIP_TRY(hipMalloc(&M->d_idx_out, cap * sizeof(uint32_t)));
       M->cap_sort = cap;
     }
     HIP_TRY(hipMemcpyAsync(M->d_sort_in, src, n * dim * sizeof(double), hipMemcpyHostToDevice, R0.h->stream));
@@ -400,10 +515,7 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
     if (max_iter > 0) {
       ICP_TRY(icp_sort_source_device(R0.h, M->d_sort_in, n, init, M->d_sort_out, M->d_sort_perm));
       d_full = M->d_sort_out;
-      if (last_idx) {
-        perm_host.resize(n);
-        HIP_TRY(hipMemcpyAsync(perm_host.data(), M->d_sort_perm, n * sizeof(uint32_t), hipMemcpyDeviceToHost, R0.h->stream));
-      }
+      sorted = true;
     }
     HIP_TRY(hipStreamSynchronize(R0.h->stream));  // the peers read the sorted cloud
   }
@@ -428,6 +540,11 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
     if (n >= 2) {
       double prev_error = DBL_MAX;
       for (int k = 0; k < ICP_INNER_MAX_ITER; ++k) {
+        if (M->loop_ok) {
+          bool finished = false, served = false;
+          ICP_TRY(multi_loop(M, n, &Ti, &prev_error, &applied, &k, &finished, &served));
+          if (finished || k >= ICP_INNER_MAX_ITER) break;
+        }
         double delta[3], err = 0.;
         const int rc = evaluate(M, n, Ti, k < 2 ? k : 2, delta, &err);
         if (rc == ICP_NONE) break;
@@ -442,25 +559,27 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
     if (inner_iters) inner_iters[it] = applied;
     T = transform_mul(Ti, T);
   }
+  // the last search's indices back to the caller's point order, on the devices: every rank puts its slice into rank 0's
+  // fold-order array (a peer write between devices), rank 0 un-permutes, one transfer to the host
+  const bool want_idx = last_idx && max_iter > 0 && n > 0;
   for (int q = 0; q < W; ++q) {
     auto &R = M->r[q];
     HIP_TRY(hipSetDevice(R.device));
+    if (want_idx && n_local[q]) HIP_TRY(launch_shard_copy(R.h, R.d_idx, M->d_idx_full, n, q, W, 1u, false));
     HIP_TRY(hipStreamSynchronize(R.h->stream));
     R.h->qsort.valid = false;
     R.h->qsort.have_prev = false;
-    if (last_idx && max_iter > 0 && n_local[q]) {  // back to the caller's point order
-      std::vector<uint32_t> li(n_local[q]);
-      HIP_TRY(hipMemcpy(li.data(), R.d_idx, n_local[q] * sizeof(uint32_t), hipMemcpyDeviceToHost));
-      int b0, b1, B;
-      size_t nl;
-      shard_geometry(n, q, W, &b0, &b1, &B, &nl);
-      const size_t G = (size_t)B * kReduceThreads, c0 = (size_t)b0 * kReduceThreads, c1 = (size_t)b1 * kReduceThreads;
-      size_t l = 0;
-      for (size_t base = 0; base < n; base += G) {
-        const size_t s = base + c0, e = base + c1 < n ? base + c1 : n;
-        for (size_t i = s; i < e; ++i) last_idx[perm_host.empty() ? i : perm_host[i]] = li[l++];
-      }
+  }
+  if (want_idx) {
+    auto &R0 = M->r[0];
+    HIP_TRY(hipSetDevice(R0.device));
+    const uint32_t *d_res = M->d_idx_full;
+    if (sorted) {
+      HIP_TRY(multi_unpermute(R0.h->stream, M->d_idx_full, M->d_sort_perm, n, M->d_idx_out));
+      d_res = M->d_idx_out;
     }
+    HIP_TRY(hipMemcpyAsync(last_idx, d_res, n * sizeof(uint32_t), hipMemcpyDeviceToHost, R0.h->stream));
+    HIP_TRY(hipStreamSynchronize(R0.h->stream));
   }
   *out = T;
   return ICP_OK;

@@ -247,6 +247,18 @@ __global__ void k_multi_put_pairs(const double2 *__restrict__ a_loc, const doubl
   b_full[i] = b_loc[l];
 }
 
+__global__ void k_multi_unpermute(const uint32_t *__restrict__ in, const uint32_t *__restrict__ perm, unsigned n,
+                                  uint32_t *__restrict__ out) {
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[perm[k]] = in[k];
+}
+// out[perm[k]] = in[k]: indices in fold order back to the caller's order
+hipError_t multi_unpermute(hipStream_t s, const uint32_t *in, const uint32_t *perm, size_t n, uint32_t *out) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_multi_unpermute, dim3(((unsigned)n + 255) / 256), dim3(256), 0, s, in, perm, (unsigned)n, out);
+  return hipGetLastError();
+}
+
 hipError_t multi_signal(hipStream_t s, unsigned *flag, unsigned value) {
   hipLaunchKernelGGL(k_multi_signal, dim3(1), dim3(1), 0, s, flag, value);
   return hipGetLastError();

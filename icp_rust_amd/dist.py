@@ -85,12 +85,35 @@ class TorchComm:
             recvs[0].view(-1).copy_(sends[0].view(-1))
 
 
+    def all_gather_object(self, objs):
+        """every rank's objs[0], rank order"""
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return [objs[0]]
+        out = [None] * self.world
+        dist.all_gather_object(out, objs[0], group=self.group)
+        return out
+
+    def barrier(self):
+        import torch.distributed as dist
+
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+
 class LocalComm:
     """All ranks live in this process (virtual ranks): the exchanges are plain copies."""
 
     def __init__(self, world):
         self.world = world
         self.local_ranks = list(range(world))
+
+    def all_gather_object(self, objs):
+        return list(objs)
+
+    def barrier(self):
+        pass
 
     def sum_(self, bufs):
         total = bufs[0].clone()
@@ -200,6 +223,40 @@ class HipStages:
     def eval_compact(self, exch_out):
         return lib().icp_shard_eval_compact_device(self.icp._h, C.c_void_p(exch_out.data_ptr()))
 
+    # -- the inner loop as one launch per rank (include/icp_mi355x.h section 5b) --
+    def loop_inbox(self, fine_grained=False):
+        """device pointer of this rank's inbox (allocated on first use)"""
+        ptr = C.c_void_p()
+        _lib.check(lib().icp_loop_inbox(self.icp._h, int(fine_grained), C.byref(ptr)), "icp_loop_inbox")
+        return int(ptr.value)
+
+    def loop_ipc_handle(self):
+        buf = C.create_string_buffer(64)
+        _lib.check(lib().icp_loop_inbox_ipc_handle(self.icp._h, buf), "icp_loop_inbox_ipc_handle")
+        return bytes(buf.raw)
+
+    def loop_ipc_open(self, handle, device):
+        ptr = C.c_void_p()
+        _lib.check(lib().icp_loop_ipc_open(int(device), C.create_string_buffer(handle, 64), C.byref(ptr)), "icp_loop_ipc_open")
+        return int(ptr.value)
+
+    def loop_connect(self, rank, world, inbox_ptrs):
+        arr = (C.c_void_p * world)(*[C.c_void_p(int(p)) for p in inbox_ptrs])
+        _lib.check(lib().icp_shard_loop_connect(self.icp._h, rank, world, arr), "icp_shard_loop_connect")
+
+    def loop_launch(self, a, b, n_total, launch_no, eval_base, it0, applied, Ti, prev_error, first_kind=0, second_kind=1):
+        return lib().icp_shard_loop_launch_device(self.icp._h, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), n_total,
+                                                  launch_no, eval_base, it0, applied, C.byref(Ti.pose), prev_error,
+                                                  first_kind, second_kind)
+
+    def loop_wait(self):
+        """(rc, Ti, prev_error, applied, it, finished, evaluations served)"""
+        Ti = Transform()
+        pe, ap, it, fin, ev = C.c_double(0.0), C.c_uint32(0), C.c_int(0), C.c_int(0), C.c_uint32(0)
+        rc = lib().icp_shard_loop_wait(self.icp._h, C.byref(Ti.pose), C.byref(pe), C.byref(ap), C.byref(it), C.byref(fin),
+                                       C.byref(ev))
+        return rc, Ti, pe.value, ap.value, it.value, bool(fin.value), ev.value
+
     def eval_finish(self, exch_all):
         delta = np.zeros(3)
         err = C.c_double(0.0)
@@ -236,6 +293,64 @@ class BlockShardedIcp:
         self.geom = {r: block_shard(n_total, r, world) for r in range(world)}
         self.n_local_max = max(g[3] for g in self.geom.values())
         self.counters = {"sharded": 0, "replicated": 0}
+
+    def connect_loop(self, fine_grained=False):
+        """Collective over the ranks: map every rank's inbox on every rank, so that an inner loop is ONE launch per rank
+        whose workgroups exchange histograms, candidates and block sums through memory (include/icp_mi355x.h section 5b;
+        gn_loop.hip).  Ranks of one process hand each other plain pointers; across processes the inboxes travel as
+        hipIpc handles (one small all_gather_object at connect time -- nothing of the per-iteration path goes through
+        torch.distributed any more, only evaluations the launch hands back).  fine_grained: for ranks on DISTINCT
+        devices of one process (peer access); hipIpc takes ordinary device memory."""
+        import os
+
+        mine = {rk.rank: rk.stages.loop_inbox(fine_grained) for rk in self.ranks}
+        if isinstance(self.comm, LocalComm):
+            ptrs_for = {rk.rank: [mine[r] for r in range(self.world)] for rk in self.ranks}
+        else:
+            rk = self.ranks[0]
+            infos = self.comm.all_gather_object([(os.getpid(), rk.stages.loop_ipc_handle(), mine[rk.rank])])
+            dev = rk.stages.torch.cuda.current_device()
+            ptrs = []
+            for r, (pid, handle, raw) in enumerate(infos):
+                if r == rk.rank:
+                    ptrs.append(mine[rk.rank])
+                elif pid == os.getpid():
+                    ptrs.append(raw)
+                else:
+                    ptrs.append(rk.stages.loop_ipc_open(handle, dev))
+            ptrs_for = {rk.rank: ptrs}
+        for rk in self.ranks:
+            rk.stages.loop_connect(rk.rank, self.world, ptrs_for[rk.rank])
+        self.comm.barrier()  # (a connect empties the own inbox: nobody may launch before everybody has connected)
+        self._loop = dict(launch=0, evals=0)
+        self.counters.update(loop_launches=0, loop_served=0, loop_handbacks=0)
+
+    def _loop_run(self, Ti, prev_error, applied, it):
+        """the inner loop from evaluation `it` on as one launch per local rank; None: nothing was launched"""
+        L = self._loop
+        launch_no = L["launch"] + 1
+        rcs = []
+        for rk in self.ranks:
+            nl = self.geom[rk.rank][3]
+            rcs.append(rk.stages.loop_launch(rk.bufs["a"][:nl], rk.bufs["b"][:nl], self.n, launch_no, L["evals"], it, applied, Ti,
+                                             prev_error))
+        if all(rc == _lib.RETRY_SHARDED for rc in rcs):
+            return None
+        for rc in rcs:
+            _lib.check(rc, "icp_shard_loop_launch_device")
+        L["launch"] = launch_no
+        outs = [rk.stages.loop_wait() for rk in self.ranks]
+        for o in outs:
+            _lib.check(o[0], "icp_shard_loop_wait", allow=(_lib.NAN_INPUT,))
+        o = outs[0]
+        assert all(x[0] == o[0] and x[1].as_array().tobytes() == o[1].as_array().tobytes() and x[2:] == o[2:] for x in outs)
+        L["evals"] += o[6]
+        self.counters["loop_launches"] += 1
+        self.counters["loop_served"] += o[6]
+        self.counters["sharded"] += o[6]
+        if not o[5]:
+            self.counters["loop_handbacks"] += 1
+        return o
 
     def set_pose_algebra(self, new, mul):
         """(tests) Transform::new / Mul implementations; default: the C ABI's"""
@@ -387,7 +502,15 @@ class BlockShardedIcp:
         applied = 0
         if self.n >= 2:
             prev_error = float(np.finfo(np.float64).max)
-            for it in range(INNER_MAX_ITER):
+            it = 0
+            while it < INNER_MAX_ITER:
+                if getattr(self, "_loop", None) is not None:
+                    o = self._loop_run(Ti, prev_error, applied, it)
+                    if o is not None:
+                        rc, Ti, prev_error, applied, it, finished, _ = o
+                        _lib.check(rc, "icp_shard_loop_wait")
+                        if finished or it >= INNER_MAX_ITER:
+                            break
                 rc, delta, err = self._evaluate(Ti, min(it, 2))
                 if rc == _lib.NONE:
                     break
@@ -399,6 +522,7 @@ class BlockShardedIcp:
                 prev_error = err
                 Ti = self._mul(self._new(delta), Ti)
                 applied += 1
+                it += 1
         return self._mul(Ti, T), applied
 
     def estimate(self, src_local, initial_transform, max_iter):

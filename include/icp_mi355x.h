@@ -268,6 +268,39 @@ int icp_shard_eval_finish_device(icp_handle *h, const void *d_exchange_all, doub
 int icp_shard_eval_status(icp_handle *h, uint32_t out[4], int from_device);
 int icp_shard_eval_abort_device(icp_handle *h);
 
+/* ---- 5b. The inner loop of a sharded registration in ONE launch per rank (estimate_transform, src/lib.rs:59-84) ----
+ * Round 4.  The stage calls above cost ten enqueues and a host wait per evaluation and rank.  Here a rank launches its
+ * tree blocks' workgroups ONCE per outer iteration; they keep the rank's pairs on chip, run evaluation after evaluation
+ * and exchange the window histograms, the candidates and the block sums with the other ranks THROUGH MEMORY while they
+ * run: every rank owns an INBOX (icp_loop_inbox, icp_loop_inbox_bytes() of device memory) that every peer has mapped --
+ * plain pointers between ranks of one process (peer access between devices), hipIpc handles between processes
+ * (icp_loop_inbox_ipc_handle / icp_loop_ipc_open) -- a producer writes its bytes into every inbox and then a flag word,
+ * a consumer polls and reads only its own.  3 x 3 solve, break tests and Transform::new run on the device (every rank
+ * computes the same bits); the host sees one result per launch.  Results: the bits of one handle, as with the stage calls.
+ *   icp_shard_loop_connect: every rank's inbox as mapped in this process (inboxes[rank] = this handle's own); empties
+ *     the own inbox, so the ranks must meet (any barrier of the driver) between connecting and the first launch.
+ *   icp_shard_loop_launch_device: from evaluation it0 with the loop's state (inner pose, previous Huber error, updates
+ *     applied: src/lib.rs:62-82); launch_no = 1, 2, ... the same on every rank for the same launch; eval_base = the
+ *     evaluations earlier launches of this connection served.  ICP_RETRY_SHARDED: nothing launched (no window
+ *     prediction for it0 yet, more than 2^20 pairs, fewer tree blocks than ranks) -- every rank answers alike, and the
+ *     stage calls of section 5 serve that evaluation.
+ *   icp_shard_loop_wait: the state after the launch; *finished, or *it = the evaluation the stage calls must serve
+ *     next (its window missed, or the rotation left the range of the restated sin / cos).  ICP_HIP_ERROR: the launch
+ *     gave up waiting for a peer (250 ms).
+ * Ranks that share a device must launch on streams that really run side by side (they wait for each other): more
+ * than four of them need GPU_MAX_HW_QUEUES raised before the HIP runtime starts. */
+size_t icp_loop_inbox_bytes(void);
+int icp_loop_inbox(icp_handle *h, int fine_grained, void **d_inbox);
+int icp_loop_inbox_ipc_handle(icp_handle *h, unsigned char out[64]);
+int icp_loop_ipc_open(int device, const unsigned char handle[64], void **d_ptr);
+int icp_loop_ipc_close(void *d_ptr);
+int icp_shard_loop_connect(icp_handle *h, int rank, int world, void *const *inboxes);
+int icp_shard_loop_launch_device(icp_handle *h, const double *d_a_xy_local, const double *d_b_xy_local, size_t n_total,
+                                 unsigned launch_no, unsigned eval_base, int it0, uint32_t applied0, const icp_pose *Ti,
+                                 double prev_error, int first_kind, int second_kind);
+int icp_shard_loop_wait(icp_handle *h, icp_pose *Ti, double *prev_error, uint32_t *applied, int *it, int *finished,
+                        uint32_t *evals);
+
 /* (STATUS: with every rank on ONE device -- "virtual ranks" -- this path runs in the test-suite; between DISTINCT
  * devices it has never run on hardware (no multi-GPU box was available to the build): experimental there.  Mixed lists
  * that repeat only some devices, e.g. {0, 0, 1, 1}, are refused.)
@@ -283,6 +316,9 @@ int icp_create_multi(icp_multi **out, int dim, const double *dst, size_t m, cons
 int icp_multi_estimate(icp_multi *M, const double *src, size_t n, const icp_pose *init, size_t max_iter,
                        icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters);
 int icp_multi_counters(const icp_multi *M, uint64_t out[2]);
+/* ... and of the one-launch inner loop across the ranks (section 5b): out[0] launches (per rank), out[1] evaluations they
+ * served, out[2] launches that handed an evaluation back to the stage calls.  ICP_MULTI_NO_LOOP=1: stage calls only. */
+int icp_multi_loop_counters(const icp_multi *M, uint64_t out[3]);
 /* EXTENSION (section 6 across the ranks; BASELINE configs[4] on several GPUs): every rank appends the same k points,
  * moved by T (NULL: as they are), to its replica of the target cloud and rebuilds its search grid; afterwards the
  * object equals a fresh icp_create_multi on the concatenated cloud, bit for bit. */

@@ -25,7 +25,10 @@ def main():
     t0 = time.perf_counter()
     T1, _, inner = one.estimate(src, I.Transform(), 20, return_info=True)
     t1 = time.perf_counter() - t0
-    print(f"one handle (host buffers, two-stream speculative loop): {1e3 * t1 / 20:.3f} ms per outer iteration")
+    t0 = time.perf_counter()
+    one.estimate(src, I.Transform(), 40)
+    t2 = time.perf_counter() - t0
+    print(f"one handle (host buffers): {1e3 * t1 / 20:.3f} ms per outer iteration; marginal {1e3 * (t2 - t1) / 20:.3f} ms")
     for W in (1, 2, 4, 8):
         mu = I.IcpMulti(dst, [0] * W)
         mu.estimate(src, I.Transform(), 5)
@@ -33,9 +36,13 @@ def main():
         T, _, inn = mu.estimate(src, I.Transform(), 20, return_info=True)
         dt = time.perf_counter() - t0
         assert np.array_equal(T.as_array(), T1.as_array())
+        t0 = time.perf_counter()
+        mu.estimate(src, I.Transform(), 40)
+        dt40 = time.perf_counter() - t0
+        print(f"    marginal outer iteration (40 against 20 iterations, per-call work cancelled): {1e3 * (dt40 - dt) / 20:.3f} ms")
         evals = int(inn.sum()) + 20
         print(f"icp_create_multi, {W} virtual ranks on one GPU: {1e3 * dt / 20:.3f} ms per outer iteration "
-              f"({evals} evaluations; counters sharded/replicated {mu.counters()})")
+              f"({evals} evaluations; counters sharded/replicated {mu.counters()}, loop launches/served/handbacks {mu.loop_counters()})")
         mu.close()
 
 
