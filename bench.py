@@ -187,6 +187,51 @@ def converging(calls, n, m, nn_mode):
             "pose_abs_err_vs_truth": float(np.max(np.abs(T.as_array() - truth)))}
 
 
+def rotating(calls, n, m, nn_mode, d_dst):
+    """Side line: consecutive estimate(src, T0, 20) calls on DIFFERENT clouds and starting poses --
+    three source clouds (independent samples with different truth motions, one of them starting from a non-identity
+    pose) alternate call by call against the headline's target cloud, so no call repeats the one before it: the
+    per-call window predictions and whatever else a handle carries from call to call start from another cloud's
+    statistics every time.  Same size, same call as the headline."""
+    import torch
+    import icp_rust_amd as I
+    from icp_rust_amd import synth
+
+    variants = [(synth.SEED + 11, (0.30, -0.20, 0.015), (0.0, 0.0, 0.0)), (synth.SEED + 23, (0.12, 0.25, -0.008), (0.0, 0.0, 0.0)),
+                (synth.SEED + 37, (-0.22, 0.10, 0.011), (-0.05, 0.02, 0.002))]
+    clouds = []
+    for seed, param, init in variants:
+        u = synth.uniforms(seed, n)
+        sc = synth.box_cloud(seed, n, u=u)
+        _, (c, sn, tx, ty) = synth._apply_se2(param, np.zeros((1, 2)))
+        dx, dy = sc[:, 0] - tx, sc[:, 1] - ty
+        sc[:, 0], sc[:, 1] = c * dx + sn * dy, -sn * dx + c * dy
+        sc[:, 0] += synth.NOISE_SIGMA * np.sqrt(-2.0 * np.log(1.0 - u[:, 4])) * np.cos(2.0 * np.pi * u[:, 5])
+        sc[:, 1] += synth.NOISE_SIGMA * np.sqrt(-2.0 * np.log(1.0 - u[:, 4])) * np.sin(2.0 * np.pi * u[:, 5])
+        sc[:, 2] += synth.NOISE_SIGMA * np.sqrt(-2.0 * np.log(1.0 - u[:, 6])) * np.cos(2.0 * np.pi * u[:, 7])
+        clouds.append((torch.from_numpy(np.ascontiguousarray(sc)).cuda(), I.Transform(list(init))))
+    icp = I.Icp3d(d_dst, nn_mode=nn_mode)
+    for d_s, T0 in clouds:  # (allocations, first statistics)
+        icp.estimate(d_s, T0, 2)
+    per_call, inner_all = [], []
+    for k in range(calls):
+        d_s, T0 = clouds[k % len(clouds)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        T, inner = icp.estimate(d_s, T0, MAX_ITER, return_info="inner")
+        torch.cuda.synchronize()
+        per_call.append(time.perf_counter() - t0)
+        inner_all.append([int(x) for x in inner])
+    icp.close()
+    med = float(np.median(per_call))
+    return {"workload": f"{len(clouds)} different {n}-point source clouds (own seeds, own truth motions, one starting from a "
+                        f"non-identity pose) alternating call by call against the headline's {m}-point target cloud; "
+                        "estimate(src_k, T0_k, 20) each",
+            "calls": calls, "ms_per_step": 1e3 * med / MAX_ITER, "value": MAX_ITER / med, "unit": "iterations/s",
+            "ms_per_step_per_call": [1e3 * t / MAX_ITER for t in per_call],
+            "inner_iterations_per_step_per_cloud": inner_all[:len(clouds)]}
+
+
 def reference_sized():
     """Part of the CPU-baseline leg.  BASELINE configs[0] / configs[1] at the reference's own sizes,
     next to the single-thread CPU oracle: a 650-point 2-D scan pair of the reference's scans/2d and a 28.8k-point 3-D frame in the
@@ -244,6 +289,11 @@ def main():
     ap.add_argument("--converging-calls", type=int, default=3,
                     help="estimate(20) calls on the CONVERGING 1M pair (src re-observes points of dst: inner loops of "
                          "several updates, the regime of the reference's real scans) timed as a side line (0 = skip)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of K steps is repeated this many times (each bracketed by barrier + synchronize); "
+                         "value = K / the MEDIAN region (a 3 ms region alone is +-3 % run to run)")
+    ap.add_argument("--rotating-calls", type=int, default=9,
+                    help="estimate(20) calls of the rotating-inputs side line: three different clouds / poses alternating (0 = skip)")
     ap.add_argument("--gn-points", type=int, default=64 * 1024 * 1024,
                     help="pairs of the separate 'reduce kernels alone, past the Infinity Cache' line (0 = skip)")
     args = ap.parse_args()
@@ -299,7 +349,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(mode, steps, warmup, want_parity=False, weak=False):
+    def measure(mode, steps, warmup, want_parity=False, weak=False, repeats=1):
         """K timed outer iterations = one Icp3d::estimate(src, T, K) call on resident data.
         N ranks: the grid engine runs block-sharded (dist.BlockShardedIcp: every rank searches and
         evaluates the points of its reduction-tree blocks, two small exchanges per evaluation, same
@@ -319,6 +369,10 @@ def main():
             if weak:
                 full = torch.from_numpy(synth.synthetic_pair(n_run, 1)[0]).cuda()
             driver = BlockShardedIcp({rank: HipStages(icp)}, n_run, world, comm)
+            # the inner loops as one launch per rank, exchanging through hipIpc-mapped inboxes (gn_loop.hip); the stage calls
+            # + collectives serve whatever a launch hands back.  ICP_DIST_NO_LOOP=1: stage calls only.
+            if os.environ.get("ICP_DIST_NO_LOOP") != "1":
+                driver.connect_loop()
             # every call: fold order of the whole cloud (the sort one GPU does per call), this rank's blocks out
             # of it, then the iterations -- all inside the timed region, like the one-GPU call's snapshot
             T, _, _ = driver.estimate_full(full, T, max(warmup, 2))  # (also seeds the window predictions)
@@ -333,36 +387,43 @@ def main():
         # stream time; 7 is coprime with the 20-step cycle, so cold searches are sampled at their share)
         icp.profile_enable(1 if steps <= 40 else 7)
         icp.profile_read()
-        barrier()
-        t0 = time.perf_counter()
-        inner = []
-        if world == 1:
-            # one rank: the library's own outer loop (icp_estimate_device), one call per 20 steps as
-            # examples/scan3d.rs:131 issues per frame; its per-call setup (cell-sorted snapshot of
-            # the source cloud) is timed too
-            done = 0
-            while done < steps:
-                k_iters = min(MAX_ITER, steps - done)
-                T, k = icp.estimate(d_src, I.Transform(), k_iters, return_info="inner")
-                inner.extend(int(x) for x in k[:k_iters])
-                done += k_iters
-        elif block:
-            done = 0
-            while done < steps:
-                k_iters = min(MAX_ITER, steps - done)
-                T, k, _ = driver.estimate_full(full, I.Transform(), k_iters)
-                inner.extend(int(x) for x in k[:k_iters])
-                done += k_iters
-        else:
-            # N ranks, sweep engine: stage calls around one index all-gather per iteration
-            for k_step in range(steps):
-                if k_step % MAX_ITER == 0:
-                    T = I.Transform()
-                    driver.stages.prepare(d_src, T)
-                T, k = driver.step(d_src, T)
-                inner.append(int(k))
-        barrier()
-        elapsed = time.perf_counter() - t0
+        regions, inner = [], []
+        for _rep in range(max(repeats, 1)):
+            barrier()
+            t0 = time.perf_counter()
+            inner = []
+            if world == 1:
+                # one rank: the library's own outer loop (icp_estimate_device), one call per 20 steps as
+                # examples/scan3d.rs:131 issues per frame; its per-call setup (cell-sorted snapshot of
+                # the source cloud) is timed too
+                done = 0
+                while done < steps:
+                    k_iters = min(MAX_ITER, steps - done)
+                    T, k = icp.estimate(d_src, I.Transform(), k_iters, return_info="inner")
+                    inner.extend(int(x) for x in k[:k_iters])
+                    done += k_iters
+            elif block:
+                done = 0
+                while done < steps:
+                    k_iters = min(MAX_ITER, steps - done)
+                    T, k, _ = driver.estimate_full(full, I.Transform(), k_iters)
+                    inner.extend(int(x) for x in k[:k_iters])
+                    done += k_iters
+            else:
+                # N ranks, sweep engine: stage calls around one index all-gather per iteration
+                for k_step in range(steps):
+                    if k_step % MAX_ITER == 0:
+                        T = I.Transform()
+                        driver.stages.prepare(d_src, T)
+                    T, k = driver.step(d_src, T)
+                    inner.append(int(k))
+            barrier()
+            regions.append(time.perf_counter() - t0)
+        if world > 1:  # every region: the slowest rank's
+            t = torch.tensor(regions, dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            regions = [float(x) for x in t.tolist()]
+        elapsed = float(np.median(regions))
         nn_ms, nn_launches = icp.profile_read()
         icp.profile_enable(0)
         alone_ms = None
@@ -381,10 +442,6 @@ def main():
             a_ms, a_n = icp.profile_read()
             icp.profile_enable(0)
             alone_ms = a_ms / max(a_n, 1)
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
         engine = {I.NN_BRUTE: "brute", I.NN_GRID: "grid"}[I.lib().icp_get_nn_mode(icp._h)]
         checked = None
         if world == 1 and want_parity:
@@ -394,7 +451,7 @@ def main():
             checked = (icp.estimate(d_src, I.Transform(), k_last, return_info=True), k_last, icp.last_fold_order(n))
         counters = dict(driver.counters) if block else None
         icp.close()
-        return dict(elapsed=elapsed, steps=steps, inner=inner, nn_ms=nn_ms, nn_launches=nn_launches, T=T,
+        return dict(elapsed=elapsed, regions=regions, steps=steps, inner=inner, nn_ms=nn_ms, nn_launches=nn_launches, T=T,
                     engine=engine, alone_ms=alone_ms, checked=checked, counters=counters, n_run=n_run)
 
     def nn_roofline(r, n_shard):
@@ -438,7 +495,7 @@ def main():
                     "avg_launch_ms": r["alone_ms"], "achieved": nn_bytes / (1e-3 * r["alone_ms"]) / 1e9,
                     "frac": nn_bytes / (1e-3 * r["alone_ms"]) / 1e9 / HBM_PEAK_GBS}}
 
-    res = measure(nn_mode, args.steps, args.warmup, want_parity=args.cpu_iters > 0)
+    res = measure(nn_mode, args.steps, args.warmup, want_parity=args.cpu_iters > 0, repeats=args.repeats)
     brute = None
     if args.brute_steps > 0 and res["engine"] != "brute":
         brute = measure(I.NN_BRUTE, args.brute_steps, 1, want_parity=args.cpu_iters > 0)
@@ -462,6 +519,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "timed_regions": {"repeats": len(res["regions"]), "steps_each": args.steps, "value_from": "median region",
+                              "ms_per_step_each": [1e3 * r / args.steps for r in res["regions"]]},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -475,8 +534,9 @@ def main():
                 "n_src": n, "n_dst": m, "nn": res["engine"], "outer_iterations_per_estimate_call": MAX_ITER,
                 "parallelism": ("one GPU" if world == 1 else
                                 f"source cloud sharded x{world} by reduction-tree block (every rank searches and evaluates "
-                                "its blocks' points; per evaluation: integer histograms all-reduced, candidate lists and "
-                                "block sums all-gathered over RCCL), target replicated; bit-identical to one GPU"
+                                "its blocks' points; every inner loop is ONE launch per rank whose workgroups exchange window "
+                                "histograms, candidates and block sums through hipIpc-mapped inboxes over xGMI; RCCL serves "
+                                "only the evaluations a launch hands back), target replicated; bit-identical to one GPU"
                                 if res["engine"] == "grid" else
                                 f"NN over contiguous source shards x{world} (index all-gather), target replicated, inner "
                                 "loop replicated"),
@@ -509,6 +569,8 @@ def main():
                 "inner_iterations_per_step": weak["inner"], "sharded_evaluations": weak["counters"],
                 "note": "compare source_points_per_second with n_src x value of the 1-GPU line",
             }
+        if world == 1 and args.rotating_calls > 0:
+            out["rotating_inputs"] = rotating(args.rotating_calls, n, m, nn_mode, d_dst)
         if world == 1 and args.converging_calls > 0:
             out["converging_pair"] = converging(args.converging_calls, n, m, nn_mode)
         if world == 1 and args.gn_points > 0:

@@ -36,6 +36,9 @@ namespace icp {
 namespace {
 
 constexpr long long kLoopTimeoutTicks = 25000000;  // wall_clock64 runs at 100 MHz: 250 ms
+// ... between ranks: processes that share ONE GPU (tests) are not always scheduled side by side at once -- the queue of
+// the second process may wait for a time slice -- so a rank waits longer for its peers than a launch for its own blocks
+constexpr long long kShardTimeoutTicks = 300000000;  // 3 s
 
 __device__ __forceinline__ double to_sgpr(double v) {
   const long long b = __double_as_longlong(v);
@@ -691,7 +694,7 @@ __device__ __forceinline__ bool poll_words(const unsigned long long *words, unsi
       int stop = 0;
       if (lane == 0) {
         if (ld_u32(abort_word) != 0u) stop = 1;
-        else if (wall_clock64() - t0 > kLoopTimeoutTicks) {
+        else if (wall_clock64() - t0 > kShardTimeoutTicks) {
           st_u32(abort_word, 1u);
           stop = 1;
         }

@@ -286,7 +286,7 @@ int icp_shard_eval_abort_device(icp_handle *h);
  *     stage calls of section 5 serve that evaluation.
  *   icp_shard_loop_wait: the state after the launch; *finished, or *it = the evaluation the stage calls must serve
  *     next (its window missed, or the rotation left the range of the restated sin / cos).  ICP_HIP_ERROR: the launch
- *     gave up waiting for a peer (250 ms).
+ *     gave up waiting for a peer (3 s).
  * Ranks that share a device must launch on streams that really run side by side (they wait for each other): more
  * than four of them need GPU_MAX_HW_QUEUES raised before the HIP runtime starts. */
 size_t icp_loop_inbox_bytes(void);
