@@ -3,6 +3,8 @@
 // (src/lib.rs:59-84) driven from the host over the device stages in nn_brute.hip /
 // gn.hip.  Nothing here falls back to a CPU computation: without a HIP device every
 // compute entry point fails with ICP_NO_DEVICE.
+#include <dlfcn.h>
+
 #include <cfloat>
 #include <chrono>
 #include <cstdio>
@@ -127,6 +129,32 @@ hipError_t alloc_ctx(GnCtx &c, hipStream_t s) {
 
 namespace icp {
 
+namespace {
+using PushFn = int (*)(const char *);
+using PopFn = int (*)();
+PushFn g_roctx_push = nullptr;
+PopFn g_roctx_pop = nullptr;
+std::once_flag g_roctx_once;
+void roctx_lookup() {
+  for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+    void *hnd = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
+    if (!hnd) continue;
+    g_roctx_push = reinterpret_cast<PushFn>(dlsym(hnd, "roctxRangePushA"));
+    g_roctx_pop = reinterpret_cast<PopFn>(dlsym(hnd, "roctxRangePop"));
+    if (g_roctx_push && g_roctx_pop) return;
+    g_roctx_push = nullptr;
+    g_roctx_pop = nullptr;
+  }
+}
+}  // namespace
+Range::Range(const char *name) {
+  std::call_once(g_roctx_once, roctx_lookup);
+  if (g_roctx_push) (void)g_roctx_push(name);
+}
+Range::~Range() {
+  if (g_roctx_pop) (void)g_roctx_pop();
+}
+
 hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
   Workspace &w = h->ws;
   hipError_t e;
@@ -137,7 +165,7 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     // ICP_EVAL_PRIORITY=low|normal: A/B switch for the evaluation stream's priority (default: highest)
     int prio = prio_greatest;
-    if (const char *pe = getenv("ICP_EVAL_PRIORITY")) prio = pe[0] == 'l' ? prio_least : (pe[0] == 'n' ? 0 : prio_greatest);
+    if (const char *pe = exp_env("ICP_EVAL_PRIORITY")) prio = pe[0] == 'l' ? prio_least : (pe[0] == 'n' ? 0 : prio_greatest);
     if ((e = hipStreamCreateWithPriority(&w.spec_stream, hipStreamNonBlocking, prio)) != hipSuccess) return e;
     // the memsets above must have landed before either stream uses the scratch
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
@@ -403,7 +431,7 @@ extern "C" void icp_destroy(icp_handle *h) {
     }
     v->clear();
   }
-  if (getenv("ICP_DBG_WIN") && h->ws.win_tried)
+  if (exp_env("ICP_DBG_WIN") && h->ws.win_tried)
     fprintf(stderr,
             "[icp] window evaluations: %llu tried, %llu missed; speculative searches: %llu hit, %llu missed; "
             "first evaluations launched ahead: %llu; refined windows (n > 4M): %llu tried, %llu missed\n",
@@ -428,11 +456,15 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->qsort.have_prev = false;
     h->qsort.slot_order = false;
     h->qsort.fold_n = 0;
+    h->qsort.last_cert_ctr = nullptr;  // (observability of the previous owner's searches)
+    h->qsort.cert_searches = 0;
+    h->qsort.last_waves = 0;
+    h->qsort.have_certs = false;
     h->shard.active = false;
     h->shard.refined_ready = h->shard.attempt_refined = false;
     h->normals_m = 0;
     h->normals_k = 0;
-    static const bool no_hints = getenv("ICP_NO_POOL_HINTS") != nullptr;
+    static const bool no_hints = exp_env("ICP_NO_POOL_HINTS") != nullptr;
     for (int k = 0; k < 5; ++k) {  // what the next owner may start from (common.hpp: hint_kind)
       w.hint_kind[k] = no_hints ? Workspace::WinPred() : w.win_kind[k];
       w.hint_kind[k].wide = false;
@@ -446,6 +478,10 @@ extern "C" void icp_destroy(icp_handle *h) {
     w.gn_dirty = w.alt.gn_dirty = true;
     w.win_tried = w.win_missed = w.short_evals = w.radix_evals = 0;
     w.spec_hits = w.spec_misses = w.pre_evals = 0;
+    w.loop_launches = w.loop_evals = w.loop_handbacks = 0;
+    w.loop_off = false;
+    w.loop_rank = -1;
+    w.loop_world = 0;
     w.tiny_calls = w.tiny_evals = w.tiny_sorted = 0;
     w.refine_tried = w.refine_missed = 0;
     w.last_inner = 0xffffffffu;
@@ -477,7 +513,7 @@ extern "C" int icp_set_nn_mode(icp_handle *h, int mode) {
 // AUTO: the grid pays off once the target cloud is large enough to amortise the
 // scattered cell reads; tiny clouds (2-D LiDAR scans, ~650 points) stay on the sweep.
 static int resolved_nn_mode(const icp_handle *h) {
-  static const long grid_min_m = getenv("ICP_NN_GRID_MIN_M") ? atol(getenv("ICP_NN_GRID_MIN_M")) : 8192;
+  static const long grid_min_m = exp_env("ICP_NN_GRID_MIN_M") ? atol(exp_env("ICP_NN_GRID_MIN_M")) : 8192;
   if (h->nn_mode == ICP_NN_BRUTE || !h->grid.built) return ICP_NN_BRUTE;
   if (h->nn_mode == ICP_NN_GRID) return ICP_NN_GRID;
   return (long)h->m >= grid_min_m ? ICP_NN_GRID : ICP_NN_BRUTE;
@@ -485,6 +521,7 @@ static int resolved_nn_mode(const icp_handle *h) {
 
 static hipError_t launch_nn(icp_handle *h, const double *d_src, size_t n, const Pose *T, double *d_a,
                             double *d_b, uint32_t *d_idx) {
+  Range range("icp: search (transform + exact nearest neighbour + pairs)");
   if (resolved_nn_mode(h) == ICP_NN_GRID) return launch_nn_grid(h, d_src, n, T, d_a, d_b, d_idx);
   return launch_nn_brute(h, d_src, n, T, d_a, d_b, d_idx);
 }
@@ -576,7 +613,7 @@ extern "C" int icp_materialize_pairs_device(icp_handle *h, const double *d_src, 
 extern "C" int icp_prepare_source_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T) {
   if (!h || !T || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
   h->qsort.valid = false;
-  static const long min_n = getenv("ICP_QSORT_MIN_N") ? atol(getenv("ICP_QSORT_MIN_N")) : 16384;
+  static const long min_n = exp_env("ICP_QSORT_MIN_N") ? atol(exp_env("ICP_QSORT_MIN_N")) : 16384;
   if (resolved_nn_mode(h) != ICP_NN_GRID || (long)n < min_n) return ICP_OK;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(prepare_queries(h, d_src, n, *T));
@@ -593,7 +630,8 @@ __global__ void k_iota_u32(uint32_t *p, unsigned n) {
 // The fold order of an estimate call that starts at pose T (icp_last_fold_order), applied: d_sorted[k] =
 // d_src[perm[k]].  For hosts that drive the stage calls themselves (the sharded drivers) and want the bits of
 // icp_estimate_device: sort first, then treat the sorted cloud as the source.  Where icp_estimate_device would
-// take no snapshot (sweep engine, n < 16384) this is a plain copy and the identity permutation.
+// take no snapshot or keeps the caller's order (sweep engine; up to grid_coop_max() = 65 536 points, ICP_NN_COOP_MAX_N) this
+// is a plain copy and the identity permutation.
 extern "C" int icp_sort_source_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T,
                                       double *d_sorted, uint32_t *d_perm) {
   if (!h || !T || (n > 0 && (!d_src || !d_sorted)) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
@@ -643,7 +681,7 @@ static inline void cpu_relax() {
 #endif
 }
 static hipError_t wait_seq(icp_handle *h, volatile unsigned *seq, unsigned want) {
-  static const bool no_poll = getenv("ICP_NO_POLL") != nullptr;
+  static const bool no_poll = exp_env("ICP_NO_POLL") != nullptr;
   if (!no_poll) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -703,7 +741,8 @@ template <typename Hook>
 static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
                     double delta[3], double *huber_err, Hook &&after_launch, bool pre_launched = false,
                     int kind = 2) {
-  static const bool force_radix = getenv("ICP_GN_RADIX") != nullptr;
+  static const bool force_radix = exp_env("ICP_GN_RADIX") != nullptr;
+  Range range("icp: evaluation (weighted_gauss_newton_update + huber_error)");
   Workspace &w = h->ws;
   bool done = false, has_median = false, hooked = false;
   // the prediction this evaluation's window is (or, pre-launched, was) centred on: its own kind's
@@ -731,7 +770,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
       HIP_TRY(wait_result(h));
       done = has_median = !w.h_res->overflow;
       if (!done) {
-        if (getenv("ICP_WIN_TRACE")) fprintf(stderr, "[win] kind %d: the window missed\n", kind);
+        if (exp_env("ICP_WIN_TRACE")) fprintf(stderr, "[win] kind %d: the window missed\n", kind);
         ++w.win_missed;
         wide = true;
       } else if (wide) {  // back to narrow windows once the statistics have settled
@@ -789,7 +828,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
     w.gn_dirty = true;
   }
   const GnResult &r = *w.h_res;
-  static const bool win_trace = getenv("ICP_WIN_TRACE") != nullptr;
+  static const bool win_trace = exp_env("ICP_WIN_TRACE") != nullptr;
   if (win_trace)
     fprintf(stderr, "[win] kind %d own %d predicted med %.6g %.6g sigma %.6g %.6g -> med %.6g %.6g sigma %.6g %.6g%s\n", kind,
             (int)own, p_med[0], p_med[1], p_sigma[0], p_sigma[1], r.median[0], r.median[1], r.sigma[0], r.sigma[1],
@@ -800,6 +839,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
     return ICP_NAN_INPUT;
   }
   if (huber_err) *huber_err = r.acc[12];
+  Range solve("icp: solve (inverse3x3, host)");
   return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
 }
 static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
@@ -931,6 +971,7 @@ static int gn_loop_run(icp_handle *h, const double *d_a, const double *d_b, size
   *served = *finished = false;
   LoopPlan pl;
   if (!loop_plan(h, n, *it, first_kind, second_kind, true, &pl)) return ICP_OK;
+  Range range("icp: inner loop (one launch: evaluations + solve + break tests on the device)");
   LoopArgs &A = pl.A;
   HIP_TRY(ensure_loop(h));
   if (w.gn_dirty) {  // (the host-driven pipelines' rest state; the launch itself does not touch it)
@@ -1280,8 +1321,8 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     if (tiny_status == 3) return ICP_NAN_INPUT;
   }
   static const bool no_spec = getenv("ICP_NO_SPECULATION") != nullptr;
-  static const bool one_stream_env = getenv("ICP_SPEC_SAME_STREAM") != nullptr;
-  static const bool nn_first = getenv("ICP_SPEC_NN_LAST") == nullptr;
+  static const bool one_stream_env = exp_env("ICP_SPEC_SAME_STREAM") != nullptr;
+  static const bool nn_first = exp_env("ICP_SPEC_NN_LAST") == nullptr;
   Workspace &w = h->ws;
   // Two ways through an outer iteration, chosen per iteration from how the previous inner loop went:
   //  * it applied exactly ONE update (a settled registration; the benchmark pair): the host steps the two evaluations
@@ -1309,7 +1350,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   double *A[2] = {w.d_a, w.d_a2}, *B[2] = {w.d_b, w.d_b2};
   int cur = 0;
   bool spec_valid = false, pre_valid = false, first_pre_launched = false;
-  static const bool no_pre = getenv("ICP_NO_PRE_EVAL") != nullptr;
+  static const bool no_pre = exp_env("ICP_NO_PRE_EVAL") != nullptr;
   Pose spec_pose = T;
   // the bet needs "the inner loop took exactly one update last time"; across calls the handle
   // remembers how its previous call ended (a new frame usually behaves like the last one)
@@ -1900,8 +1941,8 @@ extern "C" int icp_shard_geometry(size_t n_total, int rank, int world, int *b0, 
 }
 extern "C" size_t icp_shard_histogram_words(void) { return (size_t)2 * kWinBins + kShardStatusWords; }
 extern "C" size_t icp_shard_candidates_bytes(void) { return shard_cand_bytes(); }
-extern "C" size_t icp_shard_partials_bytes(int world) { return world >= 1 ? shard_part_bytes(world) : 0; }
-extern "C" size_t icp_shard_exchange_bytes(int world) { return world >= 1 ? shard_exchange_bytes(world) : 0; }
+extern "C" size_t icp_shard_partials_bytes(int world) { return world >= 1 && world <= kShardMaxWorld ? shard_part_bytes(world) : 0; }
+extern "C" size_t icp_shard_exchange_bytes(int world) { return world >= 1 && world <= kShardMaxWorld ? shard_exchange_bytes(world) : 0; }
 
 static int shard_copy(icp_handle *h, const void *src, void *dst, size_t n_total, int rank, int world, size_t elem_bytes,
                       bool take) {
@@ -1933,7 +1974,9 @@ static int shard_eval_hist_impl(icp_handle *h, const double *d_a, const double *
 // expected to take part in that sum: icp_shard_eval_status then tells every rank the same four counts.
 extern "C" int icp_shard_eval_hist_device(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, int rank,
                                           int world, const icp_pose *T, int kind, int refined, uint32_t **d_hist) {
-  if (!h || !T || !d_hist || world < 1 || rank < 0 || rank >= world || n_total >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  // (the last stage indexes its per-rank tables with at most kShardMaxWorld entries)
+  if (!h || !T || !d_hist || world < 1 || world > kShardMaxWorld || rank < 0 || rank >= world || n_total >= 0xffffffffull)
+    return ICP_BAD_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(ensure_workspace(h, 1, false));
   const int rc = shard_eval_hist_impl(h, d_a, d_b, n_total, rank, world, T, kind, refined, d_hist);

@@ -4,12 +4,34 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
 #include "pose.hpp"
 
 namespace icp {
+
+// The product library reads FIVE environment variables -- ICP_NO_POOL (icp_destroy frees instead of pooling),
+// ICP_NO_GN_LOOP (inner loops stepped from the host only), ICP_NO_SPECULATION (no bet on the next pose),
+// ICP_GN_NO_REFINE (no refined windows beyond 4M pairs), ICP_MULTI_DEBUG (icp_multi diagnostics on stderr).  Every
+// A/B switch and tuning knob of the development rounds exists only in a build with
+// -DICP_EXPERIMENTS (`make experiments` -> libicp_mi355x_exp.so), where exp_env is getenv; here it answers "unset".
+#ifdef ICP_EXPERIMENTS
+inline const char *exp_env(const char *name) { return getenv(name); }
+#else
+inline const char *exp_env(const char *) { return nullptr; }
+#endif
+
+// roctx ranges around the three device stages of an outer iteration (search, evaluation / inner
+// loop, solve), for `rocprofv3 --marker-trace`.  The marker library is looked up at run time (librocprofiler-sdk-roctx
+// or libroctx64): the product links nothing but libamdhip64, and without the library the ranges cost one branch.
+struct Range {
+  explicit Range(const char *name);
+  ~Range();
+  Range(const Range &) = delete;
+  Range &operator=(const Range &) = delete;
+};
 
 constexpr int kReduceThreads = 512;   // threads per block of the GN reduction tree
 constexpr int kReduceMaxBlocks = 256;

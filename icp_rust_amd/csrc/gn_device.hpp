@@ -107,11 +107,7 @@ __device__ __forceinline__ bool last_block_arrives(TicketSet *t) {
     const unsigned nb = gridDim.x, sh = blockIdx.x & 15u;
     const unsigned in_shard = (nb - sh + 15u) >> 4;  // workgroups with this shard id
     int last = 0;
-#ifdef ICP_AB_TICKET2
-    if (false) {
-#else
     if (nb <= 32u) {  // few enough arrivals for one word: one round trip instead of two
-#endif
       if (__hip_atomic_fetch_add(&t->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1) {
         __hip_atomic_store(&t->top[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = 1;
@@ -302,11 +298,7 @@ __device__ __forceinline__ void publish_folded(const double *s_tot, GnResult *re
       res->nan_flag = nan_flag;
       res->overflow = overflow;
     }
-#ifdef ICP_AB_FENCE2
-    __threadfence_system();
-#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     if (threadIdx.x == 0) __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

@@ -799,7 +799,7 @@ static size_t tiny_lds_bytes(int dim, unsigned m) {
 // no bounding box, disabled, or the kernel handed the call back): the caller runs the general path.
 hipError_t launch_tiny_estimate(icp_handle *h, const double *d_src, size_t n, const Pose &T0, size_t max_iter,
                                 Pose *out, uint32_t *d_last_idx, uint32_t *inner_iters, int *status) {
-  static const bool off = getenv("ICP_NO_TINY_ESTIMATE") != nullptr;
+  static const bool off = exp_env("ICP_NO_TINY_ESTIMATE") != nullptr;
   *status = -1;
   if (off || !h->single_launch || n < 1 || n > kTinyMaxN || h->m < 1 || h->m > kTinyMaxM || max_iter < 1 || max_iter > kTinyMaxIter ||
       !h->grid.built || h->nn_mode == ICP_NN_GRID)
@@ -833,7 +833,7 @@ hipError_t launch_tiny_estimate(icp_handle *h, const double *d_src, size_t n, co
   const size_t lds = tiny_lds_bytes(h->dim, (unsigned)h->m);
   // the smallest workgroup with a thread per source point: fewer waves per barrier, and registers
   // enough (1024 threads leave 128 per thread, and spill)
-  static const unsigned forced = getenv("ICP_TINY_THREADS") ? (unsigned)atoi(getenv("ICP_TINY_THREADS")) : 0u;
+  static const unsigned forced = exp_env("ICP_TINY_THREADS") ? (unsigned)atoi(exp_env("ICP_TINY_THREADS")) : 0u;
   unsigned threads = n <= 512 ? 512u : (n <= 768 ? 768u : 1024u);
   if ((forced == 768u || forced == 1024u) && forced >= threads) threads = forced;
 #define ICP_TINY_LAUNCH(D, BB)                                                                                       \
@@ -859,7 +859,7 @@ hipError_t launch_tiny_estimate(icp_handle *h, const double *d_src, size_t n, co
     w.tiny_evals += res->evals;
     w.tiny_sorted += res->sorted;
 #ifdef ICP_TINY_PROFILE
-    if (getenv("ICP_TINY_PRINT"))
+    if (exp_env("ICP_TINY_PRINT"))
       fprintf(stderr, "[tiny] evals %u sorted %u; cycles: setup %llu search %llu select %llu sums %llu step %llu all %llu; "
               "selection phases (keys, sample ranks, buckets, scan+list, ranks): %llu %llu %llu %llu %llu\n",
               res->evals, res->sorted, res->t[0], res->t[1], res->t[2], res->t[3], res->t[4], res->t[5], res->ts[0], res->ts[1],

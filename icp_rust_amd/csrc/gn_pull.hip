@@ -391,7 +391,7 @@ hipError_t launch_weighted_gn_pull(icp_handle *h, const double *d_a, const doubl
   const unsigned hb1 = hb / 2 > 0 ? hb / 2 : 1;  // later digits flush dense histograms: fewer, fatter workgroups
   // two 12-bit digits leave ~1e-4 n keys per prefix; beyond a few million points a third digit
   // keeps the candidate lists short (n <= 2^32)
-  static const size_t three_from = getenv("ICP_PULL_3DIGITS_FROM") ? (size_t)atoll(getenv("ICP_PULL_3DIGITS_FROM")) : ((size_t)4 << 20);
+  static const size_t three_from = exp_env("ICP_PULL_3DIGITS_FROM") ? (size_t)atoll(exp_env("ICP_PULL_3DIGITS_FROM")) : ((size_t)4 << 20);
   const int digits = n_ > three_from ? 3 : 2;
   const double2 *a = (const double2 *)d_a, *b = (const double2 *)d_b;
   hipStream_t s = h->stream;

@@ -277,11 +277,7 @@ __device__ __forceinline__ bool win_compact_body(const double *__restrict__ rx, 
   // the first batch of residuals does not wait for the bins to be resolved: its loads travel with the histogram's
   const unsigned G = gridDim.x * kWinThreads;
   double pre[2][kWinBatch];
-#ifdef ICP_AB_PREFETCH
-  constexpr bool kPrefetch = !LISTS;
-#else
   constexpr bool kPrefetch = false;  // (measured: no gain on the 28k frame, and 37 more registers in the kernel)
-#endif
   if (kPrefetch) {
 #pragma unroll
     for (int u = 0; u < kWinBatch; ++u) {
@@ -963,7 +959,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_shard_finish(ShardPtrs srcs,
 
 // ---- host ---------------------------------------------------------------------------
 bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind, bool any_n, double f_override) {
-  static const bool off = getenv("ICP_GN_NO_WIN") != nullptr;
+  static const bool off = exp_env("ICP_GN_NO_WIN") != nullptr;
   const Workspace &w = h->ws;
   // (any_n: the sharded evaluation, which refines a window that missed from that attempt's own counts
   // instead of giving up -- api.hip, shard_finish_common -- and so serves any number of points)
@@ -980,7 +976,7 @@ bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind, bool a
 
 // half-width of the fine windows in sigmas: the prediction may be off by about that much (4 x after a miss)
 double window_half_width(size_t n, bool wide) {
-  static const double hw_sigmas = getenv("ICP_WIN_HW") ? atof(getenv("ICP_WIN_HW")) : 0.05;
+  static const double hw_sigmas = exp_env("ICP_WIN_HW") ? atof(exp_env("ICP_WIN_HW")) : 0.05;
   double f = hw_sigmas * (wide ? 4. : 1.);
   if (n > 1000000) f *= 1e6 / (double)n;  // candidates per fine bin grow with n
   return f > 0.2 ? 0.2 : f;               // the windows must not overlap (MAD = 0.6745 sigma)
@@ -999,17 +995,17 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
   hipStream_t s = h->stream;
   // on the evaluation stream this runs beside a speculative search: the variant whose every
   // workgroup fits next to three search waves per SIMD (one extra tiny launch; latency is hidden)
-  static const bool no_co = getenv("ICP_WIN_NO_CORESIDENT") != nullptr;
+  static const bool no_co = exp_env("ICP_WIN_NO_CORESIDENT") != nullptr;
   // (round 3: the 4-launch form everywhere -- 0.1645 against 0.1660 ms per step on the 1M pair, 0.626 against 0.635 on
   // the converging pair, the 28k frame unchanged: every workgroup of the inline-selecting accumulate kernel repeats
   // 7.5 us of candidate loads and selections that the two-workgroup launch does once)
   const bool coresident = !no_co;
-  static const bool no_fuse = getenv("ICP_WIN_NO_FUSE") != nullptr;
+  static const bool no_fuse = exp_env("ICP_WIN_NO_FUSE") != nullptr;
   // Two launches (residuals + histograms + sums, then candidates + selection + fold) unless the evaluation shares
   // the CUs with a speculative search: beside three search waves per SIMD the four small launches below fit better
   // (1M pair: 0.154 ms per step against 0.157 fused everywhere and 0.158 never; profiles/r03_eval_fusion_ab.txt).
   // ICP_WIN_FUSE_MODE: 1 = everywhere, 2 = as described (default), 3 = only beside a search, 4 = search stream only.
-  static const int fuse_mode = getenv("ICP_WIN_FUSE_MODE") ? atoi(getenv("ICP_WIN_FUSE_MODE")) : 2;
+  static const int fuse_mode = exp_env("ICP_WIN_FUSE_MODE") ? atoi(exp_env("ICP_WIN_FUSE_MODE")) : 2;
   const bool on_eval_stream = w.spec_stream && s == w.spec_stream;
   const bool beside_search = on_eval_stream && w.search_beside_eval;
   if (!no_fuse && (fuse_mode == 1 || (fuse_mode == 2 && !beside_search) || (fuse_mode == 3 && beside_search) ||
@@ -1054,7 +1050,7 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
 // resolved by the usual C and A launches -- which verify everything by exact counts, so a bad
 // sample can only cost a repeat with the radix pipeline, never a different result.
 bool refine_applies(size_t n) {
-  static const bool off = getenv("ICP_GN_NO_WIN") != nullptr || getenv("ICP_GN_NO_REFINE") != nullptr;
+  static const bool off = exp_env("ICP_GN_NO_WIN") != nullptr || getenv("ICP_GN_NO_REFINE") != nullptr;
   return !off && n > kWinMaxN && n / kRefineSample >= 1 && n < 0xffffffffull;
 }
 

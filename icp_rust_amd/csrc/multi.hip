@@ -161,7 +161,8 @@ int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta
   for (int q = 0; q < W; ++q) {
     auto &R = M->r[q];
     const int rc = icp_shard_eval_hist_device(R.h, R.d_a, R.d_b, n_total, q, W, &T, kind, refined, &hist[q]);
-    if (getenv("ICP_MULTI_DEBUG"))
+    static const bool debug = getenv("ICP_MULTI_DEBUG") != nullptr;  // (read once: this runs per rank and evaluation)
+    if (debug)
       fprintf(stderr, "[multi] hist rank %d kind %d refined %d -> rc %d (win_valid %d, kinds %d %d %d %d)\n", q, kind, refined, rc,
               (int)R.h->ws.win_valid, (int)R.h->ws.win_kind[0].valid, (int)R.h->ws.win_kind[1].valid,
               (int)R.h->ws.win_kind[3].valid, (int)R.h->ws.win_kind[4].valid);
@@ -415,7 +416,7 @@ extern "C" int icp_create_multi(icp_multi **out, int dim, const double *dst, siz
   if (rc == ICP_OK && M->one_device)  // ranks on one device share one stream: lockstep order, no waiting
     for (int q = 1; q < n_devices; ++q) rc = rc == ICP_OK ? icp_set_stream(M->r[q].h, M->r[0].h->stream) : rc;
   // the one-launch inner loop: every rank's inbox mapped on every rank (plain pointers: one process)
-  if (rc == ICP_OK && getenv("ICP_MULTI_NO_LOOP") == nullptr) {
+  if (rc == ICP_OK && getenv("ICP_NO_GN_LOOP") == nullptr) {
     void *boxes[kShardMaxWorld] = {};
     for (int q = 0; q < n_devices && rc == ICP_OK; ++q) rc = icp_loop_inbox(M->r[q].h, M->one_device ? 0 : 1, &boxes[q]);
     for (int q = 0; q < n_devices && rc == ICP_OK; ++q) rc = icp_shard_loop_connect(M->r[q].h, q, n_devices, boxes);

@@ -592,7 +592,7 @@ hipError_t build_target_soa(icp_handle *h) {
 }
 
 static int env_int(const char *name, int dflt) {
-  const char *s = getenv(name);
+  const char *s = exp_env(name);
   return s ? atoi(s) : dflt;
 }
 
@@ -601,14 +601,14 @@ static void launch_one(icp_handle *h, const double *d_src, unsigned n, const Pos
                        unsigned chunks, unsigned chunk) {
   const bool full = chunk % kNnTile == 0;
   const double *tx = h->d_dst_soa, *ty = tx + h->m_pad, *tz = ty + h->m_pad;
-  static const bool no_screen = getenv("ICP_NN_NO_SCREEN") != nullptr;
+  static const bool no_screen = exp_env("ICP_NN_NO_SCREEN") != nullptr;
   if (h->screen_valid && !no_screen) {
     const float *fx = h->d_dst_f32, *fy = fx + h->m_pad, *fz = fy + h->m_pad;
     const GridParams &g = h->grid.p;
     const double cx = 0.5 * (g.lo[0] + g.hi[0]), cy = 0.5 * (g.lo[1] + g.hi[1]), cz = 0.5 * (g.lo[2] + g.hi[2]);
     // the dot-product screen (two queries per packed instruction) unless its cancellation margin would
     // swamp the distances it has to tell apart; ICP_NN_OLD_SCREEN: the difference-based screen, for A/B
-    static const bool old_screen = getenv("ICP_NN_OLD_SCREEN") != nullptr;
+    static const bool old_screen = exp_env("ICP_NN_OLD_SCREEN") != nullptr;
     const double ex = g.hi[0] - g.lo[0], ey = g.hi[1] - g.lo[1], ez = g.hi[2] - g.lo[2];
     const double half_diag = 0.5 * sqrt((ex * ex + ey * ey) + ez * ez) * 1.000001;
     if constexpr (R >= 2) {
@@ -694,7 +694,7 @@ hipError_t launch_nn_brute(icp_handle *h, const double *d_src, size_t n_, const 
   chunks = (granules + granules_per_chunk - 1) / granules_per_chunk;
   const unsigned chunk = granules_per_chunk * 64;
 
-  static const bool no_tiny = getenv("ICP_NN_NO_TINY") != nullptr;
+  static const bool no_tiny = exp_env("ICP_NN_NO_TINY") != nullptr;
   const bool tiny = !no_tiny && n <= 2048u && h->m <= 2048;
   // partial buffers
   const size_t need = tiny ? 0 : (size_t)chunks * n;

@@ -193,14 +193,14 @@ hipError_t build_grid(icp_handle *h) {
       ++k;
     }
   // ICP_GRID_OCC: targets per cell the cell size aims at (tuning knob; any value is exact)
-  static const double occ = getenv("ICP_GRID_OCC") ? atof(getenv("ICP_GRID_OCC")) : 2.;
+  static const double occ = exp_env("ICP_GRID_OCC") ? atof(exp_env("ICP_GRID_OCC")) : 2.;
   double hh = k > 0 ? pow(occ * vol / (double)m, 1. / k) : 1.;
   if (!(hh > 0.) || !std::isfinite(hh)) hh = 1.;
   // ICP_GRID_FX: cells are that many times finer along x.  A row of cells along x is one
   // contiguous run of records, so finer x cells clip the runs tighter around [qx - r, qx + r]
   // without adding rows (dense surfaces put ~10 targets into a cubic cell of the average
   // occupancy; the search radius there is a fraction of the cell).
-  static const double fx = getenv("ICP_GRID_FX") ? fmax(1., atof(getenv("ICP_GRID_FX"))) : 4.;
+  static const double fx = exp_env("ICP_GRID_FX") ? fmax(1., atof(exp_env("ICP_GRID_FX"))) : 4.;
   // The cell size grows until the cells fit BOTH the 2^24 total and the per-axis limits (16384 along
   // x, 4096 along y / z): an elongated cloud (a corridor map: 20000 x 50 x 5 m) must not collapse
   // everything beyond the capped axis into its last cell -- results would stay exact (edge cells are
@@ -333,8 +333,8 @@ __global__ void k_grid_insert(const double *__restrict__ tail, unsigned k, unsig
 hipError_t append_grid(icp_handle *h, size_t m_old_, size_t k_, bool *done) {
   *done = false;
   Grid &G = h->grid;
-  static const bool off = getenv("ICP_GRID_NO_APPEND") != nullptr;
-  static const double growth = getenv("ICP_GRID_REBUILD_GROWTH") ? atof(getenv("ICP_GRID_REBUILD_GROWTH")) : 1.5;
+  static const bool off = exp_env("ICP_GRID_NO_APPEND") != nullptr;
+  static const double growth = exp_env("ICP_GRID_REBUILD_GROWTH") ? atof(exp_env("ICP_GRID_REBUILD_GROWTH")) : 1.5;
   if (off || !G.built || m_old_ == 0 || k_ == 0 || G.m_full == 0) return hipSuccess;
   if ((double)(m_old_ + k_) > growth * (double)G.m_full) return hipSuccess;  // the cell size is due for a re-tune
   const unsigned m_old = (unsigned)m_old_, k = (unsigned)k_, m_new = m_old + k;
@@ -1025,7 +1025,6 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
         }
         // a target of this row that can still win or tie has |x - qx| <= sqrt(best - dy^2 - dz^2)
         // (v_sqrt_f32 returns 0 for a denormal argument: sqrt of it is < 1.1e-19 <= mgf, build_grid's f32_ok)
-#ifndef ICP_WARM_NOCLIP
         const float hw = __builtin_amdgcn_sqrtf(bf - dyz) * 1.000001f + mgf;
         xl = max(xl, cell_lo(qf[0] - hw, em[0], 0));
         xh = min(xh, cell_hi(qf[0] + hw, em[0], 0));
@@ -1037,7 +1036,6 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
           if (xl > lo_c[0]) skip2 = fminf(skip2, slab2(0, xl - 1) + dyz);
           if (xh < hi_c[0]) skip2 = fminf(skip2, slab2(0, xh + 1) + dyz);
         }
-#endif
       }
       const uint32_t rb = ((uint32_t)iz * g.n[1] + cy) * g.n[0];
       const uint32_t ra = rb + xl, rz = rb + xh + 1;
@@ -1096,28 +1094,9 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
         }
         sc[u] = s2;
       }
-#ifdef ICP_WARM_DEFER
-      // the best-screened survivor first (one gather round trip for the common single survivor); the
-      // tightened threshold then rejects most of the others
-      float smin = __builtin_huge_valf();
-      uint32_t imin = 0xffffffffu;
-#pragma unroll
-      for (uint32_t u = 0; u < kR; ++u) {
-        const bool pass = !(sc[u] > thr32) && t[u].idx != bi && sc[u] < smin;
-        smin = pass ? sc[u] : smin;
-        imin = pass ? t[u].idx : imin;
-      }
-      if (imin != 0xffffffffu) {
-        consider(imin);
-#pragma unroll
-        for (uint32_t u = 0; u < kR; ++u)
-          if (!(sc[u] > thr32) && t[u].idx != bi && t[u].idx != imin) consider(t[u].idx);
-      }
-#else
 #pragma unroll
       for (uint32_t u = 0; u < kR; ++u)
         if (!(sc[u] > thr32) && t[u].idx != bi) consider(t[u].idx);
-#endif
       if (CERT) {
 #pragma unroll
         for (uint32_t u = 0; u < kR; ++u) m2 = fminf(m2, t[u].idx != bi ? sc[u] : __builtin_huge_valf());
@@ -1274,6 +1253,7 @@ __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_walk_lists(
   warm_query<DIM, true>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev, cd);
 }
 
+#ifdef ICP_EXPERIMENTS  // (serves nn_tile.hip)
 // The same search for the waves the tile kernel (nn_tile.hip) handed back (a flag per wave): one workgroup
 // per wave of queries, the unflagged ones leave at once.
 template <int DIM>
@@ -1311,6 +1291,8 @@ hipError_t launch_nn_warm_flagged(icp_handle *h, const double *q_src, const uint
 // around it that holds any record -- as if it were its previous match, and the warm kernel does the
 // search proper from that radius.  Nothing here needs to be exact or even good: the warm kernel's
 // result does not depend on where it starts (a poor seed only costs it time).
+#endif  // ICP_EXPERIMENTS
+
 template <int DIM>
 __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__restrict__ src, unsigned n, Pose T,
                                                                GridParams g, const uint32_t *__restrict__ start,
@@ -1460,6 +1442,7 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   Grid &G = h->grid;
   QuerySort &Q = h->qsort;
   Q.valid = false;
+  Q.fold_n = 0;  // d_perm / d_cell are about to be rewritten: icp_estimate_device declares a fold order AFTER this call
   if (!G.built || n_ == 0) return hipSuccess;
   const unsigned n = (unsigned)n_;
   hipError_t e;
@@ -1474,6 +1457,7 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     (void)hipFree(Q.d_list);
     (void)hipFree(Q.d_cert_lists);
     (void)hipFree(Q.d_cert_ctr);
+    Q.last_cert_ctr = nullptr;  // (pointed into the buffer just freed)
     Q.d_prev = nullptr;
     Q.d_list = nullptr;
     Q.d_cert_lists = nullptr;
@@ -1501,7 +1485,7 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   // snapshot exists for the per-slot previous matches, and the sort (a cell pass, eight rocprim launches, a gather:
   // 50 us of a 1.26 ms registration of a 28k-point frame) buys such a search nothing measurable -- the targets it
   // walks fit the L2 whatever order the queries come in.  ICP_QSORT_SMALL=1 sorts them all the same.
-  static const bool sort_small = getenv("ICP_QSORT_SMALL") != nullptr;
+  static const bool sort_small = exp_env("ICP_QSORT_SMALL") != nullptr;
   Q.identity = (long)n <= grid_coop_max() && !sort_small;
   if (Q.identity) {
     Q.have_prev = false;
@@ -1516,8 +1500,8 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   // ICP_QSORT_BLOCK: log2 of the row bundle's side (0: row after row); the key must fit 32 bits
   // (row after row serves the gather walk best: 84.1 / 86.3 / 90.4 / 94.3 us per search for 0 / 1 / 2 / 3; the
   // LDS-tile search wants 1: 5 100 -> 700 of 15 625 waves beyond its LDS budget)
-  static const bool tile_on = getenv("ICP_NN_TILE") != nullptr && atoi(getenv("ICP_NN_TILE")) != 0;
-  static const int blk_env = getenv("ICP_QSORT_BLOCK") ? atoi(getenv("ICP_QSORT_BLOCK")) : (tile_on ? 1 : 0);
+  static const bool tile_on = exp_env("ICP_NN_TILE") != nullptr && atoi(exp_env("ICP_NN_TILE")) != 0;
+  static const int blk_env = exp_env("ICP_QSORT_BLOCK") ? atoi(exp_env("ICP_QSORT_BLOCK")) : (tile_on ? 1 : 0);
   int blk = blk_env < 0 ? 0 : (blk_env > 3 ? 3 : blk_env);
   unsigned long long keys;
   for (;; --blk) {
@@ -1548,7 +1532,7 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
 
 // four lanes per query while one lane per query cannot fill the chip (ICP_NN_COOP_MAX_N: largest n that gets them)
 long grid_coop_max() {
-  static const long coop_max = getenv("ICP_NN_COOP_MAX_N") ? atol(getenv("ICP_NN_COOP_MAX_N")) : 65536;
+  static const long coop_max = exp_env("ICP_NN_COOP_MAX_N") ? atol(exp_env("ICP_NN_COOP_MAX_N")) : 65536;
   return coop_max;
 }
 
@@ -1583,9 +1567,9 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   const unsigned blocks = (unsigned)(((size_t)n * (coop ? 4 : 1) + kGridThreads - 1) / kGridThreads);
   // the warm search beyond the four-lanes-per-query sizes: the f32-geometry kernel (ICP_NN_OLD_WARM: the
   // round-1 kernel, for A/B runs; both return the same indices)
-  static const bool old_warm = getenv("ICP_NN_OLD_WARM") != nullptr;
+  static const bool old_warm = exp_env("ICP_NN_OLD_WARM") != nullptr;
   // the first search of a snapshot: seeds, then the same warm kernel (ICP_NN_OLD_COLD: the general kernel)
-  static const bool old_cold = getenv("ICP_NN_OLD_COLD") != nullptr;
+  static const bool old_cold = exp_env("ICP_NN_OLD_COLD") != nullptr;
   const bool seeded = sorted && !q_prev && !coop && xform && G.p.f32_ok && !old_warm && !old_cold && h->m > 0;
   if (seeded) {
     if (h->dim == 3)
@@ -1595,10 +1579,11 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
       hipLaunchKernelGGL(k_nn_grid_seed<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, n, T, G.p, G.d_start,
                          G.d_pts, h->d_dst, Q.d_prev);
   }
+#ifdef ICP_EXPERIMENTS
   // ICP_NN_TILE=1: the LDS-tile search of nn_tile.hip (round 3; same indices).  Built, parity-green at 1M x 1M and
   // measured slower than the gather walk on the benchmark pair (109 + 42 us against 84 us: DESIGN.md section 5),
   // so it is opt-in
-  static const bool use_tile = getenv("ICP_NN_TILE") != nullptr && atoi(getenv("ICP_NN_TILE")) != 0;
+  static const bool use_tile = exp_env("ICP_NN_TILE") != nullptr && atoi(exp_env("ICP_NN_TILE")) != 0;
   if ((q_prev || seeded) && !coop && xform && G.p.f32_ok && !old_warm && use_tile) {
     hipError_t we = launch_nn_tile(h, q_src, q_perm, n, T, d_idx, (double2 *)d_a, (double2 *)d_b);
     if (ev0 && ev1) {
@@ -1607,12 +1592,13 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
     }
     return we;
   }
+#endif
   if ((q_prev || seeded) && !coop && xform && G.p.f32_ok && !old_warm) {
     // certificates (k_nn_cert above): ICP_NN_NO_CERT=1 searches every query every time, as rounds 1-2 did
-    static const bool no_cert = getenv("ICP_NN_NO_CERT") != nullptr;
+    static const bool no_cert = exp_env("ICP_NN_NO_CERT") != nullptr;
     // a step so long that too few certificates survive it: skip the check (in smallest cell sides; at 0.006 a third
     // of the certificates fail, at 0.2 six in seven, and the break-even is about one half)
-    static const double cert_max_step = getenv("ICP_NN_CERT_MAX_STEP") ? atof(getenv("ICP_NN_CERT_MAX_STEP")) : 0.01;
+    static const double cert_max_step = exp_env("ICP_NN_CERT_MAX_STEP") ? atof(exp_env("ICP_NN_CERT_MAX_STEP")) : 0.01;
     QuerySort &QW = h->qsort;
     double step = 0.;
     QW.have_pose_before = QW.have_pose;

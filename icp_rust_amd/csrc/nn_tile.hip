@@ -27,6 +27,8 @@
 // A wave whose unions do not fit the LDS budget (rows, table entries, records), or that holds a lane without
 // f32 geometry, appends its number to a worklist and leaves; k_nn_grid_warm_list (nn_grid.hip) then serves
 // those waves with the per-lane gather walk.
+// (an EXPERIMENT: compiled only into `make experiments`, never into the product library)
+#ifdef ICP_EXPERIMENTS
 #include "common.hpp"
 
 namespace icp {
@@ -492,7 +494,7 @@ hipError_t launch_nn_tile(icp_handle *h, const double *q_src, const uint32_t *q_
   const Grid &G = h->grid;
   QuerySort &Q = h->qsort;
   const unsigned nwaves = (n + 63u) / 64u;
-  static const bool no_xcd = getenv("ICP_TILE_NO_XCD") != nullptr;
+  static const bool no_xcd = exp_env("ICP_TILE_NO_XCD") != nullptr;
   const unsigned chunks = (nwaves + 7u) / 8u;
   const unsigned blocks = no_xcd ? nwaves : chunks * 8u;
   Q.last_waves = nwaves;
@@ -509,3 +511,5 @@ hipError_t launch_nn_tile(icp_handle *h, const double *q_src, const uint32_t *q_
 }
 
 }  // namespace icp
+
+#endif  // ICP_EXPERIMENTS

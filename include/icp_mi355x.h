@@ -133,7 +133,6 @@ void icp_destroy(icp_handle *h);
  * path.  icp_set_single_launch(h, 0) switches that off for a handle (tests, A/B); the counters:
  * out[0] calls served, out[1] Gauss-Newton evaluations in them, out[2] of which needed the sorting path. */
 int icp_set_single_launch(icp_handle *h, int enable);
-int icp_single_launch_counters(icp_handle *h, uint64_t out[3]);
 int icp_set_nn_mode(icp_handle *h, int mode);   /* icp_nn_mode; default ICP_NN_AUTO */
 int icp_get_nn_mode(const icp_handle *h);       /* the engine AUTO resolved to      */
 /* run the handle's kernels on a caller-chosen HIP stream (hipStream_t) instead of the handle's
@@ -315,24 +314,14 @@ typedef struct icp_multi icp_multi;
 int icp_create_multi(icp_multi **out, int dim, const double *dst, size_t m, const int *device_ids, int n_devices);
 int icp_multi_estimate(icp_multi *M, const double *src, size_t n, const icp_pose *init, size_t max_iter,
                        icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters);
-int icp_multi_counters(const icp_multi *M, uint64_t out[2]);
-/* ... and of the one-launch inner loop across the ranks (section 5b): out[0] launches (per rank), out[1] evaluations they
- * served, out[2] launches that handed an evaluation back to the stage calls.  ICP_MULTI_NO_LOOP=1: stage calls only. */
-int icp_multi_loop_counters(const icp_multi *M, uint64_t out[3]);
 /* EXTENSION (section 6 across the ranks; BASELINE configs[4] on several GPUs): every rank appends the same k points,
  * moved by T (NULL: as they are), to its replica of the target cloud and rebuilds its search grid; afterwards the
- * object equals a fresh icp_create_multi on the concatenated cloud, bit for bit. */
+ * object answers like a fresh icp_create_multi on the concatenated cloud, in the sense of section 6 (correspondences
+ * always; pose bits for source clouds that keep the caller's fold order). */
 int icp_multi_append_targets(icp_multi *M, const double *pts, size_t k, const icp_pose *T);
 size_t icp_multi_target_count(const icp_multi *M);
 void icp_destroy_multi(icp_multi *M);
 
-/* Live kernel timing for the benchmark: with enable = k > 0, HIP events bracket every
- * k-th launch of the nearest-neighbour search kernel on the handle's stream (an event pair
- * costs a few us of stream time, so the benchmark samples instead of timing every launch);
- * 0 switches it off.  icp_profile_read synchronises the stream, returns the summed device
- * time (ms) of the timed launches and their count since the last read, and clears them. */
-int icp_profile_enable(icp_handle *h, int enable);
-int icp_profile_read(icp_handle *h, double *nn_kernel_ms, uint64_t *nn_kernel_launches);
 
 /* The N-term sums (jtj, jtr, Huber error) are added in a fixed, run-to-run
  * deterministic tree; this reports its geometry for n points so a checker can
@@ -341,9 +330,12 @@ void icp_reduce_geometry(size_t n, int *blocks, int *threads);
 /* ... over the source points in FOLD ORDER.  The reference folds over the caller's order
  * (src/lib.rs:240-255, a left fold); the sum is the same up to rounding, so any fixed order meets the
  * 1e-5 pose bar.  When icp_estimate[_device] takes a cell-sorted snapshot of the source cloud (grid
- * engine, n >= 16384) the fold order IS the snapshot order -- ascending (target-grid cell of
- * init * src[i], i), a stable sort, hence a pure function of the inputs -- so that the search can store
- * its pairs with full-line writes and nothing is ever scattered back; otherwise it is the caller's order.
+ * engine, MORE THAN 65 536 source points -- the largest cloud searched with four lanes per query; the threshold can be
+ * moved with ICP_NN_COOP_MAX_N, which therefore moves result bits) the fold order IS the snapshot order -- ascending
+ * (target-grid cell of init * src[i], i), a stable sort, hence a pure function of the inputs AND OF THE HANDLE'S GRID
+ * (box and cell size: what icp_create chose for the target cloud, kept by incremental appends, section 6) -- so that
+ * the search can store its pairs with full-line writes and nothing is ever scattered back; otherwise (smaller clouds,
+ * the sweep engine, the stage calls) it is the caller's order.
  * icp_last_fold_order reports it for the last estimate call on `h` (host buffers of n words, either may be
  * NULL): perm[k] = caller's index of the k-th folded point, cell[k] = its sort key (all 0 for the identity).
  * A checker reproduces the device sums by folding the pairs of src[perm[0]], src[perm[1]], ... in the
@@ -355,29 +347,8 @@ int icp_last_fold_order(icp_handle *h, size_t n, uint32_t *perm, uint32_t *cell)
 int icp_sort_source_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T, double *d_sorted,
                            uint32_t *d_perm);
 
-/* Observability: the last LDS-tile search of `h` (the warm grid search beyond 65 536 source points): out[0] = waves
- * launched, out[1] = waves handed to the per-lane gather walk because their unions exceeded the LDS budget. */
-int icp_nn_tile_counters(icp_handle *h, uint64_t out[2]);
-/* Observability: certified matches (the searches of an estimate call after the first, beyond 65 536 source points:
- * a query whose previous match is provably still its nearest neighbour -- it has moved less than the margin the
- * last walk left it -- is not searched again).  out[0] = searches that checked certificates
- * since the handle was created, out[1] = queries whose certificate failed in the last of them (searched as ever).
- * ICP_NN_NO_CERT=1 in the environment searches every query every time. */
-int icp_nn_cert_counters(icp_handle *h, uint64_t out[2]);
 
-/* Observability for tests: which pipeline served the weighted Gauss-Newton evaluations of
- * this handle (NULL: the scratch handle behind the free functions) since it was created.
- * out[0] evaluations started with the three-launch window pipeline, out[1] how many of those
- * missed their window and were repeated, out[2] evaluations by the seven-launch (or
- * single-workgroup) pipeline, out[3] by the general radix-select path; out[4] / out[5]
- * speculative searches of icp_estimate[_device] whose pose was confirmed / discarded.  Every
- * path returns the same bits; the counters only show that a test exercised what it meant to. */
-int icp_gn_path_counters(icp_handle *h, uint64_t out[6]);
 
-/* ... and the one-launch inner loop (gn_loop.hip: the whole estimate_transform loop, src/lib.rs:59-84, of a pair set of
- * up to 2^20 in one launch): out[0] launches, out[1] evaluations they served (counted in out[0] of
- * icp_gn_path_counters as well), out[2] launches that handed an evaluation back to the host-stepped pipelines. */
-int icp_gn_loop_counters(icp_handle *h, uint64_t out[3]);
 
 /* The reference builds a new Icp per frame (examples/scan2d.rs:87, scan3d.rs:130), so icp_destroy
  * keeps the device buffers, streams and pinned memory of up to two handles per process for the
@@ -392,8 +363,12 @@ void icp_trim_pool(void);
  * registered scans are appended to.  The reference has no such thing: its Icp borrows a fixed
  * `dst` (src/lib.rs:97-102, 139-144).  What the reference does define is the registration of a
  * scan against ANY target cloud, so a map handle is an ordinary handle whose target cloud can
- * be extended; after an append every result is, bit for bit, that of a fresh icp_create on the
- * concatenated cloud (target indices = position in the concatenation).  Point-to-plane
+ * be extended; after an append every CORRESPONDENCE is that of a fresh icp_create on the
+ * concatenated cloud (target indices = position in the concatenation), and so is every pose, bit for bit, as long as
+ * the source cloud keeps the caller's fold order (up to 65 536 points, section 9a).  Larger source clouds fold
+ * their sums in the order of the handle's grid cells; an incrementally appended handle keeps the grid of its last full
+ * build where a fresh handle derives a new one, so their poses agree to the rounding of a re-ordered sum (~1e-12
+ * relative; the bar is 1e-5) -- each equals the oracle evaluated in ITS fold order (icp_last_fold_order) bit for bit.  Point-to-plane
  * residuals, also named by configs[4], have no definition in the reference (no normals
  * anywhere in src/): section 7 builds them as a second labelled extension.
  *
@@ -406,11 +381,6 @@ void icp_trim_pool(void);
  * icp_reserve_targets sizes that storage ahead of time; icp_target_count reports m. */
 int icp_append_targets(icp_handle *h, const double *pts, size_t k, const icp_pose *T);
 int icp_append_targets_device(icp_handle *h, const double *d_pts, size_t k, const icp_pose *T);
-/* Observability: out[0] = appends served incrementally (the sorted records of the search grid move up by their cells'
- * shifts and the new ones fill the gaps: possible while every new point lies within half a cell of the grid's box and
- * the cloud has grown by less than half since the grid's cell size was chosen), out[1] = appends that rebuilt the grid.
- * Either way the handle afterwards answers like a fresh handle on the concatenated cloud. */
-int icp_grid_append_counters(const icp_handle *h, uint64_t out[2]);
 int icp_reserve_targets(icp_handle *h, size_t capacity);
 size_t icp_target_count(const icp_handle *h);
 /* copy target points [first, first + k) back to the host (AoS), e.g. to save the map */

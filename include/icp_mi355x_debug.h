@@ -1,0 +1,66 @@
+/* Observability of libicp_mi355x.so: which pipeline served what, timing hooks of the benchmark.  Test and profiling
+ * infrastructure -- NOT part of the drop-in boundary (include/icp_mi355x.h, sections 1-7, is what a binding of the
+ * reference's API needs); the symbols are exported by the product library so that the -m gpu tests can prove which
+ * path ran.  No result depends on any of them. */
+#ifndef ICP_MI355X_DEBUG_H
+#define ICP_MI355X_DEBUG_H
+
+#include "icp_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Observability for tests: which pipeline served the weighted Gauss-Newton evaluations of
+ * this handle (NULL: the scratch handle behind the free functions) since it was created.
+ * out[0] evaluations started with the three-launch window pipeline, out[1] how many of those
+ * missed their window and were repeated, out[2] evaluations by the seven-launch (or
+ * single-workgroup) pipeline, out[3] by the general radix-select path; out[4] / out[5]
+ * speculative searches of icp_estimate[_device] whose pose was confirmed / discarded.  Every
+ * path returns the same bits; the counters only show that a test exercised what it meant to. */
+int icp_gn_path_counters(icp_handle *h, uint64_t out[6]);
+
+/* ... and the one-launch inner loop (gn_loop.hip: the whole estimate_transform loop, src/lib.rs:59-84, of a pair set of
+ * up to 2^20 in one launch): out[0] launches, out[1] evaluations they served (counted in out[0] of
+ * icp_gn_path_counters as well), out[2] launches that handed an evaluation back to the host-stepped pipelines. */
+int icp_gn_loop_counters(icp_handle *h, uint64_t out[3]);
+
+/* Observability: the last LDS-tile search of `h` (the warm grid search beyond 65 536 source points): out[0] = waves
+ * launched, out[1] = waves handed to the per-lane gather walk because their unions exceeded the LDS budget. */
+int icp_nn_tile_counters(icp_handle *h, uint64_t out[2]);
+
+/* Observability: certified matches (the searches of an estimate call after the first, beyond 65 536 source points:
+ * a query whose previous match is provably still its nearest neighbour -- it has moved less than the margin the
+ * last walk left it -- is not searched again).  out[0] = searches that checked certificates
+ * since the handle was created, out[1] = queries whose certificate failed in the last of them (searched as ever).
+ * ICP_NN_NO_CERT=1 in the environment searches every query every time. */
+int icp_nn_cert_counters(icp_handle *h, uint64_t out[2]);
+
+int icp_single_launch_counters(icp_handle *h, uint64_t out[3]);
+
+/* Observability: out[0] = appends served incrementally (the sorted records of the search grid move up by their cells'
+ * shifts and the new ones fill the gaps: possible while every new point lies within half a cell of the grid's box and
+ * the cloud has grown by less than half since the grid's cell size was chosen), out[1] = appends that rebuilt the grid.
+ * Either way the handle afterwards answers like a fresh handle on the concatenated cloud (in the sense stated at the
+ * top of this section). */
+int icp_grid_append_counters(const icp_handle *h, uint64_t out[2]);
+
+int icp_multi_counters(const icp_multi *M, uint64_t out[2]);
+
+/* ... and of the one-launch inner loop across the ranks (section 5b): out[0] launches (per rank), out[1] evaluations they
+ * served, out[2] launches that handed an evaluation back to the stage calls.  ICP_MULTI_NO_LOOP=1: stage calls only. */
+int icp_multi_loop_counters(const icp_multi *M, uint64_t out[3]);
+
+/* Live kernel timing for the benchmark: with enable = k > 0, HIP events bracket every
+ * k-th launch of the nearest-neighbour search kernel on the handle's stream (an event pair
+ * costs a few us of stream time, so the benchmark samples instead of timing every launch);
+ * 0 switches it off.  icp_profile_read synchronises the stream, returns the summed device
+ * time (ms) of the timed launches and their count since the last read, and clears them. */
+int icp_profile_enable(icp_handle *h, int enable);
+int icp_profile_read(icp_handle *h, double *nn_kernel_ms, uint64_t *nn_kernel_launches);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ICP_MI355X_DEBUG_H */

@@ -25,7 +25,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ICP_TRIG_FN __host__ __device__ static inline
 #else
 #define ICP_TRIG_FN static inline

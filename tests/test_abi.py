@@ -20,10 +20,14 @@ def built():
     I.build()
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "icp_mi355x.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(icp_[a-z0-9_]+)\s*\(", text)))
+def header_symbols(names=("icp_mi355x.h", "icp_mi355x_debug.h")):
+    """every function the C ABI declares: the drop-in boundary and its observability companion"""
+    out = set()
+    for name in names:
+        text = open(os.path.join(ROOT, "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(icp_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 def test_library_exports_every_declared_symbol():
@@ -32,8 +36,16 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/icp_mi355x.h but not exported"
-    # and the Python binding covers exactly the header
+    # and the Python binding covers exactly the headers
     assert sorted(_lib.SIGNATURES) == syms
+    # ... and the library exports NOTHING beyond them: no C++ internals, no kernels' host stubs (csrc/exports.map)
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if " T " in line)
+    assert exported == syms, sorted(set(exported) ^ set(syms))
+    # the boundary proper carries no counters
+    assert not [s for s in header_symbols(("icp_mi355x.h",)) if s.endswith("_counters") or s.startswith("icp_profile_")]
 
 
 def test_abi_version_and_status_strings():

@@ -248,3 +248,33 @@ def test_incremental_and_rebuilding_appends_both_equal_a_fresh_handle():
     assert rc == O.OK and np.array_equal(grown.nn_search(q[:3000]), want)
     moved, rebuilt = grown.append_counters()
     assert moved >= 3 and rebuilt >= 2, (moved, rebuilt)
+
+
+@gpu
+def test_an_appended_handle_registers_a_large_source_cloud_like_its_own_fold_order_says():
+    """a source cloud above 65 536 points folds its sums in the order of the HANDLE'S grid cells
+    (include/icp_mi355x.h section 9a).  An incrementally appended handle keeps the grid of its last full build where a
+    fresh handle on the concatenated cloud derives a new one, so the two fold in different orders: same
+    correspondences, poses equal to the rounding of a re-ordered sum -- and each equal, bit for bit, to the oracle
+    evaluated in ITS OWN fold order (icp_last_fold_order)."""
+    rng = np.random.default_rng(77)
+    base = synth.box_cloud(synth.SEED + 31, 90_000, synth.ROOM_LO, synth.ROOM_HI)
+    extra = synth.box_cloud(synth.SEED + 32, 8_000, synth.ROOM_LO, synth.ROOM_HI)
+    cloud = np.concatenate([base, extra])
+    src = cloud[rng.choice(len(cloud), 70_000, replace=False)] + rng.normal(size=(70_000, 3)) * 0.01
+    grown = I.Icp3d(base, nn_mode=I.NN_GRID)
+    grown.append(extra)
+    assert grown.append_counters()[0] == 1  # served incrementally: the grid of the 90 000-point build
+    fresh = I.Icp3d(cloud, nn_mode=I.NN_GRID)
+    T0 = I.Transform([0.02, -0.01, 0.004])
+    init = O.transform_new(np.array([0.02, -0.01, 0.004]))
+    for icp in (grown, fresh):
+        T, idx, inner = icp.estimate(src, T0, 4, return_info=True)
+        rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, cloud, src, init, 4)
+        assert rc == O.OK
+        assert np.array_equal(idx, oidx) and np.array_equal(inner, oinner)
+        assert np.array_equal(T.as_array(), oT.as_array())
+    Tg, ig, _ = grown.estimate(src, T0, 4, return_info=True)
+    Tf, i_f, _ = fresh.estimate(src, T0, 4, return_info=True)
+    assert np.array_equal(ig, i_f)
+    assert np.max(np.abs(Tg.as_array() - Tf.as_array())) <= 1e-10
