@@ -893,8 +893,16 @@ static bool loop_plan(icp_handle *h, size_t n, int it, int first_kind, int secon
   pl->second_kind = second_kind;
   pl->it0 = it;
   pl->A = LoopArgs{};
-  const int kind0 = pl->kind_of(it), kind1 = pl->kind_of(it + 1);
+  int kind0 = pl->kind_of(it);
+  const int kind1 = pl->kind_of(it + 1);
   if (hints) adopt_pool_hint(w, kind0);
+  // Whose statistics predict a loop's FIRST evaluation?  After a loop of one update (a settled registration) the
+  // previous loop's first evaluation: the populations "new correspondences" / "after the update" alternate (common.hpp:
+  // Workspace::win_kind).  After a loop of several updates the previous loop's LAST evaluation: same outer pose, and
+  // the re-matched pairs differ little from the old ones, while that loop's first evaluation lies many updates back
+  // (the converging pair: three of these windows per call missed even at 0.2 sigma, each costing a handed-back
+  // evaluation).  The statistics are still RECORDED under the evaluation's own kind.
+  if (hints && it == 0 && w.win_valid && w.last_inner != 0xffffffffu && w.last_inner >= 2u) kind0 = 2;
   if (!window_usable(h, n, &pl->A.PA, kind0, !hints)) return false;
   pl->own0 = Workspace::kind_has_slot(kind0) && w.win_kind[kind0].valid;
   for (int d = 0; d < 2; ++d) {
@@ -1179,7 +1187,7 @@ extern "C" int icp_shard_loop_wait(icp_handle *h, icp_pose *Ti, double *prev_err
   HIP_TRY(hipSetDevice(h->device));
   LoopResult *res = reinterpret_cast<LoopResult *>(w.h_loop_res);
   HIP_TRY(wait_seq(h, &res->seq, w.loop_seq));
-  if (evals) *evals = res->evals;
+  if (evals) *evals = res->rounds;  // (what the connection's eval_base advances by)
   if (res->status == 5) {
     w.loop_off = true;
     return ICP_HIP_ERROR;

@@ -300,10 +300,41 @@ struct LoopLocal {  // per workgroup, LDS: the loop's state, replicated
   Pose Ti;
   double prev_error;
   double med[2], sig[2];
+  double f;  // half-width (in sigmas) of the window the launch will centre on this evaluation's statistics
   WinParams P;
   unsigned applied;
   int done, status;
+  int retried;  // the evaluation in hand is being repeated with the widest windows
 };
+
+// A window that missed: the same evaluation once more around the same centre with the widest windows the bin layout
+// allows (0.2 sigma: it tolerates a prediction that is off by that much) -- 40 us inside the launch instead of handing
+// the evaluation to the host's pipelines (three launches, two waits, a relaunch).  false: no such window.
+__device__ __forceinline__ bool widen_window(WinParams *P) {
+  double med[2], sig[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const WinDim &w = P->d[d];
+    med[d] = 0.5 * (w.x[2] + w.x[3]);
+    sig[d] = (0.5 * (w.x[4] + w.x[5]) - med[d]) * ICP_PPF34;
+  }
+  return make_window_hd(med, sig, 0.2, P);
+}
+
+// How wide the next window has to be: the statistics of consecutive evaluations of one inner loop move less and less
+// (a converging Gauss-Newton iteration), and a window eight times the last observed move -- never wider than the
+// host's default f_max -- holds a few dozen candidates instead of several hundred: both selections then rank their
+// lists directly.  A window that turns out too narrow is a miss like any other (the host's pipelines serve that
+// evaluation and re-centre).
+__device__ __forceinline__ double next_half_width(const double (&med)[2], const double (&sig)[2], const double *pmed,
+                                                  const double *psig, bool have_prev, double f_max) {
+  if (!have_prev) return f_max;
+  double shift = 0.;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) shift = fmax(shift, (fabs(med[d] - pmed[d]) + fabs(sig[d] - psig[d])) / sig[d]);
+  const double f = 8. * shift;
+  return f != f || f > f_max ? f_max : (f < 0.004 ? 0.004 : f);
+}
 
 }  // namespace
 
@@ -345,6 +376,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
     L.applied = A.applied0;
     L.done = 0;
     L.status = 0;
+    L.retried = 0;
     L.med[0] = L.med[1] = L.sig[0] = L.sig[1] = 0.;
   }
   __syncthreads();
@@ -356,8 +388,9 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
   unsigned it = A.it0;
   LOOP_STAMP(0);
   bool aborted = false;
-  for (; it < (unsigned)ICP_INNER_MAX_ITER; ++it, ++evals) {
-    const unsigned par = evals & 1u;
+  unsigned round = 0;  // evaluation rounds of this launch, repeated ones included: parity of the double buffers, barrier generation
+  for (; it < (unsigned)ICP_INNER_MAX_ITER; ++round) {
+    const unsigned par = round & 1u;
     uint32_t *const whist = A.whist + (size_t)par * 2 * kWinBins;
     double *const partials = A.partials + (size_t)par * kReduceMaxBlocks * (kNSum + 1);
     double *const totals = A.partials + (size_t)2 * kReduceMaxBlocks * (kNSum + 1) + (size_t)par * (kNSum + 1);
@@ -410,7 +443,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
       block_reduce_store<kNSum, true>(acc, partials + (size_t)blockIdx.x * (kNSum + 1));
     }
     LOOP_STAMP(2);
-    if (!flag_barrier(ctl->flag1, ctl, evals + 1u, 0ull, nullptr)) {
+    if (!flag_barrier(ctl->flag1, ctl, round + 1u, 0ull, nullptr)) {
       aborted = true;
       break;
     }
@@ -486,7 +519,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
     }
     const bool b_fail = R.fail;
     LOOP_STAMP(5);
-    if (!flag_barrier(ctl->flag2, ctl, evals + 1u, 0ull, nullptr)) {
+    if (!flag_barrier(ctl->flag2, ctl, round + 1u, 0ull, nullptr)) {
       aborted = true;
       break;
     }
@@ -549,9 +582,16 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
           L.done = 1;
           L.status = 3;
         } else if (fail) {
-          L.done = 1;
-          L.status = 1;
+          if (!L.retried && widen_window(&L.P)) {
+            L.retried = 1;
+            L.done = 3;  // (the same evaluation again, next round)
+          } else {
+            L.done = 1;
+            L.status = 1;
+          }
         } else {
+          L.retried = 0;
+          L.f = next_half_width(med, sig, L.med, L.sig, it > A.it0, A.f_next);
           L.med[0] = med[0];
           L.med[1] = med[1];
           L.sig[0] = sig[0];
@@ -579,7 +619,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
         }
         // what the host records as this evaluation's statistics (first / second / most recent of the launch)
         if (blockIdx.x == 0 && !nan_flag && !fail) {
-          const int slot = evals < 2u ? (int)evals : 2;
+          const unsigned nth = it - A.it0;  // (which evaluation of the loop this launch has reached)
+          const int slot = nth < 2u ? (int)nth : 2;
           A.res->med[slot][0] = med[0];
           A.res->med[slot][1] = med[1];
           A.res->sigma[slot][0] = sig[0];
@@ -596,12 +637,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
       if (L.done == 2) {
         // the next evaluation's window: the prediction the host made for the loop's second evaluation, else this
         // evaluation's own statistics
-        if (evals == 0 && A.pb_valid) {
+        if (it == A.it0 && A.pb_valid) {  // (the launch's first evaluation was just applied)
           if (tid < sizeof(WinParams) / sizeof(double))
             reinterpret_cast<double *>(&L.P)[tid] = reinterpret_cast<const double *>(&A.PB)[tid];
           if (tid == 0) L.done = 0;
         } else if (tid == 0) {
-          if (make_window_hd(L.med, L.sig, A.f_next, &L.P)) {
+          if (make_window_hd(L.med, L.sig, L.f, &L.P)) {
             L.done = 0;
           } else {  // (no usable prediction: the host's pipelines serve the next evaluation)
             L.done = 1;
@@ -612,6 +653,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
       }
       LOOP_STAMP(9);
     }
+    if (L.done == 3) {  // a window missed: the same evaluation once more, widest windows (uniform: every workgroup decided so)
+      __syncthreads();
+      if (tid == 0) L.done = 0;
+      __syncthreads();
+      continue;
+    }
     if (L.done) {
       // status 0: evaluation `it` ended the loop (it is not counted as applied); 1 / 4: evaluation `it` was not served;
       // 2: evaluation `it` was served and applied, evaluation `it + 1` has no window
@@ -619,6 +666,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
       if (L.status == 2) ++it;
       break;
     }
+    ++it;
+    ++evals;
   }
   if (blockIdx.x == 0 && tid < 64) {
     LoopResult *res = A.res;
@@ -628,6 +677,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
       res->applied = L.applied;
       res->it = it;
       res->evals = evals;
+      res->rounds = round + ((aborted || L.done == 0) ? 0u : 1u);  // (L.done == 0: the loop ran out of iterations at its head)
       res->status = aborted ? 5 : L.status;
       res->finished = (!aborted && L.status == 0) ? 1 : 0;
     }
@@ -772,15 +822,17 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
     L.applied = A.applied0;
     L.done = 0;
     L.status = 0;
+    L.retried = 0;
     L.med[0] = L.med[1] = L.sig[0] = L.sig[1] = 0.;
   }
   __syncthreads();
   unsigned evals = 0;
   unsigned it = A.it0;
   bool aborted = false;
-  for (; it < (unsigned)ICP_INNER_MAX_ITER; ++it, ++evals) {
-    const unsigned par = (S.eval_base + evals) & 1u;
-    const unsigned gen = S.gen_base + evals + 1u;
+  unsigned round = 0;  // evaluation rounds of this launch, repeated ones included
+  for (; it < (unsigned)ICP_INNER_MAX_ITER; ++round) {
+    const unsigned par = (S.eval_base + round) & 1u;
+    const unsigned gen = S.gen_base + round + 1u;
     uint32_t *const whist = me->hist_local[par];
     const Pose T = pose_sgpr(L.Ti);
     WinParams P;
@@ -1017,9 +1069,16 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
           L.done = 1;
           L.status = 3;
         } else if (fail) {
-          L.done = 1;
-          L.status = 1;
+          if (!L.retried && widen_window(&L.P)) {
+            L.retried = 1;
+            L.done = 3;  // (the same evaluation again, next round)
+          } else {
+            L.done = 1;
+            L.status = 1;
+          }
         } else {
+          L.retried = 0;
+          L.f = next_half_width(med, sig, L.med, L.sig, it > A.it0, A.f_next);
           L.med[0] = med[0];
           L.med[1] = med[1];
           L.sig[0] = sig[0];
@@ -1046,7 +1105,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
           }
         }
         if (blockIdx.x == 0 && !nan_flag && !fail) {
-          const int slot = evals < 2u ? (int)evals : 2;
+          const unsigned nth = it - A.it0;  // (which evaluation of the loop this launch has reached)
+          const int slot = nth < 2u ? (int)nth : 2;
           A.res->med[slot][0] = med[0];
           A.res->med[slot][1] = med[1];
           A.res->sigma[slot][0] = sig[0];
@@ -1061,12 +1121,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
       }
       __syncthreads();
       if (L.done == 2) {
-        if (evals == 0 && A.pb_valid) {
+        if (it == A.it0 && A.pb_valid) {  // (the launch's first evaluation was just applied)
           if (tid < sizeof(WinParams) / sizeof(double))
             reinterpret_cast<double *>(&L.P)[tid] = reinterpret_cast<const double *>(&A.PB)[tid];
           if (tid == 0) L.done = 0;
         } else if (tid == 0) {
-          if (make_window_hd(L.med, L.sig, A.f_next, &L.P)) {
+          if (make_window_hd(L.med, L.sig, L.f, &L.P)) {
             L.done = 0;
           } else {
             L.done = 1;
@@ -1076,11 +1136,19 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
         __syncthreads();
       }
     }
+    if (L.done == 3) {  // a window missed: the same evaluation once more, widest windows
+      __syncthreads();
+      if (tid == 0) L.done = 0;
+      __syncthreads();
+      continue;
+    }
     if (L.done) {
       if (L.status == 0 || L.status == 2) ++evals;
       if (L.status == 2) ++it;
       break;
     }
+    ++it;
+    ++evals;
   }
   if (blockIdx.x == 0 && tid < 64) {
     LoopResult *res = A.res;
@@ -1090,6 +1158,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
       res->applied = L.applied;
       res->it = it;
       res->evals = evals;
+      res->rounds = round + ((aborted || L.done == 0) ? 0u : 1u);  // (L.done == 0: the loop ran out of iterations at its head)
       res->status = aborted ? 5 : L.status;
       res->finished = (!aborted && L.status == 0) ? 1 : 0;
     }

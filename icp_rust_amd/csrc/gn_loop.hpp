@@ -29,6 +29,7 @@ struct LoopResult {
   unsigned applied;    // updates applied so far (src/lib.rs:81)
   unsigned it;         // not finished: the evaluation the host resumes with (state = before that evaluation)
   unsigned evals;      // evaluations served by this launch
+  unsigned rounds;     // evaluation rounds it ran: a repeated evaluation (missed window, widest windows) counts twice
   int status;          // 0 ok, 1 evaluation `it` not served (window missed / no window / rotation out of sin-cos range),
                        // 3 NaN residual, 5 a grid barrier timed out (launch not resident)
   int finished;        // the loop ended inside the launch (break test, None, or ICP_INNER_MAX_ITER)

@@ -283,7 +283,9 @@ int icp_shard_eval_abort_device(icp_handle *h);
  *     evaluations earlier launches of this connection served.  ICP_RETRY_SHARDED: nothing launched (no window
  *     prediction for it0 yet, more than 2^20 pairs, fewer tree blocks than ranks) -- every rank answers alike, and the
  *     stage calls of section 5 serve that evaluation.
- *   icp_shard_loop_wait: the state after the launch; *finished, or *it = the evaluation the stage calls must serve
+ *   icp_shard_loop_wait: the state after the launch; *evals = the evaluation ROUNDS it ran (an evaluation whose
+ *     window missed is repeated once inside the launch with the widest windows and counts twice): what eval_base
+ *     advances by; *finished, or *it = the evaluation the stage calls must serve
  *     next (its window missed, or the rotation left the range of the restated sin / cos).  ICP_HIP_ERROR: the launch
  *     gave up waiting for a peer (3 s).
  * Ranks that share a device must launch on streams that really run side by side (they wait for each other): more
