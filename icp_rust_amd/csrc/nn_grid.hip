@@ -1134,6 +1134,20 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
   if (b) b[i] = make_double2(bx, by);
 }
 
+// Which wave of 64 consecutive (cell-sorted) queries a workgroup takes.  Workgroups are dealt round-robin over the 8
+// XCDs, each with an L2 of its own: taken in launch order, neighbouring waves -- which walk the same rows of cells
+// and read the same record lines -- land on eight different L2s, and every line is fetched from the fabric up to eight
+// times.  With chunk > 0 the `chunk` waves an XCD receives out of every 8 x chunk consecutive workgroups are
+// CONSECUTIVE waves (a bijection inside each complete group of 8 x chunk; the tail keeps launch order), fine enough a
+// grain to keep the load balanced across the XCDs (dense walls and sparse interior alternate along the sorted order).
+__device__ __forceinline__ unsigned xcd_wave(unsigned block, unsigned nblocks, unsigned chunk) {
+  if (chunk == 0u) return block;
+  const unsigned per = 8u * chunk, full = nblocks / per * per;
+  if (block >= full) return block;
+  const unsigned sc = block / per, r = block % per;
+  return sc * per + (r & 7u) * chunk + (r >> 3);
+}
+
 template <int DIM, bool CERT>
 __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(const double *__restrict__ src,
                                                                const uint32_t *__restrict__ perm, unsigned n, Pose T,
@@ -1141,8 +1155,8 @@ __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(con
                                                                const GridPoint *__restrict__ pts,
                                                                const double *__restrict__ dst, uint32_t *__restrict__ idx,
                                                                double2 *__restrict__ a, double2 *__restrict__ b,
-                                                               PrevMatch *prev, CertDecay cd) {
-  const unsigned k = blockIdx.x * kGridThreads + threadIdx.x;
+                                                               PrevMatch *prev, CertDecay cd, unsigned xcd_chunk) {
+  const unsigned k = xcd_wave(blockIdx.x, gridDim.x, xcd_chunk) * kGridThreads + threadIdx.x;
   if (k >= n) return;
   warm_query<DIM, CERT>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev, cd);
 }
@@ -1568,6 +1582,8 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   // the warm search beyond the four-lanes-per-query sizes: the f32-geometry kernel (ICP_NN_OLD_WARM: the
   // round-1 kernel, for A/B runs; both return the same indices)
   static const bool old_warm = exp_env("ICP_NN_OLD_WARM") != nullptr;
+  // (84.2 us in launch order, 83.2 / 81.1 / 82.4 / 83.1 us with chunks of 4 / 16 / 64 / 256 waves: profiles/r04_search_xcd_chunk.txt)
+  static const unsigned xcd_chunk = exp_env("ICP_NN_XCD_CHUNK") ? (unsigned)atoi(exp_env("ICP_NN_XCD_CHUNK")) : 16u;
   // the first search of a snapshot: seeds, then the same warm kernel (ICP_NN_OLD_COLD: the general kernel)
   static const bool old_cold = exp_env("ICP_NN_OLD_COLD") != nullptr;
   const bool seeded = sorted && !q_prev && !coop && xform && G.p.f32_ok && !old_warm && !old_cold && h->m > 0;
@@ -1663,17 +1679,17 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
       QW.have_certs = true;
       if (h->dim == 3)
         hipLaunchKernelGGL((k_nn_grid_warm<3, true>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
-                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd);
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd, xcd_chunk);
       else
         hipLaunchKernelGGL((k_nn_grid_warm<2, true>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
-                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd);
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd, xcd_chunk);
     } else {
       if (h->dim == 3)
         hipLaunchKernelGGL((k_nn_grid_warm<3, false>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
-                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd);
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd, xcd_chunk);
       else
         hipLaunchKernelGGL((k_nn_grid_warm<2, false>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
-                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd);
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd, xcd_chunk);
     }
     hipError_t we = hipGetLastError();
     if (ev0 && ev1) {
