@@ -155,6 +155,9 @@ SIGNATURES = {
     "icp_read_target_normals": (C.c_int, [_vp, _sz, _sz, _vp]),
     "icp_estimate_point_to_plane": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
     "icp_estimate_point_to_plane_device": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
+    "icp_multi_compute_target_normals": (C.c_int, [_vp, C.c_int]),
+    "icp_multi_update_target_normals": (C.c_int, [_vp, C.c_int]),
+    "icp_multi_estimate_point_to_plane": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
 }
 
 _lib = None

@@ -636,6 +636,25 @@ class IcpMulti:
         check(lib().icp_multi_counters(self._h, out), "icp_multi_counters")
         return int(out[0]), int(out[1])
 
+    def compute_target_normals(self, k=8):
+        """EXTENSION (icp_multi_compute_target_normals): every rank computes the normals of its replica of the target cloud"""
+        check(lib().icp_multi_compute_target_normals(self._h, int(k)), "icp_multi_compute_target_normals")
+
+    def update_target_normals(self, k=8):
+        check(lib().icp_multi_update_target_normals(self._h, int(k)), "icp_multi_update_target_normals")
+
+    def estimate_point_to_plane(self, src, initial_transform, max_iter, return_info=False):
+        """EXTENSION (icp_multi_estimate_point_to_plane): search sharded over the ranks, inner loop replicated"""
+        s = _host(src, 3)
+        n = s.shape[0]
+        o = Transform()
+        idx = np.zeros(max(n, 1), dtype=np.uint32)
+        inner = np.zeros(max(max_iter, 1), dtype=np.uint32)
+        check(lib().icp_multi_estimate_point_to_plane(self._h, _ptr(s), n, C.byref(initial_transform.pose), max_iter,
+                                                      C.byref(o.pose), C.c_void_p(idx.ctypes.data), C.c_void_p(inner.ctypes.data)),
+              "icp_multi_estimate_point_to_plane")
+        return (o, idx[:n], inner[:max_iter]) if return_info else o
+
     def loop_counters(self):
         """(launches per rank, evaluations served, launches that handed an evaluation back) of the one-launch inner loop"""
         out = (C.c_uint64 * 3)()

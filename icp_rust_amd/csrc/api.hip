@@ -44,6 +44,11 @@ int map_hip(hipError_t e) {
     hipError_t e__ = (expr);                         \
     if (e__ != hipSuccess) return map_hip(e__);      \
   } while (0)
+#define ICP_TRY_RC(expr)             \
+  do {                               \
+    const int rc__ = (expr);         \
+    if (rc__ != ICP_OK) return rc__; \
+  } while (0)
 
 template <typename Tp>
 hipError_t grow(Tp *&p, size_t count) {
@@ -1849,18 +1854,8 @@ extern "C" int icp_read_target_normals(icp_handle *h, size_t first, size_t count
   return ICP_OK;
 }
 
-extern "C" int icp_estimate_point_to_plane_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *init,
-                                                  size_t max_iter, icp_pose *out, uint32_t *d_last_idx,
-                                                  uint32_t *inner_iters) {
-  if (!h || h->dim != 3 || !init || !out || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
-  if (h->m == 0) {  // index.unwrap() on an empty tree, src/lib.rs:165 -- only when a search would run
-    if (n > 0 && max_iter > 0) return ICP_EMPTY_DST;
-    *out = *init;
-    return ICP_OK;
-  }
-  if (h->normals_m != h->m) return ICP_BAD_ARGUMENT;  // icp_compute_target_normals first (again after an append)
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(ensure_workspace(h, n, false));
+// the per-pair scratch of a point-to-plane inner loop
+static int ensure_plane_buffers(icp_handle *h, size_t n) {
   if (n > h->cap_plane) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     (void)hipFree(h->d_plane_pairs);
@@ -1874,6 +1869,56 @@ extern "C" int icp_estimate_point_to_plane_device(icp_handle *h, const double *d
     HIP_TRY(hipMalloc(&h->d_plane_fb, n * 2 * sizeof(double)));
     h->cap_plane = n;
   }
+  return ICP_OK;
+}
+
+// One outer iteration's inner loop (src/lib.rs:59-84 around the plane residual) for given correspondences d_idx of the
+// WHOLE source cloud under pose T: the pose update dT and the updates applied.  (icp_multi_estimate_point_to_plane runs
+// this on every rank after the ranks have exchanged the indices of their slices.)
+int icp_p2pl_inner_loop_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T, const uint32_t *d_idx,
+                               icp_pose *dT, uint32_t *applied_out) {
+  if (!h || h->dim != 3 || !T || !dT || (n > 0 && (!d_src || !d_idx)) || h->normals_m != h->m || h->m == 0) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(ensure_workspace(h, n, false));
+  ICP_TRY_RC(ensure_plane_buffers(h, n));
+  Workspace &w = h->ws;
+  HIP_TRY(launch_p2pl_gather(h, d_src, n, *T, d_idx, h->d_normals, h->d_plane_pairs));
+  Pose Ti = transform_identity();
+  uint32_t applied = 0;
+  if (n >= 2) {
+    double prev_error = DBL_MAX;
+    for (int k = 0; k < ICP_INNER_MAX_ITER; ++k) {
+      HIP_TRY(launch_p2pl_eval(h, h->d_plane_pairs, n, Ti, h->d_plane_fa, h->d_plane_fb));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      const GnResult &r = *w.h_res;
+      if (r.nan_flag) return ICP_NAN_INPUT;
+      double delta[3];
+      if (!solve_update(r.acc, r.acc + 9, delta)) break;
+      if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD) break;
+      if (r.acc[12] > prev_error) break;
+      prev_error = r.acc[12];
+      Ti = transform_mul(transform_new(delta), Ti);
+      ++applied;
+    }
+  }
+  *dT = Ti;
+  if (applied_out) *applied_out = applied;
+  return ICP_OK;
+}
+
+extern "C" int icp_estimate_point_to_plane_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *init,
+                                                  size_t max_iter, icp_pose *out, uint32_t *d_last_idx,
+                                                  uint32_t *inner_iters) {
+  if (!h || h->dim != 3 || !init || !out || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  if (h->m == 0) {  // index.unwrap() on an empty tree, src/lib.rs:165 -- only when a search would run
+    if (n > 0 && max_iter > 0) return ICP_EMPTY_DST;
+    *out = *init;
+    return ICP_OK;
+  }
+  if (h->normals_m != h->m) return ICP_BAD_ARGUMENT;  // icp_compute_target_normals first (again after an append)
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(ensure_workspace(h, n, false));
+  ICP_TRY_RC(ensure_plane_buffers(h, n));
   Workspace &w = h->ws;
   Pose T = *init;
   if (max_iter > 0) {
@@ -1892,26 +1937,10 @@ extern "C" int icp_estimate_point_to_plane_device(icp_handle *h, const double *d
     uint32_t *idx = (it + 1 == max_iter && d_last_idx) ? d_last_idx : w.d_idx;
     int rc = icp_correspond_device(h, d_src, n, &T, nullptr, nullptr, idx);  // exact 3-D NN, src/lib.rs:161-167
     if (rc != ICP_OK) return rc;
-    HIP_TRY(launch_p2pl_gather(h, d_src, n, T, idx, h->d_normals, h->d_plane_pairs));
-    // the reference's inner loop (src/lib.rs:59-84) around the plane residual
-    Pose Ti = transform_identity();
+    Pose Ti;
     uint32_t applied = 0;
-    if (n >= 2) {
-      double prev_error = DBL_MAX;
-      for (int k = 0; k < ICP_INNER_MAX_ITER; ++k) {
-        HIP_TRY(launch_p2pl_eval(h, h->d_plane_pairs, n, Ti, h->d_plane_fa, h->d_plane_fb));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        const GnResult &r = *w.h_res;
-        if (r.nan_flag) return ICP_NAN_INPUT;
-        double delta[3];
-        if (!solve_update(r.acc, r.acc + 9, delta)) break;
-        if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD) break;
-        if (r.acc[12] > prev_error) break;
-        prev_error = r.acc[12];
-        Ti = transform_mul(transform_new(delta), Ti);
-        ++applied;
-      }
-    }
+    rc = icp_p2pl_inner_loop_device(h, d_src, n, &T, idx, &Ti, &applied);
+    if (rc != ICP_OK) return rc;
     if (inner_iters) inner_iters[it] = applied;
     T = transform_mul(Ti, T);
   }

@@ -34,6 +34,8 @@ extern "C" int icp_shard_loop_launch_device(icp_handle *h, const double *d_a, co
                                             int first_kind, int second_kind);
 extern "C" int icp_shard_loop_wait(icp_handle *h, icp_pose *Ti, double *prev_error, uint32_t *applied, int *it, int *finished,
                                    uint32_t *evals);
+int icp_p2pl_inner_loop_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T, const uint32_t *d_idx, icp_pose *dT,
+                               uint32_t *applied_out);
 int icp_shard_loop_launch_fused(icp_handle *const *hs, int world, const double *const *d_a, const double *const *d_b, size_t n_total,
                                 unsigned launch_no, unsigned eval_base, int it0, uint32_t applied0, const icp_pose *Ti,
                                 double prev_error, int first_kind, int second_kind);
@@ -55,6 +57,10 @@ struct icp_multi {
     unsigned char *x_hist = nullptr, *x_exch = nullptr;  // exported: histograms; candidates + block sums
     unsigned *x_flags = nullptr;
     unsigned *d_err = nullptr;
+    // EXTENSION, point-to-plane across the ranks: the whole source cloud and every rank's indices (peer-written)
+    double *d_p_src = nullptr;
+    uint32_t *d_p_idx = nullptr;
+    size_t cap_p = 0;
   };
   std::vector<Rank> r;
   // rank 0's device: the whole source cloud, its sorted copy and the permutation (the fold order of the call)
@@ -352,6 +358,8 @@ extern "C" void icp_destroy_multi(icp_multi *M) {
     (void)hipFree(R.x_exch);
     (void)hipFree(R.x_flags);
     if (R.d_err) (void)hipHostFree(R.d_err);
+    (void)hipFree(R.d_p_src);
+    (void)hipFree(R.d_p_idx);
   }
   if (!M->r.empty()) (void)hipSetDevice(M->r[0].device);
   (void)hipFree(M->d_sort_in);
@@ -581,6 +589,106 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
     }
     HIP_TRY(hipMemcpyAsync(last_idx, d_res, n * sizeof(uint32_t), hipMemcpyDeviceToHost, R0.h->stream));
     HIP_TRY(hipStreamSynchronize(R0.h->stream));
+  }
+  *out = T;
+  return ICP_OK;
+}
+
+// ---- EXTENSION (include/icp_mi355x.h section 7 across the ranks; BASELINE configs[4]: scan-to-map, point-to-plane) ------
+// The normals belong to the TARGET cloud, which is replicated: every rank computes (or updates) the same normals from
+// the same cloud.  A registration shards the SEARCH -- contiguous slices of the source cloud, the part that grows with
+// the map -- then every rank receives every slice's indices (4 bytes per point, written into the peers' arrays) and runs
+// the same inner loop on the whole cloud: SURVEY 8(e) option 1, gather-then-replicate.  The result is, bit for bit, one
+// handle's icp_estimate_point_to_plane (same indices, same pairs in the caller's order, same kernels).
+extern "C" int icp_multi_compute_target_normals(icp_multi *M, int k) {
+  if (!M) return ICP_BAD_ARGUMENT;
+  for (auto &R : M->r) ICP_TRY(icp_compute_target_normals(R.h, k));
+  return ICP_OK;
+}
+extern "C" int icp_multi_update_target_normals(icp_multi *M, int k) {
+  if (!M) return ICP_BAD_ARGUMENT;
+  for (auto &R : M->r) ICP_TRY(icp_update_target_normals(R.h, k));
+  return ICP_OK;
+}
+
+extern "C" int icp_multi_estimate_point_to_plane(icp_multi *M, const double *src, size_t n, const icp_pose *init, size_t max_iter,
+                                                 icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters) {
+  if (!M || M->dim != 3 || !init || !out || (n > 0 && !src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
+  const int W = M->world;
+  if (M->m == 0) {
+    if (n > 0 && max_iter > 0) return ICP_EMPTY_DST;
+    *out = *init;
+    return ICP_OK;
+  }
+  struct Quiesce {
+    icp_multi *M;
+    ~Quiesce() {
+      for (auto &R : M->r)
+        if (R.h) {
+          (void)hipSetDevice(R.device);
+          (void)hipStreamSynchronize(R.h->stream);
+          R.h->qsort.valid = false;
+          R.h->qsort.have_prev = false;
+        }
+    }
+  } quiesce_on_exit{M};
+  Pose T = *init;
+  std::vector<size_t> lo(W + 1);
+  for (int q = 0; q <= W; ++q) lo[q] = n * (size_t)q / (size_t)W;
+  for (int q = 0; q < W; ++q) {
+    auto &R = M->r[q];
+    HIP_TRY(hipSetDevice(R.device));
+    if (n > R.cap_p) {
+      (void)hipFree(R.d_p_src);
+      (void)hipFree(R.d_p_idx);
+      R.d_p_src = nullptr;
+      R.d_p_idx = nullptr;
+      R.cap_p = 0;
+      const size_t cap = n + n / 8 + 1;
+      HIP_TRY(hipMalloc(&R.d_p_src, cap * 3 * sizeof(double)));
+      HIP_TRY(alloc_export((void **)&R.d_p_idx, cap * sizeof(uint32_t), !M->one_device));
+      R.cap_p = cap;
+    }
+    if (n > 0) HIP_TRY(hipMemcpyAsync(R.d_p_src, src, n * 3 * sizeof(double), hipMemcpyHostToDevice, R.h->stream));
+    if (max_iter > 0 && lo[q + 1] > lo[q]) ICP_TRY(icp_prepare_source_device(R.h, R.d_p_src + lo[q] * 3, lo[q + 1] - lo[q], init));
+  }
+  for (size_t it = 0; it < max_iter; ++it) {
+    for (int q = 0; q < W; ++q) {  // every rank searches its slice ...
+      auto &R = M->r[q];
+      const size_t cnt = lo[q + 1] - lo[q];
+      if (cnt == 0) continue;
+      ICP_TRY(icp_correspond_device(R.h, R.d_p_src + lo[q] * 3, cnt, &T, nullptr, nullptr, R.d_p_idx + lo[q]));
+      HIP_TRY(hipSetDevice(R.device));
+      for (int p = 0; p < W; ++p)  // ... and hands its indices to every other rank
+        if (p != q)
+          HIP_TRY(hipMemcpyAsync(M->r[p].d_p_idx + lo[q], R.d_p_idx + lo[q], cnt * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                                 R.h->stream));
+    }
+    for (auto &R : M->r) {
+      HIP_TRY(hipSetDevice(R.device));
+      HIP_TRY(hipStreamSynchronize(R.h->stream));
+    }
+    Pose Ti0 = transform_identity();
+    uint32_t ap0 = 0;
+    for (int q = 0; q < W; ++q) {  // the same inner loop on every rank
+      auto &R = M->r[q];
+      Pose Ti;
+      uint32_t ap = 0;
+      ICP_TRY(icp_p2pl_inner_loop_device(R.h, R.d_p_src, n, &T, R.d_p_idx, &Ti, &ap));
+      if (q == 0) {
+        Ti0 = Ti;
+        ap0 = ap;
+      } else if (memcmp(&Ti, &Ti0, sizeof(Pose)) != 0 || ap != ap0) {
+        MULTI_FAIL("the ranks finished a point-to-plane inner loop differently");
+      }
+    }
+    if (inner_iters) inner_iters[it] = ap0;
+    T = transform_mul(Ti0, T);
+  }
+  if (last_idx && max_iter > 0 && n > 0) {
+    auto &R0 = M->r[0];
+    HIP_TRY(hipSetDevice(R0.device));
+    HIP_TRY(hipMemcpy(last_idx, R0.d_p_idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   }
   *out = T;
   return ICP_OK;

@@ -412,6 +412,14 @@ int icp_estimate_point_to_plane(icp_handle *h, const double *src, size_t n, cons
 int icp_estimate_point_to_plane_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *init,
                                        size_t max_iter, icp_pose *out, uint32_t *d_last_idx,
                                        uint32_t *inner_iters);
+/* ... across the ranks of an icp_multi (round 4; BASELINE configs[4] on several GPUs): the normals belong to the replicated
+ * target cloud, so every rank computes / updates the same ones; a registration shards the SEARCH (contiguous slices of
+ * the source cloud), every rank receives every slice's indices and runs the same inner loop on the whole cloud
+ * (SURVEY.md 8(e) option 1).  Result: one handle's icp_estimate_point_to_plane, bit for bit. */
+int icp_multi_compute_target_normals(icp_multi *M, int k);
+int icp_multi_update_target_normals(icp_multi *M, int k);
+int icp_multi_estimate_point_to_plane(icp_multi *M, const double *src, size_t n, const icp_pose *init, size_t max_iter,
+                                      icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters);
 
 #ifdef __cplusplus
 }

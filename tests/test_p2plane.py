@@ -220,3 +220,93 @@ def test_scan_to_map_point_to_plane_on_gpu_tracks_the_cpu_statement():
         assert np.max(np.abs(a.as_array() - b.as_array())) < 1e-8  # tree sums vs left folds, carried through the map
     assert np.max(np.abs(world.read_targets() - oworld.dst)) < 1e-7
     assert np.max(np.abs(world.read_normals() - oworld.normals)) < 1e-6
+
+
+@gpu
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_point_to_plane_across_virtual_ranks_equals_one_handle(world):
+    """icp_multi_estimate_point_to_plane: the search sharded over the ranks, every slice's indices
+    handed to every rank, the inner loop replicated -- pose, indices and inner counts of one handle, bit for bit;
+    also after an append whose targets got their normals 'at insertion time'."""
+    rng = np.random.default_rng(100 + world)
+    dst = room(rng, 60_000)
+    Tt = I.Transform([0.03, -0.02, 0.01])
+    src = moved(dst[rng.integers(0, len(dst), 20_000)] + rng.normal(size=(20_000, 3)) * 1e-3, Tt.inverse())
+    one = I.Icp3d(dst, nn_mode=I.NN_GRID)
+    one.compute_normals(8)
+    T1, idx1, inner1 = one.estimate_point_to_plane(src, I.Transform(), 5, return_info=True)
+    multi = I.IcpMulti(dst, [0] * world)
+    multi.compute_target_normals(8)
+    T, idx, inner = multi.estimate_point_to_plane(src, I.Transform(), 5, return_info=True)
+    assert np.array_equal(T.as_array(), T1.as_array())
+    assert np.array_equal(idx, idx1) and np.array_equal(inner, inner1)
+    assert inner.sum() > 0
+    extra = room(rng, 6_000) + np.array([0.0, 0.0, 0.001])
+    one.append(extra)
+    one.update_normals(8)
+    multi.append(extra)
+    multi.update_target_normals(8)
+    T1, idx1, inner1 = one.estimate_point_to_plane(src, I.Transform(), 4, return_info=True)
+    T, idx, inner = multi.estimate_point_to_plane(src, I.Transform(), 4, return_info=True)
+    assert np.array_equal(T.as_array(), T1.as_array()) and np.array_equal(idx, idx1) and np.array_equal(inner, inner1)
+    multi.close()
+
+
+@gpu
+def test_point_to_plane_against_a_map_of_ten_million_points():
+    """BASELINE configs[4] at its size (point-to-plane had been tested at <= 20k targets): a 10.4M-point
+    target cloud, normals of all of it on the device.  There is no reference behaviour; the checks are (a) the CPU
+    statement on a SUB-BOX -- the k nearest neighbours of a target well inside the sub-box all lie inside it, so its
+    normals computed from the sub-box alone must equal the device's normals from the whole cloud; (b) properties:
+    unit length; a re-observed scan registers closer to the truth than it started; (c) two virtual ranks = one handle."""
+    import torch
+
+    from icp_rust_amd import synth
+
+    m = 10_400_000
+    cloud = synth.box_cloud(synth.SEED + 51, m)
+    d_cloud = torch.from_numpy(cloud).cuda()
+    icp = I.Icp3d(d_cloud)
+    assert I.lib().icp_get_nn_mode(icp._h) == I.NN_GRID
+    k = 8
+    icp.compute_normals(k)
+    # (a) sub-box [8, 14] x [8, 14] x [-2, -0.2] around a patch of the floor (z = -2; nothing lies below it): 455 targets
+    # per square metre on the faces, 59 per cubic metre inside -- the 8 nearest neighbours of a target lie within
+    # ~0.35 m; the core keeps 1 m from the sub-box's open sides
+    lo, hi = np.array([8.0, 8.0, -2.1]), np.array([14.0, 14.0, -0.2])
+    inside = np.all((cloud >= lo) & (cloud <= hi), axis=1)
+    sub_idx = np.nonzero(inside)[0]
+    sub = np.ascontiguousarray(cloud[sub_idx])
+    assert 4_000 < len(sub) < 200_000
+    core = np.all((sub >= lo + np.array([1.0, 1.0, 0.0])) & (sub <= hi - 1.0), axis=1)
+    O.set_threads(16)
+    try:
+        want = O.p2pl_normals(sub, k)
+    finally:
+        O.set_threads(1)
+    first, last = int(sub_idx[0]), int(sub_idx[-1]) + 1
+    got_all = icp.read_normals(first, last - first)
+    got = got_all[sub_idx - first]
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-12)
+    assert core.sum() > 2_000
+    assert np.max(np.abs(got[core] - want[core])) < 1e-9
+    # floor points (z within a millimetre of -2... the faces are exact planes): normals are +-z
+    floor = core & (np.abs(sub[:, 2] + 2.0) < 1e-9)
+    assert floor.sum() > 1_000
+    # (most of a floor target's neighbours are floor targets; a few interior points nearby tilt some normals)
+    assert np.median(np.abs(got[floor][:, 2])) > 0.99
+    # (b) a scan that re-observes map points, moved by the inverse of a frame-sized motion
+    rng = np.random.default_rng(5)
+    Tt = I.Transform([0.06, -0.04, 0.003])
+    scan = moved(cloud[rng.integers(0, m, 28_800)] + rng.normal(size=(28_800, 3)) * 2e-3, Tt.inverse())
+    T, idx, inner = icp.estimate_point_to_plane(scan, I.Transform(), 8, return_info=True)
+    err0 = np.max(np.abs(I.Transform().as_array() - Tt.as_array()))
+    err = np.max(np.abs(T.as_array() - Tt.as_array()))
+    assert inner.sum() > 0 and err < 0.25 * err0, (err0, err)
+    # (c) two virtual ranks (two replicas of the map and of its normals on this GPU)
+    multi = I.IcpMulti(cloud, [0, 0])
+    multi.compute_target_normals(k)
+    Tm, idxm, innerm = multi.estimate_point_to_plane(scan, I.Transform(), 8, return_info=True)
+    assert np.array_equal(Tm.as_array(), T.as_array()) and np.array_equal(idxm, idx) and np.array_equal(innerm, inner)
+    multi.close()
+    icp.close()
