@@ -96,8 +96,8 @@ fn kdtree_distance_summation_order() {
     let q = Vector3::new(0., 0., 0.);
     // a: dx^2 = 1e16, dy^2 = 1, dz^2 = 1  ->  (1e16 + 1) + 1 = 1e16 (each 1 is absorbed); 1e16 + (1 + 1) = 1e16 + 2
     let a = Vector3::new(1e8, 1., 1.);
-    // b: exactly 1e16 + 2 under either order (dx^2 = 1e16 + 2 is representable: spacing 2 at 1e16)
-    let b = Vector3::new((1e16f64 + 2.).sqrt(), 0., 0.);
+    // b: dx^2 = 1e16, dy^2 = 2.0000000000000004, dz^2 = 0  ->  1e16 + 2 under either order (the spacing at 1e16 is 2)
+    let b = Vector3::new(1e8, 2f64.sqrt(), 0.);
     let tree = KdTree::new(&vec![b, a], 2);
     let (idx, _) = tree.search(&q);
     // x-then-y-then-z left fold: d2(a) = 1e16 < d2(b) -> a (index 1).  Any other order: a tie or b -> index 0.
