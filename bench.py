@@ -477,7 +477,7 @@ def main():
         # separate passes and committed under profiles/ (a PMC pass cannot run inside this process); only
         # valid for the full-size single-GPU workload it was measured on
         traffic, tf_name = None, None
-        for tf_name in ("r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_traffic_pmc.json"):
+        for tf_name in ("r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_traffic_pmc.json"):
             tf_path = os.path.join(ROOT, "profiles", tf_name)
             if os.path.exists(tf_path):
                 break
