@@ -424,6 +424,21 @@ __device__ unsigned long long g_nn_hist[2][32];  // [0]: lanes by record chunks,
 // the evaluation kernels that run beside a speculative search had to wait for whole workgroups to
 // retire: 256 -> 128 -> 64 threads gave 4970 -> 5440 -> 5480 iterations/s on the 1M pair (A/B on one
 // box), the search alone 103.6 -> 97.2 -> 95.6 us.
+// Which wave of 64 consecutive (cell-sorted) queries a workgroup takes.  Workgroups are dealt round-robin over the 8
+// XCDs, each with an L2 of its own: taken in launch order, neighbouring waves -- which walk the same rows of cells
+// and read the same record lines -- land on eight different L2s, and every line is fetched from the fabric up to eight
+// times.  With chunk > 0 the `chunk` waves an XCD receives out of every 8 x chunk consecutive workgroups are
+// CONSECUTIVE waves (a bijection inside each complete group of 8 x chunk; the tail keeps launch order), fine enough a
+// grain to keep the load balanced across the XCDs (dense walls and sparse interior alternate along the sorted order).
+__device__ __forceinline__ unsigned xcd_wave(unsigned block, unsigned nblocks, unsigned chunk) {
+  if (chunk == 0u) return block;
+  const unsigned per = 8u * chunk, full = nblocks / per * per;
+  if (block >= full) return block;
+  const unsigned sc = block / per, r = block % per;
+  return sc * per + (r & 7u) * chunk + (r >> 3);
+}
+
+constexpr unsigned kXcdChunk = 16;  // (fetch per warm search: 112 MB in launch order, 72 / 65 / 72 / 75 MB with chunks of 8 / 16 / 32 / 64: profiles/r04_search_xcd_chunk_traffic.txt)
 constexpr int kGridThreads = 64;
 template <int DIM, bool XFORM, bool COLD, int L>
 __global__ __launch_bounds__(kGridThreads) void k_nn_grid(const double *__restrict__ src,
@@ -437,8 +452,9 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid(const double *__restri
   unsigned st[8] = {1, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
-  const unsigned k = (blockIdx.x * kGridThreads + threadIdx.x) / L;
-  const unsigned sub = (blockIdx.x * kGridThreads + threadIdx.x) % L;  // lane within the query's group (aligned: L divides 64)
+  const unsigned wave0 = xcd_wave(blockIdx.x, gridDim.x, kXcdChunk);
+  const unsigned k = (wave0 * kGridThreads + threadIdx.x) / L;
+  const unsigned sub = (wave0 * kGridThreads + threadIdx.x) % L;  // lane within the query's group (aligned: L divides 64)
   if (k >= n) return;  // whole groups leave together
   // perm != null: src is the cell-sorted copy made by prepare_queries (neighbouring lanes
   // search neighbouring cells); results go back to the original positions
@@ -1134,20 +1150,6 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
   if (b) b[i] = make_double2(bx, by);
 }
 
-// Which wave of 64 consecutive (cell-sorted) queries a workgroup takes.  Workgroups are dealt round-robin over the 8
-// XCDs, each with an L2 of its own: taken in launch order, neighbouring waves -- which walk the same rows of cells
-// and read the same record lines -- land on eight different L2s, and every line is fetched from the fabric up to eight
-// times.  With chunk > 0 the `chunk` waves an XCD receives out of every 8 x chunk consecutive workgroups are
-// CONSECUTIVE waves (a bijection inside each complete group of 8 x chunk; the tail keeps launch order), fine enough a
-// grain to keep the load balanced across the XCDs (dense walls and sparse interior alternate along the sorted order).
-__device__ __forceinline__ unsigned xcd_wave(unsigned block, unsigned nblocks, unsigned chunk) {
-  if (chunk == 0u) return block;
-  const unsigned per = 8u * chunk, full = nblocks / per * per;
-  if (block >= full) return block;
-  const unsigned sc = block / per, r = block % per;
-  return sc * per + (r & 7u) * chunk + (r >> 3);
-}
-
 template <int DIM, bool CERT>
 __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(const double *__restrict__ src,
                                                                const uint32_t *__restrict__ perm, unsigned n, Pose T,
@@ -1313,7 +1315,7 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__r
                                                                const GridPoint *__restrict__ pts,
                                                                const double *__restrict__ dst,
                                                                PrevMatch *__restrict__ prev) {
-  const unsigned k = blockIdx.x * kGridThreads + threadIdx.x;
+  const unsigned k = xcd_wave(blockIdx.x, gridDim.x, kXcdChunk) * kGridThreads + threadIdx.x;
   if (k >= n) return;
   double q[3];
   q[0] = src[(size_t)k * DIM + 0];
@@ -1583,7 +1585,7 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   // round-1 kernel, for A/B runs; both return the same indices)
   static const bool old_warm = exp_env("ICP_NN_OLD_WARM") != nullptr;
   // (84.2 us in launch order, 83.2 / 81.1 / 82.4 / 83.1 us with chunks of 4 / 16 / 64 / 256 waves: profiles/r04_search_xcd_chunk.txt)
-  static const unsigned xcd_chunk = exp_env("ICP_NN_XCD_CHUNK") ? (unsigned)atoi(exp_env("ICP_NN_XCD_CHUNK")) : 16u;
+  static const unsigned xcd_chunk = exp_env("ICP_NN_XCD_CHUNK") ? (unsigned)atoi(exp_env("ICP_NN_XCD_CHUNK")) : kXcdChunk;
   // the first search of a snapshot: seeds, then the same warm kernel (ICP_NN_OLD_COLD: the general kernel)
   static const bool old_cold = exp_env("ICP_NN_OLD_COLD") != nullptr;
   const bool seeded = sorted && !q_prev && !coop && xform && G.p.f32_ok && !old_warm && !old_cold && h->m > 0;
