@@ -349,6 +349,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    loop_state = {"mode": None}
+
     def measure(mode, steps, warmup, want_parity=False, weak=False, repeats=1):
         """K timed outer iterations = one Icp3d::estimate(src, T, K) call on resident data.
         N ranks: the grid engine runs block-sharded (dist.BlockShardedIcp: every rank searches and
@@ -369,13 +371,32 @@ def main():
             if weak:
                 full = torch.from_numpy(synth.synthetic_pair(n_run, 1)[0]).cuda()
             driver = BlockShardedIcp({rank: HipStages(icp)}, n_run, world, comm)
-            # the inner loops as one launch per rank, exchanging through hipIpc-mapped inboxes (gn_loop.hip); the stage calls
-            # + collectives serve whatever a launch hands back.  ICP_DIST_NO_LOOP=1: stage calls only.
-            if os.environ.get("ICP_DIST_NO_LOOP") != "1":
-                driver.connect_loop()
+            # The inner loops as one launch per rank, exchanging through hipIpc-mapped inboxes (gn_loop.hip); the stage calls
+            # + collectives serve whatever a launch hands back.  ICP_DIST_NO_LOOP=1: stage calls only.  The path has run
+            # between processes on ONE GPU only (tests/test_gpu_ipc.py): the warm-up doubles as its probation -- if any rank
+            # fails to connect or a launch gives up waiting for a peer, EVERY rank falls back to the stage calls.
             # every call: fold order of the whole cloud (the sort one GPU does per call), this rank's blocks out
             # of it, then the iterations -- all inside the timed region, like the one-GPU call's snapshot
-            T, _, _ = driver.estimate_full(full, T, max(warmup, 2))  # (also seeds the window predictions)
+            loop_state["mode"] = "stage calls + collectives (ICP_DIST_NO_LOOP=1)"
+            if os.environ.get("ICP_DIST_NO_LOOP") != "1":
+                ok, why = 1, ""
+                try:
+                    driver.connect_loop()
+                    T, _, _ = driver.estimate_full(full, T, max(warmup, 2))  # (also seeds the window predictions)
+                except Exception as e:  # noqa: BLE001
+                    ok, why = 0, repr(e)
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    loop_state["mode"] = "one launch per rank and inner loop, hipIpc inboxes"
+                else:
+                    loop_state["mode"] = "stage calls + collectives (the one-launch path failed its probation: " + (why or "on another rank") + ")"
+                    icp.close()
+                    icp = I.Icp3d(d_dst, device=local_rank, nn_mode=mode)
+                    driver = BlockShardedIcp({rank: HipStages(icp)}, n_run, world, comm)
+                    T = I.Transform()
+            if "one launch" not in loop_state["mode"]:
+                T, _, _ = driver.estimate_full(full, T, max(warmup, 2))  # (also seeds the window predictions)
         else:
             driver = ShardedIcp(HipStages(icp), n, rank, world, src_full=d_src_full)
             driver.stages.prepare(d_src, T)
@@ -552,7 +573,7 @@ def main():
             "pose_abs_err_vs_truth": float(np.max(np.abs(T.as_array() - truth))),
         }
         if res.get("counters"):
-            out["sharded_evaluations"] = res["counters"]
+            out["sharded_evaluations"] = dict(res["counters"], inner_loops=loop_state["mode"])
         if brute is not None:
             out["brute_force"] = {
                 "value": brute["steps"] / brute["elapsed"], "unit": "iterations/s", "steps": brute["steps"],

@@ -1,9 +1,10 @@
-"""What the N-rank orchestration costs, measured with VIRTUAL ranks (every rank on cuda:0, one stream,
-lockstep): the GPU work is the one-GPU work split N ways and run back to back, so (time at N) - (time at 1)
-is the price of the extra launches and exchange kernels -- the part that does NOT shrink with more GPUs.
-On N real GPUs the per-rank kernels run side by side; the expected step is
-    max over ranks (search + evaluations of n/N points) + that fixed price / 1 (it is per rank, in parallel)
-(DESIGN.md section 7 turns this into the expected scaling curve)."""
+"""What the N-rank orchestration costs, measured with VIRTUAL ranks (every rank on cuda:0).  Round 4: an outer
+iteration is, per rank, one search launch + one inner-loop launch (gn_loop.hip: k_gn_loop_shard; the launches of ranks
+that share a device are fused into one); the N searches of the virtual ranks run back to back on one stream, so
+(time at N) - (time at 1) is mostly N small searches in a row plus the exchange inside the loop launch.  On N real
+GPUs the per-rank kernels run side by side (DESIGN.md section 7 turns this into the expected scaling curve).
+"per outer iteration" = a whole estimate(20) from HOST buffers / 20 (upload, sort, shard and index read-back
+included); "marginal" = (estimate(40) - estimate(20)) / 20, the per-call work cancelled."""
 import os
 import sys
 import time
@@ -39,10 +40,11 @@ def main():
         t0 = time.perf_counter()
         mu.estimate(src, I.Transform(), 40)
         dt40 = time.perf_counter() - t0
-        print(f"    marginal outer iteration (40 against 20 iterations, per-call work cancelled): {1e3 * (dt40 - dt) / 20:.3f} ms")
+        marginal = 1e3 * (dt40 - dt) / 20
         evals = int(inn.sum()) + 20
         print(f"icp_create_multi, {W} virtual ranks on one GPU: {1e3 * dt / 20:.3f} ms per outer iteration "
               f"({evals} evaluations; counters sharded/replicated {mu.counters()}, loop launches/served/handbacks {mu.loop_counters()})")
+        print(f"    marginal outer iteration (40 against 20 iterations, per-call work cancelled): {marginal:.3f} ms")
         mu.close()
 
 
