@@ -332,7 +332,10 @@ __device__ __forceinline__ double next_half_width(const double (&med)[2], const 
   double shift = 0.;
 #pragma unroll
   for (int d = 0; d < 2; ++d) shift = fmax(shift, (fabs(med[d] - pmed[d]) + fabs(sig[d] - psig[d])) / sig[d]);
-  const double f = 8. * shift;
+#ifndef ICP_LOOP_FWIDTH
+#define ICP_LOOP_FWIDTH 8.
+#endif
+  const double f = ICP_LOOP_FWIDTH * shift;
   return f != f || f > f_max ? f_max : (f < 0.004 ? 0.004 : f);
 }
 
