@@ -1151,7 +1151,7 @@ static int shard_loop_launch_common(icp_handle *const *hs, int nh, const double 
     S.inbox[q] = reinterpret_cast<LoopInbox *>(w0.loop_peers[q]);
   }
   S.blocks_total = B;
-  S.gen_base = launch_no * 256u;
+  S.gen_base = launch_no * 1024u;  // (a launch runs at most 200 evaluations, each at most twice: rounds < 1024)
   S.eval_base = eval_base;
   A.n = (unsigned)n_total;
   A.it0 = (unsigned)it0;

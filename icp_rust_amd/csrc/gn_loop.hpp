@@ -59,7 +59,7 @@ struct LoopArgs {
 // ranks travels through INBOXES: one per rank, in that rank's memory, mapped by every peer (peer access between the
 // devices of one process, hipIpc between processes, plain pointers between virtual ranks on one device).  A producer
 // writes its bytes into every rank's inbox and then a flag word; a consumer only ever polls and reads ITS OWN inbox.
-// Flag words carry (generation | payload << 32); generations grow over the launches of a handle (launch number x 256 +
+// Flag words carry (generation | payload << 32); generations grow over the launches of a handle (launch number x 1024 +
 // evaluation), so nothing has to be reset between launches and a rank that is one launch ahead cannot be mistaken.
 constexpr int kLoopCandPerBlock = 2 * kWinBlkMed + 2 * kWinBlkRing;  // doubles a workgroup may contribute per evaluation
 struct LoopInbox {
@@ -79,7 +79,7 @@ struct LoopShardArgs {
   int b0;                // (set by the kernel) first tree block of the workgroup's rank; its workgroup j is tree block b0 + j
   int blocks_total;      // reduce_geometry(n_total)
   int first_block[kShardMaxWorld + 1];  // tree blocks of rank s: [first_block[s], first_block[s + 1])
-  unsigned gen_base;     // launch number x 256
+  unsigned gen_base;     // launch number x 1024 (a launch runs fewer rounds than that)
   unsigned eval_base;    // evaluations the handle's earlier launches ran (parity of the double buffers continues)
   LoopInbox *inbox[kShardMaxWorld];  // every rank's inbox as mapped here; inbox[rank] is this rank's own
 };
