@@ -883,13 +883,15 @@ struct CertDecay {  // how far a query can have moved since the snapshot was tak
   float r_hi, t_hi;  // upper bounds (... and checked against the decay at the time of the check)
 };
 
-template <int DIM, bool CERT = false>
+// SEEDED: the previous match comes in registers (`seed`: the first search of a snapshot, k_nn_grid_seeded) and the
+// slot's record is written whatever the walk finds.
+template <int DIM, bool CERT = false, bool SEEDED = false>
 __device__ __forceinline__ void warm_query(const unsigned k, const double *__restrict__ src,
                                            const uint32_t *__restrict__ perm, Pose T, const GridParams &g,
                                            const uint32_t *__restrict__ start, const GridPoint *__restrict__ pts,
                                            const double *__restrict__ dst, uint32_t *__restrict__ idx,
                                            double2 *__restrict__ a, double2 *__restrict__ b, PrevMatch *prev,
-                                           CertDecay cd = CertDecay{0.f, 0.f, 0.f, 0.f}) {
+                                           CertDecay cd = CertDecay{0.f, 0.f, 0.f, 0.f}, PrevMatch seed = PrevMatch{0., 0., 0., 0xffffffffu, 0u}) {
   const unsigned i = perm ? perm[k] : k;  // null: outputs in slot order
   double q[3];
   q[0] = src[(size_t)k * DIM + 0];
@@ -903,8 +905,9 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
     q[0] = nx;
     q[1] = ny;
   }
-  const PrevMatch pm = prev[k];
+  const PrevMatch pm = SEEDED ? seed : prev[k];
   if (pm.idx == 0xffffffffu) {  // no finite distance was ever found (NaN query): index 0, as a scan from 0 would
+    if (SEEDED) prev[k] = pm;
     if (idx) idx[i] = 0;
     if (a) a[i] = make_double2(q[0], q[1]);
     if (b) b[i] = make_double2(dst[0], dst[1]);
@@ -1136,7 +1139,7 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
     bz = DIM == 3 ? dst[2] : 0.;
   }
   // a slot whose match did not change already holds this record
-  if (CERT || bi != pm.idx) {
+  if (CERT || SEEDED || bi != pm.idx) {
     PrevMatch out;
     out.x = bx;
     out.y = by;
@@ -1310,13 +1313,9 @@ hipError_t launch_nn_warm_flagged(icp_handle *h, const double *q_src, const uint
 #endif  // ICP_EXPERIMENTS
 
 template <int DIM>
-__global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__restrict__ src, unsigned n, Pose T,
-                                                               GridParams g, const uint32_t *__restrict__ start,
-                                                               const GridPoint *__restrict__ pts,
-                                                               const double *__restrict__ dst,
-                                                               PrevMatch *__restrict__ prev) {
-  const unsigned k = xcd_wave(blockIdx.x, gridDim.x, kXcdChunk) * kGridThreads + threadIdx.x;
-  if (k >= n) return;
+__device__ __forceinline__ PrevMatch seed_match(const unsigned k, const double *__restrict__ src, const Pose &T,
+                                                 const GridParams &g, const uint32_t *__restrict__ start,
+                                                 const GridPoint *__restrict__ pts, const double *__restrict__ dst) {
   double q[3];
   q[0] = src[(size_t)k * DIM + 0];
   q[1] = src[(size_t)k * DIM + 1];
@@ -1390,7 +1389,34 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__r
       out.idx = bi;
     }
   }
-  prev[k] = out;
+  return out;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(kGridThreads) void k_nn_grid_seed(const double *__restrict__ src, unsigned n, Pose T,
+                                                               GridParams g, const uint32_t *__restrict__ start,
+                                                               const GridPoint *__restrict__ pts,
+                                                               const double *__restrict__ dst,
+                                                               PrevMatch *__restrict__ prev) {
+  const unsigned k = xcd_wave(blockIdx.x, gridDim.x, kXcdChunk) * kGridThreads + threadIdx.x;
+  if (k >= n) return;
+  prev[k] = seed_match<DIM>(k, src, T, g, start, pts, dst);
+}
+
+// The first search of a snapshot in ONE launch (round 4): the seed goes from registers straight into the warm walk --
+// no 32-byte record written and read back per query, no second pass over the source cloud, one launch less per call.
+template <int DIM>
+__global__ __launch_bounds__(kGridThreads) void k_nn_grid_seeded(const double *__restrict__ src,
+                                                                 const uint32_t *__restrict__ perm, unsigned n, Pose T,
+                                                                 GridParams g, const uint32_t *__restrict__ start,
+                                                                 const GridPoint *__restrict__ pts,
+                                                                 const double *__restrict__ dst, uint32_t *__restrict__ idx,
+                                                                 double2 *__restrict__ a, double2 *__restrict__ b,
+                                                                 PrevMatch *prev) {
+  const unsigned k = xcd_wave(blockIdx.x, gridDim.x, kXcdChunk) * kGridThreads + threadIdx.x;
+  if (k >= n) return;
+  const PrevMatch pm = seed_match<DIM>(k, src, T, g, start, pts, dst);
+  warm_query<DIM, false, true>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev, CertDecay{0.f, 0.f, 0.f, 0.f}, pm);
 }
 
 // ------------------------------------------------ query locality (optional) -------
@@ -1589,20 +1615,22 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   // the first search of a snapshot: seeds, then the same warm kernel (ICP_NN_OLD_COLD: the general kernel)
   static const bool old_cold = exp_env("ICP_NN_OLD_COLD") != nullptr;
   const bool seeded = sorted && !q_prev && !coop && xform && G.p.f32_ok && !old_warm && !old_cold && h->m > 0;
-  if (seeded) {
+  // (the seeds as a launch of their own: only where the warm search is not the plain one that takes them in registers)
+  auto launch_seeds = [&]() {
     if (h->dim == 3)
       hipLaunchKernelGGL(k_nn_grid_seed<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, n, T, G.p, G.d_start,
                          G.d_pts, h->d_dst, Q.d_prev);
     else
       hipLaunchKernelGGL(k_nn_grid_seed<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, n, T, G.p, G.d_start,
                          G.d_pts, h->d_dst, Q.d_prev);
-  }
+  };
 #ifdef ICP_EXPERIMENTS
   // ICP_NN_TILE=1: the LDS-tile search of nn_tile.hip (round 3; same indices).  Built, parity-green at 1M x 1M and
   // measured slower than the gather walk on the benchmark pair (109 + 42 us against 84 us: DESIGN.md section 5),
   // so it is opt-in
   static const bool use_tile = exp_env("ICP_NN_TILE") != nullptr && atoi(exp_env("ICP_NN_TILE")) != 0;
   if ((q_prev || seeded) && !coop && xform && G.p.f32_ok && !old_warm && use_tile) {
+    if (seeded) launch_seeds();
     hipError_t we = launch_nn_tile(h, q_src, q_perm, n, T, d_idx, (double2 *)d_a, (double2 *)d_b);
     if (ev0 && ev1) {
       (void)hipEventRecord(ev1, h->stream);
@@ -1653,6 +1681,10 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
     // searches run as rounds 1-2 had them.  Certificates already in the records stay valid either way.
     const bool certs = !no_cert && decay_ok && QW.d_cert_lists != nullptr && QW.have_pose_before && step <= cert_max_step * hmin;
     const bool check = certs && q_prev && QW.have_certs;
+    // the first search of a snapshot: ONE launch, the seed handed to the walk in registers (k_nn_grid_seeded)
+    static const bool no_fuse = exp_env("ICP_NN_SEED_SEPARATE") != nullptr;
+    const bool fused_seed = seeded && !check && !certs && !no_fuse;
+    if (seeded && !fused_seed) launch_seeds();
     if (check) {
       const unsigned cblocks = (n + kCertThreads - 1) / kCertThreads;
       const unsigned list_cap = ((cblocks + kCertLists - 1) / kCertLists) * kCertThreads;
@@ -1685,6 +1717,13 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
       else
         hipLaunchKernelGGL((k_nn_grid_warm<2, true>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
                            G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd, xcd_chunk);
+    } else if (fused_seed) {
+      if (h->dim == 3)
+        hipLaunchKernelGGL(k_nn_grid_seeded<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
+                           G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev);
+      else
+        hipLaunchKernelGGL(k_nn_grid_seeded<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
+                           G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev);
     } else {
       if (h->dim == 3)
         hipLaunchKernelGGL((k_nn_grid_warm<3, false>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
