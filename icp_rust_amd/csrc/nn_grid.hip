@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seeded(const double *_
 // 64 queries, and the union of their search boxes (nn_tile.hip) is that much more compact.  Any key is exact;
 // this one only shapes the waves.
 __global__ void k_query_cell(const double *__restrict__ src, unsigned n, int dim, Pose T, GridParams g, int blk,
-                             uint32_t *__restrict__ cell_of) {
+                             uint32_t *__restrict__ cell_of, int xshift) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double q[3] = {src[(size_t)i * dim], src[(size_t)i * dim + 1], dim == 3 ? src[(size_t)i * dim + 2] : 0.};
@@ -1443,10 +1443,12 @@ __global__ void k_query_cell(const double *__restrict__ src, unsigned n, int dim
   q[1] = ny;
   int c[3] = {0, 0, 0};
   for (int d = 0; d < dim; ++d) c[d] = cell_coord(q[d], g.lo[d], g.inv_h[d], g.n[d]);
+  c[0] >>= xshift;  // (runs of 2^xshift cells along x share a key: fewer key bits, one sort pass less)
+  const uint32_t nxk = ((uint32_t)g.n[0] + (1u << xshift) - 1u) >> xshift;
   const uint32_t nyb = ((uint32_t)g.n[1] + (1u << blk) - 1) >> blk, m = (1u << blk) - 1;
   const uint32_t brow = ((uint32_t)c[2] >> blk) * nyb + ((uint32_t)c[1] >> blk);
   const uint32_t sub = (((uint32_t)c[2] & m) << blk) | ((uint32_t)c[1] & m);
-  cell_of[i] = ((brow * (uint32_t)g.n[0] + (uint32_t)c[0]) << (2 * blk)) | sub;
+  cell_of[i] = ((brow * nxk + (uint32_t)c[0]) << (2 * blk)) | sub;
 }
 
 // one 16-byte store per lane (two consecutive doubles of the sorted array, each gathered on its own): stores of
@@ -1552,7 +1554,22 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     keys = (nzb * nyb * (unsigned long long)G.p.n[0]) << (2 * blk);
     if (keys <= (1ull << 32) || blk == 0) break;
   }
-  hipLaunchKernelGGL(k_query_cell, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, T, G.p, blk, Q.d_cell_of);
+  // (experiments: ICP_QSORT_XSHIFT = s drops the s low bits of the x index from the sort key -- runs of 2^s x-cells share a
+  // key, and the benchmark's 21-bit keys sort in two radix passes instead of three with s = 5.  Measured: 42 us less per
+  // call, 3-4 us MORE per search (a wave's queries spread over a longer stretch of each row): 0.1513 against 0.1492 ms
+  // per step -- the finest key stays.)
+  static const int xshift_env = exp_env("ICP_QSORT_XSHIFT") ? atoi(exp_env("ICP_QSORT_XSHIFT")) : 0;
+  int xshift = 0;
+  if (blk == 0) {
+    unsigned kb = 1;
+    while (kb < 32 && (1ull << kb) < keys) ++kb;
+    (void)kb;
+    xshift = xshift_env > 0 ? xshift_env : 0;
+    while (xshift > 0 && ((unsigned)G.p.n[0] >> xshift) == 0) --xshift;
+    const unsigned nxk = ((unsigned)G.p.n[0] + (1u << xshift) - 1) >> xshift;
+    keys = (unsigned long long)G.p.n[2] * (unsigned long long)G.p.n[1] * (unsigned long long)nxk;
+  }
+  hipLaunchKernelGGL(k_query_cell, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, T, G.p, blk, Q.d_cell_of, xshift);
   unsigned bits = 1;
   while (bits < 32 && (1ull << bits) < keys) ++bits;
   if ((e = stable_sort_cells(Q.d_cell_of, Q.d_cell, Q.d_perm, n, bits, Q.d_tmp, Q.cap_tmp, s)) != hipSuccess) return e;
