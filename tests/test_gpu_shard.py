@@ -209,3 +209,46 @@ def test_recycled_handles_start_their_sharded_evaluations_in_step():
                          text=True, timeout=600, cwd=root)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert "8 seeds" in out.stdout or "0 mismatches" in out.stdout
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_long_inner_loops_across_virtual_ranks_equal_one_handle(world):
+    """The converging millimetre pair (inner loops of tens of updates): every inner loop is one launch per rank (fused
+    for ranks that share a device) with three waits per evaluation across the ranks' inboxes, windows that follow the
+    statistics, repeats inside the launch -- pose, indices and inner counts of one handle, bit for bit."""
+    n = m = 150_000
+    src, dst = synth.converging_pair(n, m)[:2]
+    one = I.Icp3d(dst)
+    T1, idx1, inner1 = one.estimate(src, I.Transform(), 8, return_info=True)
+    assert max(int(x) for x in inner1) >= 5
+    multi = I.IcpMulti(dst, [0] * world)
+    T, idx, inner = multi.estimate(src, I.Transform(), 8, return_info=True)
+    assert np.array_equal(T.as_array(), T1.as_array())
+    assert np.array_equal(inner, inner1) and np.array_equal(idx, idx1)
+    launches, served, handbacks = multi.loop_counters()
+    assert launches >= 6 and served >= int(np.sum(inner1)), (launches, served, handbacks)
+    T2 = multi.estimate(src, I.Transform(), 8)  # (generations, parities and predictions carry over)
+    assert np.array_equal(T2.as_array(), T1.as_array())
+    multi.close()
+
+
+def test_an_inner_loop_launch_that_hands_back_across_virtual_ranks():
+    """A third of the source points sit EXACTLY on their targets along x (equal residuals on the median: more candidates
+    than a workgroup can stage): the launches of all ranks report the miss together, the stage calls (and behind them
+    the gathered pairs) serve that evaluation on every rank, and the result is still one handle's."""
+    rng = np.random.default_rng(3)
+    m = 90_000
+    dst = synth.box_cloud(synth.SEED + 61, m, synth.ROOM_LO, synth.ROOM_HI)
+    n = 60_000
+    sel = rng.choice(m, n, replace=False)
+    src = dst[sel].copy()
+    noise = rng.normal(size=(n, 3)) * 0.004
+    noise[: n // 3, 0] = 0.0  # exact x for a third of the points
+    src += noise
+    one = I.Icp3d(dst, nn_mode=I.NN_GRID)
+    T1, idx1, inner1 = one.estimate(src, I.Transform(), 4, return_info=True)
+    multi = I.IcpMulti(dst, [0, 0, 0])
+    T, idx, inner = multi.estimate(src, I.Transform(), 4, return_info=True)
+    assert np.array_equal(T.as_array(), T1.as_array())
+    assert np.array_equal(inner, inner1) and np.array_equal(idx, idx1)
+    multi.close()
