@@ -289,13 +289,12 @@ int multi_loop(icp_multi *M, size_t n_total, Pose *Ti, double *prev_error, uint3
     MULTI_FAIL("the ranks disagreed about launching the inner loop");
   }
   M->loop_launch = launch_no;
-  ++M->loop_launches;
-  *served = true;
   Pose T0 = *Ti;
   double pe0 = *prev_error;
   uint32_t ap0 = *applied, ev0 = 0;
   int k0 = *k, fin0 = 0, rc0 = ICP_OK;
-  for (int q = 0; q < W; ++q) {
+  bool gave_up = false, differ = false, have_ref = false;
+  for (int q = 0; q < W; ++q) {  // (every rank's result is awaited whatever the others say: nothing may still be running)
     auto &R = M->r[q];
     Pose Tq = *Ti;
     double pe = *prev_error;
@@ -303,10 +302,11 @@ int multi_loop(icp_multi *M, size_t n_total, Pose *Ti, double *prev_error, uint3
     int kq = *k, fin = 0;
     const int rc = icp_shard_loop_wait(R.h, &Tq, &pe, &ap, &kq, &fin, &ev);
     if (rc == ICP_HIP_ERROR) {
-      M->loop_ok = false;
-      MULTI_FAIL("an inner-loop launch gave up waiting for a peer");
+      gave_up = true;
+      continue;
     }
-    if (q == 0) {
+    if (!have_ref) {
+      have_ref = true;
       T0 = Tq;
       pe0 = pe;
       ap0 = ap;
@@ -316,10 +316,28 @@ int multi_loop(icp_multi *M, size_t n_total, Pose *Ti, double *prev_error, uint3
       rc0 = rc;
     } else if (rc != rc0 || memcmp(&Tq, &T0, sizeof(Pose)) != 0 || memcmp(&pe, &pe0, sizeof(double)) != 0 || ap != ap0 || ev != ev0 ||
                kq != k0 || fin != fin0) {
-      M->loop_ok = false;
-      MULTI_FAIL("the ranks finished an inner-loop launch differently");
+      differ = true;
     }
   }
+  if (gave_up) {
+    // A launch gave up waiting (its workgroups, or a peer's, were not all running at once: a device that is shared, fewer
+    // CUs than the launches of the ranks on it need).  Nothing of the launch is used: the loop's state is the one it
+    // was started with, the ranks' prediction histories may have diverged and are dropped, and the stage calls serve
+    // from here on (bit-identical either way).
+    M->loop_ok = false;
+    for (auto &R : M->r) {
+      R.h->ws.win_valid = false;
+      for (auto &wk : R.h->ws.win_kind) wk = Workspace::WinPred();
+    }
+    if (getenv("ICP_MULTI_DEBUG")) fprintf(stderr, "[multi] an inner-loop launch gave up waiting: stage calls from now on\n");
+    return ICP_OK;
+  }
+  if (differ) {
+    M->loop_ok = false;
+    MULTI_FAIL("the ranks finished an inner-loop launch differently");
+  }
+  ++M->loop_launches;
+  *served = true;
   M->loop_evals += ev0;
   M->loop_served += ev0;
   if (rc0 != ICP_OK) return rc0;

@@ -48,7 +48,9 @@ int icp_grid_append_counters(const icp_handle *h, uint64_t out[2]);
 int icp_multi_counters(const icp_multi *M, uint64_t out[2]);
 
 /* ... and of the one-launch inner loop across the ranks (section 5b): out[0] launches (per rank), out[1] evaluations they
- * served, out[2] launches that handed an evaluation back to the stage calls.  ICP_MULTI_NO_LOOP=1: stage calls only. */
+ * served, out[2] launches that handed an evaluation back to the stage calls.  ICP_NO_GN_LOOP=1: stage calls only; an icp_multi whose launches once gave up
+ * waiting for each other (ranks that share a device need all their workgroups running at once) serves through the stage
+ * calls from then on, silently: the results are the same bits either way. */
 int icp_multi_loop_counters(const icp_multi *M, uint64_t out[3]);
 
 /* Live kernel timing for the benchmark: with enable = k > 0, HIP events bracket every
