@@ -11,10 +11,6 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 # ICP_MI355X_LIB: load another build of the same library (e.g. the diagnostic one with counters)
-# Ranks that share a device ("virtual ranks", tests) run their one-launch inner loops side by side on streams of their
-# own and wait for each other inside the launches: each stream needs a hardware queue of its own.  The HIP runtime
-# reads this when it starts, so it is set before anything can have touched the GPU (a value of the caller's wins).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LIB_PATH = os.environ.get("ICP_MI355X_LIB") or os.path.join(_HERE, "lib", "libicp_mi355x.so")
 
 OK, NONE, EMPTY_DST, NAN_INPUT, BAD_ARGUMENT, NO_DEVICE, HIP_ERROR, OUT_OF_MEMORY, RETRY_REPLICATED, RETRY_SHARDED = range(10)

@@ -1181,11 +1181,31 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
   }
 }
 
+// Every workgroup of a launch must be running at once (they wait for each other): the device has to offer that many
+// slots for workgroups of this kernel with the most dynamic LDS a launch asks for.  Asked once per process (the current
+// device at the first call: the handles of a process live on devices of one kind).
+static int loop_slots() {
+  static int slots = -1;
+  if (slots < 0) {
+    slots = 0;
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gn_loop), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLoopMaxK * kReduceThreads * 2 * (int)sizeof(double2)) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_gn_loop), kReduceThreads,
+                                                     (size_t)kLoopMaxK * kReduceThreads * 2 * sizeof(double2)) == hipSuccess)
+      slots = per_cu * prop.multiProcessorCount;
+    (void)hipGetLastError();
+  }
+  return slots;
+}
+
 bool gn_loop_applies(size_t n) {
   static const bool off = getenv("ICP_NO_GN_LOOP") != nullptr;
   int blocks, threads;
   reduce_geometry(n, &blocks, &threads);
-  return !off && n >= (size_t)(1u << 12) && n <= (size_t)kLoopMaxK * (size_t)blocks * (size_t)threads;
+  return !off && n >= (size_t)(1u << 12) && n <= (size_t)kLoopMaxK * (size_t)blocks * (size_t)threads && blocks <= loop_slots();
 }
 
 size_t gn_loop_partials_doubles() { return (size_t)2 * kReduceMaxBlocks * (kNSum + 1) + (size_t)2 * (kNSum + 1); }
@@ -1213,8 +1233,10 @@ bool gn_loop_shard_applies(size_t n_total, int world) {
   static const bool off = getenv("ICP_NO_GN_LOOP") != nullptr;
   int blocks, threads;
   reduce_geometry(n_total, &blocks, &threads);
+  // (ranks that share a device need all `blocks` slots on it; a rank with a device of its own needs fewer: the check is
+  // the conservative one)
   return !off && world >= 1 && world <= kShardMaxWorld && blocks >= world && n_total >= (size_t)(1u << 12) &&
-         n_total <= (size_t)kLoopMaxK * (size_t)blocks * (size_t)threads;
+         n_total <= (size_t)kLoopMaxK * (size_t)blocks * (size_t)threads && blocks <= loop_slots();
 }
 
 hipError_t launch_gn_loop_shard(icp_handle *h, const LoopArgs &args, const LoopShardArgs &sh, const LoopRankPtrs &ptrs, int ranks) {
