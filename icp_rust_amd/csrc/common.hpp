@@ -297,6 +297,7 @@ struct QuerySort {
   // scatter through `perm`) and the Gauss-Newton evaluations fold the pairs in that order
   bool slot_order = false;
   bool identity = false;       // the snapshot keeps the caller's order (no sort: clouds of up to ICP_NN_COOP_MAX_N points)
+  bool presorted = false;      // one-shot hint: the next snapshot's cloud is already in cell order (a rank's slice of a sorted cloud)
   size_t fold_n = 0;           // > 0: d_perm / d_cell hold the fold order of the last estimate call on fold_n points
   const double *src = nullptr;  // the device buffer this snapshot was taken from
   size_t n = 0, cap = 0;

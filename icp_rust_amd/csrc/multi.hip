@@ -554,7 +554,10 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
     if (n_local[q] == 0) continue;
     HIP_TRY(hipSetDevice(R.device));
     HIP_TRY(launch_shard_copy(R.h, d_full, R.d_src, n, q, W, (unsigned)(dim * 2), true));
+    // (the rank's points are runs of the sorted cloud: its search snapshot needs no sort of its own)
+    R.h->qsort.presorted = sorted;
     if (max_iter > 0) ICP_TRY(icp_prepare_source_device(R.h, R.d_src, n_local[q], init));
+    R.h->qsort.presorted = false;
   }
   for (size_t it = 0; it < max_iter; ++it) {
     for (int q = 0; q < W; ++q) {

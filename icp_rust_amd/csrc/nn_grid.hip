@@ -1530,7 +1530,9 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   // 50 us of a 1.26 ms registration of a 28k-point frame) buys such a search nothing measurable -- the targets it
   // walks fit the L2 whatever order the queries come in.  ICP_QSORT_SMALL=1 sorts them all the same.
   static const bool sort_small = exp_env("ICP_QSORT_SMALL") != nullptr;
-  Q.identity = (long)n <= grid_coop_max() && !sort_small;
+  // (... and so does a cloud its owner declares sorted already: the slices icp_multi_estimate deals out of the sorted cloud)
+  Q.identity = ((long)n <= grid_coop_max() && !sort_small) || Q.presorted;
+  Q.presorted = false;
   if (Q.identity) {
     Q.have_prev = false;
     Q.have_certs = false;
