@@ -999,7 +999,12 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
   // (round 3: the 4-launch form everywhere -- 0.1645 against 0.1660 ms per step on the 1M pair, 0.626 against 0.635 on
   // the converging pair, the 28k frame unchanged: every workgroup of the inline-selecting accumulate kernel repeats
   // 7.5 us of candidate loads and selections that the two-workgroup launch does once)
+#ifdef ICP_EXPERIMENTS
   const bool coresident = !no_co;
+#else
+  constexpr bool coresident = true;
+  (void)no_co;
+#endif
   static const bool no_fuse = exp_env("ICP_WIN_NO_FUSE") != nullptr;
   // Two launches (residuals + histograms + sums, then candidates + selection + fold) unless the evaluation shares
   // the CUs with a speculative search: beside three search waves per SIMD the four small launches below fit better
@@ -1032,11 +1037,14 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
     hipLaunchKernelGGL(k_win_accumulate<false>, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
                        (const double *)w.d_ry, n, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
                        (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, ++w.seq);
-  } else {
+  }
+#ifdef ICP_EXPERIMENTS  // (ICP_WIN_NO_CORESIDENT: the selection inline in every accumulate workgroup, rounds 1-2)
+  else {
     hipLaunchKernelGGL(k_win_accumulate<true>, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
                        (const double *)w.d_ry, n, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
                        (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, ++w.seq);
   }
+#endif
   return hipGetLastError();
 }
 
