@@ -35,9 +35,6 @@ namespace icp {
 
 namespace {
 
-#ifndef ICP_LOOP_UNROLL
-#define ICP_LOOP_UNROLL 2
-#endif
 constexpr long long kLoopTimeoutTicks = 25000000;  // wall_clock64 runs at 100 MHz: 250 ms
 // ... between ranks: processes that share ONE GPU (tests) are not always scheduled side by side at once -- the queue of
 // the second process may wait for a time slice -- so a rank waits longer for its peers than a launch for its own blocks
@@ -415,7 +412,6 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
       for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
       unsigned edge[4] = {0u, 0u, 0u, 0u};  // wave-uniform: points of this WAVE in the catch-all bins {below, above} x {x, y}
       bool saw_nan = false;
-#pragma unroll ICP_LOOP_UNROLL
       for (unsigned k = 0; k < mine; ++k) {
         const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
         // residual(), src/lib.rs:34-36
@@ -469,7 +465,6 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
     }
     __syncthreads();
     if (!R.fail) {
-#pragma unroll ICP_LOOP_UNROLL
       for (unsigned k = 0; k < mine; ++k) {
         const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
         const double v[2] = {((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x, ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y};
@@ -855,7 +850,6 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
       for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
       unsigned edge[4] = {0u, 0u, 0u, 0u};
       bool saw_nan = false;
-#pragma unroll ICP_LOOP_UNROLL
       for (unsigned k = 0; k < mine; ++k) {
         const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
         const double v0 = ((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x;  // residual(), src/lib.rs:34-36
@@ -923,7 +917,6 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
     }
     __syncthreads();
     if (!R.fail) {
-#pragma unroll ICP_LOOP_UNROLL
       for (unsigned k = 0; k < mine; ++k) {
         const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
         const double v[2] = {((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x, ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y};
