@@ -45,7 +45,11 @@ extern "C" {
  * takes the gathered blocks.  Additions: icp_shard_exchange_bytes, icp_nn_cert_counters, icp_multi_append_targets,
  * icp_grid_append_counters.  Behavioural note: the sums of the weighted normal equations are kept per dimension and
  * scaled by 1 / sigma after the fold (g_x S_x + g_y S_y) instead of per term -- pose equal within rounding (~1e-13) */
-#define ICP_ABI_VERSION 4
+/* 5: additions only (section 5b: the one-launch sharded inner loop -- icp_loop_inbox*, icp_loop_ipc_*,
+ * icp_shard_loop_*; icp_multi_compute/update_target_normals, icp_multi_estimate_point_to_plane).  The counters and
+ * icp_profile_* moved to icp_mi355x_debug.h (same symbols, same library).  Behavioural note: clouds of at most 2^20
+ * points run their inner loop inside one launch; results are the same bits as the stepped loop's */
+#define ICP_ABI_VERSION 5
 
 typedef enum icp_status {
   ICP_OK = 0,
