@@ -403,6 +403,10 @@ hipError_t append_grid(icp_handle *h, size_t m_old_, size_t k_, bool *done) {
 // [5] sum over waves of lifetime in shader cycles, [6] waves, [7] warm queries.
 __device__ unsigned long long g_nn_stats[8];
 __device__ unsigned long long g_nn_hist[2][32];  // [0]: lanes by record chunks, [1]: waves by loop steps
+// the warm walk: [0] wave-level row groups, [1] wave-level record chunks, [2] ... of them with an exact test in some lane,
+// [3] lane row groups, [4] lane chunks, [5] lane exact tests, [6] lifetime (cycles, summed over waves), [7] waves
+__device__ unsigned long long g_nn_warm[8];
+__device__ unsigned long long g_nn_warm_hist[2][32];  // waves by row groups; waves by record chunks
 #define NN_STAT(i, v) (st[i] += (v))
 #else
 #define NN_STAT(i, v) ((void)0)
@@ -893,6 +897,11 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
                                            double2 *__restrict__ a, double2 *__restrict__ b, PrevMatch *prev,
                                            CertDecay cd = CertDecay{0.f, 0.f, 0.f, 0.f}, PrevMatch seed = PrevMatch{0., 0., 0., 0xffffffffu, 0u}) {
   const unsigned i = perm ? perm[k] : k;  // null: outputs in slot order
+#ifdef ICP_NN_STATS
+  unsigned ws[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long wt0 = __builtin_amdgcn_s_memtime();
+#define WARM_LEADER() ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1))
+#endif
   double q[3];
   q[0] = src[(size_t)k * DIM + 0];
   q[1] = src[(size_t)k * DIM + 1];
@@ -1065,6 +1074,10 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
       ++nr;
     }
     if (nr == 0) break;
+#ifdef ICP_NN_STATS
+    ws[3] += 1;
+    if (WARM_LEADER()) ws[0] += 1;
+#endif
     if (nr < 2) ra1 = ra0, rz1 = rz0;  // unused slots repeat row 0 (a cached address)
     if (nr < 3) ra2 = ra0, rz2 = rz0;
     if (nr < 4) ra3 = ra0, rz3 = rz0;
@@ -1113,6 +1126,16 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
         }
         sc[u] = s2;
       }
+#ifdef ICP_NN_STATS
+      {
+        bool any = false;
+        for (uint32_t u = 0; u < kR; ++u)
+          if (!(sc[u] > thr32) && t[u].idx != bi) any = true, ws[5] += 1;
+        ws[4] += 1;
+        const bool wave_any = __ballot(any) != 0ull;
+        if (WARM_LEADER()) ws[1] += 1, ws[2] += wave_any ? 1u : 0u;
+      }
+#endif
 #pragma unroll
       for (uint32_t u = 0; u < kR; ++u)
         if (!(sc[u] > thr32) && t[u].idx != bi) consider(t[u].idx);
@@ -1122,6 +1145,30 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
       }
     }
   }
+#ifdef ICP_NN_STATS
+  {
+    // (lanes leave the loops at different times: the wave-level counts belong to whichever lane led at the time)
+    unsigned w0 = ws[0], w1 = ws[1], w2 = ws[2];
+    for (int off = 32; off >= 1; off >>= 1) {
+      w0 += (unsigned)__shfl_xor((int)w0, off);
+      w1 += (unsigned)__shfl_xor((int)w1, off);
+      w2 += (unsigned)__shfl_xor((int)w2, off);
+    }
+    atomicAdd(&g_nn_warm[3], (unsigned long long)ws[3]);
+    atomicAdd(&g_nn_warm[4], (unsigned long long)ws[4]);
+    atomicAdd(&g_nn_warm[5], (unsigned long long)ws[5]);
+    if (WARM_LEADER()) {
+      atomicAdd(&g_nn_warm[0], (unsigned long long)w0);
+      atomicAdd(&g_nn_warm[1], (unsigned long long)w1);
+      atomicAdd(&g_nn_warm[2], (unsigned long long)w2);
+      atomicAdd(&g_nn_warm[6], __builtin_amdgcn_s_memtime() - wt0);
+      atomicAdd(&g_nn_warm[7], 1ull);
+      atomicAdd(&g_nn_warm_hist[0][w0 < 31 ? w0 : 31], 1ull);
+      atomicAdd(&g_nn_warm_hist[1][w1 < 31 ? w1 : 31], 1ull);
+    }
+  }
+#undef WARM_LEADER
+#endif
   uint32_t cert_bits = 0;
   if (CERT && !wide && bi != 0xffffffffu) {
     // distances from squared bounds: a screened square is within 4e-7 relative of |qf - pf|^2, and |q - p| is
@@ -1164,6 +1211,422 @@ __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_grid_warm(con
   const unsigned k = xcd_wave(blockIdx.x, gridDim.x, xcd_chunk) * kGridThreads + threadIdx.x;
   if (k >= n) return;
   warm_query<DIM, CERT>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev, cd);
+}
+
+// ------------------------------------------------------ the warm walk, shared by the wave (round 4) ----
+// In warm_query a lane walks its own query, and a wave lasts as long as its slowest lane: on the benchmark pair a lane
+// visits 2.4 chunks of records on average and its WAVE 8 -- thirteen dependent trips to memory per wave, two thirds of
+// the record slots it loads wasted on lanes that had finished (profiles/r04_warm_walk_stats.txt).  Here the lanes of a
+// wave pool their work.  Per round every lane, as OWNER of its query, picks its next (up to four) rows exactly as
+// warm_query does and fetches their bounds; the quads of all 64 owners form one flat list (a prefix sum over the lanes);
+// every lane, as WORKER, takes the quads lane, lane + 64, ... of that list whoever they belong to -- finds the owner by a
+// binary search in the prefix sums, screens the four records against the owner's query and radius (LDS) -- and records
+// that pass go to a candidate list.  The exact tests of the list run together (flush: one gather of f64 coordinates for
+// the whole wave instead of one per lane and chunk), each by whichever lane holds the entry, with the owner's f64 query
+// fetched by ds_bpermute and the SAME operations as warm_query's dist2; the owners then take the lexicographic minimum
+// (d^2, index) over their entries.  That minimum does not depend on the order of the candidates, the rows an owner
+// visits are those warm_query would visit with a radius at least as large (the radius is refreshed only at a flush), so
+// the result is the same index -- tests/test_gpu_parity.py compares the two kernels on every cloud it has.
+#ifndef ICP_COOP_ITEMS
+#define ICP_COOP_ITEMS 2
+#endif
+#ifndef ICP_COOP_ROWS
+#define ICP_COOP_ROWS 4
+#endif
+#ifndef ICP_COOP_FLUSH_AT
+#define ICP_COOP_FLUSH_AT 96
+#endif
+constexpr int kCoopItems = ICP_COOP_ITEMS;  // quads in flight per worker lane
+constexpr int kCoopRows = ICP_COOP_ROWS;    // rows an owner contributes per round (4 or 8)
+constexpr int kCoopCandCap = 256;           // >= 4 records x 64 lanes: one quad per lane always fits after a flush
+constexpr int kCoopFlushAt = ICP_COOP_FLUSH_AT;  // pending exact tests that are worth a gather between two rounds of rows
+struct CoopLds {
+  uint32_t pref[64];            // quads of the owners before this one
+  uint32_t rows_d[64][kCoopRows];  // quad j of owner's flattened rows lives at record quad j + d_r ...
+  uint32_t rows_o[64][kCoopRows];  // ... r = the number of o_1.. that j has reached (o_0 unused)
+  float4 oq[64];                // the owner's grid-relative query and screening threshold
+  uint32_t obi[64];             // the owner's current match
+  uint2 cand[kCoopCandCap];     // (owner, target index)
+};
+
+#ifdef ICP_COOP_PROFILE
+// diagnostic build: per-phase time of a wave (10 ns ticks, summed over waves; slot = workgroup % 64)
+// [0] query + previous match loaded, geometry  [1] row selection  [2] row bounds (start[]) arrived  [3] prefix + tables
+// [4] worker rounds  [5] flushes  [6] outputs  [7] waves  [8] rounds of rows  [9] worker rounds  [10] flushes  [11] candidates
+__device__ unsigned long long g_coop_prof[64][12];
+#define COOP_STAMP(i)                                                  \
+  do {                                                                 \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
+    const long long now_ = wall_clock64();                             \
+    cprof[i] += (unsigned long long)(now_ - ct_last);                  \
+    ct_last = now_;                                                    \
+  } while (0)
+#define COOP_COUNT(i, v) (cprof[i] += (v))
+#else
+#define COOP_STAMP(i) ((void)0)
+#define COOP_COUNT(i, v) ((void)0)
+#endif
+
+template <int DIM, bool SEEDED>
+__device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, const double *__restrict__ src,
+                                          const uint32_t *__restrict__ perm, Pose T, const GridParams &g,
+                                          const uint32_t *__restrict__ start, const GridPoint *__restrict__ pts,
+                                          const double *__restrict__ dst, uint32_t *__restrict__ idx,
+                                          double2 *__restrict__ a, double2 *__restrict__ b, PrevMatch *prev, PrevMatch seed,
+                                          CoopLds &S) {
+  const unsigned lane = threadIdx.x;  // one wave per workgroup
+#ifdef ICP_COOP_PROFILE
+  unsigned long long cprof[12] = {0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0};
+  long long ct_last = wall_clock64();
+#endif
+  const bool in_range = k < n;
+  const unsigned kk = in_range ? k : n - 1;  // the lanes past the end repeat the last query and store nothing
+  const unsigned i = perm ? perm[kk] : kk;
+  double q[3];
+  q[0] = src[(size_t)kk * DIM + 0];
+  q[1] = src[(size_t)kk * DIM + 1];
+  q[2] = DIM == 3 ? src[(size_t)kk * DIM + 2] : 0.;
+  {  // Transform::transform, src/transform.rs:22-24
+    const double nx = (T.r00 * q[0] + T.r01 * q[1]) + T.tx;
+    const double ny = (T.r10 * q[0] + T.r11 * q[1]) + T.ty;
+    q[0] = nx;
+    q[1] = ny;
+  }
+  const PrevMatch pm = SEEDED ? seed : prev[kk];
+  const bool no_match = pm.idx == 0xffffffffu;  // no finite distance was ever found (NaN query): index 0, no walk
+  bool alive = in_range && !no_match;
+  auto dist2 = [&](double tx, double ty, double tz) -> double {  // the contract's exact distance (warm_query)
+    const double ddx = q[0] - tx, ddy = q[1] - ty;
+    double dd = ddx * ddx + ddy * ddy;
+    if (DIM == 3) {
+      const double ddz = q[2] - tz;
+      dd = dd + ddz * ddz;
+    }
+    return dd;
+  };
+  double best = dist2(pm.x, pm.y, pm.z);
+  uint32_t bi = pm.idx;
+  double bx = pm.x, by = pm.y, bz = pm.z;
+  if (!(best == best)) {
+    best = __builtin_huge_val();
+    bi = 0xffffffffu;
+  }
+  // ---- f32 geometry relative to the grid origin: warm_query's, margin for margin ----
+  float qf[3], amax = 0.f;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    qf[d] = d < DIM ? (float)(q[d] - g.lo[d]) : 0.f;
+    amax = fmaxf(amax, fabsf(qf[d]));
+  }
+  const float mgf = 4e-7f * (amax + g.ext);
+  const float ecf = 2.1e-7f * (amax + g.ext);
+  float bf, rf, thr32;
+  auto set_radius = [&]() {
+    bf = fmaxf((float)best * 1.0000003f, 1e-37f);
+    const float rs = __builtin_amdgcn_sqrtf(bf) * 1.0000003f;
+    rf = rs + mgf;
+    thr32 = (rs + ecf) * (rs + ecf) * 1.000005f;
+  };
+  set_radius();
+  const bool wide = !(amax + rf < 1e18f);
+  if (wide) {
+    bf = __builtin_huge_valf();
+    thr32 = __builtin_huge_valf();
+  }
+  const float hf[3] = {(float)g.h[0], (float)g.h[1], (float)g.h[2]};
+  const float ihf[3] = {(float)g.inv_h[0], (float)g.inv_h[1], (float)g.inv_h[2]};
+  auto cell_lo = [&](float v, float em, int d) -> int {
+    const float t = fminf(fmaxf(__builtin_floorf(v * ihf[d] - em), 0.f), (float)(g.n[d] - 1));
+    return (int)t;
+  };
+  auto cell_hi = [&](float v, float em, int d) -> int {
+    const float t = fminf(fmaxf(__builtin_floorf(v * ihf[d] + em), 0.f), (float)(g.n[d] - 1));
+    return (int)t;
+  };
+  int lo_c[3] = {0, 0, 0}, hi_c[3] = {0, 0, 0};
+  float em[3];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    em[d] = (fabsf(qf[d]) + rf) * ihf[d] * 4e-7f + 1e-3f;
+    lo_c[d] = wide ? 0 : cell_lo(qf[d] - rf, em[d], d);
+    hi_c[d] = wide ? g.n[d] - 1 : cell_hi(qf[d] + rf, em[d], d);
+  }
+  auto slab2 = [&](int d, int c) -> float {
+    const float e0 = (float)c * hf[d];
+    const float below = c <= 0 ? -__builtin_huge_valf() : e0 - qf[d];
+    const float above = c >= g.n[d] - 1 ? -__builtin_huge_valf() : qf[d] - (e0 + hf[d]);
+    const float v = fmaxf(fmaxf(below, above) - mgf, 0.f);
+    return v * v * 0.9999997f;
+  };
+  S.oq[lane] = make_float4(qf[0], qf[1], qf[2], thr32);
+  S.obi[lane] = bi;
+  COOP_STAMP(0);
+
+  unsigned cnt = 0;  // pending candidates: the same number in every lane (ballots)
+  // the exact tests of the pending candidates, merged into their owners' matches
+  auto flush = [&]() {
+    COOP_COUNT(10, 1);
+    COOP_COUNT(11, cnt);
+    for (unsigned base = 0; base < cnt; base += 64) {
+      const unsigned e = base + lane;
+      const bool have = e < cnt;
+      const uint2 c = S.cand[have ? e : base];
+      const uint32_t ti = c.y;
+      const double tx = dst[(size_t)ti * DIM + 0], ty = dst[(size_t)ti * DIM + 1];
+      const double tz = DIM == 3 ? dst[(size_t)ti * DIM + 2] : 0.;
+      // the owner's query, bit for bit
+      const int sel = (int)(c.x << 2);
+      double oqd[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(sel, (int)__double2loint(q[d]));
+        const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(sel, (int)__double2hiint(q[d]));
+        oqd[d] = __hiloint2double((int)hi, (int)lo);
+      }
+      const double ddx = oqd[0] - tx, ddy = oqd[1] - ty;
+      double dd = ddx * ddx + ddy * ddy;
+      if (DIM == 3) {
+        const double ddz = oqd[2] - tz;
+        dd = dd + ddz * ddz;
+      }
+      const unsigned m = min(64u, cnt - base);
+      for (unsigned e2 = 0; e2 < m; ++e2) {  // (uniform: readlane takes the lane from a scalar register)
+        const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)c.x, (int)e2);
+        const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)ti, (int)e2);
+        const double d2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dd), (int)e2),
+                                           __builtin_amdgcn_readlane(__double2loint(dd), (int)e2));
+        if (lane == o && (d2 < best || (d2 == best && t2 < bi))) {
+          best = d2;
+          bi = t2;
+          bx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tx), (int)e2),
+                                __builtin_amdgcn_readlane(__double2loint(tx), (int)e2));
+          by = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ty), (int)e2),
+                                __builtin_amdgcn_readlane(__double2loint(ty), (int)e2));
+          bz = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tz), (int)e2),
+                                __builtin_amdgcn_readlane(__double2loint(tz), (int)e2));
+        }
+      }
+    }
+    cnt = 0;
+    if (!wide) set_radius();
+    __syncthreads();  // (the workers' reads of oq / obi / cand are behind us)
+    S.oq[lane].w = thr32;
+    S.obi[lane] = bi;
+    __syncthreads();
+  };
+
+  // The rows of the owner's box, a TILE of 4 x 4 (y x z) at a time: one bit per row that can hold a winner (warm_query's
+  // test: the row's slab distance against the radius), computed for all sixteen at once -- straight-line code that every
+  // lane runs once for a box of up to 4 x 4 rows, where warm_query's loop over the rows runs as long as the wave's largest
+  // box (half of the vector instructions of the first version of this kernel: profiles/r04_search_coop.txt).  A row
+  // is taken over the whole x range of the box: clipping it to the ball per row (warm_query) saved fewer records than
+  // its sqrt, two floors and eleven registers cost here, where the records are spread over the wave anyway.
+  int ty = lo_c[1], tz = lo_c[2];
+  unsigned mask = 0;
+  auto make_mask = [&]() {
+    bool vy[4], vz[4];
+    float sy[4], sz[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      vy[j] = ty + j <= hi_c[1];
+      sy[j] = wide ? 0.f : slab2(1, ty + j);
+      vz[j] = tz + j <= hi_c[2];
+      sz[j] = (DIM == 3 && !wide) ? slab2(2, tz + j) : 0.f;
+    }
+    mask = 0;
+#pragma unroll
+    for (int jz = 0; jz < (DIM == 3 ? 4 : 1); ++jz)
+#pragma unroll
+      for (int jy = 0; jy < 4; ++jy)
+        if (vy[jy] && vz[jz] && !(sy[jy] + sz[jz] > bf)) mask |= 1u << (jz * 4 + jy);
+  };
+  if (alive) make_mask();
+  for (;;) {
+    // ---- owner: the next rows of its box ----
+    int nr = 0;
+    while (alive && nr < kCoopRows) {
+      if (mask == 0) {  // the next tile of the box: along y, then z
+        ty += 4;
+        if (ty > hi_c[1]) {
+          ty = lo_c[1];
+          tz += 4;
+        }
+        if (tz > hi_c[2]) {
+          alive = false;
+          break;
+        }
+        make_mask();
+        continue;
+      }
+      const int r = __ffs((int)mask) - 1;
+      mask &= mask - 1u;
+      const int jy = r & 3, jz = r >> 2;
+      const uint32_t rb = ((uint32_t)(tz + jz) * g.n[1] + (uint32_t)(ty + jy)) * g.n[0];
+      S.rows_d[lane][nr] = rb + lo_c[0];  // (the tables of the round are written after these have been read back)
+      S.rows_o[lane][nr] = rb + hi_c[0] + 1;
+      ++nr;
+    }
+    if (__ballot(nr > 0) == 0ull) break;
+    COOP_STAMP(1);
+    COOP_COUNT(8, 1);
+    uint32_t sb[kCoopRows], se[kCoopRows];
+#pragma unroll
+    for (int r = 0; r < kCoopRows; ++r) {
+      const int rr = r < nr ? r : 0;  // unused slots repeat row 0 (a cached address; lanes without rows read cell 0)
+      const uint32_t ra = nr > 0 ? S.rows_d[lane][rr] : 0u, rz = nr > 0 ? S.rows_o[lane][rr] : 0u;
+      sb[r] = start[ra];
+      se[r] = start[rz];
+    }
+    uint32_t rd[kCoopRows], ro[kCoopRows], Q = 0;
+#pragma unroll
+    for (int r = 0; r < kCoopRows; ++r) {  // runs -> aligned quads; an empty run has no quads
+      const uint32_t qr = sb[r] >> 2, nq = (nr > r && se[r] > sb[r]) ? ((se[r] + 3) >> 2) - qr : 0u;
+      ro[r] = Q;
+      rd[r] = qr - Q;
+      Q += nq;
+    }
+    COOP_STAMP(2);
+    // ---- the flat list of this round: an exclusive prefix sum of the owners' quads ----
+    uint32_t incl = Q;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= (unsigned)off) incl += up;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    S.pref[lane] = incl - Q;
+#pragma unroll
+    for (int r = 0; r < kCoopRows; ++r) {
+      S.rows_d[lane][r] = rd[r];
+      S.rows_o[lane][r] = ro[r];
+    }
+    __syncthreads();
+    COOP_STAMP(3);
+    // ---- worker: quads lane, lane + 64, ... of the list ----
+    for (uint32_t w0 = 0; w0 < total; w0 += 64u * kCoopItems) {
+      COOP_COUNT(9, 1);
+      GridPoint t[4 * kCoopItems];
+      unsigned own[kCoopItems];
+      bool has[kCoopItems];
+#pragma unroll
+      for (int it = 0; it < kCoopItems; ++it) {
+        const uint32_t w = w0 + 64u * it + lane;
+        has[it] = w < total;
+        const uint32_t wc = has[it] ? w : total - 1;
+        unsigned L = 0;  // the last owner whose prefix is <= wc (owners without quads share their successor's prefix)
+#pragma unroll
+        for (unsigned st = 32; st >= 1; st >>= 1)
+          if (S.pref[L + st] <= wc) L += st;
+        own[it] = L;
+        const uint32_t j = wc - S.pref[L];
+        uint32_t dq = S.rows_d[L][0];
+#pragma unroll
+        for (int r = 1; r < kCoopRows; ++r)
+          if (j >= S.rows_o[L][r]) dq = S.rows_d[L][r];
+        const uint4 *line = reinterpret_cast<const uint4 *>(pts) + (size_t)(j + dq) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint4 wv = line[u];
+          t[4 * it + u].x = __uint_as_float(wv.x);
+          t[4 * it + u].y = __uint_as_float(wv.y);
+          t[4 * it + u].z = __uint_as_float(wv.z);
+          t[4 * it + u].idx = wv.w;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int it = 0; it < kCoopItems; ++it) {
+        const float4 oq = S.oq[own[it]];
+        const uint32_t obi = S.obi[own[it]];
+        bool pass[4];
+        unsigned long long bal[4];
+        unsigned fresh = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float fx = oq.x - t[4 * it + u].x, fy = oq.y - t[4 * it + u].y;
+          float s2 = __builtin_fmaf(fy, fy, fx * fx);
+          if (DIM == 3) {
+            const float fz = oq.z - t[4 * it + u].z;
+            s2 = __builtin_fmaf(fz, fz, s2);
+          }
+          pass[u] = has[it] && !(s2 > oq.w) && t[4 * it + u].idx != obi;
+          bal[u] = __ballot(pass[u]);
+          fresh += (unsigned)__popcll(bal[u]);
+        }
+        if (fresh == 0) continue;
+        if (cnt + fresh > (unsigned)kCoopCandCap) flush();  // (the owners' thresholds may have shrunk: the screen above is still valid, merely wider)
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (pass[u]) S.cand[cnt + (unsigned)__popcll(bal[u] & below)] = make_uint2(own[it], t[4 * it + u].idx);
+          cnt += (unsigned)__popcll(bal[u]);
+        }
+      }
+    }
+    __syncthreads();  // the list and the row tables are rewritten by the next round
+    COOP_STAMP(4);
+    if (cnt >= (unsigned)kCoopFlushAt) {
+      flush();
+      COOP_STAMP(5);
+    }
+  }
+  COOP_STAMP(1);
+  if (cnt > 0) flush();
+  COOP_STAMP(5);
+#ifdef ICP_COOP_PROFILE
+  auto coop_report = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    cprof[6] += (unsigned long long)(wall_clock64() - ct_last);
+    if (lane == 0)
+      for (int j = 0; j < 12; ++j) atomicAdd(&g_coop_prof[blockIdx.x & 63][j], cprof[j]);
+  };
+#endif
+
+  auto emit = [&]() {
+    if (!in_range) return;
+    if (no_match) {
+      if (SEEDED) prev[k] = pm;
+      if (idx) idx[i] = 0;
+      if (a) a[i] = make_double2(q[0], q[1]);
+      if (b) b[i] = make_double2(dst[0], dst[1]);
+      return;
+    }
+    if (bi == 0xffffffffu) {  // no finite distance at all: index 0, as a scan from 0 would
+      bi = 0;
+      bx = dst[0];
+      by = dst[1];
+      bz = DIM == 3 ? dst[2] : 0.;
+    }
+    if (SEEDED || bi != pm.idx) {
+      PrevMatch out;
+      out.x = bx;
+      out.y = by;
+      out.z = bz;
+      out.idx = bi;
+      out.pad = 0;
+      prev[k] = out;
+    }
+    if (idx) idx[i] = bi;
+    if (a) a[i] = make_double2(q[0], q[1]);
+    if (b) b[i] = make_double2(bx, by);
+  };
+  emit();
+#ifdef ICP_COOP_PROFILE
+  coop_report();
+#endif
+}
+
+template <int DIM>
+__global__ __launch_bounds__(kGridThreads) void k_nn_grid_warm_coop(const double *__restrict__ src,
+                                                                    const uint32_t *__restrict__ perm, unsigned n, Pose T,
+                                                                    GridParams g, const uint32_t *__restrict__ start,
+                                                                    const GridPoint *__restrict__ pts,
+                                                                    const double *__restrict__ dst, uint32_t *__restrict__ idx,
+                                                                    double2 *__restrict__ a, double2 *__restrict__ b,
+                                                                    PrevMatch *prev, unsigned xcd_chunk) {
+  __shared__ CoopLds S;
+  const unsigned k = xcd_wave(blockIdx.x, gridDim.x, xcd_chunk) * kGridThreads + threadIdx.x;
+  warm_wave<DIM, false>(k, n, src, perm, T, g, start, pts, dst, idx, a, b, prev, PrevMatch{0., 0., 0., 0xffffffffu, 0u}, S);
 }
 
 // ------------------------------------------------------ certified matches ----
@@ -1413,10 +1876,11 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seeded(const double *_
                                                                  const double *__restrict__ dst, uint32_t *__restrict__ idx,
                                                                  double2 *__restrict__ a, double2 *__restrict__ b,
                                                                  PrevMatch *prev) {
+  __shared__ CoopLds S;
   const unsigned k = xcd_wave(blockIdx.x, gridDim.x, kXcdChunk) * kGridThreads + threadIdx.x;
-  if (k >= n) return;
-  const PrevMatch pm = seed_match<DIM>(k, src, T, g, start, pts, dst);
-  warm_query<DIM, false, true>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev, CertDecay{0.f, 0.f, 0.f, 0.f}, pm);
+  // (the lanes past the end repeat the last query: the walk is the whole wave's)
+  const PrevMatch pm = seed_match<DIM>(k < n ? k : n - 1, src, T, g, start, pts, dst);
+  warm_wave<DIM, true>(k, n, src, perm, T, g, start, pts, dst, idx, a, b, prev, pm, S);
 }
 
 // ------------------------------------------------ query locality (optional) -------
@@ -1702,6 +2166,9 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
     const bool check = certs && q_prev && QW.have_certs;
     // the first search of a snapshot: ONE launch, the seed handed to the walk in registers (k_nn_grid_seeded)
     static const bool no_fuse = exp_env("ICP_NN_SEED_SEPARATE") != nullptr;
+#ifdef ICP_EXPERIMENTS
+    static const bool warm_coop = exp_env("ICP_NN_WARM_COOP") ? atoi(exp_env("ICP_NN_WARM_COOP")) != 0 : true;
+#endif
     const bool fused_seed = seeded && !check && !certs && !no_fuse;
     if (seeded && !fused_seed) launch_seeds();
     if (check) {
@@ -1743,13 +2210,22 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
       else
         hipLaunchKernelGGL(k_nn_grid_seeded<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
                            G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev);
-    } else {
+#ifdef ICP_EXPERIMENTS
+    } else if (!warm_coop) {  // ICP_NN_WARM_COOP=0: a lane per query from end to end (rounds 2-3; same indices)
       if (h->dim == 3)
         hipLaunchKernelGGL((k_nn_grid_warm<3, false>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
                            G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd, xcd_chunk);
       else
         hipLaunchKernelGGL((k_nn_grid_warm<2, false>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
                            G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, cd, xcd_chunk);
+#endif
+    } else {
+      if (h->dim == 3)
+        hipLaunchKernelGGL(k_nn_grid_warm_coop<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, xcd_chunk);
+      else
+        hipLaunchKernelGGL(k_nn_grid_warm_coop<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, xcd_chunk);
     }
     hipError_t we = hipGetLastError();
     if (ev0 && ev1) {
@@ -1799,6 +2275,34 @@ extern "C" int icp_debug_nn_hist(unsigned long long out[64], int reset) {
   if (reset) {
     unsigned long long z[64] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_nn_hist), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+
+#endif
+#ifdef ICP_COOP_PROFILE
+extern "C" int icp_debug_coop_profile(unsigned long long out[12], int reset) {
+  unsigned long long all[64][12];
+  if (hipMemcpyFromSymbol(all, HIP_SYMBOL(g_coop_prof), sizeof(all)) != hipSuccess) return 1;
+  for (int j = 0; j < 12; ++j) {
+    out[j] = 0;
+    for (int i = 0; i < 64; ++i) out[j] += all[i][j];
+  }
+  if (reset) {
+    memset(all, 0, sizeof(all));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_coop_prof), all, sizeof(all)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+#ifdef ICP_NN_STATS
+extern "C" int icp_debug_nn_warm(unsigned long long out[8 + 64], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_warm), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_nn_warm_hist), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_nn_warm), z, 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_nn_warm_hist), z, sizeof(z)) != hipSuccess) return 1;
   }
   return 0;
 }

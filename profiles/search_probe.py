@@ -1,6 +1,7 @@
 """The warm search kernel alone (stage calls on one stream: nothing beside it) on the 1M benchmark pair, for every
 environment given on the command line as KEY=VALUE[,KEY=VALUE] groups (one child process each, experiments build):
-    python3 profiles/search_probe.py "" ICP_NN_XCD_CHUNK=16 ICP_NN_XCD_CHUNK=64
+    python3 profiles/search_probe.py "" ICP_NN_XCD_CHUNK=16 ICP_NN_XCD_CHUNK=64 LIB=i3r4,ICP_NN_WARM_COOP=1
+(LIB=NAME: the variant icp_rust_amd/lib/libicp_ab_NAME.so of profiles/build_variant.sh instead of the experiments build)
 prints the HIP-event average of the search launches and a short whole-step figure."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,7 +40,11 @@ if __name__ == "__main__":
     for grp in (sys.argv[1:] or [""]):
         env = dict(os.environ, SEARCH_PROBE_CHILD="1", ICP_MI355X_LIB=lib)
         for kv in filter(None, grp.split(",")):
-            k, v = kv.split("="); env[k] = v
+            k, v = kv.split("=")
+            if k == "LIB":  # a variant built by profiles/build_variant.sh
+                env["ICP_MI355X_LIB"] = os.path.join(ROOT, "icp_rust_amd", "lib", f"libicp_ab_{v}.so")
+            else:
+                env[k] = v
         out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("search alone")]
         print(f"{grp or '(default)':40s} {line[-1] if line else 'FAILED ' + out.stderr[-300:]}", flush=True)

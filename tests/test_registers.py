@@ -19,7 +19,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 BUDGET = {  # demangled-name fragment -> max VGPRs
     "k_nn_gridILi3ELb1ELb0E": 120,       # 3-D search with the pose applied, f64 geometry (cold calls, extreme cell sizes)
-    "k_nn_grid_warmILi3ELb0E": 96,       # the warm search in f32 geometry: 5 waves per SIMD alone, 3 beside an evaluation
+    "k_nn_grid_warm_coopILi3E": 96,      # the warm search (walk shared by the wave): 5 waves per SIMD alone, 3 beside an evaluation
+    "k_nn_grid_seededILi3E": 96,         # ... and the first search of a snapshot (seed + the same walk)
     "k_nn_grid_warmILi3ELb1E": 104,      # ... leaving certificates (settled registrations: no speculative overlap then)
     "k_win_histE": 56,                   # the four launches of the deciding evaluation ...
     "k_win_compactILb0E": 72,            # (the list variant of the refined windows runs alone)
@@ -65,7 +66,7 @@ def test_kernels_that_share_a_simd_stay_within_their_register_budget():
     up8 = lambda x: (x + 7) // 8 * 8
     # 3 search waves + 2 waves (one workgroup of 512 threads) of any launch of the deciding evaluation, per SIMD
     for k in ("k_win_histE", "k_win_compactILb0E", "k_win_select", "k_win_accumulateILb0E", "k_win_hist_sumsE"):
-        assert 3 * up8(BUDGET["k_nn_grid_warmILi3ELb0E"]) + 2 * up8(BUDGET[k]) <= 512, k
+        assert 3 * up8(BUDGET["k_nn_grid_warm_coopILi3E"]) + 2 * up8(BUDGET[k]) <= 512, k
     for k in ("k_win_histE", "k_win_compactILb0E", "k_win_select"):
         assert 3 * up8(BUDGET["k_nn_gridILi3ELb1ELb0E"]) + 2 * up8(BUDGET[k]) <= 512, k
     # two workgroups of the finishing launch per CU (4 waves per SIMD)
