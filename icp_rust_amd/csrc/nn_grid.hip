@@ -1247,6 +1247,9 @@ struct CoopLds {
   float4 oq[64];                // the owner's grid-relative query and screening threshold
   uint32_t obi[64];             // the owner's current match
   uint2 cand[kCoopCandCap];     // (owner, target index)
+  unsigned long long fkey[64];  // flush: the smallest d^2 (as bits) among an owner's entries, ...
+  uint32_t fidx[64];            // ... the lowest index among those, ...
+  uint32_t fwin[64];            // ... and the lane that holds that entry's coordinates
 };
 
 #ifdef ICP_COOP_PROFILE
@@ -1254,6 +1257,7 @@ struct CoopLds {
 // [0] query + previous match loaded, geometry  [1] row selection  [2] row bounds (start[]) arrived  [3] prefix + tables
 // [4] worker rounds  [5] flushes  [6] outputs  [7] waves  [8] rounds of rows  [9] worker rounds  [10] flushes  [11] candidates
 __device__ unsigned long long g_coop_prof[64][12];
+__device__ long long g_coop_span[16384][2];  // start / end tick of every wave (workgroup) of the last launch
 #define COOP_STAMP(i)                                                  \
   do {                                                                 \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
@@ -1278,6 +1282,7 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
 #ifdef ICP_COOP_PROFILE
   unsigned long long cprof[12] = {0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0};
   long long ct_last = wall_clock64();
+  const long long ct_first = ct_last;
 #endif
   const bool in_range = k < n;
   const unsigned kk = in_range ? k : n - 1;  // the lanes past the end repeat the last query and store nothing
@@ -1360,6 +1365,9 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
   };
   S.oq[lane] = make_float4(qf[0], qf[1], qf[2], thr32);
   S.obi[lane] = bi;
+  S.fkey[lane] = 0x7ff0000000000000ull;
+  S.fidx[lane] = 0xffffffffu;
+  S.fwin[lane] = lane;
   COOP_STAMP(0);
 
   unsigned cnt = 0;  // pending candidates: the same number in every lane (ballots)
@@ -1389,23 +1397,40 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
         const double ddz = oqd[2] - tz;
         dd = dd + ddz * ddz;
       }
-      const unsigned m = min(64u, cnt - base);
-      for (unsigned e2 = 0; e2 < m; ++e2) {  // (uniform: readlane takes the lane from a scalar register)
-        const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)c.x, (int)e2);
-        const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)ti, (int)e2);
-        const double d2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dd), (int)e2),
-                                           __builtin_amdgcn_readlane(__double2loint(dd), (int)e2));
-        if (lane == o && (d2 < best || (d2 == best && t2 < bi))) {
-          best = d2;
-          bi = t2;
-          bx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tx), (int)e2),
-                                __builtin_amdgcn_readlane(__double2loint(tx), (int)e2));
-          by = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ty), (int)e2),
-                                __builtin_amdgcn_readlane(__double2loint(ty), (int)e2));
-          bz = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tz), (int)e2),
-                                __builtin_amdgcn_readlane(__double2loint(tz), (int)e2));
+      // every owner's lexicographic minimum (d^2, index) over the entries of this batch, by LDS atomics: d^2 >= 0 or
+      // NaN, so its bit pattern orders like the value and a NaN sorts behind +inf (never chosen, as in warm_query)
+      const unsigned long long key = (unsigned long long)__double_as_longlong(dd);
+      if (have) atomicMin(&S.fkey[c.x], key);
+      __syncthreads();
+      const bool first = have && S.fkey[c.x] == key;
+      if (first) atomicMin(&S.fidx[c.x], ti);
+      __syncthreads();
+      if (first && S.fidx[c.x] == ti) S.fwin[c.x] = lane;  // (the same target twice in the list: either lane, same values)
+      __syncthreads();
+      const double d2 = __longlong_as_double((long long)S.fkey[lane]);
+      const uint32_t t2 = S.fidx[lane];
+      const int wsel = (int)(S.fwin[lane] << 2);
+      double wx[3];
+      {
+        const double tc[3] = {tx, ty, tz};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(wsel, (int)__double2loint(tc[d]));
+          const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(wsel, (int)__double2hiint(tc[d]));
+          wx[d] = __hiloint2double((int)hi, (int)lo);
         }
       }
+      if (d2 < best || (d2 == best && t2 < bi)) {
+        best = d2;
+        bi = t2;
+        bx = wx[0];
+        by = wx[1];
+        bz = wx[2];
+      }
+      S.fkey[lane] = 0x7ff0000000000000ull;  // + infinity
+      S.fidx[lane] = 0xffffffffu;
+      S.fwin[lane] = lane;
+      __syncthreads();
     }
     cnt = 0;
     if (!wide) set_radius();
@@ -1577,8 +1602,13 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
   auto coop_report = [&]() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     cprof[6] += (unsigned long long)(wall_clock64() - ct_last);
-    if (lane == 0)
+    if (lane == 0) {
       for (int j = 0; j < 12; ++j) atomicAdd(&g_coop_prof[blockIdx.x & 63][j], cprof[j]);
+      if (blockIdx.x < 16384u) {
+        g_coop_span[blockIdx.x][0] = ct_first;
+        g_coop_span[blockIdx.x][1] = wall_clock64();
+      }
+    }
   };
 #endif
 
@@ -1616,8 +1646,13 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
 #endif
 }
 
+#ifdef ICP_COOP_WAVES
+#define ICP_COOP_ATTR __attribute__((amdgpu_waves_per_eu(ICP_COOP_WAVES, ICP_COOP_WAVES)))
+#else
+#define ICP_COOP_ATTR
+#endif
 template <int DIM>
-__global__ __launch_bounds__(kGridThreads) void k_nn_grid_warm_coop(const double *__restrict__ src,
+__global__ __launch_bounds__(kGridThreads) ICP_COOP_ATTR void k_nn_grid_warm_coop(const double *__restrict__ src,
                                                                     const uint32_t *__restrict__ perm, unsigned n, Pose T,
                                                                     GridParams g, const uint32_t *__restrict__ start,
                                                                     const GridPoint *__restrict__ pts,
@@ -2281,6 +2316,9 @@ extern "C" int icp_debug_nn_hist(unsigned long long out[64], int reset) {
 
 #endif
 #ifdef ICP_COOP_PROFILE
+extern "C" int icp_debug_coop_spans(long long *out, int n) {  // n <= 16384 (start, end) pairs by workgroup
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_span), (size_t)n * 2 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
 extern "C" int icp_debug_coop_profile(unsigned long long out[12], int reset) {
   unsigned long long all[64][12];
   if (hipMemcpyFromSymbol(all, HIP_SYMBOL(g_coop_prof), sizeof(all)) != hipSuccess) return 1;

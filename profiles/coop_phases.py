@@ -24,3 +24,20 @@ for it in range(8):
     if v[7] == 0: print(f"iter {it}: (not the shared walk)"); continue
     print(f"iter {it}: waves {v[7]} lifetime {sum(v[:7]) / w / 100:.2f} us = " + ", ".join(f"{nm} {v[j] / w / 100:.2f}" for j, nm in enumerate(names)) +
           f" | per wave: rounds of rows {v[8] / w:.2f}, worker rounds {v[9] / w:.2f}, flushes {v[10] / w:.2f}, candidates {v[11] / w:.1f}")
+
+# how many waves are resident over the launch: the (start, end) of every workgroup of the last search
+import numpy as np
+nb = min((n + 63) // 64, 16384)
+L.icp_debug_coop_spans.argtypes = [C.c_void_p, C.c_int]
+sp = np.zeros((nb, 2), dtype=np.int64)
+L.icp_debug_coop_spans(sp.ctypes.data, nb)
+t0 = sp[:, 0].min(); sp -= t0
+dur = sp[:, 1].max()
+print(f"last launch: {nb} waves, first start to last end {dur / 100:.1f} us; wave lifetime mean {np.mean(sp[:, 1] - sp[:, 0]) / 100:.2f} us, "
+      f"p50 {np.median(sp[:, 1] - sp[:, 0]) / 100:.2f}, p90 {np.percentile(sp[:, 1] - sp[:, 0], 90) / 100:.2f}, max {np.max(sp[:, 1] - sp[:, 0]) / 100:.2f}")
+edges = np.linspace(0, dur, 21)
+for a_, b_ in zip(edges[:-1], edges[1:]):
+    mid = 0.5 * (a_ + b_)
+    res = int(np.sum((sp[:, 0] <= mid) & (sp[:, 1] > mid)))
+    started = int(np.sum((sp[:, 0] >= a_) & (sp[:, 0] < b_)))
+    print(f"  t = {mid / 100:6.1f} us: resident waves {res:5d} ({res / 1024:.2f} per SIMD), started in the interval {started}")

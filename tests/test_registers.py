@@ -20,7 +20,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 BUDGET = {  # demangled-name fragment -> max VGPRs
     "k_nn_gridILi3ELb1ELb0E": 120,       # 3-D search with the pose applied, f64 geometry (cold calls, extreme cell sizes)
     "k_nn_grid_warm_coopILi3E": 96,      # the warm search (walk shared by the wave): 5 waves per SIMD alone, 3 beside an evaluation
-    "k_nn_grid_seededILi3E": 96,         # ... and the first search of a snapshot (seed + the same walk)
+    "k_nn_grid_seededILi3E": 104,        # ... and the first search of a snapshot (seed + the same walk)
     "k_nn_grid_warmILi3ELb1E": 104,      # ... leaving certificates (settled registrations: no speculative overlap then)
     "k_win_histE": 56,                   # the four launches of the deciding evaluation ...
     "k_win_compactILb0E": 72,            # (the list variant of the refined windows runs alone)
