@@ -1574,7 +1574,7 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
             const float fz = oq.z - t[4 * it + u].z;
             s2 = __builtin_fmaf(fz, fz, s2);
           }
-          pass[u] = has[it] && !(s2 > oq.w) && t[4 * it + u].idx != obi;
+          pass[u] = has[it] & !(s2 > oq.w) & (t[4 * it + u].idx != obi);  // (no short circuit: three masks and-ed)
           bal[u] = __ballot(pass[u]);
           fresh += (unsigned)__popcll(bal[u]);
         }
