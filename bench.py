@@ -504,7 +504,7 @@ def main():
                 break
         if os.path.exists(tf_path) and world == 1 and n == 1_000_000 and m == 1_000_000:
             traffic = json.load(open(tf_path))["k_nn_grid"]["traffic_bytes_per_launch"]
-        return {"kernel": "k_nn_grid_warm (one search = one launch; the first search of a call = k_nn_grid_seed + k_nn_grid_warm)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"kernel": "k_nn_grid_warm_coop (one search = one launch; the first search of a call = k_nn_grid_seeded: seeds + the same walk)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": f"profiles/{tf_name} (separate rocprofv3 --pmc passes of this command; a PMC pass "
                                   "cannot run inside the timed process)",

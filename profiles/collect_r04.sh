@@ -21,6 +21,10 @@ python3 profiles/collect_traffic.py $O/pf $O/pw $O/traffic_pmc.json > $O/traffic
 echo "== TA PMC (search kernels)"
 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE --output-format csv -d $O/pt -- python3 bench.py --steps 40 --warmup 2 $B > /dev/null 2>&1
 python3 profiles/collect_pmc.py $O/pt k_nn_grid > $O/nn_grid_ta_pmc.txt; rm -rf $O/pt
+echo "== SQ instruction counters (search kernel)"; bash profiles/sq_counters_ab.sh mi355x > $O/nn_grid_sq_pmc.txt 2>&1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+echo "== shared warm walk: in-kernel phase stamps and residency (profiling variant: bash profiles/build_variant.sh coopprof nn_grid.hip -DICP_COOP_PROFILE)"
+ICP_MI355X_LIB=$PWD/icp_rust_amd/lib/libicp_ab_coopprof.so python3 profiles/coop_phases.py 2>&1 | grep -v amdgpu.ids | tail -24 > $O/search_coop_phases.txt
 echo "== virtual ranks: what the N-rank orchestration costs"; python3 profiles/multi_virtual_timing.py > $O/multi_virtual_timing.txt 2>&1
 echo "== virtual ranks: kernel trace of one sharded estimate(20)"
 for W in 1 8; do

@@ -52,13 +52,13 @@ def main():
             "gathers (uncalibrated width): reported uncorrected. Infinity-Cache hits are counted by these "
             "fabric-side counters, so at this 1M size (working set < 256 MiB) they are an upper bound on HBM bytes.")
     doc = {"note": note, "kernels": kernels}
-    # one SEARCH = one launch of k_nn_grid_warm or of the general k_nn_grid; the first search of an
-    # estimate call is a k_nn_grid_seed launch followed by a warm launch (bench.py's HIP events bracket
-    # the pair), so the seeds' bytes are spread over all searches: with bench.py's calls of 20 outer
-    # iterations that is the 1-in-20 share the timed region has
+    # one SEARCH = one launch of k_nn_grid_warm_coop (k_nn_grid_warm in rounds 2-3), of k_nn_grid_seeded (the first
+    # search of an estimate call: seeds + the same walk) or of the general k_nn_grid; where the seeds are a launch of
+    # their own (k_nn_grid_seed: certificates on) their bytes are spread over all searches
     tot = {"f": 0.0, "w": 0.0, "searches_f": 0, "searches_w": 0}
     for k, e in kernels.items():
-        is_search = k.startswith("icp::k_nn_grid<3, true") or k.startswith("icp::k_nn_grid_warm<3")
+        is_search = (k.startswith("icp::k_nn_grid<3, true") or k.startswith("icp::k_nn_grid_warm<3") or
+                     k.startswith("icp::k_nn_grid_warm_coop<3") or k.startswith("icp::k_nn_grid_seeded<3"))
         if not (is_search or k.startswith("icp::k_nn_grid_seed<3")):
             continue
         tot["f"] += e.get("FETCH_SIZE_KB_avg_per_launch", 0.0) * e.get("launches_FETCH_SIZE", 0)
@@ -72,7 +72,7 @@ def main():
                             "corrected": False, "launches": tot["searches_f"],
                             "weighting": "all search kernels (seed + warm + general) over the number of searches of the run"}
         for k, e in kernels.items():
-            if k.startswith("icp::k_nn_grid_warm<3") and "FETCH_SIZE_KB_avg_per_launch" in e and "WRITE_SIZE_KB_avg_per_launch" in e:
+            if (k.startswith("icp::k_nn_grid_warm<3") or k.startswith("icp::k_nn_grid_warm_coop<3")) and "FETCH_SIZE_KB_avg_per_launch" in e and "WRITE_SIZE_KB_avg_per_launch" in e:
                 doc["k_nn_grid"]["warm_kernel_bytes_per_launch"] = 1024 * (e["FETCH_SIZE_KB_avg_per_launch"] +
                                                                             e["WRITE_SIZE_KB_avg_per_launch"])
             if k.startswith("icp::k_nn_grid_seed<3") and "FETCH_SIZE_KB_avg_per_launch" in e and "WRITE_SIZE_KB_avg_per_launch" in e:

@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""),
                      r.get("Queue_Id", "?")))
 rows.sort()
-warm = [i for i, r in enumerate(rows) if r[2].startswith("icp::k_nn_grid<3, true, false") or r[2].startswith("icp::k_nn_grid_warm<3")]
+warm = [i for i, r in enumerate(rows) if r[2].startswith("icp::k_nn_grid<3, true, false") or r[2].startswith("icp::k_nn_grid_warm")]
 start = warm[len(warm) * 2 // 3]  # well inside a 20-iteration call
 t0 = rows[start][0]
 print("rocprofv3 --kernel-trace of `python3 bench.py --brute-steps 0 --cpu-iters 0 --gn-points 0`: consecutive kernels of the "
