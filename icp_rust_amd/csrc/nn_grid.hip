@@ -1469,6 +1469,8 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
   for (;;) {
     // ---- owner: the next rows of its box ----
     int nr = 0;
+    S.rows_d[lane][0] = 0u;  // (a lane without rows reads the bounds of cell 0 below: a cached address, no branch)
+    S.rows_o[lane][0] = 0u;
     while (alive && nr < kCoopRows) {
       if (mask == 0) {  // the next tile of the box: along y, then z
         ty += 4;
@@ -1497,15 +1499,14 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
     uint32_t sb[kCoopRows], se[kCoopRows];
 #pragma unroll
     for (int r = 0; r < kCoopRows; ++r) {
-      const int rr = r < nr ? r : 0;  // unused slots repeat row 0 (a cached address; lanes without rows read cell 0)
-      const uint32_t ra = nr > 0 ? S.rows_d[lane][rr] : 0u, rz = nr > 0 ? S.rows_o[lane][rr] : 0u;
-      sb[r] = start[ra];
-      se[r] = start[rz];
+      const int rr = r < nr ? r : 0;  // unused slots repeat row 0 (a cached address)
+      sb[r] = start[S.rows_d[lane][rr]];
+      se[r] = start[S.rows_o[lane][rr]];
     }
     uint32_t rd[kCoopRows], ro[kCoopRows], Q = 0;
 #pragma unroll
     for (int r = 0; r < kCoopRows; ++r) {  // runs -> aligned quads; an empty run has no quads
-      const uint32_t qr = sb[r] >> 2, nq = (nr > r && se[r] > sb[r]) ? ((se[r] + 3) >> 2) - qr : 0u;
+      const uint32_t qr = sb[r] >> 2, nq = ((nr > r) & (se[r] > sb[r])) ? ((se[r] + 3) >> 2) - qr : 0u;  // (no short circuit: every bound is loaded up front)
       ro[r] = Q;
       rd[r] = qr - Q;
       Q += nq;
