@@ -32,6 +32,7 @@ L.icp_debug_coop_spans.argtypes = [C.c_void_p, C.c_int]
 sp = np.zeros((nb, 2), dtype=np.int64)
 L.icp_debug_coop_spans(sp.ctypes.data, nb)
 t0 = sp[:, 0].min(); sp -= t0
+if os.environ.get('COOP_SPANS_OUT'): np.save(os.environ['COOP_SPANS_OUT'], sp)
 dur = sp[:, 1].max()
 print(f"last launch: {nb} waves, first start to last end {dur / 100:.1f} us; wave lifetime mean {np.mean(sp[:, 1] - sp[:, 0]) / 100:.2f} us, "
       f"p50 {np.median(sp[:, 1] - sp[:, 0]) / 100:.2f}, p90 {np.percentile(sp[:, 1] - sp[:, 0], 90) / 100:.2f}, max {np.max(sp[:, 1] - sp[:, 0]) / 100:.2f}")
