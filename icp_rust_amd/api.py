@@ -288,6 +288,13 @@ def gn_loop_counters(icp=None):
     return tuple(int(x) for x in out)
 
 
+def run_ahead_counters(icp):
+    """(run-ahead searches whose device-derived pose the host confirmed bit for bit, ... that it did not)"""
+    out = (C.c_uint64 * 2)()
+    check(lib().icp_run_ahead_counters(icp._h, out), "icp_run_ahead_counters")
+    return tuple(int(x) for x in out)
+
+
 def nn_tile_counters(icp):
     """(waves launched, waves handed to the per-lane gather walk) of the handle's last LDS-tile search"""
     out = (C.c_uint64 * 2)()

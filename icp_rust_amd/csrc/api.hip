@@ -82,6 +82,9 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_b);
   (void)hipFree(w.d_a2);
   (void)hipFree(w.d_b2);
+  (void)hipFree(w.d_a3);
+  (void)hipFree(w.d_b3);
+  (void)hipFree(w.d_ahead);
   (void)hipFree(w.d_idx);
   (void)hipFree(w.d_idx_slot);
   (void)hipFree(w.d_sa);
@@ -172,6 +175,8 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     int prio = prio_greatest;
     if (const char *pe = exp_env("ICP_EVAL_PRIORITY")) prio = pe[0] == 'l' ? prio_least : (pe[0] == 'n' ? 0 : prio_greatest);
     if ((e = hipStreamCreateWithPriority(&w.spec_stream, hipStreamNonBlocking, prio)) != hipSuccess) return e;
+    if ((e = hipMalloc(&w.d_ahead, sizeof(AheadPose))) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(w.d_ahead, 0, sizeof(AheadPose), h->stream)) != hipSuccess) return e;
     // the memsets above must have landed before either stream uses the scratch
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
   }
@@ -186,6 +191,8 @@ hipError_t ensure_workspace(icp_handle *h, size_t n, bool need_src) {
     if ((e = grow(w.d_b, cap * 2)) != hipSuccess) return e;
     if ((e = grow(w.d_a2, cap * 2)) != hipSuccess) return e;
     if ((e = grow(w.d_b2, cap * 2)) != hipSuccess) return e;
+    if ((e = grow(w.d_a3, cap * 2)) != hipSuccess) return e;
+    if ((e = grow(w.d_b3, cap * 2)) != hipSuccess) return e;
     if ((e = grow(w.d_rx, cap)) != hipSuccess) return e;
     if ((e = grow(w.d_ry, cap)) != hipSuccess) return e;
     if ((e = grow(w.alt.d_rx, cap)) != hipSuccess) return e;
@@ -483,6 +490,8 @@ extern "C" void icp_destroy(icp_handle *h) {
     w.gn_dirty = w.alt.gn_dirty = true;
     w.win_tried = w.win_missed = w.short_evals = w.radix_evals = 0;
     w.spec_hits = w.spec_misses = w.pre_evals = 0;
+    w.ahead_hits = w.ahead_misses = 0;
+    w.ahead_on = w.ahead_seen_valid = false;
     w.loop_launches = w.loop_evals = w.loop_handbacks = 0;
     w.loop_off = false;
     w.loop_rank = -1;
@@ -772,8 +781,19 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
         HIP_TRY(after_launch());
         hooked = true;
       }
+#ifdef ICP_EXPERIMENTS
+      const auto tw0 = std::chrono::steady_clock::now();
+#endif
       HIP_TRY(wait_result(h));
+#ifdef ICP_EXPERIMENTS
+      (pre_launched ? w.dbg_wait_pre_us : w.dbg_wait_other_us) +=
+          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count();
+#endif
       done = has_median = !w.h_res->overflow;
+      if (pre_launched) {  // (the run-ahead search behind it read the same pose from the device)
+        w.ahead_seen_valid = w.h_res->next_valid != 0;
+        w.ahead_seen_pose = w.h_res->next_pose;
+      }
       if (!done) {
         if (exp_env("ICP_WIN_TRACE")) fprintf(stderr, "[win] kind %d: the window missed\n", kind);
         ++w.win_missed;
@@ -1360,9 +1380,16 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   h->qsort.slot_order = slot;
   if (slot) h->qsort.fold_n = n;
   uint32_t *const idx_target = slot ? w.d_idx_slot : d_last_idx;
-  double *A[2] = {w.d_a, w.d_a2}, *B[2] = {w.d_b, w.d_b2};
+  double *A[3] = {w.d_a, w.d_a2, w.d_a3}, *B[3] = {w.d_b, w.d_b2, w.d_b3};
   int cur = 0;
   bool spec_valid = false, pre_valid = false, first_pre_launched = false;
+  // Run-ahead search: behind the pre-launched first evaluation of the NEXT iteration the search of the iteration
+  // after it is enqueued at once, with its pose read from the device (k_win_finish solves the update there) -- the
+  // search stream then runs search -> evaluation -> search -> ... without waiting for the host between them.  The
+  // host still derives every pose itself and takes the pairs only if the device's pose has the same bits.
+  static const bool no_ahead = getenv("ICP_NO_RUN_AHEAD") != nullptr;
+  const bool can_ahead = two_streams && !no_ahead && resolved_nn_mode(h) == ICP_NN_GRID;
+  bool ahead_issued = false;  // an ahead search into the buffers after next is in flight behind the current pre-evaluation
   static const bool no_pre = exp_env("ICP_NO_PRE_EVAL") != nullptr;
   Pose spec_pose = T;
   // the bet needs "the inner loop took exactly one update last time"; across calls the handle
@@ -1371,11 +1398,12 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   hipStream_t search_stream = h->stream;
   for (size_t it = 0; it < max_iter; ++it) {
     if (spec_valid && memcmp(&spec_pose, &T, sizeof(Pose)) == 0) {
-      cur ^= 1;  // the pairs of this pose are already in (or on their way into) the other buffers
+      cur = (cur + 1) % 3;  // the pairs of this pose are already in (or on their way into) the next buffers
       ++w.spec_hits;
       first_pre_launched = pre_valid;
     } else {
       first_pre_launched = false;  // (a pre-launched evaluation of discarded pairs just runs out; nobody reads it)
+      ahead_issued = false;        // (... and so does a run-ahead search behind it)
       if (spec_valid) ++w.spec_misses;  // the discarded search precedes this one on the same stream
       uint32_t *idx_out = (it + 1 == max_iter && d_last_idx) ? idx_target : nullptr;
       const int rc = icp_correspond_device(h, d_src, n, &T, A[cur], B[cur], idx_out);
@@ -1388,11 +1416,18 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     auto launch_spec = [&](const Pose &T1) -> hipError_t {
       spec_pose = transform_mul(T1, T);  // src/lib.rs:127, 170 -- what the outer loop will compute
       uint32_t *idx_out = (it + 2 == max_iter && d_last_idx) ? idx_target : nullptr;
+      const int nxt = (cur + 1) % 3, nxt2 = (cur + 2) % 3;
       spec_valid = true;
       pre_valid = false;
       hipStream_t eval_stream = h->stream;  // the hook runs inside the second evaluation
       h->stream = search_stream;
-      hipError_t e = launch_nn(h, d_src, n, &spec_pose, A[cur ^ 1], B[cur ^ 1], idx_out);
+      hipError_t e = hipSuccess;
+      // the search for spec_pose: already behind this iteration's pre-launched evaluation if the device derived the
+      // same pose (its pairs go where this search's would)
+      const bool have_search = ahead_issued && w.ahead_seen_valid && memcmp(&w.ahead_seen_pose, &spec_pose, sizeof(Pose)) == 0;
+      if (ahead_issued) ++(have_search ? w.ahead_hits : w.ahead_misses);
+      ahead_issued = false;
+      if (!have_search) e = launch_nn(h, d_src, n, &spec_pose, A[nxt], B[nxt], idx_out);
       if (e == hipSuccess && two_streams && !no_pre) {
         // ... and the next iteration's FIRST evaluation (inner pose = identity) right behind it,
         // in the search stream's own evaluation scratch: if the bet holds, its result is waiting
@@ -1406,8 +1441,16 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
         if (e == hipSuccess && window_usable(h, n, &P, 0)) {
           ++w.win_tried;
           ++w.pre_evals;
-          e = launch_weighted_gn_win(h, A[cur ^ 1], B[cur ^ 1], n, transform_identity(), P);
+          const bool go_ahead = can_ahead && it + 2 < max_iter;
+          w.ahead_on = go_ahead;
+          w.ahead_outer = spec_pose;
+          e = launch_weighted_gn_win(h, A[nxt], B[nxt], n, transform_identity(), P);
+          w.ahead_on = false;
           pre_valid = true;
+          if (e == hipSuccess && go_ahead) {  // the search of the iteration after next, behind that evaluation
+            uint32_t *idx_out2 = (it + 3 == max_iter && d_last_idx) ? idx_target : nullptr;
+            e = launch_nn_grid_ahead(h, d_src, n, w.d_ahead, A[nxt2], B[nxt2], idx_out2, &ahead_issued);
+          }
         }
         w.swap_ctx();
       }
@@ -1431,6 +1474,13 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     w.last_inner = inner;
     T = transform_mul(dT, T);  // src/lib.rs:127, 170
   }
+#ifdef ICP_EXPERIMENTS
+  if (exp_env("ICP_STEP_TRACE")) {
+    fprintf(stderr, "[step trace] %zu iterations: waiting for pre-launched first evaluations %.1f us, for other evaluations %.1f us\n",
+            max_iter, w.dbg_wait_pre_us, w.dbg_wait_other_us);
+    w.dbg_wait_pre_us = w.dbg_wait_other_us = 0.;
+  }
+#endif
   if (slot && d_last_idx && max_iter > 0 && n > 0) HIP_TRY(launch_unpermute_idx(h, w.d_idx_slot, n, d_last_idx));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (two_streams) HIP_TRY(hipStreamSynchronize(w.spec_stream));
@@ -1547,6 +1597,13 @@ extern "C" int icp_gn_path_counters(icp_handle *h, uint64_t out[6]) {
   out[3] = h->ws.radix_evals;
   out[4] = h->ws.spec_hits;
   out[5] = h->ws.spec_misses;
+  return ICP_OK;
+}
+
+extern "C" int icp_run_ahead_counters(icp_handle *h, uint64_t out[2]) {
+  if (!h || !out) return ICP_BAD_ARGUMENT;
+  out[0] = h->ws.ahead_hits;
+  out[1] = h->ws.ahead_misses;
   return ICP_OK;
 }
 

@@ -135,6 +135,21 @@ struct GnResult {
   // sharded evaluations: how many ranks answered {OK, RETRY_REPLICATED, NONE, anything else} in the hist stage
   // (the status words behind the histograms, summed over the ranks with them; shard.hip:k_shard_fold)
   unsigned status[4];
+  // k_win_finish with an AheadPose to fill (icp_estimate_device's run-ahead search): the pose it derived and whether
+  // it is usable -- the host compares it bit for bit with the pose it computes itself from acc[]
+  Pose next_pose;
+  int next_valid;
+  int pad2;
+};
+
+// The pose of a search that was enqueued BEFORE the host knew it: the finishing launch of an outer iteration's first
+// evaluation solves the update on the device and leaves "update x outer pose" here; the search behind it on the same
+// stream reads it (valid == 0: every wave leaves at once).  Results never depend on it: the host derives the same pose
+// from the evaluation's sums and uses the pairs only if the two agree bit for bit.
+struct AheadPose {
+  Pose T;
+  int valid;
+  int pad;
 };
 
 // Scratch of ONE Gauss-Newton evaluation in flight.  A handle has two of them, one per stream of
@@ -170,6 +185,15 @@ struct Workspace : GnCtx {
   double *d_b = nullptr;   // matched target xy, cap_n x 2
   double *d_a2 = nullptr;  // second pair buffers: the speculative search of the next outer iteration
   double *d_b2 = nullptr;
+  double *d_a3 = nullptr;  // third: the run-ahead search of the iteration after that
+  double *d_b3 = nullptr;
+  AheadPose *d_ahead = nullptr;   // device: the run-ahead search's pose (k_win_finish writes, k_nn_grid_warm_coop reads)
+  bool ahead_on = false;          // the next two-launch evaluation fills d_ahead for ...
+  Pose ahead_outer;               // ... this outer pose
+  bool ahead_seen_valid = false;  // what the last pre-launched evaluation reported (GnResult::next_pose / next_valid)
+  Pose ahead_seen_pose;
+  unsigned long long ahead_hits = 0, ahead_misses = 0;
+  double dbg_wait_pre_us = 0., dbg_wait_other_us = 0.;  // experiments build: where the host of icp_estimate_device waits
   unsigned long long spec_hits = 0, spec_misses = 0, pre_evals = 0;
   uint32_t last_inner = 0xffffffffu;  // updates the inner loop applied in the last outer iteration of the previous call
   hipStream_t spec_stream = nullptr;  // later evaluations of an inner loop run beside the speculative search
@@ -418,6 +442,9 @@ hipError_t launch_nn_tile(icp_handle *h, const double *q_src, const uint32_t *q_
 hipError_t launch_unpermute_idx(icp_handle *h, const uint32_t *d_slot_idx, size_t n, uint32_t *d_out);
 hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n, const Pose *T, double *d_a,
                           double *d_b, uint32_t *d_idx);
+// ... with the pose read from device memory (nn_grid.hip; *launched = false: not this time, nothing enqueued)
+hipError_t launch_nn_grid_ahead(icp_handle *h, const double *d_src, size_t n, const AheadPose *d_pose, double *d_a,
+                                double *d_b, uint32_t *d_idx, bool *launched);
 
 // one inner Gauss-Newton iteration's device work; results land in h->ws.h_res after the
 // stream is synchronised

@@ -544,7 +544,8 @@ __global__ __launch_bounds__(kWinThreads) void k_win_finish(const double *__rest
                                                             uint32_t *whist, WinState *st, double *wmed, double *wring,
                                                             GnScalars *scal, const double *partials, int sum_blocks,
                                                             SelCtl *ctl, GnResult *res, unsigned seq,
-                                                            const unsigned *__restrict__ llen, unsigned lcap) {
+                                                            const unsigned *__restrict__ llen, unsigned lcap,
+                                                            AheadPose *ahead, Pose outer) {
   constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
   WinSel sel;
 #ifdef ICP_WIN_DEBUG
@@ -626,6 +627,34 @@ __global__ __launch_bounds__(kWinThreads) void k_win_finish(const double *__rest
   if (tid == 0 && fail) st->fail = 1u;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (ahead && tid == 0) {
+    // The run-ahead search (icp_estimate_device): this is the FIRST evaluation of an outer iteration (inner pose =
+    // identity, prev_error = f64::MAX); if the inner loop applies this update and stops, the next outer pose is
+    // Exp(delta) * identity * outer -- estimate_transform_loop's and icp_estimate_device's own operations, with the
+    // functions the host uses (pose.hpp), so the host can check the bits.  The search behind this launch reads it.
+    AheadPose np;
+    np.valid = 0;
+    np.pad = 0;
+    np.T = outer;
+    if (!fail && !nan_flag) {
+      double acc[kNAcc], delta[3];
+#pragma unroll
+      for (int k = 0; k < kNAcc; ++k) acc[k] = combine_sum(s_tot, k, sig);
+      if (solve_update(acc, acc + 9, delta) &&
+          !((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD)) {
+        bool in_range;
+        const Pose step = transform_new_in_range(delta, &in_range);
+        if (in_range) {
+          const Pose inner = transform_mul(step, transform_identity());  // src/lib.rs:81
+          np.T = transform_mul(inner, outer);                            // src/lib.rs:127, 170
+          np.valid = 1;
+        }
+      }
+    }
+    *ahead = np;
+    res->next_pose = np.T;  // (wave 0: ordered before the release in publish_folded)
+    res->next_valid = np.valid;
+  }
 #ifdef ICP_WIN_DEBUG
   fst[5] = wall_clock64();
 #endif
@@ -1021,7 +1050,8 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
                        w.d_wstate, w.d_scal, w.d_partials, -1);
     hipLaunchKernelGGL(k_win_finish<false>, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
                        (const double *)w.d_ry, n, P, w.d_whist, w.d_wstate, w.d_wmed, w.d_wring, w.d_scal,
-                       (const double *)w.d_partials, blocks, w.d_ctl, w.h_res, ++w.seq, (const unsigned *)nullptr, 0u);
+                       (const double *)w.d_partials, blocks, w.d_ctl, w.h_res, ++w.seq, (const unsigned *)nullptr, 0u,
+                       w.ahead_on ? w.d_ahead : (AheadPose *)nullptr, w.ahead_on ? w.ahead_outer : transform_identity());
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(kWinThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
@@ -1187,7 +1217,8 @@ hipError_t launch_win_second_pass(icp_handle *h, const double *d_a, size_t n_, c
   // candidates out of the lists; the last workgroup selects the statistics and folds the first pass' block sums
   hipLaunchKernelGGL(k_win_finish<true>, dim3(cb), dim3(kWinThreads), 0, s, (const double *)lx, (const double *)ly, n, P2,
                      w.d_whist, w.d_wstate, w.d_wmed, w.d_wring, w.d_scal, (const double *)w.d_partials, blocks, w.d_ctl,
-                     w.h_res, ++w.seq, (const unsigned *)w.d_rlist_len, (unsigned)kRefineListCap);
+                     w.h_res, ++w.seq, (const unsigned *)w.d_rlist_len, (unsigned)kRefineListCap, (AheadPose *)nullptr,
+                     transform_identity());
   return hipGetLastError();
 }
 

@@ -1659,8 +1659,13 @@ __global__ __launch_bounds__(kGridThreads) ICP_COOP_ATTR void k_nn_grid_warm_coo
                                                                     const GridPoint *__restrict__ pts,
                                                                     const double *__restrict__ dst, uint32_t *__restrict__ idx,
                                                                     double2 *__restrict__ a, double2 *__restrict__ b,
-                                                                    PrevMatch *prev, unsigned xcd_chunk) {
+                                                                    PrevMatch *prev, unsigned xcd_chunk,
+                                                                    const AheadPose *__restrict__ ahead) {
   __shared__ CoopLds S;
+  if (ahead) {  // a search enqueued before the host knew its pose (launch_nn_grid_ahead): the launch in front of it left it here
+    if (!ahead->valid) return;
+    T = ahead->T;
+  }
   const unsigned k = xcd_wave(blockIdx.x, gridDim.x, xcd_chunk) * kGridThreads + threadIdx.x;
   warm_wave<DIM, false>(k, n, src, perm, T, g, start, pts, dst, idx, a, b, prev, PrevMatch{0., 0., 0., 0xffffffffu, 0u}, S);
 }
@@ -2097,6 +2102,54 @@ long grid_coop_max() {
   return coop_max;
 }
 
+// A warm search whose pose is not known to the host yet: it is read from `d_pose` on the device, where the launch in
+// front of this one on the stream leaves it (k_win_finish, AheadPose).  Only the plain shared walk qualifies (a
+// snapshot of this cloud with previous matches, one lane per query, f32 geometry); *launched = false otherwise and
+// nothing is enqueued.  The host cannot account for how far this pose is from the previous one, so the certificates
+// of the snapshot are dropped (they would have to decay by an unknown step).
+hipError_t launch_nn_grid_ahead(icp_handle *h, const double *d_src, size_t n_, const AheadPose *d_pose, double *d_a,
+                                double *d_b, uint32_t *d_idx, bool *launched) {
+  *launched = false;
+  const Grid &G = h->grid;
+  QuerySort &Q = h->qsort;
+  if (n_ == 0 || n_ >= 0xffffffffull || !d_pose || h->m == 0 || !G.built || !G.p.f32_ok) return hipSuccess;
+  const unsigned n = (unsigned)n_;
+  if (!(Q.valid && Q.src == d_src && Q.n == n_ && Q.have_prev) || (long)n <= grid_coop_max()) return hipSuccess;
+#ifdef ICP_EXPERIMENTS
+  if (exp_env("ICP_NN_WARM_COOP") && atoi(exp_env("ICP_NN_WARM_COOP")) == 0) return hipSuccess;
+#endif
+  const double *q_src = !Q.identity ? Q.d_sorted : d_src;
+  const uint32_t *q_perm = (!Q.slot_order && !Q.identity) ? Q.d_perm : nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (h->profile > 0 && (h->prof_seen++ % (unsigned)h->profile) == 0) {
+    if (!h->prof_free.empty()) {
+      ev0 = h->prof_free.back().first;
+      ev1 = h->prof_free.back().second;
+      h->prof_free.pop_back();
+      (void)hipEventRecord(ev0, h->stream);
+    } else if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
+      (void)hipEventRecord(ev0, h->stream);
+  }
+  const unsigned blocks = (unsigned)(((size_t)n + kGridThreads - 1) / kGridThreads);
+  Q.have_pose = false;
+  Q.have_certs = false;
+  if (h->dim == 3)
+    hipLaunchKernelGGL(k_nn_grid_warm_coop<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n,
+                       transform_identity(), G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev,
+                       (unsigned)kXcdChunk, d_pose);
+  else
+    hipLaunchKernelGGL(k_nn_grid_warm_coop<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n,
+                       transform_identity(), G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev,
+                       (unsigned)kXcdChunk, d_pose);
+  const hipError_t e = hipGetLastError();
+  if (ev0 && ev1) {
+    (void)hipEventRecord(ev1, h->stream);
+    h->prof_events.emplace_back(ev0, ev1);
+  }
+  *launched = e == hipSuccess;
+  return e;
+}
+
 hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const Pose *Tp, double *d_a,
                           double *d_b, uint32_t *d_idx) {
   if (n_ == 0) return hipSuccess;
@@ -2258,10 +2311,12 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
     } else {
       if (h->dim == 3)
         hipLaunchKernelGGL(k_nn_grid_warm_coop<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
-                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, xcd_chunk);
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, xcd_chunk,
+                           (const AheadPose *)nullptr);
       else
         hipLaunchKernelGGL(k_nn_grid_warm_coop<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T,
-                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, xcd_chunk);
+                           G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev, xcd_chunk,
+                           (const AheadPose *)nullptr);
     }
     hipError_t we = hipGetLastError();
     if (ev0 && ev1) {

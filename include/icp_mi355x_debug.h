@@ -25,6 +25,11 @@ int icp_gn_path_counters(icp_handle *h, uint64_t out[6]);
  * icp_gn_path_counters as well), out[2] launches that handed an evaluation back to the host-stepped pipelines. */
 int icp_gn_loop_counters(icp_handle *h, uint64_t out[3]);
 
+/* ... and the run-ahead searches of icp_estimate[_device] (a search enqueued behind the pre-launched first evaluation
+ * of the next iteration, its pose derived on the device): out[0] the host derived the same pose bit for bit and took
+ * the pairs, out[1] it did not (the search was repeated for the host's pose). */
+int icp_run_ahead_counters(icp_handle *h, uint64_t out[2]);
+
 /* Observability: the last LDS-tile search of `h` (the warm grid search beyond 65 536 source points): out[0] = waves
  * launched, out[1] = waves handed to the per-lane gather walk because their unions exceeded the LDS budget. */
 int icp_nn_tile_counters(icp_handle *h, uint64_t out[2]);

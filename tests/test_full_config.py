@@ -28,6 +28,12 @@ def test_estimate_1m_x_1m_is_bit_equal_to_the_oracle_in_device_order():
     T, idx, inner = icp.estimate(torch.from_numpy(src).cuda(), I.Transform(), 20, return_info=True)
     blocks, threads = I.reduce_geometry(n)
     assert (blocks, threads) == (256, 512)
+    # every iteration of this pair applies one update: from the third on the search of iteration k + 2 was enqueued
+    # behind the first evaluation of iteration k + 1 with a pose the DEVICE derived -- and the host, deriving the same
+    # pose from the evaluation's sums, must have found the same bits every time (a miss would only cost time, but
+    # on this pair it means the two solves disagree)
+    hits, misses = I.run_ahead_counters(icp)
+    assert hits >= 10 and misses == 0, (hits, misses)
     # the order the call folded its sums in: the cell-sorted snapshot of the source cloud (icp_last_fold_order)
     perm, cell = icp.last_fold_order(n, with_cells=True)
     check_fold_order(perm, cell)
