@@ -1387,7 +1387,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   // after it is enqueued at once, with its pose read from the device (k_win_finish solves the update there) -- the
   // search stream then runs search -> evaluation -> search -> ... without waiting for the host between them.  The
   // host still derives every pose itself and takes the pairs only if the device's pose has the same bits.
-  static const bool no_ahead = getenv("ICP_NO_RUN_AHEAD") != nullptr;
+  static const bool no_ahead = exp_env("ICP_NO_RUN_AHEAD") != nullptr;  // (ICP_NO_SPECULATION switches it off with the bet: no second stream)
   const bool can_ahead = two_streams && !no_ahead && resolved_nn_mode(h) == ICP_NN_GRID;
   bool ahead_issued = false;  // an ahead search into the buffers after next is in flight behind the current pre-evaluation
   static const bool no_pre = exp_env("ICP_NO_PRE_EVAL") != nullptr;
