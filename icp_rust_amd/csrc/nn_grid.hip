@@ -451,11 +451,16 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid(const double *__restri
                                                  const GridPoint *__restrict__ pts,
                                                  const double *__restrict__ dst, uint32_t *__restrict__ idx,
                                                  double2 *__restrict__ a, double2 *__restrict__ b,
-                                                 const PrevMatch *__restrict__ prev, PrevMatch *prev_out) {
+                                                 const PrevMatch *__restrict__ prev, PrevMatch *prev_out,
+                                                 const AheadPose *__restrict__ ahead) {
 #ifdef ICP_NN_STATS
   unsigned st[8] = {1, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
+  if (XFORM && ahead) {  // a search enqueued before the host knew its pose (launch_nn_grid_ahead)
+    if (!ahead->valid) return;
+    T = ahead->T;
+  }
   const unsigned wave0 = xcd_wave(blockIdx.x, gridDim.x, kXcdChunk);
   const unsigned k = (wave0 * kGridThreads + threadIdx.x) / L;
   const unsigned sub = (wave0 * kGridThreads + threadIdx.x) % L;  // lane within the query's group (aligned: L divides 64)
@@ -2114,9 +2119,10 @@ hipError_t launch_nn_grid_ahead(icp_handle *h, const double *d_src, size_t n_, c
   QuerySort &Q = h->qsort;
   if (n_ == 0 || n_ >= 0xffffffffull || !d_pose || h->m == 0 || !G.built || !G.p.f32_ok) return hipSuccess;
   const unsigned n = (unsigned)n_;
-  if (!(Q.valid && Q.src == d_src && Q.n == n_ && Q.have_prev) || (long)n <= grid_coop_max()) return hipSuccess;
+  if (!(Q.valid && Q.src == d_src && Q.n == n_ && Q.have_prev)) return hipSuccess;
+  const bool coop = (long)n <= grid_coop_max();  // four lanes per query: the general kernel, warm
 #ifdef ICP_EXPERIMENTS
-  if (exp_env("ICP_NN_WARM_COOP") && atoi(exp_env("ICP_NN_WARM_COOP")) == 0) return hipSuccess;
+  if (!coop && exp_env("ICP_NN_WARM_COOP") && atoi(exp_env("ICP_NN_WARM_COOP")) == 0) return hipSuccess;
 #endif
   const double *q_src = !Q.identity ? Q.d_sorted : d_src;
   const uint32_t *q_perm = (!Q.slot_order && !Q.identity) ? Q.d_perm : nullptr;
@@ -2130,10 +2136,19 @@ hipError_t launch_nn_grid_ahead(icp_handle *h, const double *d_src, size_t n_, c
     } else if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
       (void)hipEventRecord(ev0, h->stream);
   }
-  const unsigned blocks = (unsigned)(((size_t)n + kGridThreads - 1) / kGridThreads);
+  const unsigned blocks = (unsigned)(((size_t)n * (coop ? 4 : 1) + kGridThreads - 1) / kGridThreads);
   Q.have_pose = false;
   Q.have_certs = false;
-  if (h->dim == 3)
+  if (coop) {
+    if (h->dim == 3)
+      hipLaunchKernelGGL((k_nn_grid<3, true, false, 4>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n,
+                         transform_identity(), G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b,
+                         (const PrevMatch *)Q.d_prev, Q.d_prev, d_pose);
+    else
+      hipLaunchKernelGGL((k_nn_grid<2, true, false, 4>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n,
+                         transform_identity(), G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b,
+                         (const PrevMatch *)Q.d_prev, Q.d_prev, d_pose);
+  } else if (h->dim == 3)
     hipLaunchKernelGGL(k_nn_grid_warm_coop<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n,
                        transform_identity(), G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, Q.d_prev,
                        (unsigned)kXcdChunk, d_pose);
@@ -2343,7 +2358,8 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
   } while (0)
 #define GRID3(DIM, XF, CD, LN)                                                                          \
   hipLaunchKernelGGL((k_nn_grid<DIM, XF, CD, LN>), dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, \
-                     G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, q_prev, q_prev_out)
+                     G.p, G.d_start, G.d_pts, h->d_dst, d_idx, (double2 *)d_a, (double2 *)d_b, q_prev, q_prev_out,      \
+                     (const AheadPose *)nullptr)
   if (h->dim == 3) {
     if (xform) { GRID(3, true); } else { GRID(3, false); }
   } else {
