@@ -261,7 +261,15 @@ struct TinySel {
   unsigned long long out[2][2];
   unsigned hist[2][68];
   unsigned nlist[2];
+  // round 4: the window the NEXT selection of the same kind (slot 0: medians, slot 1: MADs) tries first -- a key
+  // range around this selection's middle ranks, per dimension (tiny_select_window below)
+  unsigned long long wlo[2][2], whi[2][2];
+  unsigned wvalid[2];
+  unsigned wpos[2][2];  // where in the window's list the lower middle rank was expected (0xffffffff: unknown)
 };
+// ranks the window keeps on either side of the two middle ranks: twice the drift the last selection saw (the listed
+// keys are ranked against each other: the cost grows with the square of their number)
+constexpr unsigned kTinyWinMarginMin = 6, kTinyWinMarginMax = 32, kTinyWinMarginFirst = 16;
 
 // cross-lane sums without the LDS pipe (DPP): over aligned groups of 8 lanes, and the wave's inclusive scan
 #define ICP_DPP(v, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rows, 0xf, true)
@@ -304,7 +312,7 @@ __device__ __forceinline__ unsigned wave_scan_inclusive(unsigned v) {
 template <unsigned B>
 __device__ __forceinline__ bool tiny_select(unsigned long long k0, unsigned long long k1, bool has, unsigned n,
                                             TinySel *S, unsigned long long (*kbuf)[1024],
-                                            unsigned long long *sp = nullptr) {
+                                            unsigned long long *sp = nullptr, int wslot = -1) {
 #ifdef ICP_TINY_PROFILE
   unsigned long long st_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -380,6 +388,14 @@ __device__ __forceinline__ bool tiny_select(unsigned long long k0, unsigned long
       const unsigned pos = atomicAdd(&S->nlist[d], 1u);
       if (pos < 128u) S->list[d][pos] = key[d];
     }
+    if (wslot >= 0 && tid == 0) {  // the next selection of this kind looks two buckets either side of these first
+      const bool usable = n >= 256u && b_lo < 64u && b_hi < 64u;
+      S->wlo[wslot][d] = b_lo >= 3u ? (unsigned long long)S->spl[d][b_lo - 3] << 32 : 0ull;
+      S->whi[wslot][d] = b_hi + 2u < 64u ? ((unsigned long long)S->spl[d][b_hi + 2] << 32) | 0xffffffffull : 0xfffffffffffffffeull;
+      if (d == 0) S->wvalid[wslot] = usable ? 1u : 0u;
+      else if (!usable) S->wvalid[wslot] = 0u;
+      S->wpos[wslot][d] = 0xffffffffu;
+    }
   }
   __syncthreads();
   SEL_STAMP(3);
@@ -416,6 +432,120 @@ __device__ __forceinline__ bool tiny_select(unsigned long long k0, unsigned long
   __syncthreads();
   SEL_STAMP(4);
   return !bad;
+}
+
+// The same two order statistics from a WINDOW (round 4): consecutive evaluations of a registration see almost the
+// same residuals, so the keys between the previous selection's neighbours of the middle ranks are listed directly --
+// every thread compares its key with the window's ends, the keys below the window are counted (ballot + one LDS
+// atomic per wave), those inside are listed -- and ranked exactly as tiny_select ranks its buckets: three barriers
+// instead of five, no sampling, no splitter search.  Exact whenever it answers: it answers only if both middle ranks
+// fall among the listed keys (count below <= rank < count below + listed, at most 128 listed); otherwise false, with
+// the window dropped, and the caller runs tiny_select (which sets a fresh one).  The next window is cut from this
+// one's ranking: the keys `margin` ranks below / above the middle ranks (dropped if either side is short).
+template <unsigned B>
+__device__ __forceinline__ bool tiny_select_window(unsigned long long k0, unsigned long long k1, bool has, unsigned n,
+                                                   TinySel *S, int wslot, unsigned long long *sp = nullptr) {
+#ifdef ICP_TINY_PROFILE
+  unsigned long long st_ = __builtin_amdgcn_s_memtime();
+#endif
+  asm volatile("" : "+s"(n));
+  const unsigned tid = threadIdx.x, lane = tid & 63;
+  const unsigned lo_rank = (n - 1) / 2, hi_rank = n / 2;
+  const unsigned long long key[2] = {k0, k1};
+  if (!S->wvalid[wslot]) return false;  // (uniform: written behind a barrier of the previous selection)
+  const unsigned long long wl[2] = {S->wlo[wslot][0], S->wlo[wslot][1]}, wh[2] = {S->whi[wslot][0], S->whi[wslot][1]};
+  __syncthreads();  // (everybody has read the window and the previous selection's S->out)
+  if (tid < 2) {
+    S->hist[tid][0] = 0;
+    S->nlist[tid] = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const bool under = has && key[d] < wl[d];
+    const unsigned long long mb = __ballot(under);
+    if (lane == 0 && mb) atomicAdd(&S->hist[d][0], (unsigned)__popcll(mb));
+    if (has && !under && key[d] <= wh[d]) {
+      const unsigned pos = atomicAdd(&S->nlist[d], 1u);
+      if (pos < 128u) S->list[d][pos] = key[d];
+    }
+  }
+  __syncthreads();
+  SEL_STAMP(5);
+  const unsigned below[2] = {S->hist[0][0], S->hist[1][0]};
+  const unsigned cnt0 = S->nlist[0], cnt1 = S->nlist[1];
+  const bool bad = cnt0 > 128u || cnt1 > 128u || lo_rank < below[0] || hi_rank >= below[0] + cnt0 || lo_rank < below[1] ||
+                   hi_rank >= below[1] + cnt1;  // the same in every thread
+  if (bad) {
+    __syncthreads();  // (every thread has read the counts tiny_select is about to reset)
+    if (tid == 0) S->wvalid[wslot] = 0u;
+    return false;
+  }
+  // the next window: the keys `margin` ranks either side of the middle ranks in this list, margin = twice the drift
+  // this selection saw (how far the lower middle rank landed from where the window was cut for it) + 4; a side
+  // that cannot give half of it drops the window
+  bool keep = true;
+  unsigned t_lo[2], t_hi[2], margin = kTinyWinMarginFirst;
+  {
+    unsigned drift = 0;
+    bool known = true;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const unsigned r_lo = lo_rank - below[d], exp_pos = S->wpos[wslot][d];
+      known = known && exp_pos != 0xffffffffu;
+      const unsigned dd = r_lo > exp_pos ? r_lo - exp_pos : exp_pos - r_lo;
+      drift = dd > drift ? dd : drift;
+    }
+    if (known) {
+      margin = 2u * drift + 4u;
+      margin = margin < kTinyWinMarginMin ? kTinyWinMarginMin : (margin > kTinyWinMarginMax ? kTinyWinMarginMax : margin);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const unsigned r_lo = lo_rank - below[d], r_hi = hi_rank - below[d], c = d ? cnt1 : cnt0;
+    t_lo[d] = r_lo > margin ? r_lo - margin : 0u;
+    t_hi[d] = r_hi + margin < c ? r_hi + margin : c - 1u;
+    keep = keep && r_lo >= margin / 2 && r_hi + margin / 2 < c;
+  }
+  __syncthreads();  // (everybody has read wpos)
+  if (tid < 2) S->wpos[wslot][tid] = (lo_rank - below[tid]) - t_lo[tid];
+  {
+    const unsigned cmax = cnt0 > cnt1 ? cnt0 : cnt1;
+    for (unsigned slot = tid; slot < 8u * cmax; slot += B) {  // (whole 8-lane groups)
+      const unsigned e = slot >> 3, c = slot & 7;
+      const bool in0 = e < cnt0, in1 = e < cnt1;
+      const unsigned long long ke0 = S->list[0][in0 ? e : 0], ke1 = S->list[1][in1 ? e : 0];
+      unsigned acc0 = 0, acc1 = 0;
+      for (unsigned j = c; j < cmax; j += 8) {
+        const unsigned long long kj0 = S->list[0][j < cnt0 ? j : 0], kj1 = S->list[1][j < cnt1 ? j : 0];
+        if (j < cnt0) acc0 += (unsigned)(kj0 < ke0) + ((unsigned)(kj0 == ke0) << 16);
+        if (j < cnt1) acc1 += (unsigned)(kj1 < ke1) + ((unsigned)(kj1 == ke1) << 16);
+      }
+      acc0 = dpp_sum8(acc0);
+      acc1 = dpp_sum8(acc1);
+      if (c == 0) {
+        if (in0) {
+          const unsigned less = acc0 & 0xffffu, eq = acc0 >> 16, r_lo = lo_rank - below[0], r_hi = hi_rank - below[0];
+          if (less <= r_lo && r_lo < less + eq) S->out[0][0] = ke0;
+          if (less <= r_hi && r_hi < less + eq) S->out[0][1] = ke0;
+          if (less <= t_lo[0] && t_lo[0] < less + eq) S->wlo[wslot][0] = ke0;
+          if (less <= t_hi[0] && t_hi[0] < less + eq) S->whi[wslot][0] = ke0;
+        }
+        if (in1) {
+          const unsigned less = acc1 & 0xffffu, eq = acc1 >> 16, r_lo = lo_rank - below[1], r_hi = hi_rank - below[1];
+          if (less <= r_lo && r_lo < less + eq) S->out[1][0] = ke1;
+          if (less <= r_hi && r_hi < less + eq) S->out[1][1] = ke1;
+          if (less <= t_lo[1] && t_lo[1] < less + eq) S->wlo[wslot][1] = ke1;
+          if (less <= t_hi[1] && t_hi[1] < less + eq) S->whi[wslot][1] = ke1;
+        }
+      }
+    }
+    if (tid == 0 && !keep) S->wvalid[wslot] = 0u;
+  }
+  __syncthreads();
+  SEL_STAMP(6);
+  return true;
 }
 
 struct TinyResult {  // pinned host memory
@@ -531,6 +661,7 @@ __global__ __launch_bounds__(B) void k_tiny_estimate(const double *__restrict__ 
     C->T = T0;
     C->nan = C->bail = 0;
     C->evals = C->sorted = 0;
+    S->wvalid[0] = S->wvalid[1] = 0u;  // (no window yet: the first selections sample)
   }
   if (tid >= B / 64 && tid < 16) {  // the wave sums of the waves a smaller workgroup does not have
 #pragma unroll
@@ -656,13 +787,14 @@ __global__ __launch_bounds__(B) void k_tiny_estimate(const double *__restrict__ 
 #else
       unsigned long long *selp = nullptr;
 #endif
-      bool ok = tiny_select<B>(has ? f2k(r0) : ~0ull, has ? f2k(r1) : ~0ull, has, n, S, sbuf[0], selp);
+      const unsigned long long km0 = has ? f2k(r0) : ~0ull, km1 = has ? f2k(r1) : ~0ull;
+      bool ok = tiny_select_window<B>(km0, km1, has, n, S, 0, selp) || tiny_select<B>(km0, km1, has, n, S, sbuf[0], selp, 0);
       if (ok) {
         med[0] = middle_of_host(n, S->out[0][0], S->out[0][1]);
         med[1] = middle_of_host(n, S->out[1][0], S->out[1][1]);
-        // (S->out is next written four barriers into the next selection)
-        ok = tiny_select<B>(has ? f2k(fabs(r0 - med[0])) : ~0ull, has ? f2k(fabs(r1 - med[1])) : ~0ull, has, n, S, sbuf[0],
-                         selp);
+        // (S->out is next written behind the first barriers of the next selection)
+        const unsigned long long kd0 = has ? f2k(fabs(r0 - med[0])) : ~0ull, kd1 = has ? f2k(fabs(r1 - med[1])) : ~0ull;
+        ok = tiny_select_window<B>(kd0, kd1, has, n, S, 1, selp) || tiny_select<B>(kd0, kd1, has, n, S, sbuf[0], selp, 1);
         if (ok) {
           sig[0] = ICP_PPF34 * middle_of_host(n, S->out[0][0], S->out[0][1]);
           sig[1] = ICP_PPF34 * middle_of_host(n, S->out[1][0], S->out[1][1]);
@@ -861,9 +993,10 @@ hipError_t launch_tiny_estimate(icp_handle *h, const double *d_src, size_t n, co
 #ifdef ICP_TINY_PROFILE
     if (exp_env("ICP_TINY_PRINT"))
       fprintf(stderr, "[tiny] evals %u sorted %u; cycles: setup %llu search %llu select %llu sums %llu step %llu all %llu; "
-              "selection phases (keys, sample ranks, buckets, scan+list, ranks): %llu %llu %llu %llu %llu\n",
+              "selection phases (keys, sample ranks, buckets, scan+list, ranks): %llu %llu %llu %llu %llu; window selections "
+              "(count + list, ranks): %llu %llu\n",
               res->evals, res->sorted, res->t[0], res->t[1], res->t[2], res->t[3], res->t[4], res->t[5], res->ts[0], res->ts[1],
-              res->ts[2], res->ts[3], res->ts[4]);
+              res->ts[2], res->ts[3], res->ts[4], res->ts[5], res->ts[6]);
 #endif
   }
   return hipSuccess;
