@@ -38,7 +38,25 @@ __device__ __forceinline__ double huber_drho(double e) {
 template <int OFF>
 __device__ __forceinline__ double tree_down(double v) {
   if constexpr (OFF >= 16) {
+#ifdef ICP_TREE_BPERMUTE
     return __shfl_down(v, OFF);
+#else
+    // gfx950: v_permlane32_swap exchanges the upper 32 lanes of its first operand with the lower 32 of its second,
+    // v_permlane16_swap the odd rows of 16 with the even ones -- with both operands the same value, the SECOND result
+    // holds lane l + OFF in every lane l < OFF of each 2 OFF lanes (all the tree reads): two VALU instructions per
+    // double instead of two trips through the LDS crossbar
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)(b & 0xffffffffll), hi = (unsigned)((unsigned long long)b >> 32);
+    if constexpr (OFF == 32) {
+      const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+      const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      return __longlong_as_double((long long)(((unsigned long long)rh[1] << 32) | rl[1]));
+    } else {
+      const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+      const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+      return __longlong_as_double((long long)(((unsigned long long)rh[1] << 32) | rl[1]));
+    }
+#endif
   } else {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x100 + OFF, 0xf, 0xf, true);
