@@ -1518,12 +1518,16 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
     }
     COOP_STAMP(2);
     // ---- the flat list of this round: an exclusive prefix sum of the owners' quads ----
+    // the wave's inclusive scan without the LDS pipe: DPP row shifts inside rows of 16, then the two row broadcasts
     uint32_t incl = Q;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
-      if (lane >= (unsigned)off) incl += up;
-    }
+#define ICP_SCAN_DPP(v, ctrl, rows) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rows, 0xf, true)
+    incl += ICP_SCAN_DPP(incl, 0x111, 0xf);  // row_shr:1 (zero fill at the row's start)
+    incl += ICP_SCAN_DPP(incl, 0x112, 0xf);  // row_shr:2
+    incl += ICP_SCAN_DPP(incl, 0x114, 0xf);  // row_shr:4
+    incl += ICP_SCAN_DPP(incl, 0x118, 0xf);  // row_shr:8  -> inclusive within each row of 16
+    incl += ICP_SCAN_DPP(incl, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    incl += ICP_SCAN_DPP(incl, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef ICP_SCAN_DPP
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     S.pref[lane] = incl - Q;
 #pragma unroll
