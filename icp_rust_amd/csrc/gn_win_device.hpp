@@ -199,12 +199,16 @@ __device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, co
 __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *total) {
   __shared__ unsigned s_w[kReduceThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave's inclusive scan without the LDS pipe: DPP row shifts inside rows of 16, then the two row broadcasts
   unsigned s = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned t = __shfl_up(s, off);
-    if (lane >= off) s += t;
-  }
+#define ICP_SCAN_DPP(x, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, true)
+  s += ICP_SCAN_DPP(s, 0x111, 0xf);  // row_shr:1 (zero fill at the row's start)
+  s += ICP_SCAN_DPP(s, 0x112, 0xf);  // row_shr:2
+  s += ICP_SCAN_DPP(s, 0x114, 0xf);  // row_shr:4
+  s += ICP_SCAN_DPP(s, 0x118, 0xf);  // row_shr:8  -> inclusive within each row of 16
+  s += ICP_SCAN_DPP(s, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  s += ICP_SCAN_DPP(s, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef ICP_SCAN_DPP
   if (lane == 63) s_w[wave] = s;
   __syncthreads();
   unsigned before = 0, all = 0;
