@@ -247,6 +247,27 @@ def test_icp3d_synthetic_box_200k():
     assert inner.sum() > 0
 
 
+@pytest.mark.parametrize("n,m", [(90_000, 70_000), (30_000, 30_000)])
+def test_every_iteration_count_around_the_run_ahead_search_matches_the_oracle(n, m):
+    """icp_estimate_device enqueues the search of iteration k + 2 behind the pre-launched first evaluation of
+    iteration k + 1 (pose derived on the device) and takes its pairs only if the host derives the same bits; which
+    searches may run ahead, and which of them writes the caller's indices, depends on max_iter - it: one call per
+    count, on a handle whose previous call ended with one update per iteration (so that the first iteration bets),
+    for the one-lane-per-query search (90k points) and the four-lanes one (30k); bit-equal to the device-order oracle"""
+    src, dst = synth.synthetic_pair(n, m)
+    icp = I.Icp3d(dst)
+    icp.estimate(src, I.Transform(), 6)
+    for max_iter in (1, 2, 3, 4, 5, 7):
+        got, idx, inner = icp.estimate(src, I.Transform(), max_iter, return_info=True)
+        rc, want, oidx, oinner = oracle_in_device_order(icp, 3, dst, src, opose(I.Transform()), max_iter, use_kdtree=True)
+        assert rc == O.OK
+        assert np.array_equal(got.as_array(), want.as_array()), max_iter
+        assert np.array_equal(idx, oidx), max_iter
+        assert np.array_equal(inner, oinner), max_iter
+    hits, misses = I.run_ahead_counters(icp)
+    assert hits > 0, (hits, misses)
+
+
 def test_icp_is_run_to_run_deterministic():
     src, dst = synth.synthetic_pair(50_000, 40_000)
     icp = I.Icp3d(dst)
