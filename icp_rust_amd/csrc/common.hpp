@@ -265,6 +265,9 @@ struct GridParams {
   double scale;  // coordinate magnitude used for the rounding margin of the pruning bounds
   float ext;     // largest extent of the bounding box + one cell: magnitude of every grid-relative coordinate
   int f32_ok;    // the grid-relative geometry is representable in f32 with room to spare (k_nn_grid_warm)
+  // the f32 geometry's constants, rounded once on the host ((float) of the doubles above: the conversions the warm
+  // kernels used to repeat in every wave)
+  float hf[3], ihf[3], nm1f[3];  // cell size, its inverse, n - 1
 };
 
 struct GridPoint {  // one target, cell-sorted: a 16-B pre-filter record = one load per candidate

@@ -233,6 +233,11 @@ hipError_t build_grid(icp_handle *h) {
   for (int d = 0; d < 3; ++d)
     if (!(g.h[d] > 1e-10 && g.h[d] < 1e10)) g.f32_ok = 0;
   if (!(emax + hh < 1e10)) g.f32_ok = 0;
+  for (int d = 0; d < 3; ++d) {
+    g.hf[d] = (float)g.h[d];
+    g.ihf[d] = (float)g.inv_h[d];
+    g.nm1f[d] = (float)(g.n[d] - 1);
+  }
   G.p = g;
   G.ncell = (uint32_t)g.n[0] * g.n[1] * g.n[2];
   // 3. counting sort of the targets by cell
@@ -1343,14 +1348,14 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
     bf = __builtin_huge_valf();
     thr32 = __builtin_huge_valf();
   }
-  const float hf[3] = {(float)g.h[0], (float)g.h[1], (float)g.h[2]};
-  const float ihf[3] = {(float)g.inv_h[0], (float)g.inv_h[1], (float)g.inv_h[2]};
+  const float hf[3] = {g.hf[0], g.hf[1], g.hf[2]};
+  const float ihf[3] = {g.ihf[0], g.ihf[1], g.ihf[2]};
   auto cell_lo = [&](float v, float em, int d) -> int {
-    const float t = fminf(fmaxf(__builtin_floorf(v * ihf[d] - em), 0.f), (float)(g.n[d] - 1));
+    const float t = fminf(fmaxf(__builtin_floorf(v * ihf[d] - em), 0.f), g.nm1f[d]);
     return (int)t;
   };
   auto cell_hi = [&](float v, float em, int d) -> int {
-    const float t = fminf(fmaxf(__builtin_floorf(v * ihf[d] + em), 0.f), (float)(g.n[d] - 1));
+    const float t = fminf(fmaxf(__builtin_floorf(v * ihf[d] + em), 0.f), g.nm1f[d]);
     return (int)t;
   };
   int lo_c[3] = {0, 0, 0}, hi_c[3] = {0, 0, 0};
