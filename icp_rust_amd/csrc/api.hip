@@ -1465,7 +1465,11 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     w.search_beside_eval = speculate;
     const int rc = estimate_transform_loop(h, A[cur], B[cur], n, &dT, &inner, hook,
                                            two_streams && !device_loop ? w.spec_stream : nullptr,
-                                           two_streams && nn_first && !device_loop, first_pre_launched, it == 0 ? 3 : 0,
+                                           // (the hook -- next search / pre-evaluation / run-ahead search -- goes in front of
+                                           // the deciding evaluation's launches unless the next search is in flight already
+                                           // and the cloud is frame-sized: there the host's launches are the critical path)
+                                           two_streams && nn_first && !device_loop && !(ahead_issued && (long)n <= grid_coop_max()),
+                                           first_pre_launched, it == 0 ? 3 : 0,
                                            it == 0 ? 4 : 1, device_loop);
     w.search_beside_eval = false;
     if (rc != ICP_OK) return rc;
