@@ -513,10 +513,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
     }
     // ONE workgroup folds the block sums (they have been complete since the first barrier) and leaves the twenty
     // totals for everybody: 256 workgroups reading all 256 rows each was 10 MB of same-address traffic per evaluation
-    if (blockIdx.x == gridDim.x - 1) {
-      fold_block_sums_256(partials, (int)gridDim.x, s_tot);
-      __syncthreads();
-      if (tid < kNSum + 1) st_f64(&totals[tid], s_tot[tid]);
+    // (round 4, late: one SUM per workgroup -- the first twenty fold one each beside their candidates, where one
+    // workgroup folded all twenty and the second barrier waited two microseconds for it)
+    for (unsigned q = blockIdx.x; q < (unsigned)(kNSum + 1); q += gridDim.x) {
+      __syncthreads();  // (s_tot[0..3] of the previous sum have been read)
+      const double tot = fold_one_sum_256(partials, (int)gridDim.x, (int)q, s_tot);
+      if (tid == 0) st_f64(&totals[q], tot);
     }
     const bool b_fail = R.fail;
     LOOP_STAMP(5);
