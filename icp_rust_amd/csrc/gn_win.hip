@@ -90,10 +90,16 @@ __device__ __forceinline__ void win_hist_body(const double2 *__restrict__ a, con
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    unsigned v = edge[k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
+    unsigned v = edge[k];  // the wave's total in its lane 63, by DPP (an inclusive scan's last lane): no LDS crossbar
+#define ICP_SCAN_DPP(x, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, true)
+    v += ICP_SCAN_DPP(v, 0x111, 0xf);
+    v += ICP_SCAN_DPP(v, 0x112, 0xf);
+    v += ICP_SCAN_DPP(v, 0x114, 0xf);
+    v += ICP_SCAN_DPP(v, 0x118, 0xf);
+    v += ICP_SCAN_DPP(v, 0x142, 0xa);
+    v += ICP_SCAN_DPP(v, 0x143, 0xc);
+#undef ICP_SCAN_DPP
+    if ((threadIdx.x & 63) == 63 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
   }
   if (saw_nan) atomicOr(&scal->nan_flag, 1);
 #ifdef ICP_WIN_DEBUG
@@ -204,10 +210,16 @@ __global__ __launch_bounds__(kWinThreads) void k_win_rehist(const double *__rest
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    unsigned v = edge[k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
+    unsigned v = edge[k];  // the wave's total in its lane 63, by DPP (an inclusive scan's last lane): no LDS crossbar
+#define ICP_SCAN_DPP(x, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, true)
+    v += ICP_SCAN_DPP(v, 0x111, 0xf);
+    v += ICP_SCAN_DPP(v, 0x112, 0xf);
+    v += ICP_SCAN_DPP(v, 0x114, 0xf);
+    v += ICP_SCAN_DPP(v, 0x118, 0xf);
+    v += ICP_SCAN_DPP(v, 0x142, 0xa);
+    v += ICP_SCAN_DPP(v, 0x143, 0xc);
+#undef ICP_SCAN_DPP
+    if ((threadIdx.x & 63) == 63 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
   }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < 2u * kWinBins; i += kWinThreads) {
