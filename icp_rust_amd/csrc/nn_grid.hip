@@ -542,11 +542,20 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid(const double *__restri
   // have reconverged (after walk_box's loop).
   auto share_best = [&]() {
     if (L == 1) return;
+    // lane ^ off inside a group of at most four lanes = a quad permutation: DPP moves, no trip through the LDS crossbar
+    auto quad_xor32 = [](int v, int off) -> int {
+      return off == 1 ? __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true)    // quad_perm [1, 0, 3, 2]
+                      : __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);  // quad_perm [2, 3, 0, 1]
+    };
+    auto quad_xor64 = [&](double v, int off) -> double {
+      return __hiloint2double(quad_xor32(__double2hiint(v), off), quad_xor32(__double2loint(v), off));
+    };
+    static_assert(L <= 4, "share_best exchanges inside quads");
 #pragma unroll
     for (int off = 1; off < L; off <<= 1) {
-      const double ob = __shfl_xor(best, off);
-      const uint32_t obi = (uint32_t)__shfl_xor((int)bi, off);
-      const double ox = __shfl_xor(bx, off), oy = __shfl_xor(by, off), oz = DIM == 3 ? __shfl_xor(bz, off) : 0.;
+      const double ob = quad_xor64(best, off);
+      const uint32_t obi = (uint32_t)quad_xor32((int)bi, off);
+      const double ox = quad_xor64(bx, off), oy = quad_xor64(by, off), oz = DIM == 3 ? quad_xor64(bz, off) : 0.;
       if (ob < best || (ob == best && obi < bi)) {
         best = ob;
         bi = obi;
