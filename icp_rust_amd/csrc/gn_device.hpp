@@ -301,6 +301,24 @@ __device__ __forceinline__ void fold_block_sums_256(const double *partials, int 
 // tree, the left fold of the four wave sums, the `+ 0.`), by the first 256 threads of a workgroup: twenty workgroups
 // fold one sum each beside their other work instead of one workgroup folding all twenty while 255 wait for it.
 // sm4: four doubles of LDS.  Every thread of the workgroup must call it (one barrier); the value is valid in all.
+// (in two halves so that the load can be in flight across other work: fold_one_load early, fold_one_reduce later)
+template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT>
+__device__ __forceinline__ double fold_one_load(const double *partials, int blocks, int q) {
+  const int t = threadIdx.x;
+  return (t < 256 && t < blocks && q < kNSum) ? __hip_atomic_load(&partials[(size_t)t * (kNSum + 1) + q], __ATOMIC_RELAXED, SCOPE)
+                                               : 0.;
+}
+__device__ __forceinline__ double fold_one_reduce(double x, int blocks, double *sm4) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double v[1] = {0.};
+  if (t < 256 && t < blocks) v[0] = v[0] + x;
+  wave_tree<1>(v);
+  if (t < 256 && lane == 0) sm4[wave] = v[0];
+  __syncthreads();
+  double s = sm4[0];
+  for (int w = 1; w < 4; ++w) s = s + sm4[w];
+  return s + 0.;
+}
 template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT>
 __device__ __forceinline__ double fold_one_sum_256(const double *partials, int blocks, int q, double *sm4) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;

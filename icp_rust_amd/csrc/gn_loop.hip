@@ -467,6 +467,9 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
       if (blockIdx.x == 0 && tid < 4) st_u32(&ctl->list_cnt[par ^ 1u][tid][0], 0u);
     }
     __syncthreads();
+    // (this workgroup's share of the fold below: its load travels while the candidates are listed)
+    const bool fold_early = gridDim.x >= (unsigned)(kNSum + 1) && blockIdx.x < (unsigned)(kNSum + 1);
+    const double fold_x = fold_early ? fold_one_load(partials, (int)gridDim.x, (int)blockIdx.x) : 0.;
     if (!R.fail) {
       for (unsigned k = 0; k < mine; ++k) {
         const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
@@ -518,10 +521,15 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
     // totals for everybody: 256 workgroups reading all 256 rows each was 10 MB of same-address traffic per evaluation
     // (round 4, late: one SUM per workgroup -- the first twenty fold one each beside their candidates, where one
     // workgroup folded all twenty and the second barrier waited two microseconds for it)
-    for (unsigned q = blockIdx.x; q < (unsigned)(kNSum + 1); q += gridDim.x) {
-      __syncthreads();  // (s_tot[0..3] of the previous sum have been read)
-      const double tot = fold_one_sum_256(partials, (int)gridDim.x, (int)q, s_tot);
-      if (tid == 0) st_f64(&totals[q], tot);
+    if (fold_early) {
+      const double tot = fold_one_reduce(fold_x, (int)gridDim.x, s_tot);
+      if (tid == 0) st_f64(&totals[blockIdx.x], tot);
+    } else if (gridDim.x < (unsigned)(kNSum + 1)) {  // fewer workgroups than sums: several each
+      for (unsigned q = blockIdx.x; q < (unsigned)(kNSum + 1); q += gridDim.x) {
+        __syncthreads();  // (s_tot[0..3] of the previous sum have been read)
+        const double tot = fold_one_sum_256(partials, (int)gridDim.x, (int)q, s_tot);
+        if (tid == 0) st_f64(&totals[q], tot);
+      }
     }
     const bool b_fail = R.fail;
     LOOP_STAMP(5);
