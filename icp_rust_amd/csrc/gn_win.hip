@@ -567,7 +567,18 @@ __global__ __launch_bounds__(kWinThreads) void k_win_finish(const double *__rest
   long long fst[10];
   fst[0] = wall_clock64();
 #endif
+  // The block sums of the launch in front of this one are complete: the first twenty workgroups fold one SUM each
+  // (fold_one_load now, fold_one_reduce behind their candidate pass: gn_device.hpp) and leave the totals in the row
+  // behind the block sums; the last workgroup loads twenty doubles instead of folding 256 x 20 in its serial tail.
+  double *const totals = const_cast<double *>(partials) + (size_t)kReduceMaxBlocks * (kNSum + 1);
+  const bool fold_early = gridDim.x >= (unsigned)(kNSum + 1);
+  const double fold_x = (fold_early && blockIdx.x < (unsigned)(kNSum + 1)) ? fold_one_load(partials, sum_blocks, (int)blockIdx.x) : 0.;
   bool fail = win_compact_body<LISTS, true>(rx, ry, n, n, P, whist, st, wmed, wring, llen, lcap, sel);
+  if (fold_early && blockIdx.x < (unsigned)(kNSum + 1)) {
+    __shared__ double s_fold4[4];
+    const double tot = fold_one_reduce(fold_x, sum_blocks, s_fold4);
+    if (threadIdx.x == 0) __hip_atomic_store(&totals[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #ifdef ICP_WIN_DEBUG
   fst[1] = wall_clock64();
 #endif
@@ -585,19 +596,27 @@ __global__ __launch_bounds__(kWinThreads) void k_win_finish(const double *__rest
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
 #pragma unroll
-      for (int u = 0; u < PM; ++u)
-        vm[d][u] = __hip_atomic_load(&wmed[(size_t)d * kWinCapMed + tid + u * kReduceThreads], __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
+      for (int u = 0; u < PM; ++u)  // (only the slots the histogram says are filled: a tenth of the capacity, typically)
+        vm[d][u] = (fail || tid + u * kReduceThreads < sel.med_cnt[d])
+                       ? __hip_atomic_load(&wmed[(size_t)d * kWinCapMed + tid + u * kReduceThreads], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT)
+                       : 0.;
 #pragma unroll
       for (int u = 0; u < PR; ++u)
-        vr[d][u] = __hip_atomic_load(&wring[(size_t)d * kWinCapRing + tid + u * kReduceThreads], __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
+        vr[d][u] = (fail || tid + u * kReduceThreads < sel.ring_cnt[d])
+                       ? __hip_atomic_load(&wring[(size_t)d * kWinCapRing + tid + u * kReduceThreads], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT)
+                       : 0.;
     }
     unsigned got[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       got[k] = __hip_atomic_load(&st->list_cnt[k][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    fold_block_sums_256(partials, sum_blocks, s_tot);  // (they do not depend on the statistics selected below)
+    if (fold_early) {  // (the totals the first workgroups left: stored before their tickets)
+      if (tid < kNSum + 1) s_tot[tid] = __hip_atomic_load(&totals[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      fold_block_sums_256(partials, sum_blocks, s_tot);  // (they do not depend on the statistics selected below)
+    }
     // the histograms of the next evaluation start from zero (every workgroup has read them); write-through, and
     // drained before the barriers in front of the release below: the host may hand the next evaluation to the
     // handle's other stream as soon as it sees this result
