@@ -73,6 +73,8 @@ void free_ctx(GnCtx &c) {
   (void)hipFree(c.d_wstate);
   (void)hipFree(c.d_wmed);
   (void)hipFree(c.d_wring);
+  (void)hipFree(c.d_bkt);
+  (void)hipFree(c.d_bkt_dir);
   if (c.h_res) (void)hipHostFree(c.h_res);
 }
 
@@ -129,6 +131,8 @@ hipError_t alloc_ctx(GnCtx &c, hipStream_t s) {
   if ((e = hipMemsetAsync(c.d_wstate, 0, sizeof(WinState), s)) != hipSuccess) return e;
   if ((e = hipMalloc(&c.d_wmed, (size_t)2 * kWinCapMed * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&c.d_wring, (size_t)2 * kWinCapRing * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_bkt, (size_t)kReduceMaxBlocks * kBktStage * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_bkt_dir, (size_t)kReduceMaxBlocks * kBktDir * sizeof(unsigned short))) != hipSuccess) return e;
   if ((e = hipHostMalloc(&c.h_res, sizeof(GnResult), hipHostMallocCoherent)) != hipSuccess) return e;
   memset(c.h_res, 0, sizeof(GnResult));
   return hipSuccess;
@@ -695,7 +699,7 @@ static inline void cpu_relax() {
   __asm__ __volatile__("" ::: "memory");
 #endif
 }
-static hipError_t wait_seq(icp_handle *h, volatile unsigned *seq, unsigned want) {
+static hipError_t wait_seq(icp_handle *h, volatile unsigned *seq, unsigned want, hipStream_t stream = nullptr) {
   static const bool no_poll = exp_env("ICP_NO_POLL") != nullptr;
   if (!no_poll) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -707,9 +711,12 @@ static hipError_t wait_seq(icp_handle *h, volatile unsigned *seq, unsigned want)
       if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(250)) break;
     }
   }
-  return hipStreamSynchronize(h->stream);
+  return hipStreamSynchronize(stream ? stream : h->stream);
 }
-static hipError_t wait_result(icp_handle *h) { return wait_seq(h, &h->ws.h_res->seq, h->ws.seq); }
+// (stream: where the evaluation was enqueued, if not on h->stream)
+static hipError_t wait_result(icp_handle *h, hipStream_t stream = nullptr) {
+  return wait_seq(h, &h->ws.h_res->seq, h->ws.seq, stream);
+}
 
 // check_input_size, src/lib.rs:186-189
 static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
@@ -760,6 +767,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   Range range("icp: evaluation (weighted_gauss_newton_update + huber_error)");
   Workspace &w = h->ws;
   bool done = false, has_median = false, hooked = false;
+  hipStream_t on_stream = nullptr;  // where the evaluation in hand was enqueued, if not on h->stream
   // the prediction this evaluation's window is (or, pre-launched, was) centred on: its own kind's
   // previous evaluation if there is one, else the most recent evaluation (window_usable)
   const bool own = Workspace::kind_has_slot(kind) && w.win_kind[kind].valid;
@@ -775,8 +783,15 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   }
   if (!force_radix) {
     WinParams P;
-    if (pre_launched || window_usable(h, n, &P, kind)) {  // three launches around the predicted median and sigma
-      if (!pre_launched) {
+    if (pre_launched || w.bkt_pair_launched || window_usable(h, n, &P, kind)) {  // launches around the predicted median and sigma
+      if (!pre_launched && w.bkt_pair_launched) {
+        // this evaluation went out on the search stream, side by side with the next iteration's first evaluation
+        // (launch_bkt_pair): only its result is awaited
+        w.bkt_pair_launched = false;
+        on_stream = h->own_stream;
+        HIP_TRY(after_launch());
+        hooked = true;
+      } else if (!pre_launched) {
         ++w.win_tried;
         HIP_TRY(launch_weighted_gn_win(h, d_a, d_b, n, T, P));
         HIP_TRY(after_launch());
@@ -785,7 +800,7 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
 #ifdef ICP_EXPERIMENTS
       const auto tw0 = std::chrono::steady_clock::now();
 #endif
-      HIP_TRY(wait_result(h));
+      HIP_TRY(wait_result(h, on_stream));
 #ifdef ICP_EXPERIMENTS
       (pre_launched ? w.dbg_wait_pre_us : w.dbg_wait_other_us) +=
           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count();
@@ -795,7 +810,10 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
         w.ahead_seen_valid = w.h_res->next_valid != 0;
         w.ahead_seen_pose = w.h_res->next_pose;
       }
-      if (!done) {
+      if (!done && w.h_res->overflow == 3) {  // the buckets were too small, not the window wrong: no wider windows,
+        ++w.bkt_misses;                       // the next evaluations of this handle take the second pass instead
+        w.bkt_off = 64;
+      } else if (!done) {
         if (exp_env("ICP_WIN_TRACE")) fprintf(stderr, "[win] kind %d: the window missed\n", kind);
         ++w.win_missed;
         wide = true;
@@ -1261,6 +1279,18 @@ static int estimate_transform_loop(icp_handle *h, const double *d_a, const doubl
         h->stream = eval_stream;
         h->ws.swap_ctx();
       }
+#ifdef ICP_EXPERIMENTS
+      // (timing experiment only: what an outer iteration costs WITHOUT its deciding evaluation -- the loop is taken to end
+      // after one update, as it does on the benchmark pair)
+      if (it == 1 && exp_env("ICP_HACK_SKIP_E2")) {
+        (void)second_eval_hook(T);
+        if (on_eval_stream) {
+          h->stream = first_stream;
+          h->ws.swap_ctx();
+        }
+        break;
+      }
+#endif
       if (it == 1 && hook_first) {
         const hipError_t he = second_eval_hook(T);
         if (he != hipSuccess) {
@@ -1336,6 +1366,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   struct Quiesce {
     icp_handle *h;
     ~Quiesce() {
+      h->ws.bkt_pair_launched = h->ws.alt.bkt_pair_launched = false;  // (both halves of a pair are in flight or done: nothing stays behind)
       (void)hipStreamSynchronize(h->stream);
       if (h->ws.spec_stream) (void)hipStreamSynchronize(h->ws.spec_stream);
       h->qsort.valid = false;
@@ -1392,6 +1423,8 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
   const bool can_ahead = two_streams && !no_ahead && resolved_nn_mode(h) == ICP_NN_GRID;
   bool ahead_issued = false;  // an ahead search into the buffers after next is in flight behind the current pre-evaluation
   static const bool no_pre = exp_env("ICP_NO_PRE_EVAL") != nullptr;
+  static const bool pair_evals = !(exp_env("ICP_PAIR_EVALS") && atoi(exp_env("ICP_PAIR_EVALS")) == 0);
+  bool hooked_first = false;  // this iteration's hook runs in front of the deciding evaluation's launches
   Pose spec_pose = T;
   // the bet needs "the inner loop took exactly one update last time"; across calls the handle
   // remembers how its previous call ended (a new frame usually behaves like the last one)
@@ -1443,10 +1476,28 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
           ++w.win_tried;
           ++w.pre_evals;
           const bool go_ahead = can_ahead && it + 2 < max_iter;
-          w.ahead_on = go_ahead;
-          w.ahead_outer = spec_pose;
-          e = launch_weighted_gn_win(h, A[nxt], B[nxt], n, transform_identity(), P);
-          w.ahead_on = false;
+          // Round 5: where both evaluations can file their candidates, the launch that FINISHES this pre-launched one
+          // (one workgroup, a serial chain the next search waits for) also carries the first launch of the DECIDING
+          // evaluation of the current iteration (pairs A[cur] at T1) -- the chip is idle during that chain, and the
+          // deciding evaluation no longer shares the CUs with the search (it cost 13 us of a 123-us step there).
+          // `hooked_first`: the hook runs before the deciding evaluation's own launches, which then find their first
+          // launch done (wgn_step: bkt_pair_launched).
+          WinParams P2;
+          const int kind2 = it == 0 ? 4 : 1;
+          bool pair = pair_evals && hooked_first && w.bkt_off == 0 && !w.alt.gn_dirty && !w.alt.bkt_pair_launched && bkt_fits(n, P);
+          if (pair) {
+            adopt_pool_hint(w, kind2);  // (estimate_transform_loop would, in front of that evaluation)
+            pair = window_usable(h, n, &P2, kind2) && bkt_fits(n, P2);
+          }
+          if (pair) {
+            ++w.win_tried;
+            e = launch_bkt_pair(h, h->stream, w, A[nxt], B[nxt], P, go_ahead, spec_pose, w.alt, A[cur], B[cur], T1, P2, n);
+          } else {
+            w.ahead_on = go_ahead;
+            w.ahead_outer = spec_pose;
+            e = launch_weighted_gn_win(h, A[nxt], B[nxt], n, transform_identity(), P);
+            w.ahead_on = false;
+          }
           pre_valid = true;
           if (e == hipSuccess && go_ahead) {  // the search of the iteration after next, behind that evaluation
             uint32_t *idx_out2 = (it + 3 == max_iter && d_last_idx) ? idx_target : nullptr;
@@ -1464,12 +1515,12 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     // two streams: the search is enqueued first; the evaluation's workgroups arrive on the
     // high-priority stream and are placed as soon as a CU has room
     w.search_beside_eval = speculate;
+    // (the hook -- next search / pre-evaluation / run-ahead search -- goes in front of the deciding evaluation's launches
+    // unless the next search is in flight already and the cloud is frame-sized: there the host's launches are the
+    // critical path)
+    hooked_first = two_streams && nn_first && !device_loop && !(ahead_issued && (long)n <= grid_coop_max());
     const int rc = estimate_transform_loop(h, A[cur], B[cur], n, &dT, &inner, hook,
-                                           two_streams && !device_loop ? w.spec_stream : nullptr,
-                                           // (the hook -- next search / pre-evaluation / run-ahead search -- goes in front of
-                                           // the deciding evaluation's launches unless the next search is in flight already
-                                           // and the cloud is frame-sized: there the host's launches are the critical path)
-                                           two_streams && nn_first && !device_loop && !(ahead_issued && (long)n <= grid_coop_max()),
+                                           two_streams && !device_loop ? w.spec_stream : nullptr, hooked_first,
                                            first_pre_launched, it == 0 ? 3 : 0,
                                            it == 0 ? 4 : 1, device_loop);
     w.search_beside_eval = false;

@@ -60,6 +60,14 @@ constexpr int kWinCapRing = 4096;     // candidates around median -+ MAD, per di
 constexpr int kWinBlocks = 256;       // workgroups of the streaming launches (one per CU)
 constexpr int kWinBlkMed = 32;        // candidates one workgroup can stage, per dimension
 constexpr int kWinBlkRing = 96;
+// filed candidates (gn_win.hip: k_win_hist_sums_bkt / k_win_pick): the pass that counts the residuals also files every
+// residual of a FINE bin -- sorted by bin, in the workgroup's own segment, with a directory of where each fine bin's
+// members start -- so the candidates of whatever bins the counts resolve to are already lying there: no second pass
+// over the points.  Nothing is shared between workgroups (returning atomics on shared counters serialise per counter:
+// 6.5 us for 256 workgroups, measured).
+constexpr int kBktStage = 2048;       // fine-window members one workgroup can stage (LDS) and file (its segment)
+constexpr int kBktFine = 2 * 3 * kWinFine;  // fine bins of both dimensions, in directory order: dimension, window, bin
+constexpr int kBktDir = kBktFine + 8;       // directory entries per workgroup (u16 offsets; [kBktFine] = the total), padded
 
 inline void reduce_geometry(size_t n, int *blocks, int *threads) {
   size_t b = (n + kReduceThreads - 1) / kReduceThreads;
@@ -113,7 +121,7 @@ struct WinParams {
 // What k_win_compact resolves from the histograms for k_win_accumulate (per dimension).
 struct WinState {
   unsigned fail;           // the window missed an order statistic: evaluate again with gn_pull.hip
-  unsigned pad0;
+  unsigned stage_overflow; // bucketed candidates: a workgroup met more fine-window members than it can stage (k_win_pick clears it)
   unsigned med_base[2];    // points in bins below the median bins
   unsigned med_cnt[2];     // points in the median bins (= candidates the compaction delivers)
   unsigned ring_inner[2];  // points surely closer to the median than the MAD
@@ -174,6 +182,9 @@ struct GnCtx {
   WinState *d_wstate = nullptr;
   double *d_wmed = nullptr;     // 2 x kWinCapMed residuals
   double *d_wring = nullptr;    // 2 x kWinCapRing residuals
+  double *d_bkt = nullptr;      // kReduceMaxBlocks segments of kBktStage residuals: a workgroup's fine-window members, by bin
+  unsigned short *d_bkt_dir = nullptr;  // kReduceMaxBlocks x kBktDir: where each fine bin's members start in the segment
+  bool bkt_pair_launched = false;  // this context's evaluation is in flight on the search stream (launch_bkt_pair): only its result is awaited
 };
 
 struct Workspace : GnCtx {
@@ -239,6 +250,10 @@ struct Workspace : GnCtx {
   uint32_t hint_last_inner = 0xffffffffu;
   static bool kind_has_slot(int kind) { return kind == 0 || kind == 1 || kind == 3 || kind == 4; }
   unsigned long long win_tried = 0, win_missed = 0, short_evals = 0, radix_evals = 0;
+  // bucketed candidates (gn_win.hip): evaluations served that way, how many found their buckets too small, and for how
+  // many more window evaluations this handle keeps to the second pass over the points after such a miss
+  unsigned long long bkt_evals = 0, bkt_misses = 0;
+  unsigned bkt_off = 0;
   // one-launch inner loop (gn_loop.hip): control block, the two parity histograms / block-sum sets, the pinned result
   void *d_loop_ctl = nullptr, *h_loop_res = nullptr;
   uint32_t *d_loop_hist = nullptr;
@@ -467,6 +482,12 @@ bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind = 2, bo
                    double f_override = 0.);
 hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double *d_b, size_t n,
                                   const Pose &T, const WinParams &P);
+// filed candidates (gn_win.hip, round 5): can the workgroups stage the members of these windows; two evaluations in
+// two launches on one stream
+bool bkt_fits(size_t n, const WinParams &P);
+hipError_t launch_bkt_pair(icp_handle *h, hipStream_t s, GnCtx &first, const double *a1, const double *b1, const WinParams &P1,
+                           bool ahead_on, const Pose &ahead_outer, GnCtx &second, const double *a2, const double *b2,
+                           const Pose &T2, const WinParams &P2, size_t n);
 // n > 4M: the window is found in two passes (gn_win.hip, "refined windows"); the host part of the
 // orchestration (two waits) lives in api.hip:wgn_step
 constexpr size_t kRefineListCap = 1u << 21;  // expected: ~4e5 per dimension

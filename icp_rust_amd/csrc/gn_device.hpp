@@ -264,22 +264,26 @@ __device__ __forceinline__ void fold_block_sums(const double *partials, int bloc
 // thread t takes sums [10 h, 10 h + 10) of row t % 256, h = t / 256, so waves 0-3 and 4-7 each see the rows in the
 // lanes fold_block_sums has them in; the wave sums are left-folded per half, plus the one `+ 0.` that stands for
 // the four all-zero waves of the general form (it only matters for a sum that is -0.).
+// (in two halves, so that the loads can be in flight across other work: fold256_load early, fold256_reduce later)
+constexpr int kFoldH = (kNSum + 1) / 2;
 template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT>
-__device__ __forceinline__ void fold_block_sums_256(const double *partials, int blocks, double *s_tot) {
+__device__ __forceinline__ void fold256_load(const double *partials, int blocks, double (&x)[kFoldH]) {
   static_assert(kReduceThreads == 512 && (kNSum + 1) == 20 && kReduceMaxBlocks <= 256, "two halves of ten sums, one row per thread");
-  constexpr int H = (kNSum + 1) / 2;
+  const int t = threadIdx.x, row = t & 255, half = t >> 8;
+#pragma unroll
+  for (int k = 0; k < kFoldH; ++k)
+    x[k] = (row < blocks && half * kFoldH + k < kNSum)
+               ? __hip_atomic_load(&partials[(size_t)row * (kNSum + 1) + half * kFoldH + k], __ATOMIC_RELAXED, SCOPE)
+               : 0.;
+}
+__device__ __forceinline__ void fold256_reduce(const double (&x)[kFoldH], int blocks, double *s_tot) {
+  constexpr int H = kFoldH;
   __shared__ double sm[8][H];
-  const int t = threadIdx.x, row = t & 255, half = t >> 8, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, row = t & 255, lane = t & 63, wave = t >> 6;
   double v[H];
 #pragma unroll
   for (int k = 0; k < H; ++k) v[k] = 0.;
   if (row < blocks) {
-    double x[H];
-#pragma unroll
-    for (int k = 0; k < H; ++k)
-      x[k] = (half * H + k < kNSum) ? __hip_atomic_load(&partials[(size_t)row * (kNSum + 1) + half * H + k],
-                                                          __ATOMIC_RELAXED, SCOPE)
-                                    : 0.;
 #pragma unroll
     for (int k = 0; k < H; ++k) v[k] = v[k] + x[k];
   }
@@ -295,6 +299,12 @@ __device__ __forceinline__ void fold_block_sums_256(const double *partials, int 
     for (int w = 1; w < 4; ++w) s = s + sm[4 * h + w][k];
     s_tot[t] = s + 0.;
   }
+}
+template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT>
+__device__ __forceinline__ void fold_block_sums_256(const double *partials, int blocks, double *s_tot) {
+  double x[kFoldH];
+  fold256_load<SCOPE>(partials, blocks, x);
+  fold256_reduce(x, blocks, s_tot);
 }
 
 // ONE of those sums, folded exactly as fold_block_sums_256 folds it (row r in lane r % 64 of wave r / 64, the wave

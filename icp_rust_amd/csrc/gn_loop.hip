@@ -170,9 +170,12 @@ __device__ __forceinline__ void loop_resolve(const uint32_t *whist, unsigned n, 
   __shared__ unsigned s_wtot[2][16];
   __shared__ int s_rng[2][8];
   __shared__ int s_t[2][2];
+  __shared__ int s_j[2][2];  // the bins of the two middle ranks, found by the threads that own them (gn_win.hip: win_resolve)
   constexpr int PER = kWinBins / kReduceThreads, NW = kReduceThreads / 64;
   static_assert(PER == 4, "four bins per thread");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned klo = (n - 1) / 2, khi = n / 2;  // src/stats.rs:18-27
+  if (tid < 4) s_j[tid >> 1][tid & 1] = -1;
   unsigned v[2][PER], inc[2], tot[2];
   if (!SHARDED) {
 #pragma unroll
@@ -231,6 +234,8 @@ __device__ __forceinline__ void loop_resolve(const uint32_t *whist, unsigned n, 
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       cum[d * kWinBins + PER * tid + i] = run;
+      if (run <= klo && klo < run + v[d][i]) s_j[d][0] = PER * tid + i;
+      if (run <= khi && khi < run + v[d][i]) s_j[d][1] = PER * tid + i;
       run += v[d][i];
     }
   }
@@ -238,7 +243,7 @@ __device__ __forceinline__ void loop_resolve(const uint32_t *whist, unsigned n, 
   WinGeom geo = {};
   if (wave < 4) {  // waves 0,1: t1 of x,y; waves 2,3: t2 of x,y
     const int d = wave & 1, role = wave >> 1;
-    geo = window_geometry(cum + d * kWinBins, n, P.d[d]);
+    geo = window_geometry(cum + d * kWinBins, n, P.d[d], s_j[d][0], s_j[d][1]);
     const int t = geo.ok ? bracket_search(cum + d * kWinBins, n, P.d[d], geo, role) : -1;
     if (lane == 0) s_t[role][d] = t;
   }
@@ -355,6 +360,14 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
                                                                                                          : 2 * kWinBins * sizeof(uint32_t)];
   uint32_t *const s_bins = reinterpret_cast<uint32_t *>(s_work);
   SelectLds<2> &s_sel = *reinterpret_cast<SelectLds<2> *>(s_work);
+  // Round 5: the points whose residual landed in a FINE bin in phase A, as (point of the thread << 10 | thread << 1 |
+  // dimension) -- in the part of the selection's workspace the histograms leave free.  Every candidate of a window that
+  // holds lies in a fine bin, so phase B lists its candidates from these ~800 entries instead of binning all 4 096
+  // points of the workgroup a second time (6.6 of an evaluation's 43 us: profiles/r04_loop_phases.txt).
+  constexpr unsigned kStageCap = (sizeof(s_work) - 2 * kWinBins * sizeof(uint32_t)) / sizeof(unsigned short);
+  static_assert(kStageCap >= 4096 && kLoopMaxK <= 8, "staged members: 3 + 9 + 1 bits each");
+  unsigned short *const s_mem = reinterpret_cast<unsigned short *>(s_work + 2 * kWinBins * sizeof(uint32_t));
+  __shared__ unsigned s_nmem;
   __shared__ double s_med[2][kWinBlkMed], s_ring[2][kWinBlkRing];
   __shared__ unsigned s_cnt[4], s_base[4];
   __shared__ double s_tot[kNSum + 1], s_acc[kNAcc + 3];
@@ -408,6 +421,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
 
     // ---- A: residuals -> histograms + running sums ----------------------------------------------------------------
     for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads) s_bins[i] = 0;
+    if (tid == 0) s_nmem = 0;
     __syncthreads();
     {
       double acc[kNSum];
@@ -415,6 +429,10 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
       for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
       unsigned edge[4] = {0u, 0u, 0u, 0u};  // wave-uniform: points of this WAVE in the catch-all bins {below, above} x {x, y}
       bool saw_nan = false;
+      auto stage = [&](unsigned code) {
+        const unsigned pos = atomicAdd(&s_nmem, 1u);
+        if (pos < kStageCap) s_mem[pos] = (unsigned short)code;
+      };
       for (unsigned k = 0; k < mine; ++k) {
         const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
         // residual(), src/lib.rs:34-36
@@ -431,6 +449,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
         edge[3] += (unsigned)__popcll(__ballot(hi1));
         if (!lo0 && !hi0) atomicAdd(&s_bins[j0], 1u);
         if (!lo1 && !hi1) atomicAdd(&s_bins[kWinBins + j1], 1u);
+        if (fine_bin(j0)) stage((k << 10) | (tid << 1));
+        if (fine_bin(j1)) stage((k << 10) | (tid << 1) | 1u);
         accumulate_pair<true>(ak, v0, v1, T, acc);  // (this thread's points in index order: the tree's first level)
       }
       if ((tid & 63) == 0) {
@@ -471,31 +491,52 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
     const bool fold_early = gridDim.x >= (unsigned)(kNSum + 1) && blockIdx.x < (unsigned)(kNSum + 1);
     const double fold_x = fold_early ? fold_one_load(partials, (int)gridDim.x, (int)blockIdx.x) : 0.;
     if (!R.fail) {
-      for (unsigned k = 0; k < mine; ++k) {
-        const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
-        const double v[2] = {((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x, ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y};
+      // residual r of dimension d, in bin j: a median candidate, a ring candidate, both or neither
+      auto consider = [&](const int d, const double r, const unsigned j) {
+        if (j >= R.mlo[d] && j <= R.mhi[d]) {
+          const unsigned pos = atomicAdd(&s_cnt[d], 1u);
+          if (pos < (unsigned)kWinBlkMed) {
+            s_med[d][pos] = r;
+          } else {
+            const unsigned g = atomicAdd(&lcnt[d * 32], 1u);
+            if (g < (unsigned)kWinCapMed) st_f64(&A.wmed[(size_t)d * kWinCapMed + g], r);
+          }
+        }
+        if (j >= R.a0[d] && j <= R.b1[d] && !(j >= R.i0[d] && j <= R.i1[d])) {
+          const unsigned pos = atomicAdd(&s_cnt[2 + d], 1u);
+          if (pos < (unsigned)kWinBlkRing) {
+            s_ring[d][pos] = r;
+          } else {
+            const unsigned g = atomicAdd(&lcnt[(2 + d) * 32], 1u);
+            if (g < (unsigned)kWinCapRing) st_f64(&A.wring[(size_t)d * kWinCapRing + g], r);
+          }
+        }
+      };
+      // the staged members hold every candidate when all candidate bins are fine ones and nothing was dropped
+      const unsigned nmem = s_nmem;
+      bool staged = nmem <= kStageCap;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const double r = v[d];
-          const unsigned j = wbin_cold(r, P.d[d]);
-          if (j >= R.mlo[d] && j <= R.mhi[d]) {
-            const unsigned pos = atomicAdd(&s_cnt[d], 1u);
-            if (pos < (unsigned)kWinBlkMed) {
-              s_med[d][pos] = r;
-            } else {
-              const unsigned g = atomicAdd(&lcnt[d * 32], 1u);
-              if (g < (unsigned)kWinCapMed) st_f64(&A.wmed[(size_t)d * kWinCapMed + g], r);
-            }
+      for (int d = 0; d < 2; ++d)
+        staged = staged && R.mlo[d] >= (unsigned)kF1 && R.mhi[d] < (unsigned)kC1 && R.i0[d] <= R.i1[d] && R.a0[d] >= (unsigned)kF0 &&
+                 R.i0[d] - 1u < (unsigned)kC0 && R.i1[d] + 1u >= (unsigned)kF2 && R.b1[d] <= (unsigned)(kWinBins - 2);
+      if (staged) {  // (uniform)
+        for (unsigned e = tid; e < nmem; e += kReduceThreads) {
+          const unsigned code = s_mem[e], k = code >> 10, t = (code >> 1) & 511u;
+          const double2 ak = s_a[k * kReduceThreads + t], bk = s_b[k * kReduceThreads + t];
+          if (code & 1u) {
+            const double r = ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y;
+            consider(1, r, wbin_cold(r, P.d[1]));
+          } else {
+            const double r = ((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x;
+            consider(0, r, wbin_cold(r, P.d[0]));
           }
-          if (j >= R.a0[d] && j <= R.b1[d] && !(j >= R.i0[d] && j <= R.i1[d])) {
-            const unsigned pos = atomicAdd(&s_cnt[2 + d], 1u);
-            if (pos < (unsigned)kWinBlkRing) {
-              s_ring[d][pos] = r;
-            } else {
-              const unsigned g = atomicAdd(&lcnt[(2 + d) * 32], 1u);
-              if (g < (unsigned)kWinCapRing) st_f64(&A.wring[(size_t)d * kWinCapRing + g], r);
-            }
-          }
+        }
+      } else {
+        for (unsigned k = 0; k < mine; ++k) {
+          const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
+          const double v[2] = {((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x, ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y};
+#pragma unroll
+          for (int d = 0; d < 2; ++d) consider(d, v[d], wbin_cold(v[d], P.d[d]));
         }
       }
     }
@@ -811,6 +852,11 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
   // (the flag words of the second wait and the prefix of their counts overlay the same workspace: they live between
   // phase B's last look at the cumulative counts and the first selection)
   unsigned long long *const s_seen = reinterpret_cast<unsigned long long *>(s_work), *const s_incl = s_seen + kReduceMaxBlocks;
+  // (the members of the fine bins, staged by phase A behind the histograms: k_gn_loop has the explanation)
+  constexpr unsigned kStageCap = (sizeof(s_work) - 2 * kWinBins * sizeof(uint32_t)) / sizeof(unsigned short);
+  static_assert(kStageCap >= 4096 && kLoopMaxK <= 8, "staged members: 3 + 9 + 1 bits each");
+  unsigned short *const s_mem = reinterpret_cast<unsigned short *>(s_work + 2 * kWinBins * sizeof(uint32_t));
+  __shared__ unsigned s_nmem;
   __shared__ unsigned long long s_wsum[4];
   __shared__ unsigned s_flags;
   __shared__ WinSel s_ws;
@@ -855,7 +901,10 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
 
     // ---- A ----------------------------------------------------------------------------------------------------------
     for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads) s_bins[i] = 0;
-    if (tid == 0) s_flags = 0u;
+    if (tid == 0) {
+      s_flags = 0u;
+      s_nmem = 0u;
+    }
     __syncthreads();
     {
       double acc[kNSum];
@@ -863,6 +912,10 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
       for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
       unsigned edge[4] = {0u, 0u, 0u, 0u};
       bool saw_nan = false;
+      auto stage = [&](unsigned code) {
+        const unsigned pos = atomicAdd(&s_nmem, 1u);
+        if (pos < kStageCap) s_mem[pos] = (unsigned short)code;
+      };
       for (unsigned k = 0; k < mine; ++k) {
         const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
         const double v0 = ((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x;  // residual(), src/lib.rs:34-36
@@ -876,6 +929,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
         edge[3] += (unsigned)__popcll(__ballot(hi1));
         if (!lo0 && !hi0) atomicAdd(&s_bins[j0], 1u);
         if (!lo1 && !hi1) atomicAdd(&s_bins[kWinBins + j1], 1u);
+        if (fine_bin(j0)) stage((k << 10) | (tid << 1));
+        if (fine_bin(j1)) stage((k << 10) | (tid << 1) | 1u);
         accumulate_pair<true>(ak, v0, v1, T, acc);
       }
       if ((tid & 63) == 0) {
@@ -930,21 +985,40 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
     }
     __syncthreads();
     if (!R.fail) {
-      for (unsigned k = 0; k < mine; ++k) {
-        const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
-        const double v[2] = {((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x, ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y};
+      auto consider = [&](const int d, const double r, const unsigned j) {
+        if (j >= R.mlo[d] && j <= R.mhi[d]) {
+          const unsigned pos = atomicAdd(&s_cnt[d], 1u);
+          if (pos < (unsigned)kWinBlkMed) s_med[d][pos] = r;
+        }
+        if (j >= R.a0[d] && j <= R.b1[d] && !(j >= R.i0[d] && j <= R.i1[d])) {
+          const unsigned pos = atomicAdd(&s_cnt[2 + d], 1u);
+          if (pos < (unsigned)kWinBlkRing) s_ring[d][pos] = r;
+        }
+      };
+      const unsigned nmem = s_nmem;
+      bool staged = nmem <= kStageCap;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const double r = v[d];
-          const unsigned j = wbin_cold(r, P.d[d]);
-          if (j >= R.mlo[d] && j <= R.mhi[d]) {
-            const unsigned pos = atomicAdd(&s_cnt[d], 1u);
-            if (pos < (unsigned)kWinBlkMed) s_med[d][pos] = r;
+      for (int d = 0; d < 2; ++d)
+        staged = staged && R.mlo[d] >= (unsigned)kF1 && R.mhi[d] < (unsigned)kC1 && R.i0[d] <= R.i1[d] && R.a0[d] >= (unsigned)kF0 &&
+                 R.i0[d] - 1u < (unsigned)kC0 && R.i1[d] + 1u >= (unsigned)kF2 && R.b1[d] <= (unsigned)(kWinBins - 2);
+      if (staged) {  // (uniform)
+        for (unsigned e = tid; e < nmem; e += kReduceThreads) {
+          const unsigned code = s_mem[e], k = code >> 10, t = (code >> 1) & 511u;
+          const double2 ak = s_a[k * kReduceThreads + t], bk = s_b[k * kReduceThreads + t];
+          if (code & 1u) {
+            const double r = ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y;
+            consider(1, r, wbin_cold(r, P.d[1]));
+          } else {
+            const double r = ((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x;
+            consider(0, r, wbin_cold(r, P.d[0]));
           }
-          if (j >= R.a0[d] && j <= R.b1[d] && !(j >= R.i0[d] && j <= R.i1[d])) {
-            const unsigned pos = atomicAdd(&s_cnt[2 + d], 1u);
-            if (pos < (unsigned)kWinBlkRing) s_ring[d][pos] = r;
-          }
+        }
+      } else {
+        for (unsigned k = 0; k < mine; ++k) {
+          const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
+          const double v[2] = {((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x, ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y};
+#pragma unroll
+          for (int d = 0; d < 2; ++d) consider(d, v[d], wbin_cold(v[d], P.d[d]));
         }
       }
     }

@@ -154,6 +154,208 @@ __global__ __launch_bounds__(kWinThreads) void k_win_hist_sums_deep(const double
   win_hist_body<true, ICP_DEEP_BATCH>(a, b, T, rx, ry, n, P, whist, st, scal, partials, -1);
 }
 
+// ---- W + filed candidates (round 5) ---------------------------------------------------
+// k_win_hist_sums that also FILES the candidates: every residual that lands in a fine bin is staged in LDS beside the
+// count; once the counts of the workgroup are complete, an exclusive scan over its fine bins (directory order:
+// dimension, window, bin) sorts the members by bin into the workgroup's OWN segment, and the scan itself -- where
+// each fine bin's members start -- goes out as the segment's directory.  Whatever bins the complete histogram
+// resolves to afterwards (k_win_pick), their residuals are lying in the 256 segments: the second pass over the
+// points (k_win_finish's 16 MB at 1M pairs, its 343 instructions per point, its ticket and its 256 workgroups) is
+// gone, and so are the stores of rx / ry.  A window of 0.05 sigma puts a tenth of the residuals of each dimension
+// into fine bins: ~800 members per workgroup at 1M pairs.  (Measured and dropped: one bucket per bin for all
+// workgroups, slots handed out by returning atomics -- on the histogram words themselves 6.5 us per launch, 256
+// workgroups serialise on each of its 128 lines; on one padded counter per bin 14 us.)
+// directory index f (dimension, window, bin) -> the histogram word
+__host__ __device__ __forceinline__ unsigned fine_to_word(unsigned f) {
+  const unsigned d = f / (3u * kWinFine), r = f % (3u * kWinFine), w = r / (unsigned)kWinFine, k = r % (unsigned)kWinFine;
+  return d * (unsigned)kWinBins + (w == 0 ? (unsigned)kF0 : (w == 1 ? (unsigned)kF1 : (unsigned)kF2)) + k;
+}
+// ... and back, for a regular bin j of dimension d that IS fine
+__device__ __forceinline__ unsigned word_to_fine(unsigned d, unsigned j) {
+  const unsigned w = j >= (unsigned)kF2 ? 2u : (j >= (unsigned)kF1 ? 1u : 0u);
+  return d * 3u * kWinFine + w * (unsigned)kWinFine + (j - (w == 0 ? (unsigned)kF0 : (w == 1 ? (unsigned)kF1 : (unsigned)kF2)));
+}
+
+// the arguments of the two launches of such an evaluation (kernel arguments by value; one definition for the plain
+// launches and for the launch that carries one evaluation's second and another's first)
+struct HistBktArgs {
+  const double2 *a, *b;
+  Pose T;
+  unsigned n;
+  WinParams P;
+  uint32_t *whist;
+  WinState *st;
+  GnScalars *scal;
+  double *partials;
+  double *seg_all;
+  unsigned short *dir_all;
+};
+struct HistBktLds {
+  uint32_t lh[2 * kWinBins];
+  double mv[kBktStage];
+  unsigned short mk[kBktStage];
+  unsigned nmem;
+};
+
+// blk of nblk: this workgroup's place in the reduction tree's geometry (a launch may carry other work in front)
+__device__ __forceinline__ void win_hist_sums_bkt_body(const HistBktArgs &A, const unsigned blk, const unsigned nblk,
+                                                       HistBktLds &S) {
+  constexpr int BATCH = kWinBatch;
+  const double2 *__restrict__ a = A.a, *__restrict__ b = A.b;
+  const Pose T = A.T;
+  const unsigned n = A.n;
+  const WinParams &P = A.P;
+  uint32_t *const whist = A.whist;
+  WinState *const st = A.st;
+  GnScalars *const scal = A.scal;
+  double *const partials = A.partials;
+  double *const seg_all = A.seg_all;
+  unsigned short *const dir_all = A.dir_all;
+  auto &lh = S.lh;
+  auto &s_mv = S.mv;
+  auto &s_mk = S.mk;
+  unsigned &s_nmem = S.nmem;
+  double acc[kNSum];
+#pragma unroll
+  for (int k = 0; k < kNSum; ++k) acc[k] = 0.;
+#ifdef ICP_WIN_DEBUG
+  long long bst[8];
+  bst[0] = wall_clock64();
+#endif
+  for (unsigned i = threadIdx.x; i < 2u * kWinBins; i += kWinThreads) lh[i] = 0;
+  if (threadIdx.x == 0) s_nmem = 0;
+  __syncthreads();
+  auto stage = [&](double v, unsigned key) {
+    const unsigned pos = atomicAdd(&s_nmem, 1u);
+    if (pos < (unsigned)kBktStage) {
+      s_mv[pos] = v;
+      s_mk[pos] = (unsigned short)key;
+    }
+  };
+  unsigned edge[4] = {0u, 0u, 0u, 0u};  // {below, above} x {x, y}: one word each, kept out of the LDS atomics
+  bool saw_nan = false;
+  const unsigned G = nblk * kWinThreads;
+  for (unsigned base = blk * kWinThreads + threadIdx.x; base < n; base += G * BATCH) {
+    double2 s[BATCH], d[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const unsigned i = base + u * G;
+      if (i < n) {
+        s[u] = a[i];
+        d[u] = b[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const unsigned i = base + u * G;
+      if (i >= n) continue;
+      // residual(), src/lib.rs:34-36
+      const double v0 = ((T.r00 * s[u].x + T.r01 * s[u].y) + T.tx) - d[u].x;
+      const double v1 = ((T.r10 * s[u].x + T.r11 * s[u].y) + T.ty) - d[u].y;
+      saw_nan |= (v0 != v0) | (v1 != v1);
+      const unsigned j0 = wbin(v0, P.d[0]), j1 = wbin(v1, P.d[1]);
+      if (j0 == 0u) ++edge[0];
+      else if (j0 == (unsigned)(kWinBins - 1)) ++edge[1];
+      else {
+        atomicAdd(&lh[j0], 1u);
+        if (fine_bin(j0)) stage(v0, j0);
+      }
+      if (j1 == 0u) ++edge[2];
+      else if (j1 == (unsigned)(kWinBins - 1)) ++edge[3];
+      else {
+        atomicAdd(&lh[kWinBins + j1], 1u);
+        if (fine_bin(j1)) stage(v1, (unsigned)kWinBins + j1);
+      }
+      accumulate_pair<true>(s[u], v0, v1, T, acc);  // (this thread's points in index order: the tree's first level)
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned v = edge[k];  // the wave's total in its lane 63, by DPP (an inclusive scan's last lane): no LDS crossbar
+#define ICP_SCAN_DPP(x, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, true)
+    v += ICP_SCAN_DPP(v, 0x111, 0xf);
+    v += ICP_SCAN_DPP(v, 0x112, 0xf);
+    v += ICP_SCAN_DPP(v, 0x114, 0xf);
+    v += ICP_SCAN_DPP(v, 0x118, 0xf);
+    v += ICP_SCAN_DPP(v, 0x142, 0xa);
+    v += ICP_SCAN_DPP(v, 0x143, 0xc);
+#undef ICP_SCAN_DPP
+    if ((threadIdx.x & 63) == 63 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
+  }
+  if (saw_nan) atomicOr(&scal->nan_flag, 1);
+#ifdef ICP_WIN_DEBUG
+  bst[1] = wall_clock64();
+#endif
+  __syncthreads();
+#ifdef ICP_WIN_DEBUG
+  bst[2] = wall_clock64();
+#endif
+  for (unsigned i = threadIdx.x; i < 2u * kWinBins; i += kWinThreads) {  // dense flush: contiguous words, nobody waits
+    const uint32_t c = lh[i];
+    if (c) atomicAdd(&whist[i], c);
+  }
+  // the directory: eight consecutive fine bins per thread (they never straddle a window), one scan over the workgroup
+  constexpr unsigned kDirPer = 8;
+  static_assert(kWinFine % kDirPer == 0 && kBktFine / kDirPer <= kWinThreads, "directory slices");
+  const unsigned f0 = threadIdx.x * kDirPer;
+  const bool has_slice = f0 < (unsigned)kBktFine;
+  const unsigned w0 = has_slice ? fine_to_word(f0) : 0u;
+  unsigned cnt[kDirPer], sum = 0;
+#pragma unroll
+  for (unsigned q = 0; q < kDirPer; ++q) {
+    cnt[q] = has_slice ? lh[w0 + q] : 0u;
+    sum += cnt[q];
+  }
+  unsigned total;
+  unsigned run = block_excl_scan(sum, &total);  // (two barriers: every count above is read before any is overwritten)
+  unsigned short *const dir = dir_all + (size_t)blk * kBktDir;
+  double *const seg = seg_all + (size_t)blk * kBktStage;
+  if (has_slice) {
+    unsigned o[kDirPer];
+#pragma unroll
+    for (unsigned q = 0; q < kDirPer; ++q) {
+      o[q] = run;
+      lh[w0 + q] = run;  // the bin's word now hands out the positions of its members
+      run += cnt[q];
+    }
+    uint4 pk;
+    pk.x = o[0] | (o[1] << 16);
+    pk.y = o[2] | (o[3] << 16);
+    pk.z = o[4] | (o[5] << 16);
+    pk.w = o[6] | (o[7] << 16);
+    *reinterpret_cast<uint4 *>(dir + f0) = pk;
+  }
+  if (threadIdx.x == 0) dir[kBktFine] = (unsigned short)(total < 0xffffu ? total : 0xffffu);
+  // (the block sums go out while the directory lands in LDS)
+  block_reduce_store<kNSum, true>(acc, partials + (size_t)blk * (kNSum + 1));
+  __syncthreads();
+#ifdef ICP_WIN_DEBUG
+  bst[3] = wall_clock64();
+#endif
+  const unsigned nm_all = s_nmem;
+  if (nm_all > (unsigned)kBktStage) {  // more members than the stage holds: nothing of this evaluation's files is usable
+    if (threadIdx.x == 0) atomicOr(&st->stage_overflow, 1u);
+  } else {
+    for (unsigned e = threadIdx.x; e < nm_all; e += kWinThreads) {
+      const unsigned key = s_mk[e];
+      const unsigned pos = atomicAdd(&lh[key], 1u);  // (returning LDS atomic: directory offset + rank inside the bin)
+      if (pos < (unsigned)kBktStage) seg[pos] = s_mv[e];
+    }
+  }
+#ifdef ICP_WIN_DEBUG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bst[4] = wall_clock64();
+  if (threadIdx.x == 0 && (blk == 0 || blk == 200) && (bst[0] & 0x1f0) == 0)
+    printf("[B blk %d] stream %lld barrier %lld flush+dir+reduce %lld scatter %lld (x10ns) members %u\n", blk,
+           bst[1] - bst[0], bst[2] - bst[1], bst[3] - bst[2], bst[4] - bst[3], nm_all);
+#endif
+}
+
+__global__ __launch_bounds__(kWinThreads) void k_win_hist_sums_bkt(HistBktArgs A) {
+  __shared__ HistBktLds S;
+  win_hist_sums_bkt_body(A, blockIdx.x, gridDim.x, S);
+}
+
 // ---- W' (refined windows, n > 4M): the histograms again for new windows, from the stored residuals
 // ... and the points inside the three fine windows of each dimension (where every candidate of the
 // compaction will be) go to two dense lists: staged in LDS, one reservation per workgroup and list.
@@ -261,45 +463,39 @@ __global__ void k_sample_pairs(const double2 *__restrict__ a, const double2 *__r
 // stored write-through for the workgroup that arrives last, a missed window does not end the workgroup early, and
 // what the histogram says about the candidate lists is handed back in `sel` (every workgroup derives the same).
 
-template <bool LISTS, bool FINISH>
-__device__ __forceinline__ bool win_compact_body(const double *__restrict__ rx, const double *__restrict__ ry,
-                                                 unsigned n_local, unsigned n, const WinParams &P,
-                                                 const uint32_t *__restrict__ whist, WinState *st, double *wmed,
-                                                 double *wring, const unsigned *__restrict__ llen, unsigned lcap,
-                                                 WinSel &sel) {
-  __shared__ uint32_t cum[2 * kWinBins];  // points in lower bins
+// What the histograms resolve to, per dimension: the bins of the median candidates and of the ring (in every thread).
+struct WinBins {
+  unsigned mlo[2], mhi[2], a0[2], b1[2], i0[2], i1[2];
+  bool fail;
+};
+
+// The front half of C, by the whole workgroup (five barriers): the histograms of both dimensions -> `cum` (LDS, 2 x
+// kWinBins words: points in lower bins) -> the bracket (window_geometry / bracket_search / resolve_window, four waves
+// side by side) -> the candidate bins.  REQUIRE_FINE: the median bins must lie in the middle fine window and the two
+// arcs of the ring in the outer ones (the callers whose candidates exist only there: lists, buckets).  WANT_SEL: `sel`
+// is filled (what the histogram says about the candidate lists).  Workgroup 0 also leaves everything in `st`.
+template <bool REQUIRE_FINE, bool WANT_SEL>
+__device__ __forceinline__ WinBins win_resolve(const uint32_t *__restrict__ whist, unsigned n, const WinParams &P,
+                                               WinState *st, const unsigned *__restrict__ llen, unsigned lcap,
+                                               uint32_t *cum, WinSel &sel) {
   __shared__ unsigned s_selu[2][4];
   __shared__ double s_seld[2][4];
-  auto put = [](double *p, double v) {
-    if (FINISH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-  };
   __shared__ unsigned s_wtot[2][16];
   __shared__ int s_rng[2][8];
-  __shared__ double s_med[2][kWinBlkMed], s_ring[2][kWinBlkRing];
-  __shared__ unsigned s_cnt[4];
+  __shared__ int s_t[2][2];
+  __shared__ int s_j[2][2];  // the bins of the two middle ranks (-1: the counts do not add up to n -- a miss either way)
   constexpr int PER = kWinBins / kWinThreads, NW = kWinThreads / 64;
   static_assert(PER * kWinThreads == kWinBins && (PER == 2 || PER == 4), "bins per thread");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned klo = (n - 1) / 2, khi = n / 2;  // src/stats.rs:18-27
+  if (tid < 4) s_j[tid >> 1][tid & 1] = -1;
 #ifdef ICP_WIN_DEBUG
-  long long cst[6];
-  cst[0] = wall_clock64();
+  __shared__ long long s_rdbg[8];
+  if (tid == 0) s_rdbg[0] = wall_clock64();
+#define RSTAMP(k) if (tid == 0) s_rdbg[k] = wall_clock64()
+#else
+#define RSTAMP(k)
 #endif
-  if (tid < 4) s_cnt[tid] = 0;
-  // the first batch of residuals does not wait for the bins to be resolved: its loads travel with the histogram's
-  const unsigned G = gridDim.x * kWinThreads;
-  double pre[2][kWinBatch];
-  constexpr bool kPrefetch = false;  // (measured: no gain on the 28k frame, and 37 more registers in the kernel)
-  if (kPrefetch) {
-#pragma unroll
-    for (int u = 0; u < kWinBatch; ++u) {
-      const unsigned i = blockIdx.x * kWinThreads + tid + u * G;
-      if (i < n_local) {
-        pre[0][u] = rx[i];
-        pre[1][u] = ry[i];
-      }
-    }
-  }
   unsigned v[2][PER], inc[2], tot[2];
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
@@ -329,6 +525,7 @@ __device__ __forceinline__ bool win_compact_body(const double *__restrict__ rx, 
     inc[d] = s;
     if (lane == 63) s_wtot[d][wave] = s;
   }
+  RSTAMP(1);
   __syncthreads();
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
@@ -339,43 +536,25 @@ __device__ __forceinline__ bool win_compact_body(const double *__restrict__ rx, 
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       cum[d * kWinBins + PER * tid + i] = run;
+      // (the bin that holds a middle rank: exactly one thread sees it -- the last bin whose cumulative count is <= the rank)
+      if (run <= klo && klo < run + v[d][i]) s_j[d][0] = PER * tid + i;
+      if (run <= khi && khi < run + v[d][i]) s_j[d][1] = PER * tid + i;
       run += v[d][i];
     }
   }
   __syncthreads();
-#ifdef ICP_WIN_DEBUG
-  cst[1] = wall_clock64();
-#endif
-  __shared__ int s_t[2][2];
+  RSTAMP(2);
   WinGeom geo = {};
-#ifdef ICP_WIN_DEBUG
-  long long rst[4] = {0, 0, 0, 0};
-  __shared__ long long s_rst[4][4];
-#endif
   if (wave < 4) {  // waves 0,1: t1 of x,y; waves 2,3: t2 of x,y -- the two halves of the bracket side by side
     const int d = wave & 1, role = wave >> 1;
-#ifdef ICP_WIN_DEBUG
-    rst[0] = wall_clock64();
-#endif
-    geo = window_geometry(cum + d * kWinBins, n, P.d[d]);
-#ifdef ICP_WIN_DEBUG
-    rst[1] = wall_clock64();
-#endif
+    geo = window_geometry(cum + d * kWinBins, n, P.d[d], s_j[d][0], s_j[d][1]);
+    RSTAMP(3);
     const int t = geo.ok ? bracket_search(cum + d * kWinBins, n, P.d[d], geo, role) : -1;
-#ifdef ICP_WIN_DEBUG
-    rst[2] = wall_clock64();
-    if (lane == 0) {
-      s_rst[wave][0] = rst[0];
-      s_rst[wave][1] = rst[1];
-      s_rst[wave][2] = rst[2];
-    }
-#endif
     if (lane == 0) s_t[role][d] = t;
   }
+  RSTAMP(4);
   __syncthreads();
-#ifdef ICP_WIN_DEBUG
-  const long long t_b1 = wall_clock64();
-#endif
+  RSTAMP(5);
   if (wave < 2) {  // one wave per dimension
     const int d = wave;
     WinRanges R = {};
@@ -386,9 +565,9 @@ __device__ __forceinline__ bool win_compact_body(const double *__restrict__ rx, 
     for (int w = 0; w < NW; ++w) counted += s_wtot[d][w];
     bool ok = counted == n && resolve_window(cum + d * kWinBins, n, P.d[d], geo, s_t[0][d], s_t[1][d], R,
                                              med_base, med_cnt, inner, ring_cnt, range);
-    if (LISTS && ok)  // the median bins in the middle window, the two arcs of the ring in the outer ones
-      ok = llen[d] <= lcap && R.mlo >= kF1 && R.mhi < kC1 && R.i0 <= R.i1 && R.a0 >= kF0 && R.i0 - 1 < kC0 &&
-           R.i1 + 1 >= kF2 && R.b1 <= kWinBins - 2;
+    if (REQUIRE_FINE && ok)  // the median bins in the middle window, the two arcs of the ring in the outer ones
+      ok = (!llen || llen[d] <= lcap) && R.mlo >= kF1 && R.mhi < kC1 && R.i0 <= R.i1 && R.a0 >= kF0 &&
+           R.i0 - 1 < kC0 && R.i1 + 1 >= kF2 && R.b1 <= kWinBins - 2;
     if (lane == 0) {
       s_rng[d][0] = R.mlo;
       s_rng[d][1] = R.mhi;
@@ -397,7 +576,7 @@ __device__ __forceinline__ bool win_compact_body(const double *__restrict__ rx, 
       s_rng[d][4] = R.i0;
       s_rng[d][5] = R.i1;
       s_rng[d][6] = ok ? 0 : 1;
-      if (FINISH) {
+      if (WANT_SEL) {
         s_selu[d][0] = med_base;
         s_selu[d][1] = med_cnt;
         s_selu[d][2] = inner;
@@ -417,20 +596,18 @@ __device__ __forceinline__ bool win_compact_body(const double *__restrict__ rx, 
       }
     }
   }
-#ifdef ICP_WIN_DEBUG
-  const long long t_b2 = wall_clock64();
-#endif
+  RSTAMP(6);
   __syncthreads();
 #ifdef ICP_WIN_DEBUG
-  cst[2] = wall_clock64();
-  if (tid == 0 && blockIdx.x == 0 && (clock64() & 15) == 0)
-    printf("[C resolve] start->geo %lld geometry %lld bracket %lld (wave 3: %lld %lld) barrier1 %lld resolve_window %lld barrier2 %lld (x10ns)\n",
-           s_rst[0][0] - cst[1], s_rst[0][1] - s_rst[0][0], s_rst[0][2] - s_rst[0][1], s_rst[3][1] - s_rst[3][0],
-           s_rst[3][2] - s_rst[3][1], t_b1 - s_rst[0][2], t_b2 - t_b1, cst[2] - t_b2);
+  if (tid == 0 && gridDim.x <= 2 && blockIdx.x == 0 && (s_rdbg[0] & 0x3c0) == 0)
+    printf("[R] loads+scan %lld cum %lld geometry %lld bracket %lld barrier %lld resolve_window %lld (x10ns)\n", s_rdbg[1] - s_rdbg[0],
+           s_rdbg[2] - s_rdbg[1], s_rdbg[3] - s_rdbg[2], s_rdbg[4] - s_rdbg[3], s_rdbg[5] - s_rdbg[4], s_rdbg[6] - s_rdbg[5]);
 #endif
-  const bool fail = (s_rng[0][6] | s_rng[1][6]) != 0;
-  if (blockIdx.x == 0 && tid == 0) st->fail = fail ? 1u : 0u;
-  if (FINISH) {
+#undef RSTAMP
+  WinBins B;
+  B.fail = (s_rng[0][6] | s_rng[1][6]) != 0;
+  if (blockIdx.x == 0 && tid == 0) st->fail = B.fail ? 1u : 0u;
+  if (WANT_SEL) {
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       sel.med_base[d] = s_selu[d][0];
@@ -440,37 +617,57 @@ __device__ __forceinline__ bool win_compact_body(const double *__restrict__ rx, 
 #pragma unroll
       for (int k = 0; k < 4; ++k) sel.range[d][k] = s_seld[d][k];
     }
-  } else if (fail) {
-    return true;
   }
-  unsigned mlo[2], mhi[2], a0[2], b1[2], i0[2], i1[2];
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
-    mlo[d] = (unsigned)s_rng[d][0];
-    mhi[d] = (unsigned)s_rng[d][1];
-    a0[d] = (unsigned)s_rng[d][2];
-    b1[d] = (unsigned)s_rng[d][3];
-    i0[d] = (unsigned)s_rng[d][4];
-    i1[d] = (unsigned)s_rng[d][5];
+    B.mlo[d] = (unsigned)s_rng[d][0];
+    B.mhi[d] = (unsigned)s_rng[d][1];
+    B.a0[d] = (unsigned)s_rng[d][2];
+    B.b1[d] = (unsigned)s_rng[d][3];
+    B.i0[d] = (unsigned)s_rng[d][4];
+    B.i1[d] = (unsigned)s_rng[d][5];
   }
+  return B;
+}
+
+template <bool LISTS, bool FINISH>
+__device__ __forceinline__ bool win_compact_body(const double *__restrict__ rx, const double *__restrict__ ry,
+                                                 unsigned n_local, unsigned n, const WinParams &P,
+                                                 const uint32_t *__restrict__ whist, WinState *st, double *wmed,
+                                                 double *wring, const unsigned *__restrict__ llen, unsigned lcap,
+                                                 WinSel &sel) {
+  __shared__ uint32_t cum[2 * kWinBins];  // points in lower bins
+  auto put = [](double *p, double v) {
+    if (FINISH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+  };
+  __shared__ double s_med[2][kWinBlkMed], s_ring[2][kWinBlkRing];
+  __shared__ unsigned s_cnt[4];
+  const int tid = threadIdx.x;
+#ifdef ICP_WIN_DEBUG
+  long long cst[6];
+  cst[0] = wall_clock64();
+  cst[1] = cst[0];
+#endif
+  if (tid < 4) s_cnt[tid] = 0;
+  const unsigned G = gridDim.x * kWinThreads;
+  const WinBins R = win_resolve<LISTS, FINISH>(whist, n, P, st, llen, lcap, cum, sel);
+#ifdef ICP_WIN_DEBUG
+  cst[2] = wall_clock64();
+#endif
+  const bool fail = R.fail;
+  if (!FINISH && fail) return true;
+  const unsigned(&mlo)[2] = R.mlo, (&mhi)[2] = R.mhi, (&a0)[2] = R.a0, (&b1)[2] = R.b1, (&i0)[2] = R.i0, (&i1)[2] = R.i1;
   const unsigned lim[2] = {LISTS ? llen[0] : n_local, LISTS ? llen[1] : n_local};
   const unsigned nmax = fail ? 0u : (lim[0] > lim[1] ? lim[0] : lim[1]);  // (a missed window: nothing to collect)
   const unsigned base0 = blockIdx.x * kWinThreads + tid;
   for (unsigned base = base0; base < nmax; base += G * kWinBatch) {
     double v[2][kWinBatch];
-    if (kPrefetch && base == base0) {
 #pragma unroll
-      for (int u = 0; u < kWinBatch; ++u) {
-        v[0][u] = pre[0][u];
-        v[1][u] = pre[1][u];
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < kWinBatch; ++u) {
-        const unsigned i = base + u * G;
-        if (i < lim[0]) v[0][u] = rx[i];
-        if (i < lim[1]) v[1][u] = ry[i];
-      }
+    for (int u = 0; u < kWinBatch; ++u) {
+      const unsigned i = base + u * G;
+      if (i < lim[0]) v[0][u] = rx[i];
+      if (i < lim[1]) v[1][u] = ry[i];
     }
 #pragma unroll
     for (int u = 0; u < kWinBatch; ++u) {
@@ -547,6 +744,37 @@ __global__ __launch_bounds__(kWinThreads) void k_win_compact(const double *__res
   win_compact_body<LISTS, false>(rx, ry, n_local, n, P, whist, st, wmed, wring, llen, lcap, sel);
 }
 
+
+// The run-ahead search (icp_estimate_device): this is the FIRST evaluation of an outer iteration (inner pose =
+// identity, prev_error = f64::MAX); if the inner loop applies this update and stops, the next outer pose is
+// Exp(delta) * identity * outer -- estimate_transform_loop's and icp_estimate_device's own operations, with the
+// functions the host uses (pose.hpp), so the host can check the bits.  The search behind this launch reads it.
+// (one thread of wave 0: ordered before the release in publish_folded)
+__device__ __forceinline__ void fill_ahead_pose(const double *s_tot, const double (&sig)[2], bool usable, const Pose &outer,
+                                                AheadPose *ahead, GnResult *res) {
+  AheadPose np;
+  np.valid = 0;
+  np.pad = 0;
+  np.T = outer;
+  if (usable) {
+    double acc[kNAcc], delta[3];
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k) acc[k] = combine_sum(s_tot, k, sig);
+    if (solve_update(acc, acc + 9, delta) &&
+        !((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD)) {
+      bool in_range;
+      const Pose step = transform_new_in_range(delta, &in_range);
+      if (in_range) {
+        const Pose inner = transform_mul(step, transform_identity());  // src/lib.rs:81
+        np.T = transform_mul(inner, outer);                            // src/lib.rs:127, 170
+        np.valid = 1;
+      }
+    }
+  }
+  *ahead = np;
+  res->next_pose = np.T;
+  res->next_valid = np.valid;
+}
 
 // C + the rest of the evaluation, for sums that were accumulated beside the histograms (k_win_hist_sums): the
 // workgroup that arrives last has every candidate of the launch in reach (write-through stores, sc1 loads), ranks
@@ -661,34 +889,7 @@ __global__ __launch_bounds__(kWinThreads) void k_win_finish(const double *__rest
   if (tid == 0 && fail) st->fail = 1u;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (ahead && tid == 0) {
-    // The run-ahead search (icp_estimate_device): this is the FIRST evaluation of an outer iteration (inner pose =
-    // identity, prev_error = f64::MAX); if the inner loop applies this update and stops, the next outer pose is
-    // Exp(delta) * identity * outer -- estimate_transform_loop's and icp_estimate_device's own operations, with the
-    // functions the host uses (pose.hpp), so the host can check the bits.  The search behind this launch reads it.
-    AheadPose np;
-    np.valid = 0;
-    np.pad = 0;
-    np.T = outer;
-    if (!fail && !nan_flag) {
-      double acc[kNAcc], delta[3];
-#pragma unroll
-      for (int k = 0; k < kNAcc; ++k) acc[k] = combine_sum(s_tot, k, sig);
-      if (solve_update(acc, acc + 9, delta) &&
-          !((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD)) {
-        bool in_range;
-        const Pose step = transform_new_in_range(delta, &in_range);
-        if (in_range) {
-          const Pose inner = transform_mul(step, transform_identity());  // src/lib.rs:81
-          np.T = transform_mul(inner, outer);                            // src/lib.rs:127, 170
-          np.valid = 1;
-        }
-      }
-    }
-    *ahead = np;
-    res->next_pose = np.T;  // (wave 0: ordered before the release in publish_folded)
-    res->next_valid = np.valid;
-  }
+  if (ahead && tid == 0) fill_ahead_pose(s_tot, sig, !fail && !nan_flag, outer, ahead, res);
 #ifdef ICP_WIN_DEBUG
   fst[5] = wall_clock64();
 #endif
@@ -701,6 +902,222 @@ __global__ __launch_bounds__(kWinThreads) void k_win_finish(const double *__rest
            gridDim.x, fst[1] - fst[0], fst[2] - fst[1], fst[3] - fst[2], fst[4] - fst[3], fst[5] - fst[4], fst[6] - fst[5],
            sel.med_cnt[0], sel.med_cnt[1], sel.ring_cnt[0], sel.ring_cnt[1]);
 #endif
+}
+
+// ---- P (round 5): the rest of an evaluation whose candidates are filed in the workgroups' segments ----------
+// ONE workgroup: the histograms -> the candidate bins (win_resolve) -> thread (w, d) reads the directory of segment w
+// for the (few) candidate bins of dimension d and lists its members of them -- (segment, position) words in LDS, the
+// order does not matter to a selection -- -> every thread loads the candidates of its slots straight into registers
+// -> the two exact selections -> the fold of the block sums (the tree's second stage, loaded before anything else)
+// -> the solve for the run-ahead search -> the result.  No ticket, no second pass: a chain of dependent steps on one
+// CU while the rest of the chip works on something else.
+struct PickLds {  // (the descriptor lists are dead when the selections start: their LDS is overlaid)
+  union {
+    struct {
+      uint32_t cum[2 * kWinBins];
+      uint32_t med[2][kWinCapMed], ring[2][kWinCapRing];
+    } g;
+    SelectLds<2> sel;
+  };
+};
+
+struct PickArgs {
+  unsigned n;
+  WinParams P;
+  uint32_t *whist;
+  WinState *st;
+  const double *seg_all;
+  const unsigned short *dir_all;
+  int segments;
+  GnScalars *scal;
+  const double *partials;
+  int sum_blocks;
+  GnResult *res;
+  unsigned seq;
+  AheadPose *ahead;
+  Pose outer;
+};
+
+// (by the workgroup with blockIdx.x == 0 of its launch: win_resolve leaves the state in `st` from there)
+__device__ __forceinline__ void win_pick_body(const PickArgs &A, PickLds &L) {
+  const unsigned n = A.n;
+  const WinParams &P = A.P;
+  uint32_t *const whist = A.whist;
+  WinState *const st = A.st;
+  const double *__restrict__ seg_all = A.seg_all;
+  const unsigned short *__restrict__ dir_all = A.dir_all;
+  const int segments = A.segments;
+  GnScalars *const scal = A.scal;
+  const double *const partials = A.partials;
+  const int sum_blocks = A.sum_blocks;
+  GnResult *const res = A.res;
+  const unsigned seq = A.seq;
+  AheadPose *const ahead = A.ahead;
+  const Pose outer = A.outer;
+  constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
+  static_assert(kReduceMaxBlocks * 2 == kReduceThreads, "one thread per segment and dimension");
+  static_assert(kBktStage <= (1 << 12), "descriptor: segment << 12 | position");
+  __shared__ double s_tot[kNSum + 1];
+  __shared__ unsigned s_cnt[4];
+  const unsigned tid = threadIdx.x;
+#ifdef ICP_WIN_DEBUG
+  long long pst[10];
+  pst[0] = wall_clock64();
+#define PSTAMP(k) pst[k] = wall_clock64()
+#else
+#define PSTAMP(k)
+#endif
+  if (tid < 4) s_cnt[tid] = 0;
+  WinSel sel;
+  const WinBins R = win_resolve<true, true>(whist, n, P, st, nullptr, 0u, L.g.cum, sel);
+  // (the block sums and the flags travel while the candidates are listed: the histograms went first)
+  double fx[kFoldH];
+  fold256_load(partials, sum_blocks, fx);
+  const int nan_flag = __hip_atomic_load(&scal->nan_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned stage_overflow = __hip_atomic_load(&st->stage_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  PSTAMP(1);
+  bool fail = R.fail;
+  bool bucket_miss = stage_overflow != 0;
+  double med[2] = {0., 0.}, sig[2] = {0., 0.};
+  {
+    // the runs of candidate bins of this thread's dimension, in directory order: the median's, the ring's two arcs
+    const unsigned w = tid & (unsigned)(kReduceMaxBlocks - 1), d = tid / (unsigned)kReduceMaxBlocks;
+    const bool usable = !fail && !bucket_miss;  // (uniform)
+    const unsigned len_m = usable ? R.mhi[d] - R.mlo[d] + 1u : 0u;
+    const unsigned len_a = usable ? R.i0[d] - R.a0[d] : 0u, len_b = usable ? R.b1[d] - R.i1[d] : 0u;
+    __syncthreads();  // (s_cnt's zeros)
+    if (usable && !bucket_miss && (int)w < segments) {
+      const unsigned short *dir = dir_all + (size_t)w * kBktDir;
+      const unsigned fm = word_to_fine(d, R.mlo[d]), fa = word_to_fine(d, R.a0[d]), fb = word_to_fine(d, R.i1[d] + 1u);
+      // (the members of a run of consecutive bins are contiguous in the segment: the run's first offset .. the offset
+      // behind its last bin -- six directory entries per thread, one trip)
+      const unsigned short q0 = dir[fm], q1 = dir[fm + len_m], q2 = dir[fa], q3 = dir[fa + len_a], q4 = dir[fb],
+                           q5 = dir[fb + len_b];
+      const unsigned m0 = q0, m_end = q1, a_beg = q2, a_end = q3, b_beg = q4, b_end = q5;
+      const unsigned cm = m_end - m0, cr = (a_end - a_beg) + (b_end - b_beg);
+      if (cm) {
+        const unsigned pos = atomicAdd(&s_cnt[d], cm);
+        for (unsigned k = 0; k < cm; ++k)
+          if (pos + k < (unsigned)kWinCapMed) L.g.med[d][pos + k] = (w << 12) | (m0 + k);
+      }
+      if (cr) {
+        unsigned pos = atomicAdd(&s_cnt[2 + d], cr);
+        for (unsigned k = a_beg; k < a_end; ++k, ++pos)
+          if (pos < (unsigned)kWinCapRing) L.g.ring[d][pos] = (w << 12) | k;
+        for (unsigned k = b_beg; k < b_end; ++k, ++pos)
+          if (pos < (unsigned)kWinCapRing) L.g.ring[d][pos] = (w << 12) | k;
+      }
+    }
+    __syncthreads();
+    PSTAMP(2);
+    // (the listed counts are cross-checked against the histogram: a mismatch is a miss)
+    if (usable && !bucket_miss)
+      bucket_miss = s_cnt[0] != sel.med_cnt[0] || s_cnt[1] != sel.med_cnt[1] || s_cnt[2] != sel.ring_cnt[0] ||
+                    s_cnt[3] != sel.ring_cnt[1];
+    double vm[2][PM], vr[2][PR];
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+#pragma unroll
+      for (int u = 0; u < PM; ++u) {
+        const unsigned e = tid + u * kReduceThreads;
+        vm[dd][u] = 0.;
+        if (usable && !bucket_miss && e < sel.med_cnt[dd]) {
+          const uint32_t x = L.g.med[dd][e];
+          vm[dd][u] = seg_all[(size_t)(x >> 12) * kBktStage + (x & 0xfffu)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PR; ++u) {
+        const unsigned e = tid + u * kReduceThreads;
+        vr[dd][u] = 0.;
+        if (usable && !bucket_miss && e < sel.ring_cnt[dd]) {
+          const uint32_t x = L.g.ring[dd][e];
+          vr[dd][u] = seg_all[(size_t)(x >> 12) * kBktStage + (x & 0xfffu)];
+        }
+      }
+    }
+    // the histograms of the next evaluation start from zero (write-through, drained before the release below: the
+    // host may hand the next evaluation to the handle's other stream as soon as it sees this result)
+    for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads)
+      __hip_atomic_store(&whist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && stage_overflow) __hip_atomic_store(&st->stage_overflow, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fold256_reduce(fx, sum_blocks, s_tot);  // (a barrier inside)
+    __syncthreads();                        // (the descriptor lists are read: the selections may overlay them)
+    PSTAMP(3);
+    const unsigned klo = (n - 1) / 2, khi = n / 2;
+    if (!fail && !bucket_miss) {
+      unsigned long long key[2][2];
+      const double m_lo[2] = {sel.range[0][0], sel.range[1][0]}, m_hi[2] = {sel.range[0][1], sel.range[1][1]};
+      const long long mlo[2] = {(long long)klo - sel.med_base[0], (long long)klo - sel.med_base[1]};
+      const long long mhi[2] = {(long long)khi - sel.med_base[0], (long long)khi - sel.med_base[1]};
+      select_n_lds<2, PM>(vm, sel.med_cnt, m_lo, m_hi, mlo, mhi, key, fail, L.sel);
+      PSTAMP(4);
+      if (!fail) {
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+          med[dd] = middle_of(n, key[dd][0], key[dd][1]);
+#pragma unroll
+          for (int u = 0; u < PR; ++u) vr[dd][u] = fabs(vr[dd][u] - med[dd]);  // src/stats.rs:35
+        }
+        const double r_lo[2] = {sel.range[0][2], sel.range[1][2]}, r_hi[2] = {sel.range[0][3], sel.range[1][3]};
+        const long long dlo[2] = {(long long)klo - sel.inner[0], (long long)klo - sel.inner[1]};
+        const long long dhi[2] = {(long long)khi - sel.inner[0], (long long)khi - sel.inner[1]};
+        select_n_lds<2, PR>(vr, sel.ring_cnt, r_lo, r_hi, dlo, dhi, key, fail, L.sel);
+        PSTAMP(5);
+        if (!fail) {
+          sig[0] = ICP_PPF34 * middle_of(n, key[0][0], key[0][1]);  // src/stats.rs:42-46
+          sig[1] = ICP_PPF34 * middle_of(n, key[1][0], key[1][1]);
+        } else {
+          med[0] = med[1] = 0.;
+        }
+      }
+    }
+  }
+  const bool missed = fail || bucket_miss;
+  if (tid == 0 && missed) st->fail = 1u;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  PSTAMP(6);
+  if (ahead && tid == 0) fill_ahead_pose(s_tot, sig, !missed && !nan_flag, outer, ahead, res);
+  PSTAMP(7);
+  // overflow 3: the window may have been right, the FILES were not usable (the host steps back to the second pass)
+  publish_folded(s_tot, res, seq, sig, med, nan_flag, missed ? (fail ? 2 : 3) : 0);
+#ifdef ICP_WIN_DEBUG
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PSTAMP(8);
+  if (tid == 0 && seq % 16 == 5)
+    printf("[P] resolve %lld list %lld load+fold %lld sel1 %lld sel2 %lld drain %lld ahead %lld publish %lld (x10ns) cnt %u %u %u %u\n",
+           pst[1] - pst[0], pst[2] - pst[1], pst[3] - pst[2], pst[4] - pst[3], pst[5] - pst[4], pst[6] - pst[5],
+           pst[7] - pst[6], pst[8] - pst[7], sel.med_cnt[0], sel.med_cnt[1], sel.ring_cnt[0], sel.ring_cnt[1]);
+#endif
+#undef PSTAMP
+}
+
+__global__ __launch_bounds__(kReduceThreads) void k_win_pick(PickArgs A) {
+  __shared__ PickLds L;
+  win_pick_body(A, L);
+}
+
+// Two evaluations side by side (icp_estimate_device with a bet in flight: the next outer iteration's first evaluation
+// and the deciding evaluation of the current one): ONE launch files the candidates of both (2 B workgroups: two per
+// CU, four waves per SIMD instead of two hide each other's latencies), ONE launch of two workgroups finishes both.
+// The deciding evaluation then neither shares the CUs with the search nor needs a stream of its own.
+union EvalLds {
+  PickLds pick;
+  HistBktLds hist;
+};
+__global__ __launch_bounds__(kWinThreads) void k_win_hist_sums_bkt2(HistBktArgs A, HistBktArgs B) {
+  __shared__ HistBktLds S;
+  const unsigned half = gridDim.x >> 1;
+  if (blockIdx.x < half) win_hist_sums_bkt_body(A, blockIdx.x, half, S);
+  else win_hist_sums_bkt_body(B, blockIdx.x - half, half, S);
+}
+// (win_resolve leaves the state in `st` from the workgroup with blockIdx.x == 0: the second evaluation's `st` is not
+// maintained -- nothing reads it on this path)
+__global__ __launch_bounds__(kReduceThreads) void k_win_pick2(PickArgs A, PickArgs B) {
+  __shared__ PickLds L;
+  if (blockIdx.x == 0) win_pick_body(A, L);
+  else win_pick_body(B, L);
 }
 
 // The order statistics of one evaluation from its candidate lists, one workgroup per dimension
@@ -1047,6 +1464,79 @@ double window_half_width(size_t n, bool wide) {
 
 bool make_window(const double med[2], const double sigma[2], double f, WinParams *P) { return make_window_hd(med, sigma, f, P); }
 
+// ---- filed candidates: host side ------------------------------------------------------
+static unsigned HA_blocks(size_t n) {
+  int blocks, threads;
+  reduce_geometry(n, &blocks, &threads);
+  return (unsigned)blocks;
+}
+// Can a workgroup stage its fine-window members?  Their expected number under a bell is 1.04 (x[1] - x[0]) / sigma of
+// its points per dimension; a factor two to spare.  (Wider windows -- after a miss -- and handles whose files were not
+// usable recently take the second pass over the points: Workspace::bkt_off.)
+bool bkt_fits(size_t n, const WinParams &P) {
+  double frac = 0.;
+  for (int d = 0; d < 2; ++d) {
+    const WinDim &D = P.d[d];
+    const double mad = 0.5 * ((D.x[4] + D.x[5]) - (D.x[2] + D.x[3]));
+    frac += 1.04 * (D.x[1] - D.x[0]) / (ICP_PPF34 * mad);
+  }
+  return 2. * frac * ((double)n / HA_blocks(n)) <= (double)kBktStage;
+}
+static HistBktArgs bkt_hist_args(GnCtx &c, const double2 *a, const double2 *b, const Pose &T, unsigned n, const WinParams &P) {
+  HistBktArgs A;
+  A.a = a;
+  A.b = b;
+  A.T = T;
+  A.n = n;
+  A.P = P;
+  A.whist = c.d_whist;
+  A.st = c.d_wstate;
+  A.scal = c.d_scal;
+  A.partials = c.d_partials;
+  A.seg_all = c.d_bkt;
+  A.dir_all = c.d_bkt_dir;
+  return A;
+}
+static PickArgs bkt_pick_args(GnCtx &c, unsigned n, const WinParams &P, bool ahead_on, const Pose &ahead_outer,
+                              AheadPose *d_ahead = nullptr) {
+  PickArgs A;
+  A.n = n;
+  A.P = P;
+  A.whist = c.d_whist;
+  A.st = c.d_wstate;
+  A.seg_all = c.d_bkt;
+  A.dir_all = c.d_bkt_dir;
+  A.segments = (int)HA_blocks(n);
+  A.scal = c.d_scal;
+  A.partials = c.d_partials;
+  A.sum_blocks = A.segments;
+  A.res = c.h_res;
+  A.seq = ++c.seq;
+  A.ahead = ahead_on ? d_ahead : nullptr;
+  A.outer = ahead_on ? ahead_outer : transform_identity();
+  return A;
+}
+
+// Two evaluations in two launches on ONE stream (icp_estimate_device, a bet in flight): `first` -- the next outer
+// iteration's first evaluation, on pairs a1 / b1 at the identity -- and `second`, the deciding evaluation of the current
+// iteration (pairs a2 / b2 at T2).  Both results are released by the second launch (second.bkt_pair_launched says so:
+// wgn_step only waits for it).
+hipError_t launch_bkt_pair(icp_handle *h, hipStream_t s, GnCtx &first, const double *a1, const double *b1, const WinParams &P1,
+                           bool ahead_on, const Pose &ahead_outer, GnCtx &second, const double *a2, const double *b2,
+                           const Pose &T2, const WinParams &P2, size_t n_) {
+  Workspace &w = h->ws;
+  const unsigned n = (unsigned)n_, blocks = HA_blocks(n_);
+  w.bkt_evals += 2;
+  hipLaunchKernelGGL(k_win_hist_sums_bkt2, dim3(2 * blocks), dim3(kWinThreads), 0, s,
+                     bkt_hist_args(first, (const double2 *)a1, (const double2 *)b1, transform_identity(), n, P1),
+                     bkt_hist_args(second, (const double2 *)a2, (const double2 *)b2, T2, n, P2));
+  hipLaunchKernelGGL(k_win_pick2, dim3(2), dim3(kReduceThreads), 0, s,
+                     bkt_pick_args(first, n, P1, ahead_on, ahead_outer, w.d_ahead),
+                     bkt_pick_args(second, n, P2, false, transform_identity()));
+  second.bkt_pair_launched = true;
+  return hipGetLastError();
+}
+
 hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double *d_b, size_t n_, const Pose &T,
                                   const WinParams &P) {
   Workspace &w = h->ws;
@@ -1076,6 +1566,18 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
   static const int fuse_mode = exp_env("ICP_WIN_FUSE_MODE") ? atoi(exp_env("ICP_WIN_FUSE_MODE")) : 2;
   const bool on_eval_stream = w.spec_stream && s == w.spec_stream;
   const bool beside_search = on_eval_stream && w.search_beside_eval;
+  // Round 5: candidates filed by the first launch, the second is ONE workgroup (k_win_hist_sums_bkt / k_win_pick)
+  // wherever bkt_usable says so.  ICP_WIN_BKT (experiments): 0 = never, 1 = wherever it fits (default), 2 = not beside
+  // a search, 3 = only there.
+  static const int bkt_mode = exp_env("ICP_WIN_BKT") ? atoi(exp_env("ICP_WIN_BKT")) : 1;
+  if (w.bkt_off > 0) --w.bkt_off;
+  else if ((bkt_mode == 1 || (bkt_mode == 2 && !beside_search) || (bkt_mode == 3 && beside_search)) && bkt_fits(n_, P)) {
+    ++w.bkt_evals;
+    const HistBktArgs HA = bkt_hist_args(w, a, b, T, n, P);
+    hipLaunchKernelGGL(k_win_hist_sums_bkt, dim3(HA_blocks(n_)), dim3(kWinThreads), 0, s, HA);
+    hipLaunchKernelGGL(k_win_pick, dim3(1), dim3(kReduceThreads), 0, s, bkt_pick_args(w, n, P, w.ahead_on, w.ahead_outer, w.d_ahead));
+    return hipGetLastError();
+  }
   if (!no_fuse && (fuse_mode == 1 || (fuse_mode == 2 && !beside_search) || (fuse_mode == 3 && beside_search) ||
                    (fuse_mode == 4 && !on_eval_stream))) {
     int blocks, threads;

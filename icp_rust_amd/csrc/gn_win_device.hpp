@@ -56,6 +56,12 @@ __device__ __forceinline__ unsigned wbin_cold(double r, const WinDim &w) {
   return r >= w.x[5] ? (unsigned)(kWinBins - 1) : j;
 }
 
+// is regular bin j one of the three fine windows' (where every candidate of a window that holds lies)?
+__device__ __forceinline__ bool fine_bin(unsigned j) {
+  return (j - (unsigned)kF0 < (unsigned)kWinFine) | (j - (unsigned)kF1 < (unsigned)kWinFine) |
+         (j - (unsigned)kF2 < (unsigned)kWinFine);
+}
+
 // lower edge of regular bin j (1 <= j <= kWinBins-1; the upper edge of j is the lower edge of j+1)
 __device__ __forceinline__ double wedge(int j, const WinDim &w) {
   if (j >= kWinBins - 1) return w.x[5];
@@ -116,13 +122,21 @@ struct WinGeom {  // what both halves of the bracket search need, per dimension
 };
 
 // bins of the two middle ranks and the median's interval
-__device__ __forceinline__ WinGeom window_geometry(const uint32_t *c, unsigned n, const WinDim &w) {
+// (jlo_known / jhi_known >= 0: the bins that hold ranks (n - 1) / 2 and n / 2, found by whoever made the cumulative
+// counts -- the thread whose bin contains the rank -- instead of by two searches over them)
+__device__ __forceinline__ WinGeom window_geometry(const uint32_t *c, unsigned n, const WinDim &w, int jlo_known = -1,
+                                                   int jhi_known = -1) {
   auto C = [&](int j) -> unsigned { return j >= kWinBins ? n : c[j]; };  // points in bins < j
   const unsigned klo = (n - 1) / 2, khi = n / 2;                          // src/stats.rs:18-27
   WinGeom g;
-  g.jlo = wave_last_true(0, kWinBins - 1, [&](int j) { return c[j] <= klo; });
-  // khi is klo or klo + 1: almost always the same bin
-  g.jhi = (C(g.jlo + 1) > khi) ? g.jlo : wave_last_true(0, kWinBins - 1, [&](int j) { return c[j] <= khi; });
+  if (jlo_known >= 0 && jhi_known >= 0) {
+    g.jlo = jlo_known;
+    g.jhi = jhi_known;
+  } else {
+    g.jlo = wave_last_true(0, kWinBins - 1, [&](int j) { return c[j] <= klo; });
+    // khi is klo or klo + 1: almost always the same bin
+    g.jhi = (C(g.jlo + 1) > khi) ? g.jlo : wave_last_true(0, kWinBins - 1, [&](int j) { return c[j] <= khi; });
+  }
   g.ok = !(g.jlo < 1 || g.jhi > kWinBins - 2);  // else: a middle rank outside the windows
   g.mL = g.ok ? wedge(g.jlo, w) : 0.;
   g.mU = g.ok ? wedge(g.jhi + 1, w) : 0.;
@@ -238,7 +252,7 @@ struct SelectLds {  // the LDS a selection works in (a caller that is short of L
   unsigned nsmall[ND], sb[ND][2], below[ND];
 };
 
-template <int ND, int NV>
+template <int ND, int NV, int DIRECT = ICP_SELECT_DIRECT>
 __device__ __forceinline__ void select_n_lds(const double (&v)[ND][NV], const unsigned (&cnt)[ND],
                                              const double (&lo)[ND], const double (&hi)[ND],
                                              const long long (&rlo)[ND], const long long (&rhi)[ND],
@@ -260,7 +274,8 @@ __device__ __forceinline__ void select_n_lds(const double (&v)[ND][NV], const un
   if (fail) return;  // uniform
   // a handful of candidates (clouds of tens of thousands of points: a fine bin holds one or two): rank
   // them against each other directly -- two barriers instead of the sub-bin machinery's seven
-  constexpr unsigned kDirect = ICP_SELECT_DIRECT;
+  constexpr unsigned kDirect = DIRECT;
+  static_assert(DIRECT <= kReduceThreads && DIRECT <= kSmallCap, "one candidate per thread");
   bool direct = true;
 #pragma unroll
   for (int d = 0; d < ND; ++d) direct = direct && cnt[d] <= kDirect;
