@@ -153,6 +153,74 @@ def gn_large(npts):
                     "prices them, selection passes not counted"}
 
 
+def nn_large(npts, warm_searches=6):
+    """the SEARCH kernel alone where HBM bandwidth is what it runs against -- N = M = `npts`
+    (default 16M: target cloud + grid records + cell table + source snapshot are ~1.3 GB, five times the 256 MiB
+    Infinity Cache; at the headline's 1M x 1M the same structures are 90 MB and sit in it).  Two estimate calls on
+    device-generated clouds of the benchmark's shape -- one outer iteration (the seeded first search only) and
+    1 + `warm_searches` -- timed by the library's HIP events around every search launch; their difference is the warm
+    searches, the kernel of the headline's roofline line.  Bytes per launch as SURVEY prices them: 28 N + 24 M."""
+    import torch
+    import icp_rust_amd as I
+
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    lo = torch.tensor([-40.0, -40.0, -2.0], dtype=torch.float64, device="cuda")
+    hi = torch.tensor([40.0, 40.0, 6.0], dtype=torch.float64, device="cuda")
+    # the box of the 1M pair scaled to keep its point density (2 targets per grid cell either way)
+    scale = (npts / 1.0e6) ** (1.0 / 3.0)
+    lo, hi = lo * scale, hi * scale
+
+    def cloud(n):  # 70 % on the six faces of the box, 30 % inside it (synth.box_cloud, on the device)
+        u = torch.rand((n, 4), dtype=torch.float64, device="cuda", generator=g)
+        p = lo + u[:, 1:4] * (hi - lo)
+        ext = hi - lo
+        areas = torch.stack([ext[0] * ext[1]] * 2 + [ext[1] * ext[2]] * 2 + [ext[0] * ext[2]] * 2)  # +-z, +-x, +-y
+        cum = torch.cumsum(areas, 0) / areas.sum()
+        face = torch.searchsorted(cum, ((u[:, 0] - 0.3) / 0.7).clamp(0.0, 1.0).contiguous(), right=True).clamp(0, 5)
+        on_face = u[:, 0] >= 0.3
+        axis = torch.tensor([2, 2, 0, 0, 1, 1], device="cuda")[face]
+        side = torch.tensor([0, 1, 0, 1, 0, 1], device="cuda")[face]
+        val = torch.where(side == 1, hi[axis], lo[axis])
+        rows = torch.nonzero(on_face).squeeze(1)
+        p[rows, axis[rows]] = val[rows]
+        return p.contiguous()
+
+    dst = cloud(npts)
+    src = cloud(npts)
+    c, s_ = np.cos(0.015), np.sin(0.015)  # moved by the inverse of the truth pose of the 1M pair, + noise
+    x, y = src[:, 0] - 0.3, src[:, 1] + 0.2
+    src[:, 0] = c * x + s_ * y
+    src[:, 1] = -s_ * x + c * y
+    src += torch.randn((npts, 3), dtype=torch.float64, device="cuda", generator=g) * 0.01
+    icp = I.Icp3d(dst)
+    icp.estimate(src, I.Transform(), 2)  # warm-up: allocations, first touch
+    icp.profile_enable(1)
+    icp.profile_read()
+    icp.estimate(src, I.Transform(), 1)
+    ms1, k1 = icp.profile_read()
+    _, _, inner = icp.estimate(src, I.Transform(), 1 + warm_searches, return_info=True)
+    ms2, k2 = icp.profile_read()
+    icp.profile_enable(0)
+    engine = {I.NN_BRUTE: "brute", I.NN_GRID: "grid"}.get(I.lib().icp_get_nn_mode(icp._h), "?")
+    icp.close()
+    launches = int(k2 - k1)
+    per = 1e-3 * (ms2 - ms1) / max(launches, 1)
+    nn_bytes = 52.0 * npts
+    gbs = nn_bytes / per / 1e9 if per > 0 else 0.0
+    traffic, tf_src = None, None
+    tf_path = os.path.join(ROOT, "profiles", "r05_traffic_pmc_nn_large.json")
+    if os.path.exists(tf_path) and npts == 16 * 1024 * 1024:
+        traffic = json.load(open(tf_path))["k_nn_grid"]["traffic_bytes_per_launch"]
+        tf_src = "profiles/r05_traffic_pmc_nn_large.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/nn_large_only.py)"
+    return {"points": npts, "kernel": "k_nn_grid_warm_coop", "warm_searches": launches, "first_search_ms": ms1 / max(k1, 1),
+            "ms_per_search": 1e3 * per, "algorithmic_bytes_per_launch": nn_bytes, "achieved_GBs": gbs, "peak_GBs": HBM_PEAK_GBS,
+            "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tf_src,
+            "traffic_ratio": None if not traffic else traffic / nn_bytes, "inner_iterations": [int(v) for v in inner],
+            "engine": engine,
+            "note": "the search kernel alone on clouds past the 256 MiB Infinity Cache (SURVEY 8(d)(ii)): target records, "
+                    "cell table and source snapshot stream from HBM; timed by HIP events around each launch inside estimate()"}
+
+
 def converging(calls, n, m, nn_mode):
     """Side line: the same 1M x 1M size on a pair that CONVERGES, in the regime of the reference's
     real scans (synth.converging_pair: millimetre coordinates, re-observed points + clutter), where the inner
@@ -294,6 +362,8 @@ def main():
                          "value = K / the MEDIAN region (a 3 ms region alone is +-3 % run to run)")
     ap.add_argument("--rotating-calls", type=int, default=9,
                     help="estimate(20) calls of the rotating-inputs side line: three different clouds / poses alternating (0 = skip)")
+    ap.add_argument("--nn-points", type=int, default=16 * 1024 * 1024,
+                    help="points of each cloud of the `nn_large` line: the search kernel past the Infinity Cache (0: skip)")
     ap.add_argument("--gn-points", type=int, default=64 * 1024 * 1024,
                     help="pairs of the separate 'reduce kernels alone, past the Infinity Cache' line (0 = skip)")
     args = ap.parse_args()
@@ -379,18 +449,31 @@ def main():
             # of it, then the iterations -- all inside the timed region, like the one-GPU call's snapshot
             loop_state["mode"] = "stage calls + collectives (ICP_DIST_NO_LOOP=1)"
             if os.environ.get("ICP_DIST_NO_LOOP") != "1":
-                ok, why = 1, ""
+                ok, why, transport = 1, "", None
                 try:
-                    driver.connect_loop()
-                    T, _, _ = driver.estimate_full(full, T, max(warmup, 2))  # (also seeds the window predictions)
+                    # the first transport whose ping-pong probe passes on every rank: device memory through hipIpc for
+                    # ranks that share a device, fine-grained device memory through hipIpc, pinned host memory in a
+                    # shared-memory object (dist.BlockShardedIcp.connect_loop); none: the stage calls serve
+                    transport = driver.connect_loop()
+                    if transport is None:
+                        ok, why = 0, "no transport passed the ping-pong probe"
+                    else:
+                        T, _, _ = driver.estimate_full(full, T, max(warmup, 2))  # (also seeds the window predictions)
+                        if driver.counters.get("loop_gave_up", 0):
+                            ok, why = 0, "a launch gave up waiting for a peer"
                 except Exception as e:  # noqa: BLE001
                     ok, why = 0, repr(e)
                 flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag.item()) == 1:
-                    loop_state["mode"] = "one launch per rank and inner loop, hipIpc inboxes"
+                    loop_state["mode"] = f"one launch per rank and inner loop, inboxes: {transport}"
+                    loop_state["transport"] = transport
                 else:
                     loop_state["mode"] = "stage calls + collectives (the one-launch path failed its probation: " + (why or "on another rank") + ")"
+                    try:
+                        driver.disconnect_loop()
+                    except Exception:  # noqa: BLE001
+                        pass
                     icp.close()
                     icp = I.Icp3d(d_dst, device=local_rank, nn_mode=mode)
                     driver = BlockShardedIcp({rank: HipStages(icp)}, n_run, world, comm)
@@ -471,6 +554,8 @@ def main():
             k_last = min(MAX_ITER, steps)
             checked = (icp.estimate(d_src, I.Transform(), k_last, return_info=True), k_last, icp.last_fold_order(n))
         counters = dict(driver.counters) if block else None
+        if block and getattr(driver, "_loop", None) is not None:
+            driver.disconnect_loop()  # (the peers' mappings go back before any rank pools its handle)
         icp.close()
         return dict(elapsed=elapsed, regions=regions, steps=steps, inner=inner, nn_ms=nn_ms, nn_launches=nn_launches, T=T,
                     engine=engine, alone_ms=alone_ms, checked=checked, counters=counters, n_run=n_run)
@@ -573,7 +658,9 @@ def main():
             "pose_abs_err_vs_truth": float(np.max(np.abs(T.as_array() - truth))),
         }
         if res.get("counters"):
-            out["sharded_evaluations"] = dict(res["counters"], inner_loops=loop_state["mode"])
+            out["sharded_evaluations"] = dict(res["counters"], inner_loops=loop_state["mode"], transport=loop_state.get("transport"),
+                                              rccl_world=dist.get_world_size() if dist.is_initialized() else 1,
+                                              backend=dist.get_backend() if dist.is_initialized() else None)
         if brute is not None:
             out["brute_force"] = {
                 "value": brute["steps"] / brute["elapsed"], "unit": "iterations/s", "steps": brute["steps"],
@@ -596,6 +683,8 @@ def main():
             out["converging_pair"] = converging(args.converging_calls, n, m, nn_mode)
         if world == 1 and args.gn_points > 0:
             out["gn_large"] = gn_large(args.gn_points)
+        if world == 1 and args.nn_points > 0 and nn_mode != I.NN_BRUTE:
+            out["nn_large"] = nn_large(args.nn_points)
         if world == 1 and args.cpu_iters > 0:
             par = None
             if res["checked"] is not None:

@@ -120,6 +120,12 @@ SIGNATURES = {
     "icp_loop_inbox_ipc_handle": (C.c_int, [_vp, C.c_char_p]),
     "icp_loop_ipc_open": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "icp_loop_ipc_close": (C.c_int, [_vp]),
+    "icp_loop_inbox_shm_name": (C.c_int, [_vp, C.c_char_p]),
+    "icp_loop_inbox_shm_unlink": (C.c_int, [_vp]),
+    "icp_loop_shm_open": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "icp_loop_shm_close": (C.c_int, [_vp]),
+    "icp_loop_transport_probe": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    "icp_reset_window_predictions": (C.c_int, [_vp]),
     "icp_shard_loop_connect": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "icp_shard_loop_launch_device": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint, C.c_uint, C.c_int, C.c_uint32, _pp, C.c_double,
                                                C.c_int, C.c_int]),

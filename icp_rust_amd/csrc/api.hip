@@ -4,11 +4,16 @@
 // gn.hip.  Nothing here falls back to a CPU computation: without a HIP device every
 // compute entry point fails with ICP_NO_DEVICE.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <cfloat>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <map>
 #include <mutex>
 #include <new>
 
@@ -24,6 +29,7 @@ hipError_t launch_stddevs(icp_handle *h, const double *d_a, const double *d_b, s
 
 struct LoopPlan;
 static void free_loop_plan(void *p);
+static void free_loop_inbox_fwd(icp::Workspace &w);
 
 namespace {
 
@@ -97,7 +103,7 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_rlist_len);
   (void)hipFree(w.d_part_d);
   (void)hipFree(w.d_part_i);
-  (void)hipFree(w.d_loop_inbox);
+  free_loop_inbox_fwd(w);
   free_loop_plan(w.loop_plan);
   (void)hipFree(w.d_loop_ctl);
   (void)hipFree(w.d_loop_hist);
@@ -1061,28 +1067,132 @@ static int gn_loop_run(icp_handle *h, const double *d_a, const double *d_b, size
 }
 
 static void free_loop_plan(void *p) { delete reinterpret_cast<LoopPlan *>(p); }
+static void free_loop_inbox(Workspace &w);
+static void free_loop_inbox_fwd(icp::Workspace &w) { free_loop_inbox(w); }
 
 // ---- ... and over the ranks of a sharded registration (include/icp_mi355x.h section 5b) ---------------------------------
 extern "C" size_t icp_loop_inbox_bytes(void) { return sizeof(LoopInbox); }
 
-extern "C" int icp_loop_inbox(icp_handle *h, int fine_grained, void **d_inbox) {
-  if (!h || !d_inbox) return ICP_BAD_ARGUMENT;
+// (the inbox of a handle, whatever it is made of, released)
+static void free_loop_inbox(Workspace &w) {
+  if (!w.d_loop_inbox) return;
+  if (w.loop_inbox_kind == ICP_INBOX_HOST) {
+    (void)hipHostUnregister(w.loop_inbox_host);
+    (void)munmap(w.loop_inbox_host, sizeof(LoopInbox));
+    if (w.loop_shm_name[0]) (void)shm_unlink(w.loop_shm_name);
+    w.loop_shm_name[0] = 0;
+    w.loop_inbox_host = nullptr;
+  } else {
+    (void)hipFree(w.d_loop_inbox);
+  }
+  w.d_loop_inbox = nullptr;
+}
+
+// kind (include/icp_mi355x.h: ICP_INBOX_*): what the inbox is made of -- ordinary device memory (ranks on ONE device:
+// virtual ranks, processes sharing a GPU), fine-grained device memory (peer devices write it while this device's
+// kernels poll it), or pinned host memory in a POSIX shared-memory object that every process of the node can map and
+// register (coherent by construction; the exchange then crosses the host link instead of xGMI).
+extern "C" int icp_loop_inbox(icp_handle *h, int kind, void **d_inbox) {
+  if (!h || !d_inbox || kind < ICP_INBOX_DEVICE || kind > ICP_INBOX_HOST) return ICP_BAD_ARGUMENT;
   Workspace &w = h->ws;
   HIP_TRY(hipSetDevice(h->device));
-  if (w.d_loop_inbox && w.loop_inbox_fine != (fine_grained != 0)) {
+  if (w.d_loop_inbox && w.loop_inbox_kind != kind) {
     HIP_TRY(hipStreamSynchronize(h->stream));
-    (void)hipFree(w.d_loop_inbox);
-    w.d_loop_inbox = nullptr;
+    free_loop_inbox(w);
   }
   if (!w.d_loop_inbox) {
-    // memory a peer DEVICE writes while this device's kernels poll it must be fine-grained; ranks on one device
-    // (virtual ranks, or processes sharing a GPU through hipIpc) use ordinary device memory
-    if (fine_grained) HIP_TRY(hipExtMallocWithFlags(&w.d_loop_inbox, sizeof(LoopInbox), hipDeviceMallocFinegrained));
-    else HIP_TRY(hipMalloc(&w.d_loop_inbox, sizeof(LoopInbox)));
-    w.loop_inbox_fine = fine_grained != 0;
-    HIP_TRY(hipMemset(w.d_loop_inbox, 0, sizeof(LoopInbox)));
+    if (kind == ICP_INBOX_HOST) {
+      static std::atomic<unsigned> serial{0};
+      snprintf(w.loop_shm_name, sizeof(w.loop_shm_name), "/icp_inbox_%d_%u", (int)getpid(), serial.fetch_add(1u));
+      const int fd = shm_open(w.loop_shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0) {
+        w.loop_shm_name[0] = 0;
+        return ICP_HIP_ERROR;
+      }
+      void *p = MAP_FAILED;
+      if (ftruncate(fd, (off_t)sizeof(LoopInbox)) == 0) p = mmap(nullptr, sizeof(LoopInbox), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      (void)close(fd);
+      void *d = nullptr;
+      if (p == MAP_FAILED || hipHostRegister(p, sizeof(LoopInbox), hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
+        if (p != MAP_FAILED) (void)munmap(p, sizeof(LoopInbox));
+        (void)shm_unlink(w.loop_shm_name);
+        w.loop_shm_name[0] = 0;
+        (void)hipGetLastError();
+        return ICP_HIP_ERROR;
+      }
+      if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) {
+        (void)hipHostUnregister(p);
+        (void)munmap(p, sizeof(LoopInbox));
+        (void)shm_unlink(w.loop_shm_name);
+        w.loop_shm_name[0] = 0;
+        (void)hipGetLastError();
+        return ICP_HIP_ERROR;
+      }
+      memset(p, 0, sizeof(LoopInbox));
+      w.loop_inbox_host = p;
+      w.d_loop_inbox = d;
+    } else {
+      if (kind == ICP_INBOX_FINE) HIP_TRY(hipExtMallocWithFlags(&w.d_loop_inbox, sizeof(LoopInbox), hipDeviceMallocFinegrained));
+      else HIP_TRY(hipMalloc(&w.d_loop_inbox, sizeof(LoopInbox)));
+      HIP_TRY(hipMemset(w.d_loop_inbox, 0, sizeof(LoopInbox)));
+    }
+    w.loop_inbox_kind = kind;
   }
   *d_inbox = w.d_loop_inbox;
+  return ICP_OK;
+}
+
+// ICP_INBOX_HOST: the name of the shared-memory object behind this handle's inbox (what a peer process hands to
+// icp_loop_shm_open), and its removal from the name space once every peer has opened it (the mappings live on)
+extern "C" int icp_loop_inbox_shm_name(icp_handle *h, char out[64]) {
+  if (!h || !out || !h->ws.d_loop_inbox || h->ws.loop_inbox_kind != ICP_INBOX_HOST) return ICP_BAD_ARGUMENT;
+  memcpy(out, h->ws.loop_shm_name, 64);
+  return ICP_OK;
+}
+extern "C" int icp_loop_inbox_shm_unlink(icp_handle *h) {
+  if (!h) return ICP_BAD_ARGUMENT;
+  if (h->ws.loop_shm_name[0]) (void)shm_unlink(h->ws.loop_shm_name);
+  h->ws.loop_shm_name[0] = 0;
+  return ICP_OK;
+}
+namespace {
+std::mutex g_shm_mu;
+std::map<void *, void *> g_shm_maps;  // device pointer -> host mapping of a peer's inbox opened here
+}  // namespace
+extern "C" int icp_loop_shm_open(int device, const char *name, void **d_ptr) {
+  if (!name || !d_ptr) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(device));
+  const int fd = shm_open(name, O_RDWR, 0600);
+  if (fd < 0) return ICP_HIP_ERROR;
+  void *p = mmap(nullptr, sizeof(LoopInbox), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  (void)close(fd);
+  if (p == MAP_FAILED) return ICP_HIP_ERROR;
+  void *d = nullptr;
+  if (hipHostRegister(p, sizeof(LoopInbox), hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess ||
+      hipHostGetDevicePointer(&d, p, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostUnregister(p);
+    (void)hipGetLastError();
+    (void)munmap(p, sizeof(LoopInbox));
+    return ICP_HIP_ERROR;
+  }
+  std::lock_guard<std::mutex> lk(g_shm_mu);
+  g_shm_maps[d] = p;
+  *d_ptr = d;
+  return ICP_OK;
+}
+extern "C" int icp_loop_shm_close(void *d_ptr) {
+  if (!d_ptr) return ICP_OK;
+  void *p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_shm_mu);
+    auto it = g_shm_maps.find(d_ptr);
+    if (it == g_shm_maps.end()) return ICP_BAD_ARGUMENT;
+    p = it->second;
+    g_shm_maps.erase(it);
+  }
+  (void)hipHostUnregister(p);
+  (void)munmap(p, sizeof(LoopInbox));
   return ICP_OK;
 }
 
@@ -1127,6 +1237,42 @@ extern "C" int icp_shard_loop_connect(icp_handle *h, int rank, int world, void *
   HIP_TRY(ensure_loop(h));  // (the pinned result block)
   w.loop_seq = 0;           // launch numbers restart with the connection
   memset(w.h_loop_res, 0, sizeof(LoopResult));
+  return ICP_OK;
+}
+
+// Ping-pong over the connected inboxes (gn_loop.hip: k_loop_probe): collective -- every rank calls it at about the same
+// time (a barrier of the driver in front); *ok = 1 when this rank saw every token of every peer.  A transport whose
+// probe fails on ANY rank must not carry the loop (the driver agrees on that and tries the next one).
+extern "C" int icp_loop_transport_probe(icp_handle *h, int rounds, int *ok) {
+  if (!h || !ok || rounds < 1 || rounds > 1024) return ICP_BAD_ARGUMENT;
+  Workspace &w = h->ws;
+  if (!w.d_loop_inbox || w.loop_world < 1 || w.loop_rank < 0) return ICP_BAD_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  unsigned *d_ok = nullptr;
+  HIP_TRY(hipMalloc(&d_ok, sizeof(unsigned)));
+  HIP_TRY(hipMemsetAsync(d_ok, 0, sizeof(unsigned), h->stream));
+  const unsigned base = (++w.loop_probe_gen) * 2048u;
+  hipError_t e = launch_loop_probe(h, w.loop_rank, w.loop_world, w.loop_peers, base, (unsigned)rounds, d_ok);
+  unsigned got = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&got, d_ok, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d_ok);
+  HIP_TRY(e);
+  *ok = got == 1u ? 1 : 0;
+  return ICP_OK;
+}
+
+// Forget every window prediction of this handle (the next evaluations take the pipelines that need none and re-centre).
+// What a rank of a sharded registration does when a one-launch inner loop gave up (icp_shard_loop_wait: ICP_HIP_ERROR):
+// the ranks' prediction histories may have diverged inside the abandoned launch, and the stage calls that serve from
+// there on must see the same windows on every rank.
+extern "C" int icp_reset_window_predictions(icp_handle *h) {
+  if (!h) return ICP_BAD_ARGUMENT;
+  Workspace &w = h->ws;
+  w.win_valid = false;
+  w.win_wide = false;
+  for (auto &wk : w.win_kind) wk = Workspace::WinPred();
+  for (auto &wk : w.hint_kind) wk = Workspace::WinPred();
   return ICP_OK;
 }
 

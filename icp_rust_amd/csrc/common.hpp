@@ -264,7 +264,11 @@ struct Workspace : GnCtx {
   // ... over the ranks of a sharded registration (gn_loop.hpp: LoopInbox): this rank's inbox, every rank's as mapped
   // here, and the launch in flight (api.hip: icp_shard_loop_launch_device / icp_shard_loop_wait)
   void *d_loop_inbox = nullptr;
-  bool loop_inbox_fine = false;
+  int loop_inbox_kind = 0;           // ICP_INBOX_DEVICE / _FINE / _HOST (include/icp_mi355x.h section 5b)
+  void *loop_inbox_host = nullptr;   // _HOST: the mapping of the shared-memory object behind d_loop_inbox
+  char loop_shm_name[64] = {0};      // ... and its name (unlinked once every peer has opened it)
+  unsigned loop_probe_gen = 0;       // tokens of the transport probes so far
+  unsigned loop_off_calls = 0;       // launches left to skip after one that was not resident (loop_off decays)
   void *loop_peers[kShardMaxWorld] = {};
   int loop_rank = -1, loop_world = 0;
   void *loop_plan = nullptr;  // LoopPlan of the launch in flight (api.hip)

@@ -777,8 +777,16 @@ __device__ __forceinline__ void st_sys_u32(unsigned *p, unsigned v) {
 
 // wave 0 polls `count` (<= 256) flag words until each carries a generation >= gen; the words it saw last go to
 // s_seen (LDS, 256 words) when given.  Callers have drained their stores and stand behind a workgroup barrier.
+// A rank that gives up raises `abort` in EVERY rank's inbox (peers: null-terminated list of the other ranks' abort words,
+// or null): its peers are waiting for data it will never send, and would otherwise sit out their own three seconds --
+// with the raise they all leave within a poll, every rank's launch reports the same "gave up" and every host takes the
+// same fallback without a collective.
+struct AbortPeers {
+  unsigned *w[kShardMaxWorld];
+  int n;
+};
 __device__ __forceinline__ bool poll_words(const unsigned long long *words, unsigned count, unsigned gen, unsigned *abort_word,
-                                           unsigned long long *s_seen) {
+                                           unsigned long long *s_seen, const AbortPeers *peers = nullptr) {
   __shared__ int s_okw;
   if (threadIdx.x < 64) {
     const unsigned lane = threadIdx.x;
@@ -798,9 +806,11 @@ __device__ __forceinline__ bool poll_words(const unsigned long long *words, unsi
       if (__all(all)) break;
       int stop = 0;
       if (lane == 0) {
-        if (ld_u32(abort_word) != 0u) stop = 1;
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) stop = 1;
         else if (wall_clock64() - t0 > kShardTimeoutTicks) {
-          st_u32(abort_word, 1u);
+          st_sys_u32(abort_word, 1u);
+          if (peers)
+            for (int q = 0; q < peers->n; ++q) st_sys_u32(peers->w[q], 1u);
           stop = 1;
         }
       }
@@ -868,6 +878,10 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
   const unsigned G = B * kReduceThreads, first = gb * kReduceThreads + tid;
   const unsigned row_w = nbl * kReduceThreads, loc0 = blockIdx.x * kReduceThreads + tid;  // local layout (shard.hip)
   LoopInbox *const me = S.inbox[rank];
+  AbortPeers peers;
+  peers.n = 0;
+  for (int q = 0; q < W; ++q)
+    if (S.inbox[q] != me) peers.w[peers.n++] = &S.inbox[q]->abort[0];
   double2 *const s_a = s_pts, *const s_b = s_pts + (size_t)K * kReduceThreads;
   const unsigned mine = first < n ? (n - 1u - first) / G + 1u : 0u;
   for (unsigned k = 0; k < mine; ++k) {
@@ -956,7 +970,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&me->flag_block[gb], (unsigned long long)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!poll_words(&me->flag_block[S.b0], nbl, gen, &me->abort[0], nullptr)) {
+    if (!poll_words(&me->flag_block[S.b0], nbl, gen, &me->abort[0], nullptr, &peers)) {
       aborted = true;
       break;
     }
@@ -970,7 +984,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
         __hip_atomic_store(&S.inbox[q]->flag_rank[rank], (unsigned long long)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // ---- W1 ----------------------------------------------------------------------------------------------------------
-    if (!poll_words(me->flag_rank, (unsigned)W, gen, &me->abort[0], nullptr)) {
+    if (!poll_words(me->flag_rank, (unsigned)W, gen, &me->abort[0], nullptr, &peers)) {
       aborted = true;
       break;
     }
@@ -1049,7 +1063,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
       }
     }
     // ---- W2 ----------------------------------------------------------------------------------------------------------
-    if (!poll_words(me->flag_cand, B, gen, &me->abort[0], s_seen)) {
+    if (!poll_words(me->flag_cand, B, gen, &me->abort[0], s_seen, &peers)) {
       aborted = true;
       break;
     }
@@ -1341,6 +1355,47 @@ hipError_t launch_gn_loop_shard(icp_handle *h, const LoopArgs &args, const LoopS
     return hipErrorInvalidValue;
   const size_t lds = (size_t)K * kReduceThreads * 2 * sizeof(double2);
   hipLaunchKernelGGL(k_gn_loop_shard, dim3(nb, ranks), dim3(threads), lds, h->stream, args, sh, ptrs, K);
+  return hipGetLastError();
+}
+
+// ---- transport probe -------------------------------------------------------------------------------------------
+// Does memory written by a peer (another device, another process) become visible to a kernel of THIS device that is
+// already running and polling it?  That is what the exchange above relies on, and it depends on how the inboxes were
+// allocated and mapped (coarse-grained device memory is coherent between devices at kernel boundaries only).  One
+// wave per rank: in round r it stores the token base + r into its slot of every peer's inbox and waits, bounded, for
+// the same token from every peer in its own -- each round overwrites the word of the round before, so a mapping
+// that serves a stale copy fails at the latest in round two.  Every rank runs it at the same time (the driver's
+// barrier in front); *ok = 1 when every token of every round arrived.
+struct ProbePtrs {
+  LoopInbox *inbox[kShardMaxWorld];
+};
+__global__ __launch_bounds__(64) void k_loop_probe(ProbePtrs P, int rank, int world, unsigned base, unsigned rounds, unsigned *ok) {
+  const int lane = (int)threadIdx.x;
+  LoopInbox *const me = P.inbox[rank];
+  int good = 1;
+  for (unsigned r = 1; r <= rounds && good; ++r) {
+    const unsigned long long token = (unsigned long long)base + r;
+    if (lane < world) __hip_atomic_store(&P.inbox[lane]->probe[rank], token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long long t0 = wall_clock64();
+    for (;;) {
+      const bool have = lane >= world || ld_sys64(&me->probe[lane]) >= token;
+      if (__all(have)) break;
+      if (wall_clock64() - t0 > kShardTimeoutTicks) {  // (uniform enough: every lane reads the same clock within a poll)
+        good = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    good = __all(good != 0) ? 1 : 0;
+  }
+  if (lane == 0) *ok = (unsigned)good;
+}
+
+hipError_t launch_loop_probe(icp_handle *h, int rank, int world, void *const *inboxes, unsigned base, unsigned rounds,
+                             unsigned *d_ok) {
+  ProbePtrs P;
+  for (int q = 0; q < kShardMaxWorld; ++q) P.inbox[q] = q < world ? reinterpret_cast<LoopInbox *>(inboxes[q]) : nullptr;
+  hipLaunchKernelGGL(k_loop_probe, dim3(1), dim3(64), 0, h->stream, P, rank, world, base, rounds, d_ok);
   return hipGetLastError();
 }
 

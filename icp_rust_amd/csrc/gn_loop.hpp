@@ -72,6 +72,7 @@ struct LoopInbox {
   uint32_t hist_from[kShardMaxWorld][2][2 * kWinBins];    // ... and every rank's, pushed
   double partials[2][kReduceMaxBlocks][kNSum + 1];        // block sums by global block, by parity
   double cand[kReduceMaxBlocks][kLoopCandPerBlock];       // med x | med y | ring x | ring y of every workgroup
+  unsigned long long probe[kShardMaxWorld];               // transport probe (icp_loop_transport_probe): rank s' last token
 };
 
 struct LoopShardArgs {
@@ -97,5 +98,9 @@ struct LoopRankPtrs {
 hipError_t launch_gn_loop_shard(icp_handle *h, const LoopArgs &a, const LoopShardArgs &s, const LoopRankPtrs &ptrs, int ranks);
 size_t gn_loop_partials_doubles();
 hipError_t launch_gn_loop(icp_handle *h, const LoopArgs &args);
+// ping-pong over the connected inboxes: `rounds` tokens written into every peer's inbox and awaited from every peer in
+// the own one (bounded wait); *d_ok (device word) = 1 if every token of every round arrived
+hipError_t launch_loop_probe(icp_handle *h, int rank, int world, void *const *inboxes, unsigned base, unsigned rounds,
+                             unsigned *d_ok);
 
 }  // namespace icp

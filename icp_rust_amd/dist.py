@@ -224,10 +224,11 @@ class HipStages:
         return lib().icp_shard_eval_compact_device(self.icp._h, C.c_void_p(exch_out.data_ptr()))
 
     # -- the inner loop as one launch per rank (include/icp_mi355x.h section 5b) --
-    def loop_inbox(self, fine_grained=False):
-        """device pointer of this rank's inbox (allocated on first use)"""
+    def loop_inbox(self, kind=0):
+        """device pointer of this rank's inbox (allocated on first use); kind: 0 device memory, 1 fine-grained device
+        memory, 2 pinned host memory in a shared-memory object (include/icp_mi355x.h: ICP_INBOX_*)"""
         ptr = C.c_void_p()
-        _lib.check(lib().icp_loop_inbox(self.icp._h, int(fine_grained), C.byref(ptr)), "icp_loop_inbox")
+        _lib.check(lib().icp_loop_inbox(self.icp._h, int(kind), C.byref(ptr)), "icp_loop_inbox")
         return int(ptr.value)
 
     def loop_ipc_handle(self):
@@ -239,6 +240,39 @@ class HipStages:
         ptr = C.c_void_p()
         _lib.check(lib().icp_loop_ipc_open(int(device), C.create_string_buffer(handle, 64), C.byref(ptr)), "icp_loop_ipc_open")
         return int(ptr.value)
+
+    def loop_ipc_close(self, ptr):
+        lib().icp_loop_ipc_close(C.c_void_p(int(ptr)))
+
+    def loop_shm_name(self):
+        buf = C.create_string_buffer(64)
+        _lib.check(lib().icp_loop_inbox_shm_name(self.icp._h, buf), "icp_loop_inbox_shm_name")
+        return bytes(buf.value)
+
+    def loop_shm_unlink(self):
+        lib().icp_loop_inbox_shm_unlink(self.icp._h)
+
+    def loop_shm_open(self, name, device):
+        ptr = C.c_void_p()
+        _lib.check(lib().icp_loop_shm_open(int(device), C.c_char_p(name), C.byref(ptr)), "icp_loop_shm_open")
+        return int(ptr.value)
+
+    def loop_shm_close(self, ptr):
+        lib().icp_loop_shm_close(C.c_void_p(int(ptr)))
+
+    def loop_probe(self, rounds=8):
+        ok = C.c_int(0)
+        _lib.check(lib().icp_loop_transport_probe(self.icp._h, int(rounds), C.byref(ok)), "icp_loop_transport_probe")
+        return bool(ok.value)
+
+    def reset_predictions(self):
+        _lib.check(lib().icp_reset_window_predictions(self.icp._h), "icp_reset_window_predictions")
+
+    def device_id(self):
+        """what tells two devices of one node apart (ranks that share a device share its L2)"""
+        dev = self.torch.cuda.current_device()
+        props = self.torch.cuda.get_device_properties(dev)
+        return str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or dev), dev
 
     def loop_connect(self, rank, world, inbox_ptrs):
         arr = (C.c_void_p * world)(*[C.c_void_p(int(p)) for p in inbox_ptrs])
@@ -294,39 +328,103 @@ class BlockShardedIcp:
         self.n_local_max = max(g[3] for g in self.geom.values())
         self.counters = {"sharded": 0, "replicated": 0}
 
-    def connect_loop(self, fine_grained=False):
+    TRANSPORTS = {"device_ipc": 0, "fine_ipc": 1, "host_shm": 2}
+
+    def connect_loop(self, fine_grained=False, transport="auto", probe=True):
         """Collective over the ranks: map every rank's inbox on every rank, so that an inner loop is ONE launch per rank
         whose workgroups exchange histograms, candidates and block sums through memory (include/icp_mi355x.h section 5b;
-        gn_loop.hip).  Ranks of one process hand each other plain pointers; across processes the inboxes travel as
-        hipIpc handles (one small all_gather_object at connect time -- nothing of the per-iteration path goes through
-        torch.distributed any more, only evaluations the launch hands back).  fine_grained: for ranks on DISTINCT
-        devices of one process (peer access); hipIpc takes ordinary device memory."""
+        gn_loop.hip).  Ranks of one process hand each other plain pointers (fine_grained: they sit on DISTINCT devices
+        and use peer access).  Across processes a TRANSPORT carries the inboxes (one small all_gather_object at connect
+        time -- nothing of the per-iteration path goes through torch.distributed, only evaluations a launch hands back):
+          device_ipc  ordinary device memory through hipIpc -- for processes that share ONE device (its L2 keeps them
+                      coherent); between distinct devices such memory is coherent at kernel boundaries only
+          fine_ipc    fine-grained device memory through hipIpc (where the runtime exports it)
+          host_shm    pinned host memory in a POSIX shared-memory object, registered by every process
+        "auto": device_ipc when every rank reports the same device, else fine_ipc, then host_shm -- the first whose
+        ping-pong probe (icp_loop_transport_probe: every rank at once, bounded waits) passes on EVERY rank.  Returns the
+        transport's name, or None: no transport passed, the stage calls + collectives serve (self._loop stays unset)."""
         import os
 
-        mine = {rk.rank: rk.stages.loop_inbox(fine_grained) for rk in self.ranks}
+        self._loop = None
+        self.loop_transport = None
+        self._loop_opened = []
+        self.counters.update(loop_launches=0, loop_served=0, loop_handbacks=0, loop_gave_up=0)
         if isinstance(self.comm, LocalComm):
-            ptrs_for = {rk.rank: [mine[r] for r in range(self.world)] for rk in self.ranks}
-        else:
-            rk = self.ranks[0]
-            infos = self.comm.all_gather_object([(os.getpid(), rk.stages.loop_ipc_handle(), mine[rk.rank])])
-            dev = rk.stages.torch.cuda.current_device()
-            ptrs = []
-            for r, (pid, handle, raw) in enumerate(infos):
-                if r == rk.rank:
-                    ptrs.append(mine[rk.rank])
-                elif pid == os.getpid():
-                    ptrs.append(raw)
-                else:
-                    ptrs.append(rk.stages.loop_ipc_open(handle, dev))
-            ptrs_for = {rk.rank: ptrs}
-        for rk in self.ranks:
-            rk.stages.loop_connect(rk.rank, self.world, ptrs_for[rk.rank])
-        self.comm.barrier()  # (a connect empties the own inbox: nobody may launch before everybody has connected)
-        self._loop = dict(launch=0, evals=0)
-        self.counters.update(loop_launches=0, loop_served=0, loop_handbacks=0)
+            mine = {rk.rank: rk.stages.loop_inbox(1 if fine_grained else 0) for rk in self.ranks}
+            for rk in self.ranks:
+                rk.stages.loop_connect(rk.rank, self.world, [mine[r] for r in range(self.world)])
+            self._loop = dict(launch=0, evals=0)
+            self.loop_transport = "pointers (one process" + (", peer access)" if fine_grained else ")")
+            return self.loop_transport
+        rk = self.ranks[0]
+        st = rk.stages
+        dev_id, dev = st.device_id() if hasattr(st, "device_id") else ("0", 0)
+        ids = self.comm.all_gather_object([(os.uname().nodename, dev_id)])
+        if len({h for h, _ in ids}) > 1:
+            return None  # (more than one node: no memory to share)
+        same_device = len({d for _, d in ids}) == 1
+        order = [transport] if transport != "auto" else (["device_ipc"] if same_device else ["fine_ipc", "host_shm"])
+        for name in order:
+            kind = self.TRANSPORTS[name]
+            ok, err, opened, ptrs = 1, "", [], []
+            try:
+                raw = st.loop_inbox(kind)
+                token = st.loop_shm_name() if kind == 2 else st.loop_ipc_handle()
+            except Exception as e:  # noqa: BLE001  (e.g. the runtime does not export a fine-grained allocation)
+                ok, err, raw, token = 0, repr(e), 0, b""
+            infos = self.comm.all_gather_object([(os.getpid(), ok, token, raw)])
+            ok = min(i[1] for i in infos)
+            if ok:
+                try:
+                    for r, (pid, _, tok, rawp) in enumerate(infos):
+                        if r == rk.rank:
+                            ptrs.append(raw)
+                        elif pid == os.getpid():
+                            ptrs.append(rawp)
+                        else:
+                            ptr = st.loop_shm_open(tok, dev) if kind == 2 else st.loop_ipc_open(tok, dev)
+                            opened.append((kind, ptr))
+                            ptrs.append(ptr)
+                    st.loop_connect(rk.rank, self.world, ptrs)
+                except Exception as e:  # noqa: BLE001
+                    ok, err = 0, repr(e)
+            ok = min(self.comm.all_gather_object([ok]))
+            self.comm.barrier()  # (a connect empties the own inbox: nobody may write before everybody has connected)
+            if kind == 2:
+                st.loop_shm_unlink()  # every peer has opened it: the name can go, the mappings live on
+            if ok and probe:
+                try:
+                    ok = 1 if st.loop_probe() else 0
+                except Exception as e:  # noqa: BLE001
+                    ok, err = 0, repr(e)
+                ok = min(self.comm.all_gather_object([ok]))
+            if ok:
+                self._loop = dict(launch=0, evals=0)
+                self._loop_opened = opened
+                self.loop_transport = name
+                return name
+            self._close_opened(opened)
+            self.comm.barrier()
+        return None
+
+    def _close_opened(self, opened):
+        st = self.ranks[0].stages
+        for kind, ptr in opened:
+            (st.loop_shm_close if kind == 2 else st.loop_ipc_close)(ptr)
+
+    def disconnect_loop(self):
+        """Collective: give the peers' inboxes back (the mappings connect_loop opened), after a barrier -- nobody may
+        still be launching into them -- and before any rank frees or pools its handle."""
+        self._loop = None
+        if not isinstance(self.comm, LocalComm):
+            self.comm.barrier()
+            self._close_opened(getattr(self, "_loop_opened", []))
+            self._loop_opened = []
+            self.comm.barrier()
 
     def _loop_run(self, Ti, prev_error, applied, it):
-        """the inner loop from evaluation `it` on as one launch per local rank; None: nothing was launched"""
+        """the inner loop from evaluation `it` on as one launch per local rank; None: nothing was launched, or the
+        launch gave up (the loop's state is then the one it was started with, and the stage calls serve from here on)"""
         L = self._loop
         launch_no = L["launch"] + 1
         rcs = []
@@ -340,6 +438,17 @@ class BlockShardedIcp:
             _lib.check(rc, "icp_shard_loop_launch_device")
         L["launch"] = launch_no
         outs = [rk.stages.loop_wait() for rk in self.ranks]
+        if any(o[0] == _lib.HIP_ERROR for o in outs):
+            # A launch gave up waiting for a peer.  The rank whose wait ran out raised the abort word in EVERY inbox, so
+            # every rank's launch ended the same way and every host is here (no collective needed to agree).  Nothing
+            # of the launch is used; the prediction histories may have diverged inside it and are dropped; the stage
+            # calls + collectives serve this evaluation and all later ones (same bits either way).
+            for rk in self.ranks:
+                if hasattr(rk.stages, "reset_predictions"):
+                    rk.stages.reset_predictions()
+            self._loop = None
+            self.counters["loop_gave_up"] += 1
+            return None
         for o in outs:
             _lib.check(o[0], "icp_shard_loop_wait", allow=(_lib.NAN_INPUT,))
         o = outs[0]

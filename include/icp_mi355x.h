@@ -49,7 +49,13 @@ extern "C" {
  * icp_shard_loop_*; icp_multi_compute/update_target_normals, icp_multi_estimate_point_to_plane).  The counters and
  * icp_profile_* moved to icp_mi355x_debug.h (same symbols, same library).  Behavioural note: clouds of at most 2^20
  * points run their inner loop inside one launch; results are the same bits as the stepped loop's */
-#define ICP_ABI_VERSION 5
+/* 6: icp_loop_inbox takes the KIND of memory (ICP_INBOX_*: 0 and 1 are what `fine_grained` 0 / 1 meant); additions:
+ * ICP_INBOX_HOST and icp_loop_inbox_shm_name / _shm_unlink / icp_loop_shm_open / _shm_close (inboxes in pinned host
+ * memory shared between processes), icp_loop_transport_probe, icp_reset_window_predictions.  Behavioural notes: a
+ * sharded one-launch inner loop that gives up raises the abort word in every rank's inbox, so all ranks report
+ * ICP_HIP_ERROR for that launch; the evaluations of icp_estimate[_device] file their candidates in the first pass over
+ * the pairs and finish in one workgroup (same bits: the order statistics are exact either way) */
+#define ICP_ABI_VERSION 6
 
 typedef enum icp_status {
   ICP_OK = 0,
@@ -291,15 +297,42 @@ int icp_shard_eval_abort_device(icp_handle *h);
  *     window missed is repeated once inside the launch with the widest windows and counts twice): what eval_base
  *     advances by; *finished, or *it = the evaluation the stage calls must serve
  *     next (its window missed, or the rotation left the range of the restated sin / cos).  ICP_HIP_ERROR: the launch
- *     gave up waiting for a peer (3 s).
+ *     gave up waiting for a peer (3 s) -- on EVERY rank: the rank whose wait ran out raises the abort word in all
+ *     inboxes, so its peers leave at once and every host takes the same way out (nothing of the launch is used: the
+ *     loop's state is the one it was started with; icp_reset_window_predictions, then the stage calls).
  * Ranks that share a device must launch on streams that really run side by side (they wait for each other): more
  * than four of them need GPU_MAX_HW_QUEUES raised before the HIP runtime starts. */
+/* What an inbox is made of.  Memory that a PEER DEVICE writes while this device's kernels are polling it has to be
+ * coherent between the two at every access, not only at kernel boundaries:
+ *   ICP_INBOX_DEVICE  ordinary device memory (hipMalloc).  Right for ranks that share ONE device (virtual ranks of a
+ *                     process; processes sharing a GPU through hipIpc): they share its L2.
+ *   ICP_INBOX_FINE    fine-grained device memory (hipExtMallocWithFlags): peer access inside a process, hipIpc between
+ *                     processes where the runtime exports such an allocation (icp_loop_inbox_ipc_handle fails otherwise).
+ *   ICP_INBOX_HOST    pinned host memory in a POSIX shared-memory object: every process of the node maps it
+ *                     (icp_loop_inbox_shm_name -> icp_loop_shm_open), registers it with its own device and gets a device
+ *                     pointer.  Coherent by construction; the exchange crosses the host link instead of xGMI (a few
+ *                     KB per evaluation).  The owner unlinks the name once every peer has opened it (_shm_unlink).
+ * Which of them carries the loop between distinct devices is decided AT RUN TIME: icp_loop_transport_probe plays
+ * ping-pong over the connected inboxes (every rank at once, bounded waits) and reports whether every token arrived; the
+ * driver takes the first transport whose probe passes on every rank (icp_rust_amd/dist.py: connect_loop), else the
+ * stage calls of section 5. */
+#define ICP_INBOX_DEVICE 0
+#define ICP_INBOX_FINE 1
+#define ICP_INBOX_HOST 2
 size_t icp_loop_inbox_bytes(void);
-int icp_loop_inbox(icp_handle *h, int fine_grained, void **d_inbox);
+int icp_loop_inbox(icp_handle *h, int kind, void **d_inbox);
 int icp_loop_inbox_ipc_handle(icp_handle *h, unsigned char out[64]);
 int icp_loop_ipc_open(int device, const unsigned char handle[64], void **d_ptr);
 int icp_loop_ipc_close(void *d_ptr);
+int icp_loop_inbox_shm_name(icp_handle *h, char out[64]);
+int icp_loop_inbox_shm_unlink(icp_handle *h);
+int icp_loop_shm_open(int device, const char *name, void **d_ptr);
+int icp_loop_shm_close(void *d_ptr);
 int icp_shard_loop_connect(icp_handle *h, int rank, int world, void *const *inboxes);
+int icp_loop_transport_probe(icp_handle *h, int rounds, int *ok);
+/* every window prediction of the handle forgotten (what a rank does after a one-launch loop gave up: the stage calls
+ * that serve from there on must see the same windows on every rank) */
+int icp_reset_window_predictions(icp_handle *h);
 int icp_shard_loop_launch_device(icp_handle *h, const double *d_a_xy_local, const double *d_b_xy_local, size_t n_total,
                                  unsigned launch_no, unsigned eval_base, int it0, uint32_t applied0, const icp_pose *Ti,
                                  double prev_error, int first_kind, int second_kind);

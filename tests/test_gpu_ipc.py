@@ -40,19 +40,29 @@ def run_ranks(world, *args):
 
 
 # (two processes: three on one GPU did not run side by side on the test box -- the third queue waited for a slice and the
-# launches, which wait for each other, gave up after their 250 ms: a property of sharing ONE GPU, not of the protocol)
-@pytest.mark.parametrize("world,n,m,kind", [(2, 150_000, 120_000, "independent"), (2, 200_000, 200_000, "converging")])
-def test_processes_sharing_a_gpu_exchange_through_ipc_inboxes(world, n, m, kind):
+# launches, which wait for each other, gave up after their bounded wait: a property of sharing ONE GPU, not of the protocol)
+# Transports (dist.BlockShardedIcp.connect_loop): "auto" picks ordinary device memory through hipIpc for processes that
+# share a device; the two a run over DISTINCT devices would try -- fine-grained device memory through hipIpc, pinned host
+# memory in a shared-memory object -- are forced here on the one device the box has: their mapping, probe and exchange
+# run, what cannot be shown here is coherence between two devices (the probe decides that at run time).
+@pytest.mark.parametrize("world,n,m,kind,transport", [(2, 150_000, 120_000, "independent", "auto"),
+                                                      (2, 200_000, 200_000, "converging", "auto"),
+                                                      (2, 150_000, 120_000, "independent", "fine_ipc"),
+                                                      (2, 150_000, 120_000, "independent", "host_shm")])
+def test_processes_sharing_a_gpu_exchange_through_mapped_inboxes(world, n, m, kind, transport):
     # The launches of the two processes wait for each other, so both must be RUNNING on the one GPU at once; the platform
     # does not promise that to two processes (the second queue may sit out a time slice), and a launch gives up after its
-    # bounded wait (ICP_HIP_ERROR from icp_shard_loop_wait) rather than hang.  That -- and only that -- is retried, and
-    # skipped if the box never runs the two side by side; wrong bits or any other error fail at once.
+    # bounded wait rather than hang: every rank then reports so, drops its predictions and the stage calls serve the rest
+    # (exit code 4: the pose must STILL be one handle's).  That -- and only that -- is retried, and skipped if the box
+    # never runs the two side by side; wrong bits or any other error fail at once.
     for attempt in range(3):
-        rcs, outs = run_ranks(world, n, m, 6, kind)
+        rcs, outs = run_ranks(world, n, m, 6, kind, transport)
+        text = "\n".join(outs)
+        if all(rc == 5 for rc in rcs):
+            pytest.skip(f"transport {transport} is not available on this runtime: " + outs[0].strip().splitlines()[-1])
+        assert "pose equals one handle's: False" not in text, text
         if all(rc == 0 for rc in rcs):
             assert "pose equals one handle's: True" in outs[0], outs[0]
             return
-        text = "\n".join(outs)
-        gave_up = "icp_shard_loop_wait: HIP error" in text
-        assert gave_up and "pose equals one handle's: False" not in text, text
+        assert all(rc in (0, 4) for rc in rcs) and "gave up" in text, text
     pytest.skip("two processes were not scheduled side by side on this GPU in three attempts (bounded waits gave up)")
