@@ -288,6 +288,13 @@ def gn_loop_counters(icp=None):
     return tuple(int(x) for x in out)
 
 
+def gn_loop_timeouts(icp):
+    """launches of the one-launch inner loop that gave up their bounded wait (not fully resident)"""
+    out = C.c_uint64(0)
+    check(lib().icp_gn_loop_timeouts(icp._h, C.byref(out)), "icp_gn_loop_timeouts")
+    return int(out.value)
+
+
 def run_ahead_counters(icp):
     """(run-ahead searches whose device-derived pose the host confirmed bit for bit, ... that it did not)"""
     out = (C.c_uint64 * 2)()

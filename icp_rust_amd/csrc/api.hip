@@ -898,8 +898,30 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
 }
 
 // ---- the inner loop in one launch (gn_loop.hip) --------------------------------------------------------------
-static std::mutex g_loop_mu;  // one resident loop launch per process at a time: two of them, each waiting at its grid
-                              // barrier for workgroups the other one keeps off the CUs, would only end by timeout
+// One resident loop launch per DEVICE and process at a time: two of them on one device, each waiting at its grid barrier
+// for workgroups the other one keeps off the CUs, would only end by timeout.  (Launches of other processes, and the
+// sharded launches of this one -- whose launch and wait are two calls of the caller -- are not covered: such a
+// collision ends in a bounded wait, the handle steps from the host for the next kLoopOffCalls loops and tries again.)
+constexpr int kLoopMutexes = 64;
+static std::mutex g_loop_mu[kLoopMutexes];
+static std::mutex &loop_mutex(const icp_handle *h) { return g_loop_mu[(unsigned)h->device % kLoopMutexes]; }
+// A launch that was not resident switches the one-launch loop off for the handle's next kLoopOffCalls inner loops (they
+// are stepped from the host), then the handle tries again: a co-tenant that has left costs nothing further, one that
+// stays costs one bounded wait (2 ms) in kLoopOffCalls loops.
+constexpr unsigned kLoopOffCalls = 64;
+static void loop_timed_out(Workspace &w) {
+  w.loop_off = true;
+  w.loop_off_calls = kLoopOffCalls;
+  ++w.loop_timeouts;
+}
+static bool loop_allowed(Workspace &w) {
+  if (!w.loop_off) return true;
+  if (w.loop_off_calls > 0 && --w.loop_off_calls == 0) {
+    w.loop_off = false;
+    return true;
+  }
+  return false;
+}
 
 static hipError_t ensure_loop(icp_handle *h) {
   Workspace &w = h->ws;
@@ -1052,7 +1074,7 @@ static int gn_loop_run(icp_handle *h, const double *d_a, const double *d_b, size
   A.res = res;
   A.seq = ++w.loop_seq;
   {
-    std::lock_guard<std::mutex> lk(g_loop_mu);
+    std::lock_guard<std::mutex> lk(loop_mutex(h));
     HIP_TRY(launch_gn_loop(h, A));
     HIP_TRY(wait_seq(h, &res->seq, A.seq));
   }
@@ -1061,7 +1083,7 @@ static int gn_loop_run(icp_handle *h, const double *d_a, const double *d_b, size
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemsetAsync(w.d_loop_ctl, 0, sizeof(LoopCtl), h->stream));
     HIP_TRY(hipMemsetAsync(w.d_loop_hist, 0, (size_t)4 * kWinBins * sizeof(uint32_t), h->stream));
-    w.loop_off = true;
+    loop_timed_out(w);
   }
   return loop_finish(h, pl, res, T, prev_error, applied, it, finished);
 }
@@ -1379,7 +1401,7 @@ extern "C" int icp_shard_loop_wait(icp_handle *h, icp_pose *Ti, double *prev_err
   HIP_TRY(wait_seq(h, &res->seq, w.loop_seq));
   if (evals) *evals = res->rounds;  // (what the connection's eval_base advances by)
   if (res->status == 5) {
-    w.loop_off = true;
+    loop_timed_out(w);
     return ICP_HIP_ERROR;
   }
   bool fin = false;
@@ -1409,7 +1431,7 @@ static int estimate_transform_loop(icp_handle *h, const double *d_a, const doubl
     double prev_error = DBL_MAX;  // f64::MAX, src/lib.rs:63
     const bool device_loop = allow_device_loop && !first_pre_launched && gn_loop_applies(n);
     for (int it = 0; it < ICP_INNER_MAX_ITER; ++it) {
-      if (device_loop && !h->ws.loop_off) {
+      if (device_loop && loop_allowed(h->ws)) {
         bool finished = false, served = false;
         const int rc = gn_loop_run(h, d_a, d_b, n, first_kind, second_kind, &T, &prev_error, &applied, &it, &finished,
                                    &served);
@@ -1591,7 +1613,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     }
     spec_valid = false;
     pre_valid = false;
-    const bool device_loop = loop_ok && !w.loop_off && !first_pre_launched && !(two_streams && prev_inner == 1);
+    const bool device_loop = loop_ok && !first_pre_launched && !(two_streams && prev_inner == 1) && loop_allowed(w);
     const bool speculate = !device_loop && !no_spec && n > 0 && h->m > 0 && it + 1 < max_iter && prev_inner == 1;
     auto launch_spec = [&](const Pose &T1) -> hipError_t {
       spec_pose = transform_mul(T1, T);  // src/lib.rs:127, 170 -- what the outer loop will compute
@@ -1806,6 +1828,13 @@ extern "C" int icp_run_ahead_counters(icp_handle *h, uint64_t out[2]) {
   if (!h || !out) return ICP_BAD_ARGUMENT;
   out[0] = h->ws.ahead_hits;
   out[1] = h->ws.ahead_misses;
+  return ICP_OK;
+}
+
+// launches of the one-launch inner loop (single handle or sharded) that were not resident and gave up their bounded wait
+extern "C" int icp_gn_loop_timeouts(icp_handle *h, uint64_t *out) {
+  if (!h || !out) return ICP_BAD_ARGUMENT;
+  *out = h->ws.loop_timeouts;
   return ICP_OK;
 }
 

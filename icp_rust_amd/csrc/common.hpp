@@ -260,7 +260,7 @@ struct Workspace : GnCtx {
   double *d_loop_part = nullptr;
   unsigned loop_seq = 0;
   bool loop_off = false;  // a launch was not resident (its grid barrier timed out): this handle steps from the host
-  unsigned long long loop_launches = 0, loop_evals = 0, loop_handbacks = 0;
+  unsigned long long loop_launches = 0, loop_evals = 0, loop_handbacks = 0, loop_timeouts = 0;
   // ... over the ranks of a sharded registration (gn_loop.hpp: LoopInbox): this rank's inbox, every rank's as mapped
   // here, and the launch in flight (api.hip: icp_shard_loop_launch_device / icp_shard_loop_wait)
   void *d_loop_inbox = nullptr;

@@ -35,7 +35,10 @@ namespace icp {
 
 namespace {
 
-constexpr long long kLoopTimeoutTicks = 25000000;  // wall_clock64 runs at 100 MHz: 250 ms
+// A grid barrier of a launch whose workgroups are all resident ends within microseconds.  Where some are not (another
+// tenant holds CUs), waiting is only worth while they keep ARRIVING: the wait gives up 2 ms after the last arrival it
+// saw (round 4 waited 250 ms flat: a frame that takes a millisecond took a quarter of a second beside a co-tenant).
+constexpr long long kLoopTimeoutTicks = 200000;  // wall_clock64 runs at 100 MHz: 2 ms without progress
 // ... between ranks: processes that share ONE GPU (tests) are not always scheduled side by side at once -- the queue of
 // the second process may wait for a time slice -- so a rank waits longer for its peers than a launch for its own blocks
 constexpr long long kShardTimeoutTicks = 300000000;  // 3 s
@@ -101,18 +104,27 @@ __device__ __forceinline__ bool flag_barrier(unsigned long long *flags, LoopCtl 
       __hip_atomic_store(&flags[blockIdx.x], (unsigned long long)gen | (payload << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long seen[4] = {0, 0, 0, 0};
     int ok = 1;
-    const long long t0 = wall_clock64();
+    long long t0 = wall_clock64();
+    unsigned arrived_before = 0;
     for (;;) {
       bool all = true;
+      unsigned arrived = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const unsigned b = lane + 64u * j;
+        bool here = true;
         if (b < nb) {
           seen[j] = ld_u64(&flags[b]);
-          all = all && (seen[j] & kFlagGenMask) >= (unsigned long long)gen;
+          here = (seen[j] & kFlagGenMask) >= (unsigned long long)gen;
+          all = all && here;
         }
+        arrived += (unsigned)__popcll(__ballot(here));
       }
       if (__all(all)) break;
+      if (arrived > arrived_before) {  // (progress: the clock starts again)
+        arrived_before = arrived;
+        t0 = wall_clock64();
+      }
       int stop = 0;
       if (lane == 0) {
         if (ld_u32(&c->abort[0]) != 0u) stop = 1;

@@ -30,8 +30,10 @@ struct LoopResult {
   unsigned it;         // not finished: the evaluation the host resumes with (state = before that evaluation)
   unsigned evals;      // evaluations served by this launch
   unsigned rounds;     // evaluation rounds it ran: a repeated evaluation (missed window, widest windows) counts twice
-  int status;          // 0 ok, 1 evaluation `it` not served (window missed / no window / rotation out of sin-cos range),
-                       // 3 NaN residual, 5 a grid barrier timed out (launch not resident)
+  int status;          // 0 ok; 1 evaluation `it` not served (its window missed twice); 2 evaluation `it - 1` was served and
+                       // applied, evaluation `it` has no usable window; 3 NaN residual; 4 evaluation `it` not served: its
+                       // rotation lies outside the restated range of sin / cos (the host applies it); 5 a grid barrier
+                       // gave up waiting (launch not resident, or a peer of a sharded launch raised abort)
   int finished;        // the loop ended inside the launch (break test, None, or ICP_INNER_MAX_ITER)
   unsigned seq;        // written last, system scope
 };

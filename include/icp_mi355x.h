@@ -369,8 +369,9 @@ void icp_reduce_geometry(size_t n, int *blocks, int *threads);
 /* ... over the source points in FOLD ORDER.  The reference folds over the caller's order
  * (src/lib.rs:240-255, a left fold); the sum is the same up to rounding, so any fixed order meets the
  * 1e-5 pose bar.  When icp_estimate[_device] takes a cell-sorted snapshot of the source cloud (grid
- * engine, MORE THAN 65 536 source points -- the largest cloud searched with four lanes per query; the threshold can be
- * moved with ICP_NN_COOP_MAX_N, which therefore moves result bits) the fold order IS the snapshot order -- ascending
+ * engine, MORE THAN 65 536 source points -- the largest cloud searched with four lanes per query; the threshold is a
+ * constant of the product library: the development build libicp_mi355x_exp.so (`make experiments`) can move it with
+ * ICP_NN_COOP_MAX_N, which moves result bits with it) the fold order IS the snapshot order -- ascending
  * (target-grid cell of init * src[i], i), a stable sort, hence a pure function of the inputs AND OF THE HANDLE'S GRID
  * (box and cell size: what icp_create chose for the target cloud, kept by incremental appends, section 6) -- so that
  * the search can store its pairs with full-line writes and nothing is ever scattered back; otherwise (smaller clouds,

@@ -24,6 +24,10 @@ int icp_gn_path_counters(icp_handle *h, uint64_t out[6]);
  * up to 2^20 in one launch): out[0] launches, out[1] evaluations they served (counted in out[0] of
  * icp_gn_path_counters as well), out[2] launches that handed an evaluation back to the host-stepped pipelines. */
 int icp_gn_loop_counters(icp_handle *h, uint64_t out[3]);
+/* launches of the one-launch inner loop that were not fully resident and gave up their bounded wait (2 ms without a
+ * workgroup arriving at the grid barrier; 3 s between the ranks of a sharded launch).  After one, the handle steps its
+ * next 64 inner loops from the host and then tries the launch again. */
+int icp_gn_loop_timeouts(icp_handle *h, uint64_t *out);
 
 /* ... and the run-ahead searches of icp_estimate[_device] (a search enqueued behind the pre-launched first evaluation
  * of the next iteration, its pose derived on the device): out[0] the host derived the same pose bit for bit and took
@@ -38,7 +42,8 @@ int icp_nn_tile_counters(icp_handle *h, uint64_t out[2]);
  * a query whose previous match is provably still its nearest neighbour -- it has moved less than the margin the
  * last walk left it -- is not searched again).  out[0] = searches that checked certificates
  * since the handle was created, out[1] = queries whose certificate failed in the last of them (searched as ever).
- * ICP_NN_NO_CERT=1 in the environment searches every query every time. */
+ * (ICP_NN_NO_CERT=1 searches every query every time -- in the development build libicp_mi355x_exp.so only: the product
+ * library reads no tuning variables) */
 int icp_nn_cert_counters(icp_handle *h, uint64_t out[2]);
 
 int icp_single_launch_counters(icp_handle *h, uint64_t out[3]);

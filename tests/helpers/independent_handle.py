@@ -1,0 +1,47 @@
+"""One of the INDEPENDENT processes of tests/test_gpu_tenants.py: its own handle on the one GPU, `calls` registrations
+of a frame-sized cloud (a 28k-point window: what examples/scan3d.rs:113-133 runs per frame), each timed.  The processes
+share nothing but the device: the one-launch inner loops of one may find the CUs held by the other's kernels, and must
+then cost a bounded wait -- never a wrong bit, never a quarter of a second."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import icp_rust_amd as I  # noqa: E402
+from icp_rust_amd import synth  # noqa: E402
+
+
+def main():
+    calls, seed_off = int(sys.argv[1]), int(sys.argv[2])
+    pk = synth.synthetic_scan3d_packets(150)
+    s3 = synth.remove_invalid_values(pk[:75])
+    d3 = synth.remove_invalid_values(pk[75:150])
+    init = I.Transform([0.01 * seed_off, -0.005, 0.0005 * seed_off])  # (each process its own registration)
+    icp = I.Icp3d(d3)
+    ref, _, ref_inner = icp.estimate(s3, init, 20, return_info=True)  # (first call: allocations)
+    # wait for the other tenant to be up (a file each, in the directory the test made)
+    sync = sys.argv[3]
+    open(os.path.join(sync, f"ready_{os.getpid()}"), "w").close()
+    t_end = time.time() + 60
+    while len([f for f in os.listdir(sync) if f.startswith("ready_")]) < int(sys.argv[4]) and time.time() < t_end:
+        time.sleep(0.005)
+    worst, total, same = 0.0, 0.0, True
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        T, _, inner = icp.estimate(s3, init, 20, return_info=True)
+        dt = time.perf_counter() - t0
+        worst, total = max(worst, dt), total + dt
+        same = same and np.array_equal(T.as_array(), ref.as_array()) and np.array_equal(inner, ref_inner)
+    print(f"tenant {seed_off}: {calls} calls, mean {1e3 * total / calls:.3f} ms, worst {1e3 * worst:.3f} ms, same bits every call: {same}, "
+          f"loop (launches, evals, handbacks) {I.gn_loop_counters(icp)} timeouts {I.gn_loop_timeouts(icp)} pose {ref.as_array().tolist()}",
+          flush=True)
+    icp.close()
+    sys.exit(0 if same else 3)
+
+
+if __name__ == "__main__":
+    main()
