@@ -17,22 +17,13 @@
 #include <mutex>
 #include <new>
 
-#include "common.hpp"
-#include "gn_loop.hpp"
+#include "api_internal.hpp"
 
 using namespace icp;
+using namespace icp::api;
 
 namespace icp {
-hipError_t launch_sel_init(icp_handle *h, size_t n);
-hipError_t launch_stddevs(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T);
-}  // namespace icp
-
-struct LoopPlan;
-static void free_loop_plan(void *p);
-static void free_loop_inbox_fwd(icp::Workspace &w);
-
-namespace {
-
+namespace api {
 int map_hip(hipError_t e) {
   switch (e) {
     case hipSuccess: return ICP_OK;
@@ -44,17 +35,10 @@ int map_hip(hipError_t e) {
     default: return ICP_HIP_ERROR;
   }
 }
+}  // namespace api
+}  // namespace icp
 
-#define HIP_TRY(expr)                                \
-  do {                                               \
-    hipError_t e__ = (expr);                         \
-    if (e__ != hipSuccess) return map_hip(e__);      \
-  } while (0)
-#define ICP_TRY_RC(expr)             \
-  do {                               \
-    const int rc__ = (expr);         \
-    if (rc__ != ICP_OK) return rc__; \
-  } while (0)
+namespace {
 
 template <typename Tp>
 hipError_t grow(Tp *&p, size_t count) {
@@ -103,7 +87,7 @@ void free_workspace(Workspace &w) {
   (void)hipFree(w.d_rlist_len);
   (void)hipFree(w.d_part_d);
   (void)hipFree(w.d_part_i);
-  free_loop_inbox_fwd(w);
+  free_loop_inbox(w);
   free_loop_plan(w.loop_plan);
   (void)hipFree(w.d_loop_ctl);
   (void)hipFree(w.d_loop_hist);
@@ -316,7 +300,6 @@ extern "C" int icp_transform_new_device(const double *params, size_t n, icp_pose
 
 // ---------------------------------------------------------------- handle ---------
 static icp_handle *pool_take(int device);
-static int resolved_nn_mode(const icp_handle *h);
 static void destroy_failed(icp_handle *h);
 
 static int create_common(icp_handle **out, int dim, const double *dst, size_t m, int device, bool dst_on_device) {
@@ -537,7 +520,7 @@ extern "C" int icp_set_nn_mode(icp_handle *h, int mode) {
 
 // AUTO: the grid pays off once the target cloud is large enough to amortise the
 // scattered cell reads; tiny clouds (2-D LiDAR scans, ~650 points) stay on the sweep.
-static int resolved_nn_mode(const icp_handle *h) {
+int icp::api::resolved_nn_mode(const icp_handle *h) {
   static const long grid_min_m = exp_env("ICP_NN_GRID_MIN_M") ? atol(exp_env("ICP_NN_GRID_MIN_M")) : 8192;
   if (h->nn_mode == ICP_NN_BRUTE || !h->grid.built) return ICP_NN_BRUTE;
   if (h->nn_mode == ICP_NN_GRID) return ICP_NN_GRID;
@@ -705,7 +688,7 @@ static inline void cpu_relax() {
   __asm__ __volatile__("" ::: "memory");
 #endif
 }
-static hipError_t wait_seq(icp_handle *h, volatile unsigned *seq, unsigned want, hipStream_t stream = nullptr) {
+hipError_t icp::api::wait_seq(icp_handle *h, volatile unsigned *seq, unsigned want, hipStream_t stream) {
   static const bool no_poll = exp_env("ICP_NO_POLL") != nullptr;
   if (!no_poll) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -720,16 +703,14 @@ static hipError_t wait_seq(icp_handle *h, volatile unsigned *seq, unsigned want,
   return hipStreamSynchronize(stream ? stream : h->stream);
 }
 // (stream: where the evaluation was enqueued, if not on h->stream)
-static hipError_t wait_result(icp_handle *h, hipStream_t stream = nullptr) {
+hipError_t icp::api::wait_result(icp_handle *h, hipStream_t stream) {
   return wait_seq(h, &h->ws.h_res->seq, h->ws.seq, stream);
 }
 
-// check_input_size, src/lib.rs:186-189
-static inline bool input_size_ok(size_t n) { return n > 0 && n >= 2; }
 
 // what the next evaluation's window is centred on: this evaluation's exact median and sigma, kept per
 // kind of evaluation (common.hpp, Workspace::win_kind) and as "the most recent one"
-static void record_statistics(Workspace &w, int kind, bool has_median, const GnResult &r) {
+void icp::api::record_statistics(Workspace &w, int kind, bool has_median, const GnResult &r) {
   w.win_valid = has_median;
   if (Workspace::kind_has_slot(kind)) w.win_kind[kind].valid = has_median;
   if (kind == 3 || kind == 4) w.win_kind[kind - 3].valid = has_median;  // (the next iteration's evaluations follow on from these)
@@ -892,8 +873,8 @@ static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t 
   Range solve("icp: solve (inverse3x3, host)");
   return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
 }
-static int wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
-                    double delta[3], double *huber_err, bool pre_launched = false, int kind = 2) {
+int icp::api::wgn_step(icp_handle *h, const double *d_a, const double *d_b, size_t n, const Pose &T,
+                       double delta[3], double *huber_err, bool pre_launched, int kind) {
   return wgn_step(h, d_a, d_b, n, T, delta, huber_err, [] { return hipSuccess; }, pre_launched, kind);
 }
 
@@ -909,7 +890,7 @@ static std::mutex &loop_mutex(const icp_handle *h) { return g_loop_mu[(unsigned)
 // are stepped from the host), then the handle tries again: a co-tenant that has left costs nothing further, one that
 // stays costs one bounded wait (2 ms) in kLoopOffCalls loops.
 constexpr unsigned kLoopOffCalls = 64;
-static void loop_timed_out(Workspace &w) {
+void icp::api::loop_timed_out(Workspace &w) {
   w.loop_off = true;
   w.loop_off_calls = kLoopOffCalls;
   ++w.loop_timeouts;
@@ -923,7 +904,7 @@ static bool loop_allowed(Workspace &w) {
   return false;
 }
 
-static hipError_t ensure_loop(icp_handle *h) {
+hipError_t icp::api::ensure_loop(icp_handle *h) {
   Workspace &w = h->ws;
   if (w.d_loop_ctl) return hipSuccess;
   hipError_t e;
@@ -946,20 +927,10 @@ static void record_values(Workspace &w, int kind, const double med[2], const dou
   record_statistics(w, kind, true, r);
 }
 
-// What a launch of the device-resident loop is planned with, and what its result is read against: the window
-// predictions for its first two evaluations (taken from the handle's per-kind history, common.hpp: Workspace::win_kind).
-struct LoopPlan {
-  LoopArgs A;
-  int first_kind = 0, second_kind = 1, it0 = 0;
-  bool own0 = false;
-  double p_med[2][2], p_sigma[2][2];
-  int kind_of(int i) const { return i == 0 ? first_kind : (i == 1 ? second_kind : 2); }
-};
-
 // false: the handle has no prediction for evaluation `it` (nothing is launched).  `hints`: a handle fresh from the pool
 // may adopt its previous owner's predictions -- never a rank of a sharded registration, whose windows must be the
 // other ranks' (DESIGN.md section 7).
-static bool loop_plan(icp_handle *h, size_t n, int it, int first_kind, int second_kind, bool hints, LoopPlan *pl) {
+bool icp::api::loop_plan(icp_handle *h, size_t n, int it, int first_kind, int second_kind, bool hints, LoopPlan *pl) {
   Workspace &w = h->ws;
   pl->first_kind = first_kind;
   pl->second_kind = second_kind;
@@ -998,7 +969,7 @@ static bool loop_plan(icp_handle *h, size_t n, int it, int first_kind, int secon
 
 // The launch's result into the loop's state and the handle's prediction history.  *finished, or evaluation *it is the
 // caller's to serve (a window missed, a rotation beyond the restated sin / cos).
-static int loop_finish(icp_handle *h, const LoopPlan &pl, const LoopResult *res, Pose *T, double *prev_error,
+int icp::api::loop_finish(icp_handle *h, const LoopPlan &pl, const LoopResult *res, Pose *T, double *prev_error,
                        uint32_t *applied, int *it, bool *finished) {
   Workspace &w = h->ws;
   *finished = false;
@@ -1088,327 +1059,7 @@ static int gn_loop_run(icp_handle *h, const double *d_a, const double *d_b, size
   return loop_finish(h, pl, res, T, prev_error, applied, it, finished);
 }
 
-static void free_loop_plan(void *p) { delete reinterpret_cast<LoopPlan *>(p); }
-static void free_loop_inbox(Workspace &w);
-static void free_loop_inbox_fwd(icp::Workspace &w) { free_loop_inbox(w); }
-
-// ---- ... and over the ranks of a sharded registration (include/icp_mi355x.h section 5b) ---------------------------------
-extern "C" size_t icp_loop_inbox_bytes(void) { return sizeof(LoopInbox); }
-
-// (the inbox of a handle, whatever it is made of, released)
-static void free_loop_inbox(Workspace &w) {
-  if (!w.d_loop_inbox) return;
-  if (w.loop_inbox_kind == ICP_INBOX_HOST) {
-    (void)hipHostUnregister(w.loop_inbox_host);
-    (void)munmap(w.loop_inbox_host, sizeof(LoopInbox));
-    if (w.loop_shm_name[0]) (void)shm_unlink(w.loop_shm_name);
-    w.loop_shm_name[0] = 0;
-    w.loop_inbox_host = nullptr;
-  } else {
-    (void)hipFree(w.d_loop_inbox);
-  }
-  w.d_loop_inbox = nullptr;
-}
-
-// kind (include/icp_mi355x.h: ICP_INBOX_*): what the inbox is made of -- ordinary device memory (ranks on ONE device:
-// virtual ranks, processes sharing a GPU), fine-grained device memory (peer devices write it while this device's
-// kernels poll it), or pinned host memory in a POSIX shared-memory object that every process of the node can map and
-// register (coherent by construction; the exchange then crosses the host link instead of xGMI).
-extern "C" int icp_loop_inbox(icp_handle *h, int kind, void **d_inbox) {
-  if (!h || !d_inbox || kind < ICP_INBOX_DEVICE || kind > ICP_INBOX_HOST) return ICP_BAD_ARGUMENT;
-  Workspace &w = h->ws;
-  HIP_TRY(hipSetDevice(h->device));
-  if (w.d_loop_inbox && w.loop_inbox_kind != kind) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    free_loop_inbox(w);
-  }
-  if (!w.d_loop_inbox) {
-    if (kind == ICP_INBOX_HOST) {
-      static std::atomic<unsigned> serial{0};
-      snprintf(w.loop_shm_name, sizeof(w.loop_shm_name), "/icp_inbox_%d_%u", (int)getpid(), serial.fetch_add(1u));
-      const int fd = shm_open(w.loop_shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
-      if (fd < 0) {
-        w.loop_shm_name[0] = 0;
-        return ICP_HIP_ERROR;
-      }
-      void *p = MAP_FAILED;
-      if (ftruncate(fd, (off_t)sizeof(LoopInbox)) == 0) p = mmap(nullptr, sizeof(LoopInbox), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-      (void)close(fd);
-      void *d = nullptr;
-      if (p == MAP_FAILED || hipHostRegister(p, sizeof(LoopInbox), hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
-        if (p != MAP_FAILED) (void)munmap(p, sizeof(LoopInbox));
-        (void)shm_unlink(w.loop_shm_name);
-        w.loop_shm_name[0] = 0;
-        (void)hipGetLastError();
-        return ICP_HIP_ERROR;
-      }
-      if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) {
-        (void)hipHostUnregister(p);
-        (void)munmap(p, sizeof(LoopInbox));
-        (void)shm_unlink(w.loop_shm_name);
-        w.loop_shm_name[0] = 0;
-        (void)hipGetLastError();
-        return ICP_HIP_ERROR;
-      }
-      memset(p, 0, sizeof(LoopInbox));
-      w.loop_inbox_host = p;
-      w.d_loop_inbox = d;
-    } else {
-      if (kind == ICP_INBOX_FINE) HIP_TRY(hipExtMallocWithFlags(&w.d_loop_inbox, sizeof(LoopInbox), hipDeviceMallocFinegrained));
-      else HIP_TRY(hipMalloc(&w.d_loop_inbox, sizeof(LoopInbox)));
-      HIP_TRY(hipMemset(w.d_loop_inbox, 0, sizeof(LoopInbox)));
-    }
-    w.loop_inbox_kind = kind;
-  }
-  *d_inbox = w.d_loop_inbox;
-  return ICP_OK;
-}
-
-// ICP_INBOX_HOST: the name of the shared-memory object behind this handle's inbox (what a peer process hands to
-// icp_loop_shm_open), and its removal from the name space once every peer has opened it (the mappings live on)
-extern "C" int icp_loop_inbox_shm_name(icp_handle *h, char out[64]) {
-  if (!h || !out || !h->ws.d_loop_inbox || h->ws.loop_inbox_kind != ICP_INBOX_HOST) return ICP_BAD_ARGUMENT;
-  memcpy(out, h->ws.loop_shm_name, 64);
-  return ICP_OK;
-}
-extern "C" int icp_loop_inbox_shm_unlink(icp_handle *h) {
-  if (!h) return ICP_BAD_ARGUMENT;
-  if (h->ws.loop_shm_name[0]) (void)shm_unlink(h->ws.loop_shm_name);
-  h->ws.loop_shm_name[0] = 0;
-  return ICP_OK;
-}
-namespace {
-std::mutex g_shm_mu;
-std::map<void *, void *> g_shm_maps;  // device pointer -> host mapping of a peer's inbox opened here
-}  // namespace
-extern "C" int icp_loop_shm_open(int device, const char *name, void **d_ptr) {
-  if (!name || !d_ptr) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(device));
-  const int fd = shm_open(name, O_RDWR, 0600);
-  if (fd < 0) return ICP_HIP_ERROR;
-  void *p = mmap(nullptr, sizeof(LoopInbox), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  (void)close(fd);
-  if (p == MAP_FAILED) return ICP_HIP_ERROR;
-  void *d = nullptr;
-  if (hipHostRegister(p, sizeof(LoopInbox), hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess ||
-      hipHostGetDevicePointer(&d, p, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    (void)hipHostUnregister(p);
-    (void)hipGetLastError();
-    (void)munmap(p, sizeof(LoopInbox));
-    return ICP_HIP_ERROR;
-  }
-  std::lock_guard<std::mutex> lk(g_shm_mu);
-  g_shm_maps[d] = p;
-  *d_ptr = d;
-  return ICP_OK;
-}
-extern "C" int icp_loop_shm_close(void *d_ptr) {
-  if (!d_ptr) return ICP_OK;
-  void *p = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(g_shm_mu);
-    auto it = g_shm_maps.find(d_ptr);
-    if (it == g_shm_maps.end()) return ICP_BAD_ARGUMENT;
-    p = it->second;
-    g_shm_maps.erase(it);
-  }
-  (void)hipHostUnregister(p);
-  (void)munmap(p, sizeof(LoopInbox));
-  return ICP_OK;
-}
-
-extern "C" int icp_loop_inbox_ipc_handle(icp_handle *h, unsigned char out[64]) {
-  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI hands an IPC handle over as 64 bytes");
-  if (!h || !out || !h->ws.d_loop_inbox) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  hipIpcMemHandle_t mh;
-  HIP_TRY(hipIpcGetMemHandle(&mh, h->ws.d_loop_inbox));
-  memcpy(out, &mh, 64);
-  return ICP_OK;
-}
-extern "C" int icp_loop_ipc_open(int device, const unsigned char handle[64], void **d_ptr) {
-  if (!handle || !d_ptr) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(device));
-  hipIpcMemHandle_t mh;
-  memcpy(&mh, handle, 64);
-  HIP_TRY(hipIpcOpenMemHandle(d_ptr, mh, hipIpcMemLazyEnablePeerAccess));
-  return ICP_OK;
-}
-extern "C" int icp_loop_ipc_close(void *d_ptr) {
-  if (!d_ptr) return ICP_OK;
-  HIP_TRY(hipIpcCloseMemHandle(d_ptr));
-  return ICP_OK;
-}
-
-// every rank's inbox as mapped in this process, this rank's own among them; empties the own inbox: the ranks must meet
-// (a barrier of the driver) between their connects and the first launch
-extern "C" int icp_shard_loop_connect(icp_handle *h, int rank, int world, void *const *inboxes) {
-  if (!h || !inboxes || world < 1 || world > kShardMaxWorld || rank < 0 || rank >= world) return ICP_BAD_ARGUMENT;
-  Workspace &w = h->ws;
-  if (!w.d_loop_inbox || inboxes[rank] != w.d_loop_inbox) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemset(w.d_loop_inbox, 0, sizeof(LoopInbox)));
-  for (int q = 0; q < world; ++q) {
-    if (!inboxes[q]) return ICP_BAD_ARGUMENT;
-    w.loop_peers[q] = inboxes[q];
-  }
-  w.loop_rank = rank;
-  w.loop_world = world;
-  HIP_TRY(ensure_loop(h));  // (the pinned result block)
-  w.loop_seq = 0;           // launch numbers restart with the connection
-  memset(w.h_loop_res, 0, sizeof(LoopResult));
-  return ICP_OK;
-}
-
-// Ping-pong over the connected inboxes (gn_loop.hip: k_loop_probe): collective -- every rank calls it at about the same
-// time (a barrier of the driver in front); *ok = 1 when this rank saw every token of every peer.  A transport whose
-// probe fails on ANY rank must not carry the loop (the driver agrees on that and tries the next one).
-extern "C" int icp_loop_transport_probe(icp_handle *h, int rounds, int *ok) {
-  if (!h || !ok || rounds < 1 || rounds > 1024) return ICP_BAD_ARGUMENT;
-  Workspace &w = h->ws;
-  if (!w.d_loop_inbox || w.loop_world < 1 || w.loop_rank < 0) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  unsigned *d_ok = nullptr;
-  HIP_TRY(hipMalloc(&d_ok, sizeof(unsigned)));
-  HIP_TRY(hipMemsetAsync(d_ok, 0, sizeof(unsigned), h->stream));
-  const unsigned base = (++w.loop_probe_gen) * 2048u;
-  hipError_t e = launch_loop_probe(h, w.loop_rank, w.loop_world, w.loop_peers, base, (unsigned)rounds, d_ok);
-  unsigned got = 0;
-  if (e == hipSuccess) e = hipMemcpyAsync(&got, d_ok, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(d_ok);
-  HIP_TRY(e);
-  *ok = got == 1u ? 1 : 0;
-  return ICP_OK;
-}
-
-// Forget every window prediction of this handle (the next evaluations take the pipelines that need none and re-centre).
-// What a rank of a sharded registration does when a one-launch inner loop gave up (icp_shard_loop_wait: ICP_HIP_ERROR):
-// the ranks' prediction histories may have diverged inside the abandoned launch, and the stage calls that serve from
-// there on must see the same windows on every rank.
-extern "C" int icp_reset_window_predictions(icp_handle *h) {
-  if (!h) return ICP_BAD_ARGUMENT;
-  Workspace &w = h->ws;
-  w.win_valid = false;
-  w.win_wide = false;
-  for (auto &wk : w.win_kind) wk = Workspace::WinPred();
-  for (auto &wk : w.hint_kind) wk = Workspace::WinPred();
-  return ICP_OK;
-}
-
-// The inner loop of a sharded registration from evaluation `it0` on, in one launch per rank (gn_loop.hip:
-// k_gn_loop_shard).  d_a / d_b: this rank's pairs (icp_shard_geometry: compact, fold order); the state is the loop's
-// (src/lib.rs:62-82).  launch_no: 1, 2, ... -- the same number on every rank for the same launch, growing over the life
-// of the connection; eval_base: evaluations the earlier launches of the connection served (every rank's results say the
-// same).  ICP_RETRY_SHARDED: not launched -- no window prediction for evaluation it0, a pair set beyond the launch's
-// size, fewer tree blocks than ranks: the stage calls (icp_shard_eval_*) serve that evaluation; the answer depends on
-// replicated state only, so every rank gives it.
-// nh = 1: the rank of hs[0]; nh = world: ALL ranks (hs[q] = rank q, one device) in one launch on hs[0]'s stream.
-static int shard_loop_launch_common(icp_handle *const *hs, int nh, const double *const *d_a, const double *const *d_b,
-                                    size_t n_total, unsigned launch_no, unsigned eval_base, int it0, uint32_t applied0,
-                                    const icp_pose *Ti, double prev_error, int first_kind, int second_kind) {
-  icp_handle *h0 = hs[0];
-  Workspace &w0 = h0->ws;
-  if (w0.loop_rank < 0 || !w0.d_loop_inbox || (nh != 1 && nh != w0.loop_world)) return ICP_BAD_ARGUMENT;
-  const int world = w0.loop_world;
-  if (!gn_loop_shard_applies(n_total, world)) return ICP_RETRY_SHARDED;  // (before the pointers: a rank without points has none)
-  for (int q = 0; q < nh; ++q) {
-    Workspace &w = hs[q]->ws;
-    if (!d_a[q] || !d_b[q] || w.loop_world != world || (nh > 1 && w.loop_rank != q) || !w.d_loop_inbox) return ICP_BAD_ARGUMENT;
-    if (w.loop_off) return ICP_RETRY_SHARDED;
-  }
-  HIP_TRY(hipSetDevice(h0->device));
-  LoopRankPtrs ptrs = {};
-  for (int q = 0; q < nh; ++q) {
-    Workspace &w = hs[q]->ws;
-    if (!w.loop_plan) w.loop_plan = new (std::nothrow) LoopPlan();
-    if (!w.loop_plan) return ICP_OUT_OF_MEMORY;
-    LoopPlan &pl = *reinterpret_cast<LoopPlan *>(w.loop_plan);
-    if (!loop_plan(hs[q], n_total, it0, first_kind, second_kind, false, &pl)) {
-      if (q > 0) return ICP_HIP_ERROR;  // (the ranks' prediction state diverged: cannot happen)
-      return ICP_RETRY_SHARDED;
-    }
-    if (q > 0) {  // every rank must bin with the same windows
-      const LoopPlan &p0 = *reinterpret_cast<LoopPlan *>(w0.loop_plan);
-      if (memcmp(&pl.A.PA, &p0.A.PA, sizeof(WinParams)) != 0 || pl.A.pb_valid != p0.A.pb_valid ||
-          (pl.A.pb_valid && memcmp(&pl.A.PB, &p0.A.PB, sizeof(WinParams)) != 0) ||
-          memcmp(&pl.A.f_next, &p0.A.f_next, sizeof(double)) != 0)
-        return ICP_HIP_ERROR;
-    }
-    const int r = nh > 1 ? q : w.loop_rank;
-    ptrs.a[r] = (const double2 *)d_a[q];
-    ptrs.b[r] = (const double2 *)d_b[q];
-    ptrs.res[r] = reinterpret_cast<LoopResult *>(w.h_loop_res);
-    w.loop_seq = launch_no;
-  }
-  LoopPlan &pl = *reinterpret_cast<LoopPlan *>(w0.loop_plan);
-  LoopArgs A = pl.A;
-  LoopShardArgs S = {};
-  S.rank = nh > 1 ? 0 : w0.loop_rank;
-  S.world = world;
-  int B = 0;
-  for (int q = 0; q < world; ++q) {
-    int b0, b1;
-    size_t nl;
-    shard_geometry(n_total, q, world, &b0, &b1, &B, &nl);
-    S.first_block[q] = b0;
-    S.first_block[q + 1] = b1;
-    S.inbox[q] = reinterpret_cast<LoopInbox *>(w0.loop_peers[q]);
-  }
-  S.blocks_total = B;
-  S.gen_base = launch_no * 1024u;  // (a launch runs at most 200 evaluations, each at most twice: rounds < 1024)
-  S.eval_base = eval_base;
-  A.n = (unsigned)n_total;
-  A.it0 = (unsigned)it0;
-  A.applied0 = applied0;
-  A.T0 = *Ti;
-  A.prev_error0 = prev_error;
-  A.seq = launch_no;
-  HIP_TRY(launch_gn_loop_shard(h0, A, S, ptrs, nh));
-  return ICP_OK;
-}
-
-extern "C" int icp_shard_loop_launch_device(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, unsigned launch_no,
-                                            unsigned eval_base, int it0, uint32_t applied0, const icp_pose *Ti, double prev_error,
-                                            int first_kind, int second_kind) {
-  if (!h || !Ti || n_total >= 0xffffffffull || it0 < 0 || launch_no == 0) return ICP_BAD_ARGUMENT;
-  return shard_loop_launch_common(&h, 1, &d_a, &d_b, n_total, launch_no, eval_base, it0, applied0, Ti, prev_error, first_kind,
-                                  second_kind);
-}
-
-// (multi.hip) all the ranks of one device in one launch on rank 0's stream
-int icp_shard_loop_launch_fused(icp_handle *const *hs, int world, const double *const *d_a, const double *const *d_b, size_t n_total,
-                                unsigned launch_no, unsigned eval_base, int it0, uint32_t applied0, const icp_pose *Ti,
-                                double prev_error, int first_kind, int second_kind) {
-  if (!hs || world < 1 || world > kShardMaxWorld || !Ti || !d_a || !d_b || n_total >= 0xffffffffull || it0 < 0 || launch_no == 0)
-    return ICP_BAD_ARGUMENT;
-  for (int q = 0; q < world; ++q)
-    if (!hs[q]) return ICP_BAD_ARGUMENT;
-  return shard_loop_launch_common(hs, world, d_a, d_b, n_total, launch_no, eval_base, it0, applied0, Ti, prev_error, first_kind,
-                                  second_kind);
-}
-
-// ... its result (blocks until this rank's launch has published it): the loop's state, *finished, or the evaluation
-// *it that the stage calls must serve before the next launch.  ICP_HIP_ERROR: the launch gave up waiting for a peer.
-extern "C" int icp_shard_loop_wait(icp_handle *h, icp_pose *Ti, double *prev_error, uint32_t *applied, int *it, int *finished,
-                                   uint32_t *evals) {
-  if (!h || !Ti || !prev_error || !applied || !it || !finished || !h->ws.loop_plan) return ICP_BAD_ARGUMENT;
-  Workspace &w = h->ws;
-  HIP_TRY(hipSetDevice(h->device));
-  LoopResult *res = reinterpret_cast<LoopResult *>(w.h_loop_res);
-  HIP_TRY(wait_seq(h, &res->seq, w.loop_seq));
-  if (evals) *evals = res->rounds;  // (what the connection's eval_base advances by)
-  if (res->status == 5) {
-    loop_timed_out(w);
-    return ICP_HIP_ERROR;
-  }
-  bool fin = false;
-  const int rc = loop_finish(h, *reinterpret_cast<LoopPlan *>(w.loop_plan), res, Ti, prev_error, applied, it, &fin);
-  *finished = fin ? 1 : 0;
-  return rc;
-}
+void icp::api::free_loop_plan(void *p) { delete reinterpret_cast<LoopPlan *>(p); }
 
 // estimate_transform (src/lib.rs:59-84) on device pairs.  Pair sets of up to 2^20 run the loop on the device
 // (gn_loop.hip: one launch, gn_loop_run above); the host steps only where that launch hands an evaluation back, and
@@ -1939,524 +1590,3 @@ extern "C" int icp_residual_stddevs(const icp_pose *T, const double *a, const do
   return ICP_OK;
 }
 
-// ------------------------------------------- EXTENSION: a growing target cloud ----
-// Scan-to-map (BASELINE.json configs[4]; not in the reference, see include/icp_mi355x.h section 6).
-// After an append the handle is indistinguishable from a fresh icp_create on the concatenated
-// cloud: same target indices, same search results, same poses.
-namespace {
-
-// Transform::transform on every appended point (transform.rs:22-24; products, add, then + t; the
-// library is compiled with -ffp-contract=off), z carried through as in transform_xy (lib.rs:52-57)
-template <int DIM>
-__global__ void k_append_targets(const double *__restrict__ pts, unsigned k, Pose T, bool xform,
-                                 double *__restrict__ out) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= k) return;
-  double x = pts[(size_t)i * DIM], y = pts[(size_t)i * DIM + 1];
-  if (xform) {
-    const double nx = (T.r00 * x + T.r01 * y) + T.tx;
-    const double ny = (T.r10 * x + T.r11 * y) + T.ty;
-    x = nx;
-    y = ny;
-  }
-  out[(size_t)i * DIM] = x;
-  out[(size_t)i * DIM + 1] = y;
-  if (DIM == 3) out[(size_t)i * DIM + 2] = pts[(size_t)i * DIM + 2];
-}
-
-int quiesce(icp_handle *h) {
-  HIP_TRY(hipSetDevice(h->device));
-  if (h->own_stream) HIP_TRY(hipStreamSynchronize(h->own_stream));
-  if (h->stream != h->own_stream) HIP_TRY(hipStreamSynchronize(h->stream));
-  if (h->ws.spec_stream) HIP_TRY(hipStreamSynchronize(h->ws.spec_stream));
-  return ICP_OK;
-}
-
-// make the target cloud live in storage the handle owns, with room for `points` points
-int own_targets(icp_handle *h, size_t points) {
-  const size_t need = points * (size_t)h->dim;
-  if (h->owns_dst && need <= h->cap_dst_own) return ICP_OK;
-  if (!h->owns_dst && need <= h->cap_dst_own && h->d_dst_own) {
-    // a pooled buffer is large enough: move the borrowed cloud in
-    if (h->m > 0)
-      HIP_TRY(hipMemcpyAsync(h->d_dst_own, h->d_dst, h->m * h->dim * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  } else {
-    // grow geometrically: a map that gains one scan per frame is copied O(log) times
-    size_t cap = h->owns_dst ? h->cap_dst_own * 2 : 0;
-    if (cap < need) cap = need + need / 8 + 1;
-    double *p = nullptr;
-    HIP_TRY(hipMalloc(&p, cap * sizeof(double)));
-    if (h->m > 0) {
-      const hipError_t e =
-          hipMemcpyAsync(p, h->d_dst, h->m * h->dim * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
-      if (e != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
-        (void)hipFree(p);
-        return ICP_HIP_ERROR;
-      }
-    }
-    (void)hipFree(h->d_dst_own);
-    h->d_dst_own = p;
-    h->cap_dst_own = cap;
-  }
-  h->d_dst = h->d_dst_own;
-  h->owns_dst = true;
-  return ICP_OK;
-}
-
-int append_common(icp_handle *h, const double *pts, size_t k, const icp_pose *T, bool on_device) {
-  if (!h || (k > 0 && !pts) || h->m + k >= 0xffffffffull) return ICP_BAD_ARGUMENT;
-  if (k == 0) return ICP_OK;
-  int rc = quiesce(h);
-  if (rc != ICP_OK) return rc;
-  const double *d_pts = pts;
-  if (!on_device) {
-    // stage through the handle's source buffer (the same one icp_estimate stages a scan in)
-    HIP_TRY(ensure_workspace(h, k, true));
-    HIP_TRY(hipMemcpyAsync(h->ws.d_src, pts, k * h->dim * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    d_pts = h->ws.d_src;
-  }
-  if ((rc = own_targets(h, h->m + k)) != ICP_OK) return rc;
-  double *tail = h->d_dst_own + h->m * h->dim;
-  const Pose P = T ? *T : transform_identity();
-  const unsigned blocks = (unsigned)((k + 255) / 256);
-  if (h->dim == 3)
-    hipLaunchKernelGGL(k_append_targets<3>, dim3(blocks), dim3(256), 0, h->stream, d_pts, (unsigned)k, P, T != nullptr, tail);
-  else
-    hipLaunchKernelGGL(k_append_targets<2>, dim3(blocks), dim3(256), 0, h->stream, d_pts, (unsigned)k, P, T != nullptr, tail);
-  HIP_TRY(hipGetLastError());
-  const size_t m_before = h->m;
-  h->m += k;
-  // (extension) the normals of the targets that were there stay; the new ones have none until
-  // icp_update_target_normals / icp_compute_target_normals (normals_m < m: point-to-plane calls refuse)
-  h->qsort.valid = false;  // snapshots and previous matches refer to the old grid
-  h->qsort.have_prev = false;
-  h->brute_valid = h->screen_valid = false;
-  // the grid is what a map-sized cloud is searched with; the sweep's structures (SoA + f32 screen,
-  // 36 B per target) are rebuilt right away only where the sweep is the engine in use
-  bool appended = false;
-  hipError_t e = append_grid(h, m_before, k, &appended);  // (the sorted records move, nothing is re-sorted: nn_grid.hip)
-  if (e == hipSuccess && !appended) e = build_grid(h);
-  if (e == hipSuccess) ++(appended ? h->grid.appends_moved : h->grid.appends_rebuilt);
-  if (e == hipSuccess && resolved_nn_mode(h) == ICP_NN_BRUTE) {
-    if ((e = build_target_soa(h)) == hipSuccess) e = build_target_screen(h);
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // host `pts` may be freed; later calls may use another stream
-  if (e != hipSuccess) {
-    // back to the cloud as it was: the old points are untouched, the search structures are rebuilt
-    // for them (if even that fails the handle has no grid and the sweep rebuilds its copies on demand)
-    h->m = m_before;
-    (void)build_grid(h);
-    (void)hipStreamSynchronize(h->stream);
-    return map_hip(e);
-  }
-  return ICP_OK;
-}
-
-}  // namespace
-
-extern "C" int icp_append_targets(icp_handle *h, const double *pts, size_t k, const icp_pose *T) {
-  return append_common(h, pts, k, T, false);
-}
-extern "C" int icp_append_targets_device(icp_handle *h, const double *d_pts, size_t k, const icp_pose *T) {
-  return append_common(h, d_pts, k, T, true);
-}
-extern "C" int icp_reserve_targets(icp_handle *h, size_t capacity) {
-  if (!h || capacity >= 0xffffffffull) return ICP_BAD_ARGUMENT;
-  if (capacity <= h->m) return ICP_OK;
-  const int rc = quiesce(h);
-  if (rc != ICP_OK) return rc;
-  return own_targets(h, capacity);
-}
-extern "C" size_t icp_target_count(const icp_handle *h) { return h ? h->m : 0; }
-// Observability: out[0] = appends served by moving the sorted records (append_grid), out[1] = appends that rebuilt the grid
-extern "C" int icp_grid_append_counters(const icp_handle *h, uint64_t out[2]) {
-  if (!h || !out) return ICP_BAD_ARGUMENT;
-  out[0] = h->grid.appends_moved;
-  out[1] = h->grid.appends_rebuilt;
-  return ICP_OK;
-}
-extern "C" int icp_read_targets(icp_handle *h, size_t first, size_t k, double *out) {
-  if (!h || first > h->m || k > h->m - first || (k > 0 && !out)) return ICP_BAD_ARGUMENT;
-  if (k == 0) return ICP_OK;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemcpyAsync(out, h->d_dst + first * h->dim, k * h->dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return ICP_OK;
-}
-
-// ------------------------------------------- EXTENSION: point-to-plane residuals -----
-// Not in the reference (no normals anywhere in src/); definition and CPU restatement: p2plane.hip,
-// the CPU checker under tests (tests/test_p2plane.py).  Everything around the residual is the reference's: exact 3-D
-// nearest neighbour, SE(2) pose on xy, Huber / MAD Gauss-Newton, the inner loop's break tests.
-extern "C" int icp_compute_target_normals(icp_handle *h, int k) {
-  if (!h || h->dim != 3 || k < 3 || k > 16) return ICP_BAD_ARGUMENT;
-  if (h->m == 0) return ICP_EMPTY_DST;
-  if (!h->grid.built) return ICP_BAD_ARGUMENT;  // non-finite targets: no grid to search neighbourhoods with
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(reserve(h->d_normals, h->cap_normals, h->m * 3));
-  HIP_TRY(launch_target_normals(h, k, h->d_normals));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  h->normals_m = h->m;
-  h->normals_k = k;
-  return ICP_OK;
-}
-
-// The targets appended since the normals were last computed get theirs (from their k nearest targets in the cloud
-// as it is NOW); the older targets keep the normals they have -- "normals at insertion time", the definition a map that
-// grows frame by frame uses (a full icp_compute_target_normals re-derives all of them from the current cloud).
-extern "C" int icp_update_target_normals(icp_handle *h, int k) {
-  if (!h || h->dim != 3 || k < 3 || k > 16) return ICP_BAD_ARGUMENT;
-  if (h->m == 0) return ICP_EMPTY_DST;
-  if (!h->grid.built || h->normals_m > h->m) return ICP_BAD_ARGUMENT;
-  if (h->normals_m > 0 && h->normals_k != k) return ICP_BAD_ARGUMENT;  // one neighbourhood size per cloud
-  HIP_TRY(hipSetDevice(h->device));
-  if (h->m * 3 > h->cap_normals || !h->d_normals) {  // grow, keeping the normals that exist
-    double *old = h->d_normals;
-    const size_t keep = h->normals_m * 3;
-    h->d_normals = nullptr;
-    h->cap_normals = 0;
-    hipError_t e = reserve(h->d_normals, h->cap_normals, h->m * 3);
-    if (e == hipSuccess && old && keep)
-      e = hipMemcpyAsync(h->d_normals, old, keep * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(old);
-    if (e != hipSuccess) {
-      h->normals_m = 0;
-      return map_hip(e);
-    }
-  }
-  HIP_TRY(launch_target_normals(h, k, h->d_normals, h->normals_m));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  h->normals_m = h->m;
-  h->normals_k = k;
-  return ICP_OK;
-}
-
-extern "C" int icp_read_target_normals(icp_handle *h, size_t first, size_t count, double *out) {
-  if (!h || h->normals_m != h->m || h->m == 0 || first > h->m || count > h->m - first || (count > 0 && !out))
-    return ICP_BAD_ARGUMENT;
-  if (count == 0) return ICP_OK;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemcpyAsync(out, h->d_normals + first * 3, count * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return ICP_OK;
-}
-
-// the per-pair scratch of a point-to-plane inner loop
-static int ensure_plane_buffers(icp_handle *h, size_t n) {
-  if (n > h->cap_plane) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    (void)hipFree(h->d_plane_pairs);
-    (void)hipFree(h->d_plane_fa);
-    (void)hipFree(h->d_plane_fb);
-    h->d_plane_pairs = nullptr;
-    h->d_plane_fa = h->d_plane_fb = nullptr;
-    h->cap_plane = 0;
-    HIP_TRY(hipMalloc(&h->d_plane_pairs, n * p2pl_pair_bytes()));
-    HIP_TRY(hipMalloc(&h->d_plane_fa, n * 2 * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->d_plane_fb, n * 2 * sizeof(double)));
-    h->cap_plane = n;
-  }
-  return ICP_OK;
-}
-
-// One outer iteration's inner loop (src/lib.rs:59-84 around the plane residual) for given correspondences d_idx of the
-// WHOLE source cloud under pose T: the pose update dT and the updates applied.  (icp_multi_estimate_point_to_plane runs
-// this on every rank after the ranks have exchanged the indices of their slices.)
-int icp_p2pl_inner_loop_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *T, const uint32_t *d_idx,
-                               icp_pose *dT, uint32_t *applied_out) {
-  if (!h || h->dim != 3 || !T || !dT || (n > 0 && (!d_src || !d_idx)) || h->normals_m != h->m || h->m == 0) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(ensure_workspace(h, n, false));
-  ICP_TRY_RC(ensure_plane_buffers(h, n));
-  Workspace &w = h->ws;
-  HIP_TRY(launch_p2pl_gather(h, d_src, n, *T, d_idx, h->d_normals, h->d_plane_pairs));
-  Pose Ti = transform_identity();
-  uint32_t applied = 0;
-  if (n >= 2) {
-    double prev_error = DBL_MAX;
-    for (int k = 0; k < ICP_INNER_MAX_ITER; ++k) {
-      HIP_TRY(launch_p2pl_eval(h, h->d_plane_pairs, n, Ti, h->d_plane_fa, h->d_plane_fb));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      const GnResult &r = *w.h_res;
-      if (r.nan_flag) return ICP_NAN_INPUT;
-      double delta[3];
-      if (!solve_update(r.acc, r.acc + 9, delta)) break;
-      if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD) break;
-      if (r.acc[12] > prev_error) break;
-      prev_error = r.acc[12];
-      Ti = transform_mul(transform_new(delta), Ti);
-      ++applied;
-    }
-  }
-  *dT = Ti;
-  if (applied_out) *applied_out = applied;
-  return ICP_OK;
-}
-
-extern "C" int icp_estimate_point_to_plane_device(icp_handle *h, const double *d_src, size_t n, const icp_pose *init,
-                                                  size_t max_iter, icp_pose *out, uint32_t *d_last_idx,
-                                                  uint32_t *inner_iters) {
-  if (!h || h->dim != 3 || !init || !out || (n > 0 && !d_src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
-  if (h->m == 0) {  // index.unwrap() on an empty tree, src/lib.rs:165 -- only when a search would run
-    if (n > 0 && max_iter > 0) return ICP_EMPTY_DST;
-    *out = *init;
-    return ICP_OK;
-  }
-  if (h->normals_m != h->m) return ICP_BAD_ARGUMENT;  // icp_compute_target_normals first (again after an append)
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(ensure_workspace(h, n, false));
-  ICP_TRY_RC(ensure_plane_buffers(h, n));
-  Workspace &w = h->ws;
-  Pose T = *init;
-  if (max_iter > 0) {
-    const int prc = icp_prepare_source_device(h, d_src, n, init);
-    if (prc != ICP_OK) return prc;
-  }
-  struct Quiesce {
-    icp_handle *h;
-    ~Quiesce() {
-      (void)hipStreamSynchronize(h->stream);
-      h->qsort.valid = false;
-      h->qsort.have_prev = false;
-    }
-  } quiesce_on_exit{h};
-  for (size_t it = 0; it < max_iter; ++it) {
-    uint32_t *idx = (it + 1 == max_iter && d_last_idx) ? d_last_idx : w.d_idx;
-    int rc = icp_correspond_device(h, d_src, n, &T, nullptr, nullptr, idx);  // exact 3-D NN, src/lib.rs:161-167
-    if (rc != ICP_OK) return rc;
-    Pose Ti;
-    uint32_t applied = 0;
-    rc = icp_p2pl_inner_loop_device(h, d_src, n, &T, idx, &Ti, &applied);
-    if (rc != ICP_OK) return rc;
-    if (inner_iters) inner_iters[it] = applied;
-    T = transform_mul(Ti, T);
-  }
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  *out = T;
-  return ICP_OK;
-}
-
-extern "C" int icp_estimate_point_to_plane(icp_handle *h, const double *src, size_t n, const icp_pose *init,
-                                           size_t max_iter, icp_pose *out, uint32_t *last_idx, uint32_t *inner_iters) {
-  if (!h || h->dim != 3 || !init || !out || (n > 0 && !src) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(ensure_workspace(h, n, true));
-  if (n > 0)
-    HIP_TRY(hipMemcpyAsync(h->ws.d_src, src, n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  uint32_t *d_li = nullptr;
-  if (last_idx && n > 0) HIP_TRY(hipMalloc(&d_li, n * sizeof(uint32_t)));
-  int rc = icp_estimate_point_to_plane_device(h, h->ws.d_src, n, init, max_iter, out, d_li, inner_iters);
-  if (rc == ICP_OK && d_li && max_iter > 0) {
-    if (hipMemcpy(last_idx, d_li, n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = ICP_HIP_ERROR;
-  }
-  (void)hipFree(d_li);
-  return rc;
-}
-
-// ------------------------------------------------ sharded evaluation (stage calls) -----
-// shard.hip has the design.  One evaluation = hist (residuals, histograms, block sums) -> [sum the histograms over
-// ranks] -> compact -> [gather every rank's candidates + block sums] -> finish.  ICP_RETRY_REPLICATED
-// from hist (no prediction yet) or finish (the window missed) means: gather the pairs of all ranks in
-// global order and call icp_weighted_gn_step_device on them -- same bits, and it seeds the prediction.
-extern "C" int icp_shard_geometry(size_t n_total, int rank, int world, int *b0, int *b1, int *blocks, size_t *n_local) {
-  if (world < 1 || rank < 0 || rank >= world || !b0 || !b1 || !n_local || n_total >= 0xffffffffull) return ICP_BAD_ARGUMENT;
-  shard_geometry(n_total, rank, world, b0, b1, blocks, n_local);
-  return ICP_OK;
-}
-extern "C" size_t icp_shard_histogram_words(void) { return (size_t)2 * kWinBins + kShardStatusWords; }
-extern "C" size_t icp_shard_candidates_bytes(void) { return shard_cand_bytes(); }
-extern "C" size_t icp_shard_partials_bytes(int world) { return world >= 1 && world <= kShardMaxWorld ? shard_part_bytes(world) : 0; }
-extern "C" size_t icp_shard_exchange_bytes(int world) { return world >= 1 && world <= kShardMaxWorld ? shard_exchange_bytes(world) : 0; }
-
-static int shard_copy(icp_handle *h, const void *src, void *dst, size_t n_total, int rank, int world, size_t elem_bytes,
-                      bool take) {
-  if (!h || world < 1 || rank < 0 || rank >= world || elem_bytes == 0 || elem_bytes % 4 || n_total >= 0xffffffffull)
-    return ICP_BAD_ARGUMENT;
-  int b0, b1, blocks;
-  size_t n_local;
-  shard_geometry(n_total, rank, world, &b0, &b1, &blocks, &n_local);
-  if (n_local == 0) return ICP_OK;  // (more ranks than reduction blocks: this rank owns no point, its buffers may be empty)
-  if (!src || !dst) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(launch_shard_copy(h, src, dst, n_total, rank, world, (unsigned)(elem_bytes / 4), take));
-  return ICP_OK;
-}
-extern "C" int icp_shard_take_device(icp_handle *h, const void *d_full, void *d_local, size_t n_total, int rank, int world,
-                                     size_t elem_bytes) {
-  return shard_copy(h, d_full, d_local, n_total, rank, world, elem_bytes, true);
-}
-extern "C" int icp_shard_put_device(icp_handle *h, const void *d_local, void *d_full, size_t n_total, int rank, int world,
-                                    size_t elem_bytes) {
-  return shard_copy(h, d_local, d_full, n_total, rank, world, elem_bytes, false);
-}
-
-static int shard_eval_hist_impl(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, int rank, int world,
-                                const icp_pose *T, int kind, int refined, uint32_t **d_hist);
-
-// Whatever this returns (short of ICP_BAD_ARGUMENT / ICP_NO_DEVICE), *d_hist is the buffer to sum over the ranks --
-// histograms (all zero unless ICP_OK) followed by four status words, one-hot by the answer -- and EVERY rank is
-// expected to take part in that sum: icp_shard_eval_status then tells every rank the same four counts.
-extern "C" int icp_shard_eval_hist_device(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, int rank,
-                                          int world, const icp_pose *T, int kind, int refined, uint32_t **d_hist) {
-  // (the last stage indexes its per-rank tables with at most kShardMaxWorld entries)
-  if (!h || !T || !d_hist || world < 1 || world > kShardMaxWorld || rank < 0 || rank >= world || n_total >= 0xffffffffull)
-    return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(ensure_workspace(h, 1, false));
-  const int rc = shard_eval_hist_impl(h, d_a, d_b, n_total, rank, world, T, kind, refined, d_hist);
-  if (rc == ICP_BAD_ARGUMENT) return rc;
-  *d_hist = h->ws.d_whist;
-  // the status words: written by the hist launch itself when this rank answers OK and owns blocks, else by a launch of their own
-  if (!(rc == ICP_OK && h->shard.b1 - h->shard.b0 >= 1) && shard_launch_status(h, rc) != hipSuccess) return ICP_HIP_ERROR;
-  return rc;
-}
-
-// The four counts {ranks that answered OK, RETRY_REPLICATED, NONE, anything else} of the evaluation in flight.
-// from_device = 0: as the fold kernel of icp_shard_eval_finish_device left them in host memory (no wait: valid once
-// finish has returned); 1: read from the summed buffer behind the stream (a rank whose own answer was not OK and
-// which therefore ran no finish).
-extern "C" int icp_shard_eval_status(icp_handle *h, uint32_t out[4], int from_device) {
-  if (!h || !out) return ICP_BAD_ARGUMENT;
-  if (!from_device) {
-    if (!h->ws.h_res) return ICP_BAD_ARGUMENT;
-    for (int k = 0; k < kShardStatusWords; ++k) out[k] = h->ws.h_res->status[k];
-    return ICP_OK;
-  }
-  if (!h->ws.d_whist) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemcpyAsync(out, h->ws.d_whist + 2 * kWinBins, kShardStatusWords * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                         h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return ICP_OK;
-}
-
-// After an evaluation that the ranks did NOT all answer with ICP_OK: the summed buffer of a rank that had no
-// histogram of its own holds its peers' counts; back to the all-zero rest state the next evaluation expects.
-extern "C" int icp_shard_eval_abort_device(icp_handle *h) {
-  if (!h || !h->ws.d_whist) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemsetAsync(h->ws.d_whist, 0, ((size_t)2 * kWinBins + kShardStatusWords) * sizeof(uint32_t), h->stream));
-  h->shard.active = false;
-  h->ws.gn_dirty = true;  // (the stages that did run may have left selection state behind)
-  return ICP_OK;
-}
-
-static int shard_eval_hist_impl(icp_handle *h, const double *d_a, const double *d_b, size_t n_total, int rank, int world,
-                                const icp_pose *T, int kind, int refined, uint32_t **d_hist) {
-  icp_handle::ShardEval &S = h->shard;
-  S.active = false;
-  if (refined && !S.refined_ready) return ICP_BAD_ARGUMENT;  // only right after ICP_RETRY_SHARDED
-  if (!input_size_ok(n_total)) return ICP_NONE;  // check_input_size, src/lib.rs:225-228
-  shard_geometry(n_total, rank, world, &S.b0, &S.b1, &S.blocks, &S.n_local);
-  if (S.blocks < world || (S.n_local > 0 && (!d_a || !d_b))) return S.blocks < world ? ICP_RETRY_REPLICATED : ICP_BAD_ARGUMENT;
-  HIP_TRY(ensure_workspace(h, S.n_local, false));
-  Workspace &w = h->ws;
-  if (refined) {
-    S.P = S.P2;
-  } else if (!window_usable(h, n_total, &S.P, kind, true, n_total > 1000000 ? 0.2 : 0.)) {
-    // (beyond 1M points a window narrow enough for the candidate lists would have to be predicted to
-    // ~0.01 sigma: the first attempt is instead as WIDE as the layout allows -- it tolerates a
-    // prediction that is off by 0.2 sigma -- and serves as the counting pass whose exact, global
-    // counts place the narrow window of the second attempt: two sharded passes, like the one-GPU path
-    // beyond 4M points, instead of a gather of all pairs)
-    return ICP_RETRY_REPLICATED;
-  }
-  S.attempt_refined = refined != 0;
-  S.refined_ready = false;
-  if (!S.d_ordered) HIP_TRY(hipMalloc(&S.d_ordered, (size_t)kReduceMaxBlocks * (kNSum + 1) * sizeof(double)));
-  if (!w.h_whist) HIP_TRY(hipHostMalloc(&w.h_whist, (size_t)2 * kWinBins * sizeof(uint32_t), hipHostMallocDefault));
-  if (w.gn_dirty) {
-    HIP_TRY(launch_sel_init(h, S.n_local));
-    w.gn_dirty = false;
-  }
-  S.kind = kind;
-  S.rank = rank;
-  S.world = world;
-  S.n_total = n_total;
-  S.d_a = d_a;
-  S.T = *T;
-  ++w.win_tried;
-  HIP_TRY(shard_launch_hist(h, d_a, d_b, S.n_local, S.T, S.P, S.b1 - S.b0));
-  *d_hist = w.d_whist;
-  S.active = true;
-  return ICP_OK;
-}
-
-extern "C" int icp_shard_eval_compact_device(icp_handle *h, void *d_exchange_out) {
-  if (!h || !h->shard.active || !d_exchange_out) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  // (the global counts go to the host only if this window misses -- they place the next attempt's: k_shard_finish)
-  const icp_handle::ShardEval &S = h->shard;
-  HIP_TRY(shard_launch_compact(h, S.n_local, S.n_total, S.P, S.world, S.b1 - S.b0, d_exchange_out));
-  return ICP_OK;
-}
-
-// the host half of `finish`: wait for the folded result, keep the prediction state, solve
-static int shard_finish_common(icp_handle *h, double delta[3], double *huber_err) {
-  icp_handle::ShardEval &S = h->shard;
-  Workspace &w = h->ws;
-  HIP_TRY(wait_result(h));
-  S.active = false;
-  const GnResult &r = *w.h_res;
-  const int kind = S.kind;
-  const bool own = Workspace::kind_has_slot(kind) && w.win_kind[kind].valid;
-  bool &wide = own ? w.win_kind[kind].wide : w.win_wide;
-  if (r.nan_flag) {
-    w.gn_dirty = true;
-    return ICP_NAN_INPUT;
-  }
-  if (r.overflow) {
-    // The window missed (an order statistic outside its fine bins, or more candidates than the lists
-    // hold).  Its counts are still exact counts of ALL ranks' residuals: they place the median and the
-    // MAD to within a bin, and windows as narrow as the lists require go around them (refine_window,
-    // the host half of the one-GPU path beyond 4M points) -- the next attempt, still sharded, then
-    // hits.  Only a refined attempt that misses too goes back to the gathered pairs.
-    ++w.win_missed;
-    wide = true;
-    if (!S.attempt_refined && refine_window(w.h_whist, S.n_total, S.P, &S.P2)) {
-      S.refined_ready = true;
-      return ICP_RETRY_SHARDED;
-    }
-    return ICP_RETRY_REPLICATED;
-  }
-  if (wide) {
-    double shift = 0.;
-    for (int d = 0; d < 2; ++d) {
-      const double pm = own ? w.win_kind[kind].med[d] : w.win_med[d], ps = own ? w.win_kind[kind].sigma[d] : w.win_sigma[d];
-      shift = fmax(shift, (fabs(r.median[d] - pm) + fabs(r.sigma[d] - ps)) / ps);
-    }
-    if (shift < 0.01) wide = false;
-  }
-  record_statistics(w, kind, true, r);
-  if (huber_err) *huber_err = r.acc[12];
-  return solve_update(r.acc, r.acc + 9, delta) ? ICP_OK : ICP_NONE;
-}
-
-extern "C" int icp_shard_eval_finish_device(icp_handle *h, const void *d_exchange_all, double delta[3], double *huber_err) {
-  if (!h || !h->shard.active || !d_exchange_all || !delta) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(shard_launch_finish(h, d_exchange_all, h->shard.world, h->shard.n_total, h->shard.blocks, h->shard.d_ordered));
-  return shard_finish_common(h, delta, huber_err);
-}
-
-// (multi.hip) the same with the block of every rank read where it lies: one pointer per rank
-int icp_shard_eval_finish_ptrs(icp_handle *h, const void *const *exch_ptrs, double delta[3], double *huber_err) {
-  if (!h || !h->shard.active || !exch_ptrs || !delta) return ICP_BAD_ARGUMENT;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(shard_launch_finish_ptrs(h, exch_ptrs, h->shard.world, h->shard.n_total, h->shard.blocks, h->shard.d_ordered));
-  return shard_finish_common(h, delta, huber_err);
-}
-
-// One evaluation of weighted_gauss_newton_update (+ the Huber error of the same pose) on device pairs,
-// through whichever pipeline serves it -- what the inner loop of icp_estimate_transform_device calls per
-// iteration, exposed for hosts that drive that loop themselves (the sharded driver's replicated fallback).
-// kind: 0 first evaluation on new correspondences, 1 the one after the first update, 2 later ones.
-extern "C" int icp_weighted_gn_step_device(icp_handle *h, const double *d_a, const double *d_b, size_t n,
-                                           const icp_pose *T, int kind, double delta[3], double *huber_err) {
-  if (!h || !T || !delta || (n > 0 && (!d_a || !d_b)) || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
-  if (!input_size_ok(n)) return ICP_NONE;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(ensure_workspace(h, n, false));
-  return wgn_step(h, d_a, d_b, n, *T, delta, huber_err, false, kind);
-}

@@ -124,6 +124,7 @@ __device__ __forceinline__ void win_hist_body(const double2 *__restrict__ a, con
   if (SUMS) block_reduce_store<SUMS ? kNSum : 1, true>(acc, partials + (size_t)blockIdx.x * (kNSum + 1));
 }
 
+#ifdef ICP_EXPERIMENTS  // (the histograms alone: first launch of the four-launch forms of rounds 1-3)
 __global__ __launch_bounds__(kWinThreads) void k_win_hist(const double2 *__restrict__ a,
                                                           const double2 *__restrict__ b, Pose T,
                                                           double *__restrict__ rx, double *__restrict__ ry,
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(kWinThreads) void k_win_hist(const double2 *__restr
                                                           GnScalars *scal) {
   win_hist_body<false>(a, b, T, rx, ry, n, P, whist, st, scal, nullptr);
 }
+#endif
 
 // launched with reduce_geometry(n): workgroup i leaves block sum i of the fixed reduction tree in `partials`
 __global__ __launch_bounds__(kWinThreads) void k_win_hist_sums(const double2 *__restrict__ a,
@@ -1120,6 +1122,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_pick2(PickArgs A, PickAr
   else win_pick_body(B, L);
 }
 
+#ifdef ICP_EXPERIMENTS  // ---- the four-launch forms of rounds 1-3 (W, C, selection, A): `make experiments` only ----
 // The order statistics of one evaluation from its candidate lists, one workgroup per dimension
 // (half the registers of doing both at once): the co-resident variant of the pipeline runs this
 // as its own tiny launch so that the accumulate kernel stays small.
@@ -1281,6 +1284,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_accumulate(
   if (!last_block_arrives(&ctl->t[2])) return;
   publish_result(partials, res, seq, sig, med, scal->nan_flag, fail ? 2 : 0);
 }
+#endif  // ICP_EXPERIMENTS
 
 // the sharded evaluation (shard.hip) launches this one from another translation unit
 template __global__ void k_win_compact<false>(const double *__restrict__, const double *__restrict__, unsigned, unsigned,
@@ -1546,71 +1550,60 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
   if (hb > (unsigned)kWinBlocks) hb = kWinBlocks;
   const double2 *a = (const double2 *)d_a, *b = (const double2 *)d_b;
   hipStream_t s = h->stream;
-  // on the evaluation stream this runs beside a speculative search: the variant whose every
-  // workgroup fits next to three search waves per SIMD (one extra tiny launch; latency is hidden)
-  static const bool no_co = exp_env("ICP_WIN_NO_CORESIDENT") != nullptr;
-  // (round 3: the 4-launch form everywhere -- 0.1645 against 0.1660 ms per step on the 1M pair, 0.626 against 0.635 on
-  // the converging pair, the 28k frame unchanged: every workgroup of the inline-selecting accumulate kernel repeats
-  // 7.5 us of candidate loads and selections that the two-workgroup launch does once)
+  // Two launches either way.  Round 5: the first files the candidates, the second is ONE workgroup (k_win_hist_sums_bkt
+  // / k_win_pick) wherever bkt_fits says so; windows too wide for that (after a miss) and handles whose files were not
+  // usable recently take the second pass over the points (k_win_hist_sums / k_win_finish, round 3).
 #ifdef ICP_EXPERIMENTS
-  const bool coresident = !no_co;
-#else
-  constexpr bool coresident = true;
-  (void)no_co;
-#endif
-  static const bool no_fuse = exp_env("ICP_WIN_NO_FUSE") != nullptr;
-  // Two launches (residuals + histograms + sums, then candidates + selection + fold) unless the evaluation shares
-  // the CUs with a speculative search: beside three search waves per SIMD the four small launches below fit better
-  // (1M pair: 0.154 ms per step against 0.157 fused everywhere and 0.158 never; profiles/r03_eval_fusion_ab.txt).
-  // ICP_WIN_FUSE_MODE: 1 = everywhere, 2 = as described (default), 3 = only beside a search, 4 = search stream only.
-  static const int fuse_mode = exp_env("ICP_WIN_FUSE_MODE") ? atoi(exp_env("ICP_WIN_FUSE_MODE")) : 2;
+  // ICP_WIN_BKT: 0 = never, 1 = wherever it fits (default), 2 = not beside a search, 3 = only there.  ICP_WIN_FUSE_MODE /
+  // ICP_WIN_NO_FUSE / ICP_WIN_NO_CORESIDENT: the four-launch forms of rounds 1-3 (experiments build only).
+  static const int bkt_mode = exp_env("ICP_WIN_BKT") ? atoi(exp_env("ICP_WIN_BKT")) : 1;
   const bool on_eval_stream = w.spec_stream && s == w.spec_stream;
   const bool beside_search = on_eval_stream && w.search_beside_eval;
-  // Round 5: candidates filed by the first launch, the second is ONE workgroup (k_win_hist_sums_bkt / k_win_pick)
-  // wherever bkt_usable says so.  ICP_WIN_BKT (experiments): 0 = never, 1 = wherever it fits (default), 2 = not beside
-  // a search, 3 = only there.
-  static const int bkt_mode = exp_env("ICP_WIN_BKT") ? atoi(exp_env("ICP_WIN_BKT")) : 1;
+  const bool bkt_here = bkt_mode == 1 || (bkt_mode == 2 && !beside_search) || (bkt_mode == 3 && beside_search);
+#else
+  constexpr bool bkt_here = true;
+#endif
   if (w.bkt_off > 0) --w.bkt_off;
-  else if ((bkt_mode == 1 || (bkt_mode == 2 && !beside_search) || (bkt_mode == 3 && beside_search)) && bkt_fits(n_, P)) {
+  else if (bkt_here && bkt_fits(n_, P)) {
     ++w.bkt_evals;
     const HistBktArgs HA = bkt_hist_args(w, a, b, T, n, P);
     hipLaunchKernelGGL(k_win_hist_sums_bkt, dim3(HA_blocks(n_)), dim3(kWinThreads), 0, s, HA);
     hipLaunchKernelGGL(k_win_pick, dim3(1), dim3(kReduceThreads), 0, s, bkt_pick_args(w, n, P, w.ahead_on, w.ahead_outer, w.d_ahead));
     return hipGetLastError();
   }
-  if (!no_fuse && (fuse_mode == 1 || (fuse_mode == 2 && !beside_search) || (fuse_mode == 3 && beside_search) ||
-                   (fuse_mode == 4 && !on_eval_stream))) {
-    int blocks, threads;
-    reduce_geometry(n_, &blocks, &threads);
-    hipLaunchKernelGGL(k_win_hist_sums, dim3(blocks), dim3(threads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
-                       w.d_wstate, w.d_scal, w.d_partials, -1);
-    hipLaunchKernelGGL(k_win_finish<false>, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
-                       (const double *)w.d_ry, n, P, w.d_whist, w.d_wstate, w.d_wmed, w.d_wring, w.d_scal,
-                       (const double *)w.d_partials, blocks, w.d_ctl, w.h_res, ++w.seq, (const unsigned *)nullptr, 0u,
-                       w.ahead_on ? w.d_ahead : (AheadPose *)nullptr, w.ahead_on ? w.ahead_outer : transform_identity());
-    return hipGetLastError();
-  }
-  hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(kWinThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
-                     w.d_wstate, w.d_scal);
-  hipLaunchKernelGGL(k_win_compact<false>, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
-                     (const double *)w.d_ry, n, n, P, (const uint32_t *)w.d_whist, w.d_wstate, w.d_wmed,
-                     w.d_wring, (const unsigned *)nullptr, 0u);
   int blocks, threads;
   reduce_geometry(n_, &blocks, &threads);
-  if (coresident) {
-    hipLaunchKernelGGL(k_win_select, dim3(2), dim3(kReduceThreads), 0, s, n, w.d_wstate, (const double *)w.d_wmed,
-                       (const double *)w.d_wring, w.d_scal);
-    hipLaunchKernelGGL(k_win_accumulate<false>, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
-                       (const double *)w.d_ry, n, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
-                       (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, ++w.seq);
-  }
-#ifdef ICP_EXPERIMENTS  // (ICP_WIN_NO_CORESIDENT: the selection inline in every accumulate workgroup, rounds 1-2)
-  else {
-    hipLaunchKernelGGL(k_win_accumulate<true>, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
-                       (const double *)w.d_ry, n, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
-                       (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, ++w.seq);
+#ifdef ICP_EXPERIMENTS
+  static const bool no_co = exp_env("ICP_WIN_NO_CORESIDENT") != nullptr;
+  static const bool no_fuse = exp_env("ICP_WIN_NO_FUSE") != nullptr;
+  static const int fuse_mode = exp_env("ICP_WIN_FUSE_MODE") ? atoi(exp_env("ICP_WIN_FUSE_MODE")) : 1;
+  if (no_fuse || !(fuse_mode == 1 || (fuse_mode == 2 && !beside_search) || (fuse_mode == 3 && beside_search) ||
+                   (fuse_mode == 4 && !on_eval_stream))) {
+    hipLaunchKernelGGL(k_win_hist, dim3(hb), dim3(kWinThreads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
+                       w.d_wstate, w.d_scal);
+    hipLaunchKernelGGL(k_win_compact<false>, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
+                       (const double *)w.d_ry, n, n, P, (const uint32_t *)w.d_whist, w.d_wstate, w.d_wmed,
+                       w.d_wring, (const unsigned *)nullptr, 0u);
+    if (!no_co) {
+      hipLaunchKernelGGL(k_win_select, dim3(2), dim3(kReduceThreads), 0, s, n, w.d_wstate, (const double *)w.d_wmed,
+                         (const double *)w.d_wring, w.d_scal);
+      hipLaunchKernelGGL(k_win_accumulate<false>, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
+                         (const double *)w.d_ry, n, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
+                         (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, ++w.seq);
+    } else {
+      hipLaunchKernelGGL(k_win_accumulate<true>, dim3(blocks), dim3(threads), 0, s, a, (const double *)w.d_rx,
+                         (const double *)w.d_ry, n, n, T, (const WinState *)w.d_wstate, (const double *)w.d_wmed,
+                         (const double *)w.d_wring, w.d_scal, w.d_partials, w.d_whist, w.d_ctl, w.h_res, ++w.seq);
+    }
+    return hipGetLastError();
   }
 #endif
+  hipLaunchKernelGGL(k_win_hist_sums, dim3(blocks), dim3(threads), 0, s, a, b, T, w.d_rx, w.d_ry, n, P, w.d_whist,
+                     w.d_wstate, w.d_scal, w.d_partials, -1);
+  hipLaunchKernelGGL(k_win_finish<false>, dim3(hb), dim3(kWinThreads), 0, s, (const double *)w.d_rx,
+                     (const double *)w.d_ry, n, P, w.d_whist, w.d_wstate, w.d_wmed, w.d_wring, w.d_scal,
+                     (const double *)w.d_partials, blocks, w.d_ctl, w.h_res, ++w.seq, (const unsigned *)nullptr, 0u,
+                     w.ahead_on ? w.d_ahead : (AheadPose *)nullptr, w.ahead_on ? w.ahead_outer : transform_identity());
   return hipGetLastError();
 }
 
