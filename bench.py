@@ -210,7 +210,7 @@ def nn_large(npts, warm_searches=6):
     traffic, tf_src = None, None
     tf_path = os.path.join(ROOT, "profiles", "r05_traffic_pmc_nn_large.json")
     if os.path.exists(tf_path) and npts == 16 * 1024 * 1024:
-        traffic = json.load(open(tf_path))["k_nn_grid"]["traffic_bytes_per_launch"]
+        traffic = json.load(open(tf_path))["k_nn_grid"]["warm_kernel_bytes_per_launch"]  # (the line times warm searches)
         tf_src = "profiles/r05_traffic_pmc_nn_large.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/nn_large_only.py)"
     return {"points": npts, "kernel": "k_nn_grid_warm_coop", "warm_searches": launches, "first_search_ms": ms1 / max(k1, 1),
             "ms_per_search": 1e3 * per, "algorithmic_bytes_per_launch": nn_bytes, "achieved_GBs": gbs, "peak_GBs": HBM_PEAK_GBS,
@@ -583,7 +583,7 @@ def main():
         # separate passes and committed under profiles/ (a PMC pass cannot run inside this process); only
         # valid for the full-size single-GPU workload it was measured on
         traffic, tf_name = None, None
-        for tf_name in ("r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_traffic_pmc.json"):
+        for tf_name in ("r05_traffic_pmc.json", "r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_traffic_pmc.json"):
             tf_path = os.path.join(ROOT, "profiles", tf_name)
             if os.path.exists(tf_path):
                 break
