@@ -985,12 +985,15 @@ __device__ __forceinline__ void win_pick_body(const PickArgs &A, PickLds &L) {
     // the runs of candidate bins of this thread's dimension, in directory order: the median's, the ring's two arcs
     const unsigned w = tid & (unsigned)(kReduceMaxBlocks - 1), d = tid / (unsigned)kReduceMaxBlocks;
     const bool usable = !fail && !bucket_miss;  // (uniform)
-    const unsigned len_m = usable ? R.mhi[d] - R.mlo[d] + 1u : 0u;
-    const unsigned len_a = usable ? R.i0[d] - R.a0[d] : 0u, len_b = usable ? R.b1[d] - R.i1[d] : 0u;
+    // (this thread's dimension by selects: a run-time index into the arrays of R would put them into scratch memory)
+    const unsigned mlo_d = d ? R.mlo[1] : R.mlo[0], mhi_d = d ? R.mhi[1] : R.mhi[0], a0_d = d ? R.a0[1] : R.a0[0];
+    const unsigned b1_d = d ? R.b1[1] : R.b1[0], i0_d = d ? R.i0[1] : R.i0[0], i1_d = d ? R.i1[1] : R.i1[0];
+    const unsigned len_m = usable ? mhi_d - mlo_d + 1u : 0u;
+    const unsigned len_a = usable ? i0_d - a0_d : 0u, len_b = usable ? b1_d - i1_d : 0u;
     __syncthreads();  // (s_cnt's zeros)
     if (usable && !bucket_miss && (int)w < segments) {
       const unsigned short *dir = dir_all + (size_t)w * kBktDir;
-      const unsigned fm = word_to_fine(d, R.mlo[d]), fa = word_to_fine(d, R.a0[d]), fb = word_to_fine(d, R.i1[d] + 1u);
+      const unsigned fm = word_to_fine(d, mlo_d), fa = word_to_fine(d, a0_d), fb = word_to_fine(d, i1_d + 1u);
       // (the members of a run of consecutive bins are contiguous in the segment: the run's first offset .. the offset
       // behind its last bin -- six directory entries per thread, one trip)
       const unsigned short q0 = dir[fm], q1 = dir[fm + len_m], q2 = dir[fa], q3 = dir[fa + len_a], q4 = dir[fb],

@@ -1,9 +1,11 @@
-"""The speculative search and the evaluations around it only run side by side because their workgroups fit on a
-SIMD together (512 registers per lane, allocation granule 8):
-  * the deciding evaluation (four small launches on the evaluation stream) runs beside three search waves;
-  * the two-launch evaluation behind the search (k_win_hist_sums / k_win_finish) must leave room for a second
+"""Kernels that share a SIMD only do so while their workgroups fit on it together (512 registers per lane,
+allocation granule 8):
+  * round 5: the two evaluations of an outer iteration run side by side in ONE launch of 2 x 256 workgroups
+    (k_win_hist_sums_bkt2): two workgroups of 512 threads per CU = four waves per SIMD, i.e. at most 128 registers;
+  * the second-pass form behind a search (k_win_hist_sums / k_win_finish, wide windows) must leave room for a second
     workgroup per CU -- two evaluations in flight at once otherwise queue behind each other, which cost the 1M
-    pair 4 % when k_win_finish needed 152 registers (profiles/r03_eval_fusion_ab.txt).
+    pair 4 % when k_win_finish needed 152 registers (profiles/r03_eval_fusion_ab.txt);
+  * the stage kernels of a sharded evaluation (k_win_compact) run beside three search waves.
 A few registers more in any of these kernels silently turns the overlap back into a queue, so the budget is pinned
 here (hipcc cross-compiles without a GPU; -Rpass-analysis prints the allocation)."""
 import os
@@ -22,11 +24,12 @@ BUDGET = {  # demangled-name fragment -> max VGPRs
     "k_nn_grid_warm_coopILi3E": 96,      # the warm search (walk shared by the wave): 5 waves per SIMD alone, 3 beside an evaluation
     "k_nn_grid_seededILi3E": 104,        # ... and the first search of a snapshot (seed + the same walk)
     "k_nn_grid_warmILi3ELb1E": 104,      # ... leaving certificates (settled registrations: no speculative overlap then)
-    "k_win_histE": 56,                   # the four launches of the deciding evaluation ...
-    "k_win_compactILb0E": 72,            # (the list variant of the refined windows runs alone)
-    "k_win_select": 72,
-    "k_win_accumulateILb0E": 88,         # ... (19 running sums since round 3)
-    "k_win_hist_sumsE": 112,             # the two launches of the evaluation behind the search (not the deep-batch variant beyond 4M points, which runs alone)
+    "k_win_compactILb0E": 72,            # sharded stage call (the list variant of the refined windows runs alone)
+    "k_win_hist_sumsE": 112,             # the second-pass form (not the deep-batch variant beyond 4M points, which runs alone)
+    "k_win_hist_sums_bktE": 128,         # filed candidates: first launch ...
+    "k_win_hist_sums_bkt2E": 128,        # ... of two evaluations side by side: two workgroups per CU
+    "k_win_pickE": 128,                  # the one-workgroup finish (a workgroup of 512 threads: 128 registers at most)
+    "k_win_pick2E": 128,
     "k_win_finish": 120,
 }
 
@@ -64,11 +67,12 @@ def test_kernels_that_share_a_simd_stay_within_their_register_budget():
                 assert regs.get(name + "#scratch", 0) == 0, f"{name} spills"
     assert seen == set(BUDGET), sorted(set(BUDGET) - seen)
     up8 = lambda x: (x + 7) // 8 * 8
-    # 3 search waves + 2 waves (one workgroup of 512 threads) of any launch of the deciding evaluation, per SIMD
-    for k in ("k_win_histE", "k_win_compactILb0E", "k_win_select", "k_win_accumulateILb0E", "k_win_hist_sumsE"):
+    # 3 search waves + 2 waves (one workgroup of 512 threads) of a stage kernel / the second-pass form, per SIMD
+    for k in ("k_win_compactILb0E", "k_win_hist_sumsE"):
         assert 3 * up8(BUDGET["k_nn_grid_warm_coopILi3E"]) + 2 * up8(BUDGET[k]) <= 512, k
-    for k in ("k_win_histE", "k_win_compactILb0E", "k_win_select"):
-        assert 3 * up8(BUDGET["k_nn_gridILi3ELb1ELb0E"]) + 2 * up8(BUDGET[k]) <= 512, k
+    assert 3 * up8(BUDGET["k_nn_gridILi3ELb1ELb0E"]) + 2 * up8(BUDGET["k_win_compactILb0E"]) <= 512
+    # two workgroups per CU of the paired first launch (4 waves per SIMD)
+    assert 4 * up8(BUDGET["k_win_hist_sums_bkt2E"]) <= 512
     # two workgroups of the finishing launch per CU (4 waves per SIMD)
     assert 4 * up8(BUDGET["k_win_finish"]) <= 512
 
