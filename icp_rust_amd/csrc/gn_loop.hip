@@ -855,6 +855,10 @@ __device__ __forceinline__ unsigned payload_count(unsigned p, int k) {
 // gridDim.y > 1: several ranks in ONE launch (ranks that share a device -- "virtual ranks": the launches of ranks wait
 // for each other, and more streams than hardware queues would queue one behind the other); blockIdx.y picks the rank,
 // R has each rank's pairs and result block.
+// STREAM (round 5): more pairs per thread than LDS holds (K > kLoopMaxK: more than 2^20 pairs in total) are read from
+// the rank's arrays again in every phase that needs them -- they sit in L2 / the Infinity Cache (a rank of W holds
+// n / W pairs) -- instead of once per launch; everything else, and every bit of the result, is the same.
+template <bool STREAM>
 __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, LoopShardArgs S, LoopRankPtrs R_, unsigned K) {
   const int rank = S.rank + (int)blockIdx.y;
   const unsigned nbl = (unsigned)(S.first_block[rank + 1] - S.first_block[rank]);  // this rank's workgroups
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
   unsigned long long *const s_seen = reinterpret_cast<unsigned long long *>(s_work), *const s_incl = s_seen + kReduceMaxBlocks;
   // (the members of the fine bins, staged by phase A behind the histograms: k_gn_loop has the explanation)
   constexpr unsigned kStageCap = (sizeof(s_work) - 2 * kWinBins * sizeof(uint32_t)) / sizeof(unsigned short);
-  static_assert(kStageCap >= 4096 && kLoopMaxK <= 8, "staged members: 3 + 9 + 1 bits each");
+  static_assert(kStageCap >= 4096 && kLoopStreamMaxK <= 32, "staged members: 5 + 9 + 1 bits each");
   unsigned short *const s_mem = reinterpret_cast<unsigned short *>(s_work + 2 * kWinBins * sizeof(uint32_t));
   __shared__ unsigned s_nmem;
   __shared__ unsigned long long s_wsum[4];
@@ -896,10 +900,22 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
     if (S.inbox[q] != me) peers.w[peers.n++] = &S.inbox[q]->abort[0];
   double2 *const s_a = s_pts, *const s_b = s_pts + (size_t)K * kReduceThreads;
   const unsigned mine = first < n ? (n - 1u - first) / G + 1u : 0u;
-  for (unsigned k = 0; k < mine; ++k) {
-    s_a[k * kReduceThreads + tid] = A.a[(size_t)k * row_w + loc0];
-    s_b[k * kReduceThreads + tid] = A.b[(size_t)k * row_w + loc0];
-  }
+  if (!STREAM)
+    for (unsigned k = 0; k < mine; ++k) {
+      s_a[k * kReduceThreads + tid] = A.a[(size_t)k * row_w + loc0];
+      s_b[k * kReduceThreads + tid] = A.b[(size_t)k * row_w + loc0];
+    }
+  // point k of thread t of this workgroup (LDS, or the rank's arrays in the local layout of shard.hip)
+  auto pair_of = [&](unsigned k, unsigned t, double2 &ak, double2 &bk) {
+    if (STREAM) {
+      const size_t at = (size_t)k * row_w + blockIdx.x * kReduceThreads + t;
+      ak = A.a[at];
+      bk = A.b[at];
+    } else {
+      ak = s_a[k * kReduceThreads + t];
+      bk = s_b[k * kReduceThreads + t];
+    }
+  };
   if (tid < sizeof(WinParams) / sizeof(double))
     reinterpret_cast<double *>(&L.P)[tid] = reinterpret_cast<const double *>(&A.PA)[tid];
   if (tid == 0) {
@@ -942,8 +958,11 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
         const unsigned pos = atomicAdd(&s_nmem, 1u);
         if (pos < kStageCap) s_mem[pos] = (unsigned short)code;
       };
+      double2 nak = {0., 0.}, nbk = {0., 0.};
+      if (mine) pair_of(0, tid, nak, nbk);
       for (unsigned k = 0; k < mine; ++k) {
-        const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
+        const double2 ak = nak, bk = nbk;
+        if (k + 1 < mine) pair_of(k + 1, tid, nak, nbk);  // (STREAM: the next pair travels while this one is worked on)
         const double v0 = ((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x;  // residual(), src/lib.rs:34-36
         const double v1 = ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y;
         saw_nan |= (v0 != v0) | (v1 != v1);
@@ -1030,7 +1049,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
       if (staged) {  // (uniform)
         for (unsigned e = tid; e < nmem; e += kReduceThreads) {
           const unsigned code = s_mem[e], k = code >> 10, t = (code >> 1) & 511u;
-          const double2 ak = s_a[k * kReduceThreads + t], bk = s_b[k * kReduceThreads + t];
+          double2 ak, bk;
+          pair_of(k, t, ak, bk);
           if (code & 1u) {
             const double r = ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y;
             consider(1, r, wbin_cold(r, P.d[1]));
@@ -1041,7 +1061,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
         }
       } else {
         for (unsigned k = 0; k < mine; ++k) {
-          const double2 ak = s_a[k * kReduceThreads + tid], bk = s_b[k * kReduceThreads + tid];
+          double2 ak, bk;
+          pair_of(k, tid, ak, bk);
           const double v[2] = {((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x, ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y};
 #pragma unroll
           for (int d = 0; d < 2; ++d) consider(d, v[d], wbin_cold(v[d], P.d[d]));
@@ -1345,7 +1366,7 @@ bool gn_loop_shard_applies(size_t n_total, int world) {
   // (ranks that share a device need all `blocks` slots on it; a rank with a device of its own needs fewer: the check is
   // the conservative one)
   return !off && world >= 1 && world <= kShardMaxWorld && blocks >= world && n_total >= (size_t)(1u << 12) &&
-         n_total <= (size_t)kLoopMaxK * (size_t)blocks * (size_t)threads && blocks <= loop_slots();
+         n_total <= (size_t)kLoopStreamMaxK * (size_t)blocks * (size_t)threads && blocks <= loop_slots();
 }
 
 hipError_t launch_gn_loop_shard(icp_handle *h, const LoopArgs &args, const LoopShardArgs &sh, const LoopRankPtrs &ptrs, int ranks) {
@@ -1355,7 +1376,7 @@ hipError_t launch_gn_loop_shard(icp_handle *h, const LoopArgs &args, const LoopS
   const unsigned K = (unsigned)((args.n + G - 1) / G);
   static int lds_granted = 0;
   if (lds_granted == 0) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gn_loop_shard),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gn_loop_shard<false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              kLoopMaxK * kReduceThreads * 2 * (int)sizeof(double2));
     lds_granted = e == hipSuccess ? 1 : -1;
@@ -1363,10 +1384,14 @@ hipError_t launch_gn_loop_shard(icp_handle *h, const LoopArgs &args, const LoopS
   }
   int nb = 0;  // the widest of the ranks this launch carries
   for (int q = sh.rank; q < sh.rank + ranks; ++q) nb = std::max(nb, sh.first_block[q + 1] - sh.first_block[q]);
-  if (lds_granted < 0 || K > (unsigned)kLoopMaxK || nb < 1 || ranks < 1 || sh.rank + ranks > sh.world || sh.blocks_total != blocks)
+  if (lds_granted < 0 || K > (unsigned)kLoopStreamMaxK || nb < 1 || ranks < 1 || sh.rank + ranks > sh.world || sh.blocks_total != blocks)
     return hipErrorInvalidValue;
+  if (K > (unsigned)kLoopMaxK) {  // more pairs per thread than LDS holds: streamed from the rank's arrays
+    hipLaunchKernelGGL(k_gn_loop_shard<true>, dim3(nb, ranks), dim3(threads), 0, h->stream, args, sh, ptrs, K);
+    return hipGetLastError();
+  }
   const size_t lds = (size_t)K * kReduceThreads * 2 * sizeof(double2);
-  hipLaunchKernelGGL(k_gn_loop_shard, dim3(nb, ranks), dim3(threads), lds, h->stream, args, sh, ptrs, K);
+  hipLaunchKernelGGL(k_gn_loop_shard<false>, dim3(nb, ranks), dim3(threads), lds, h->stream, args, sh, ptrs, K);
   return hipGetLastError();
 }
 

@@ -4,7 +4,8 @@
 
 namespace icp {
 
-constexpr int kLoopMaxK = 8;  // pairs a thread of the reduction tree keeps in registers
+constexpr int kLoopMaxK = 8;  // pairs per thread of the reduction tree that a launch keeps in LDS (2^20 pairs in all)
+constexpr int kLoopStreamMaxK = 32;  // ... the sharded launch takes up to this many, streamed from memory beyond kLoopMaxK (2^22 pairs)
 
 // Device-resident control block of the launch; all zero between launches (the last workgroup to leave resets it).
 // One 128-byte line per word that is polled or hit by atomics.

@@ -145,6 +145,28 @@ def test_icp_create_multi_with_virtual_ranks_equals_one_handle(world, n, m, dim)
     multi.close()
 
 
+@pytest.mark.parametrize("world,n", [(2, 2_000_000), (4, 4_000_000)])
+def test_the_one_launch_loop_serves_more_than_a_million_pairs_across_ranks(world, n):
+    """the sharded inner loop used to stop at 2^20 pairs IN TOTAL (its launch keeps a rank's pairs in
+    LDS, eight per thread); clouds beyond that -- the weak-scaling regime, the only one where more GPUs can pay -- fell
+    back to the stage calls.  Now a rank streams what LDS does not hold (k_gn_loop_shard<true>, up to 2^22 pairs): the
+    result must be ONE handle's, bit for bit (one handle steps such clouds from the host: /root/reference/src/lib.rs:59-84),
+    and the loop launches must really have served the evaluations."""
+    m = 500_000
+    src, dst = synth.synthetic_pair(n, m)
+    init = I.Transform([0.01, -0.02, 0.001])
+    one = I.Icp3d(dst)
+    T1, idx1, inner1 = one.estimate(src, init, 3, return_info=True)
+    one.close()
+    multi = I.IcpMulti(dst, [0] * world)
+    T, idx, inner = multi.estimate(src, init, 3, return_info=True)
+    assert np.array_equal(T.as_array(), T1.as_array())
+    assert np.array_equal(inner, inner1) and np.array_equal(idx, idx1)
+    launches, served, handbacks = multi.loop_counters()
+    assert launches >= 2 and served >= 3, (launches, served, handbacks)
+    multi.close()
+
+
 def test_grown_multi_equals_fresh_multi_equals_one_handle():
     """BASELINE configs[4] across ranks (EXTENSION, include/icp_mi355x.h section 6): every rank appends the registered
     scan to its replica of the target cloud; the grown object must answer like a fresh one on the concatenated cloud
