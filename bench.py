@@ -569,12 +569,11 @@ def main():
         if r["engine"] == "brute":
             # 3 sub, 3 mul, 2 add per (source, target) pair.  The sweep screens every pair in f32 and
             # re-evaluates only possible winners/ties in f64 (~ln M per query), so the arithmetic that
-            # bounds it is the FP32 vector rate; the fraction of the FP64 rate is given beside it.
+            # bounds it is the FP32 vector rate.
             flops = 8.0 * n_shard * m
             tf = flops / avg_s / 1e12 if avg_s > 0 else 0.0
             return {"kernel": "k_nn_brute_dot", "bound": "fp32_valu", "achieved": tf, "peak": FP32_VALU_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TFLOPS,
-                    "frac_of_fp64_valu_peak": tf / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TFLOPS, "traffic": None,
                     "avg_launch_ms": 1e3 * avg_s, "launches": int(r["nn_launches"]),
                     "algorithmic_flops_per_launch": flops,
                     "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
