@@ -1107,10 +1107,6 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_pick(PickArgs A) {
 // and the deciding evaluation of the current one): ONE launch files the candidates of both (2 B workgroups: two per
 // CU, four waves per SIMD instead of two hide each other's latencies), ONE launch of two workgroups finishes both.
 // The deciding evaluation then neither shares the CUs with the search nor needs a stream of its own.
-union EvalLds {
-  PickLds pick;
-  HistBktLds hist;
-};
 __global__ __launch_bounds__(kWinThreads) void k_win_hist_sums_bkt2(HistBktArgs A, HistBktArgs B) {
   __shared__ HistBktLds S;
   const unsigned half = gridDim.x >> 1;
@@ -1472,7 +1468,7 @@ double window_half_width(size_t n, bool wide) {
 bool make_window(const double med[2], const double sigma[2], double f, WinParams *P) { return make_window_hd(med, sigma, f, P); }
 
 // ---- filed candidates: host side ------------------------------------------------------
-static unsigned HA_blocks(size_t n) {
+static unsigned tree_blocks(size_t n) {
   int blocks, threads;
   reduce_geometry(n, &blocks, &threads);
   return (unsigned)blocks;
@@ -1487,7 +1483,7 @@ bool bkt_fits(size_t n, const WinParams &P) {
     const double mad = 0.5 * ((D.x[4] + D.x[5]) - (D.x[2] + D.x[3]));
     frac += 1.04 * (D.x[1] - D.x[0]) / (ICP_PPF34 * mad);
   }
-  return 2. * frac * ((double)n / HA_blocks(n)) <= (double)kBktStage;
+  return 2. * frac * ((double)n / tree_blocks(n)) <= (double)kBktStage;
 }
 static HistBktArgs bkt_hist_args(GnCtx &c, const double2 *a, const double2 *b, const Pose &T, unsigned n, const WinParams &P) {
   HistBktArgs A;
@@ -1513,7 +1509,7 @@ static PickArgs bkt_pick_args(GnCtx &c, unsigned n, const WinParams &P, bool ahe
   A.st = c.d_wstate;
   A.seg_all = c.d_bkt;
   A.dir_all = c.d_bkt_dir;
-  A.segments = (int)HA_blocks(n);
+  A.segments = (int)tree_blocks(n);
   A.scal = c.d_scal;
   A.partials = c.d_partials;
   A.sum_blocks = A.segments;
@@ -1532,7 +1528,7 @@ hipError_t launch_bkt_pair(icp_handle *h, hipStream_t s, GnCtx &first, const dou
                            bool ahead_on, const Pose &ahead_outer, GnCtx &second, const double *a2, const double *b2,
                            const Pose &T2, const WinParams &P2, size_t n_) {
   Workspace &w = h->ws;
-  const unsigned n = (unsigned)n_, blocks = HA_blocks(n_);
+  const unsigned n = (unsigned)n_, blocks = tree_blocks(n_);
   w.bkt_evals += 2;
   hipLaunchKernelGGL(k_win_hist_sums_bkt2, dim3(2 * blocks), dim3(kWinThreads), 0, s,
                      bkt_hist_args(first, (const double2 *)a1, (const double2 *)b1, transform_identity(), n, P1),
@@ -1570,7 +1566,7 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
   else if (bkt_here && bkt_fits(n_, P)) {
     ++w.bkt_evals;
     const HistBktArgs HA = bkt_hist_args(w, a, b, T, n, P);
-    hipLaunchKernelGGL(k_win_hist_sums_bkt, dim3(HA_blocks(n_)), dim3(kWinThreads), 0, s, HA);
+    hipLaunchKernelGGL(k_win_hist_sums_bkt, dim3(tree_blocks(n_)), dim3(kWinThreads), 0, s, HA);
     hipLaunchKernelGGL(k_win_pick, dim3(1), dim3(kReduceThreads), 0, s, bkt_pick_args(w, n, P, w.ahead_on, w.ahead_outer, w.d_ahead));
     return hipGetLastError();
   }
