@@ -293,6 +293,53 @@ def test_block_sharded_driver_with_virtual_ranks_equals_one_rank(world, n, miss_
     assert all(s.prepared == 1 for s in stages.values())
 
 
+class GivingUpLoopStages(OracleBlockStages):
+    """OracleBlockStages + a stand-in for the one-launch inner loop (include/icp_mi355x.h section 5b) that connects,
+    accepts `good` launches without serving an evaluation (it hands evaluation `it` back at once, state untouched) and
+    then GIVES UP: icp_shard_loop_wait -> ICP_HIP_ERROR, as when a peer did not arrive.  The driver must take nothing
+    from such a launch, drop the rank's window predictions and go on with the stage calls -- on every rank alike."""
+
+    def __init__(self, dst, n_total, world, good=1):
+        super().__init__(dst, n_total, world)
+        self.good, self.launched, self.resets, self.state = good, 0, 0, None
+
+    def loop_inbox(self, kind=0):
+        return 1000 + id(self) % 1000
+
+    def loop_connect(self, rank, world, ptrs):
+        assert len(ptrs) == world
+
+    def loop_launch(self, a, b, n_total, launch_no, eval_base, it0, applied, Ti, prev_error, first_kind=0, second_kind=1):
+        self.launched += 1
+        self.state = (Ti, prev_error, applied, it0)
+        return I._lib.OK
+
+    def loop_wait(self):
+        Ti, pe, ap, it = self.state
+        if self.launched > self.good:
+            return I._lib.HIP_ERROR, I.Transform(), 0.0, 0, 0, False, 0
+        return I._lib.OK, Ti, pe, ap, it, False, 0  # (evaluation `it` handed back, nothing served)
+
+    def reset_predictions(self):
+        self.resets += 1
+
+
+@pytest.mark.parametrize("world,n", [(2, 5000), (3, 9001)])
+def test_a_loop_launch_that_gives_up_sends_every_rank_to_the_stage_calls(world, n):
+    """a sharded launch that gave up used to raise on ONE rank while the others went on.  Now the kernel
+    raises abort in every inbox, every rank's wait reports ICP_HIP_ERROR for that launch and the driver falls back on
+    all of them: same pose as a run that never had the loop, predictions dropped once per rank, no launch afterwards."""
+    m, max_iter = 3000, 4
+    src, dst, want_T, _, want_inner = _reference(n, m, max_iter)
+    stages = {r: GivingUpLoopStages(dst, n, world, good=2) for r in range(world)}
+    drv = BlockShardedIcp(stages, n, world, LocalComm(world))
+    assert drv.connect_loop() is not None
+    T, inner = drv.estimate(drv.take_source(torch.from_numpy(src)), I.Transform(), max_iter)
+    assert np.array_equal(T.as_array(), want_T.as_array()) and np.array_equal(inner, want_inner)
+    assert drv.counters["loop_gave_up"] == 1 and drv._loop is None
+    assert all(s.resets == 1 and s.launched == 3 for s in stages.values()), [(s.resets, s.launched) for s in stages.values()]
+
+
 def _block_worker(rank, world, port, n, m, max_iter, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
