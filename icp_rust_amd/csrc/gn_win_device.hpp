@@ -11,7 +11,7 @@ constexpr int kWinThreads = 512;  // workgroups small enough to be placed beside
 constexpr int kWinBatch = 4;
 constexpr int kWinAccBatch = 4;  // loads in flight per lane in A (2 saves 16 VGPRs but loses more than the better placement gains)
 #ifndef ICP_SELECT_DIRECT
-#define ICP_SELECT_DIRECT 128  // select_n: lists up to this long are ranked directly
+#define ICP_SELECT_DIRECT 256  // select_n: lists up to this long are ranked directly (128 until round 5)
 #endif
 constexpr int kSubBins = 1024;   // select_n: linear sub-bins over the candidates
 constexpr int kSmallCap = 1024;  // select_n: keys ranked by counting, per dimension (a run of equal keys lands here)
@@ -284,20 +284,48 @@ __device__ __forceinline__ void select_n_lds(const double (&v)[ND][NV], const un
     for (int d = 0; d < ND; ++d)
       if (tid < cnt[d]) s_small[d][tid] = f2k(v[d][0]);
     __syncthreads();
-#pragma unroll
-    for (int d = 0; d < ND; ++d)
-      if (tid < cnt[d]) {
-        const unsigned long long ki = s_small[d][tid];
-        const unsigned rl = (unsigned)rlo[d], rh = (unsigned)rhi[d];
+    if (ND == 2 && kDirect <= kReduceThreads / 2) {
+      // round 5: ONE candidate of ONE dimension per thread (threads 0 .. 255: x, 256 .. 511: y) -- both lists ranked side
+      // by side, each thread one pass over its list with the reads four ahead (the two dimensions one after the other,
+      // read by read, was 2 x 128 dependent LDS trips per thread: 3 us of every finishing launch and 3.4 us of every
+      // evaluation of the one-launch loop; lists of up to 256 are now cheaper this way than through the sub-bins)
+      const unsigned d = tid >> 8, i = tid & 255u;
+      const unsigned c = d ? cnt[ND - 1] : cnt[0];
+      if (i < c) {
+        const unsigned long long *list = s_small[d];
+        const unsigned long long ki = list[i];
+        const unsigned rl = (unsigned)(d ? rlo[ND - 1] : rlo[0]), rh = (unsigned)(d ? rhi[ND - 1] : rhi[0]);
         unsigned less = 0, eq = 0;
-        for (unsigned j = 0; j < cnt[d]; ++j) {
-          const unsigned long long kj = s_small[d][j];
+        unsigned j = 0;
+        for (; j + 4 <= c; j += 4) {
+          const unsigned long long k0 = list[j], k1 = list[j + 1], k2 = list[j + 2], k3 = list[j + 3];
+          less += (k0 < ki) + (k1 < ki) + (k2 < ki) + (k3 < ki);
+          eq += (k0 == ki) + (k1 == ki) + (k2 == ki) + (k3 == ki);
+        }
+        for (; j < c; ++j) {
+          const unsigned long long kj = list[j];
           less += kj < ki;
           eq += kj == ki;
         }
         if (less <= rl && rl < less + eq) s_out[d][0] = ki;
         if (less <= rh && rh < less + eq) s_out[d][1] = ki;
       }
+    } else {
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+        if (tid < cnt[d]) {
+          const unsigned long long ki = s_small[d][tid];
+          const unsigned rl = (unsigned)rlo[d], rh = (unsigned)rhi[d];
+          unsigned less = 0, eq = 0;
+          for (unsigned j = 0; j < cnt[d]; ++j) {
+            const unsigned long long kj = s_small[d][j];
+            less += kj < ki;
+            eq += kj == ki;
+          }
+          if (less <= rl && rl < less + eq) s_out[d][0] = ki;
+          if (less <= rh && rh < less + eq) s_out[d][1] = ki;
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
