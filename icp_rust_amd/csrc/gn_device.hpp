@@ -29,6 +29,20 @@ __device__ __forceinline__ double huber_drho(double e) {
   return (e <= k2) ? 1. : (k / __dsqrt_rn(e));
 }
 
+// The wave's inclusive prefix sum without the LDS pipe: DPP row shifts inside rows of 16, then the two row broadcasts
+// (every lane of the wave active; lane 63 ends up with the wave's total).
+__device__ __forceinline__ unsigned wave_scan_inclusive(unsigned v) {
+#define ICP_SCAN_DPP(x, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, true)
+  v += ICP_SCAN_DPP(v, 0x111, 0xf);  // row_shr:1 (zero fill at the row's start)
+  v += ICP_SCAN_DPP(v, 0x112, 0xf);  // row_shr:2
+  v += ICP_SCAN_DPP(v, 0x114, 0xf);  // row_shr:4
+  v += ICP_SCAN_DPP(v, 0x118, 0xf);  // row_shr:8  -> inclusive within each row of 16
+  v += ICP_SCAN_DPP(v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  v += ICP_SCAN_DPP(v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef ICP_SCAN_DPP
+  return v;
+}
+
 // ------------------------------------------------------------- reductions --------
 // v[l + OFF] for the wave tree below.  Offsets below 16 stay inside a row of 16 lanes for every lane
 // whose result is still needed (after the step with offset OFF only lanes < OFF matter, and they read

@@ -279,15 +279,6 @@ __device__ __forceinline__ unsigned dpp_sum8(unsigned v) {
   v += ICP_DPP(v, 0x141, 0xf);  // row_half_mirror: lane i of an 8-group reads lane 7-i, in the other quad
   return v;
 }
-__device__ __forceinline__ unsigned wave_scan_inclusive(unsigned v) {
-  v += ICP_DPP(v, 0x111, 0xf);  // row_shr:1 (zero fill at the row's start)
-  v += ICP_DPP(v, 0x112, 0xf);  // row_shr:2
-  v += ICP_DPP(v, 0x114, 0xf);  // row_shr:4
-  v += ICP_DPP(v, 0x118, 0xf);  // row_shr:8  -> inclusive within each row of 16
-  v += ICP_DPP(v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-  v += ICP_DPP(v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
-  return v;
-}
 
 #ifdef ICP_TINY_PROFILE
 #define SEL_STAMP(slot)                                             \

@@ -225,14 +225,7 @@ __device__ __forceinline__ void loop_resolve(const uint32_t *whist, unsigned n, 
 #pragma unroll
     for (int i = 0; i < PER; ++i) tot[d] += v[d][i];
     unsigned s = tot[d];  // the wave's inclusive scan by DPP (row shifts, then the two row broadcasts): no LDS crossbar
-#define ICP_SCAN_DPP(x, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, true)
-    s += ICP_SCAN_DPP(s, 0x111, 0xf);
-    s += ICP_SCAN_DPP(s, 0x112, 0xf);
-    s += ICP_SCAN_DPP(s, 0x114, 0xf);
-    s += ICP_SCAN_DPP(s, 0x118, 0xf);
-    s += ICP_SCAN_DPP(s, 0x142, 0xa);
-    s += ICP_SCAN_DPP(s, 0x143, 0xc);
-#undef ICP_SCAN_DPP
+    s = wave_scan_inclusive(s);
     inc[d] = s;
     if (lane == 63) s_wtot[d][wave] = s;
   }

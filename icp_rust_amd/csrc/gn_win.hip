@@ -91,14 +91,7 @@ __device__ __forceinline__ void win_hist_body(const double2 *__restrict__ a, con
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     unsigned v = edge[k];  // the wave's total in its lane 63, by DPP (an inclusive scan's last lane): no LDS crossbar
-#define ICP_SCAN_DPP(x, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, true)
-    v += ICP_SCAN_DPP(v, 0x111, 0xf);
-    v += ICP_SCAN_DPP(v, 0x112, 0xf);
-    v += ICP_SCAN_DPP(v, 0x114, 0xf);
-    v += ICP_SCAN_DPP(v, 0x118, 0xf);
-    v += ICP_SCAN_DPP(v, 0x142, 0xa);
-    v += ICP_SCAN_DPP(v, 0x143, 0xc);
-#undef ICP_SCAN_DPP
+    v = wave_scan_inclusive(v);
     if ((threadIdx.x & 63) == 63 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
   }
   if (saw_nan) atomicOr(&scal->nan_flag, 1);
@@ -196,13 +189,17 @@ struct HistBktLds {
   uint32_t lh[2 * kWinBins];
   double mv[kBktStage];
   unsigned short mk[kBktStage];
+  WinRegion tab[2][8];  // (five rows each: wbin_tab)
   unsigned nmem;
 };
 
 // blk of nblk: this workgroup's place in the reduction tree's geometry (a launch may carry other work in front)
 __device__ __forceinline__ void win_hist_sums_bkt_body(const HistBktArgs &A, const unsigned blk, const unsigned nblk,
                                                        HistBktLds &S) {
-  constexpr int BATCH = kWinBatch;
+#ifndef ICP_BKT_BATCH
+#define ICP_BKT_BATCH 2
+#endif
+  constexpr int BATCH = ICP_BKT_BATCH;
   const double2 *__restrict__ a = A.a, *__restrict__ b = A.b;
   const Pose T = A.T;
   const unsigned n = A.n;
@@ -226,62 +223,99 @@ __device__ __forceinline__ void win_hist_sums_bkt_body(const HistBktArgs &A, con
 #endif
   for (unsigned i = threadIdx.x; i < 2u * kWinBins; i += kWinThreads) lh[i] = 0;
   if (threadIdx.x == 0) s_nmem = 0;
+  if (threadIdx.x < 10) win_region_table(P.d[threadIdx.x / 5], S.tab[threadIdx.x / 5], (int)(threadIdx.x % 5));
   __syncthreads();
-  auto stage = [&](double v, unsigned key) {
-    const unsigned pos = atomicAdd(&s_nmem, 1u);
-    if (pos < (unsigned)kBktStage) {
-      s_mv[pos] = v;
-      s_mk[pos] = (unsigned short)key;
-    }
-  };
   unsigned edge[4] = {0u, 0u, 0u, 0u};  // {below, above} x {x, y}: one word each, kept out of the LDS atomics
   bool saw_nan = false;
   const unsigned G = nblk * kWinThreads;
-  for (unsigned base = blk * kWinThreads + threadIdx.x; base < n; base += G * BATCH) {
+  const unsigned lane = threadIdx.x & 63u;
+  // The loop's condition is the WAVE's (every lane stays active for the scan below).
+  // The pairs of the NEXT batch are in flight while this one is worked on: the workgroups of a launch start together,
+  // and with load-then-compute batches the whole chip alternated between a burst of loads and a burst of arithmetic.
+  double2 ns[BATCH], nd[BATCH];
+  auto fetch = [&](unsigned from) {
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const unsigned i = from + u * G;
+      if (i < n) {
+        ns[u] = a[i];
+        nd[u] = b[i];
+      }
+    }
+  };
+#ifdef ICP_WIN_DEBUG
+  bst[5] = wall_clock64();
+  bst[6] = bst[7] = 0;
+#endif
+  fetch(blk * kWinThreads + threadIdx.x);
+  for (unsigned base = blk * kWinThreads + threadIdx.x; base - lane < n; base += G * BATCH) {
     double2 s[BATCH], d[BATCH];
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
-      const unsigned i = base + u * G;
-      if (i < n) {
-        s[u] = a[i];
-        d[u] = b[i];
-      }
+      s[u] = ns[u];
+      d[u] = nd[u];
     }
+#ifdef ICP_WIN_DEBUG
+    if (!bst[6]) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bst[6] = wall_clock64();
+    }
+#endif
+    if (base + G * BATCH - lane < n) fetch(base + G * BATCH);
+#ifdef ICP_WIN_DEBUG
+    if (!bst[7] && !(base + G * BATCH - lane < n)) bst[7] = wall_clock64();  // (start of the last batch's arithmetic)
+#endif
+    // the members of the fine windows among this thread's 2 x BATCH residuals: ONE reservation in the stage per wave
+    // and batch (a returning LDS atomic per member made the wave wait eight times per batch)
+    double mv[2 * BATCH];
+    unsigned mj[BATCH];  // both bins of a pair, 16 bits each
+    unsigned mem = 0;    // bit 2 u + dim
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
       const unsigned i = base + u * G;
+      mv[2 * u] = mv[2 * u + 1] = 0.;
+      mj[u] = 0u;
       if (i >= n) continue;
       // residual(), src/lib.rs:34-36
       const double v0 = ((T.r00 * s[u].x + T.r01 * s[u].y) + T.tx) - d[u].x;
       const double v1 = ((T.r10 * s[u].x + T.r11 * s[u].y) + T.ty) - d[u].y;
       saw_nan |= (v0 != v0) | (v1 != v1);
-      const unsigned j0 = wbin(v0, P.d[0]), j1 = wbin(v1, P.d[1]);
-      if (j0 == 0u) ++edge[0];
-      else if (j0 == (unsigned)(kWinBins - 1)) ++edge[1];
-      else {
-        atomicAdd(&lh[j0], 1u);
-        if (fine_bin(j0)) stage(v0, j0);
-      }
-      if (j1 == 0u) ++edge[2];
-      else if (j1 == (unsigned)(kWinBins - 1)) ++edge[3];
-      else {
-        atomicAdd(&lh[kWinBins + j1], 1u);
-        if (fine_bin(j1)) stage(v1, (unsigned)kWinBins + j1);
-      }
+      bool lo0, hi0, f0, lo1, hi1, f1;
+      const unsigned j0 = wbin_tab(v0, P.d[0], S.tab[0], lo0, hi0, f0), j1 = wbin_tab(v1, P.d[1], S.tab[1], lo1, hi1, f1);
+      edge[0] += (unsigned)lo0;
+      edge[1] += (unsigned)hi0;
+      edge[2] += (unsigned)lo1;
+      edge[3] += (unsigned)hi1;
+      if (!(lo0 | hi0)) atomicAdd(&lh[j0], 1u);
+      if (!(lo1 | hi1)) atomicAdd(&lh[kWinBins + j1], 1u);
+      mv[2 * u] = v0;
+      mv[2 * u + 1] = v1;
+      mj[u] = j0 | (j1 << 16);
+      mem |= ((unsigned)f0 << (2 * u)) | ((unsigned)f1 << (2 * u + 1));
       accumulate_pair<true>(s[u], v0, v1, T, acc);  // (this thread's points in index order: the tree's first level)
+    }
+    const unsigned mine = (unsigned)__popc(mem), incl = wave_scan_inclusive(mine);
+    const unsigned wave_total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    if (wave_total) {
+      unsigned got = 0;
+      if (lane == 63u) got = atomicAdd(&s_nmem, wave_total);
+      unsigned pos = (unsigned)__builtin_amdgcn_readlane((int)got, 63) + incl - mine;
+#pragma unroll
+      for (int q = 0; q < 2 * BATCH; ++q) {
+        if (mem & (1u << q)) {
+          if (pos < (unsigned)kBktStage) {
+            s_mv[pos] = mv[q];
+            s_mk[pos] = (unsigned short)((q & 1) ? (unsigned)kWinBins + (mj[q >> 1] >> 16) : (mj[q >> 1] & 0xffffu));
+          }
+          ++pos;
+        }
+      }
     }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     unsigned v = edge[k];  // the wave's total in its lane 63, by DPP (an inclusive scan's last lane): no LDS crossbar
-#define ICP_SCAN_DPP(x, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, true)
-    v += ICP_SCAN_DPP(v, 0x111, 0xf);
-    v += ICP_SCAN_DPP(v, 0x112, 0xf);
-    v += ICP_SCAN_DPP(v, 0x114, 0xf);
-    v += ICP_SCAN_DPP(v, 0x118, 0xf);
-    v += ICP_SCAN_DPP(v, 0x142, 0xa);
-    v += ICP_SCAN_DPP(v, 0x143, 0xc);
-#undef ICP_SCAN_DPP
+    v = wave_scan_inclusive(v);
     if ((threadIdx.x & 63) == 63 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
   }
   if (saw_nan) atomicOr(&scal->nan_flag, 1);
@@ -348,12 +382,13 @@ __device__ __forceinline__ void win_hist_sums_bkt_body(const HistBktArgs &A, con
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   bst[4] = wall_clock64();
   if (threadIdx.x == 0 && (blk == 0 || blk == 200) && (bst[0] & 0x1f0) == 0)
-    printf("[B blk %d] stream %lld barrier %lld flush+dir+reduce %lld scatter %lld (x10ns) members %u\n", blk,
-           bst[1] - bst[0], bst[2] - bst[1], bst[3] - bst[2], bst[4] - bst[3], nm_all);
+    printf("[B blk %d] stream %lld (prologue %lld first pairs %lld batches but the last %lld last %lld) barrier %lld flush+dir+reduce %lld "
+           "scatter %lld (x10ns) members %u\n", blk, bst[1] - bst[0], bst[5] - bst[0], bst[6] - bst[5], bst[7] - bst[6],
+           bst[1] - bst[7], bst[2] - bst[1], bst[3] - bst[2], bst[4] - bst[3], nm_all);
 #endif
 }
 
-__global__ __launch_bounds__(kWinThreads) void k_win_hist_sums_bkt(HistBktArgs A) {
+__global__ __launch_bounds__(kWinThreads, 4) void k_win_hist_sums_bkt(HistBktArgs A) {
   __shared__ HistBktLds S;
   win_hist_sums_bkt_body(A, blockIdx.x, gridDim.x, S);
 }
@@ -415,14 +450,7 @@ __global__ __launch_bounds__(kWinThreads) void k_win_rehist(const double *__rest
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     unsigned v = edge[k];  // the wave's total in its lane 63, by DPP (an inclusive scan's last lane): no LDS crossbar
-#define ICP_SCAN_DPP(x, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, true)
-    v += ICP_SCAN_DPP(v, 0x111, 0xf);
-    v += ICP_SCAN_DPP(v, 0x112, 0xf);
-    v += ICP_SCAN_DPP(v, 0x114, 0xf);
-    v += ICP_SCAN_DPP(v, 0x118, 0xf);
-    v += ICP_SCAN_DPP(v, 0x142, 0xa);
-    v += ICP_SCAN_DPP(v, 0x143, 0xc);
-#undef ICP_SCAN_DPP
+    v = wave_scan_inclusive(v);
     if ((threadIdx.x & 63) == 63 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
   }
   __syncthreads();
@@ -516,14 +544,7 @@ __device__ __forceinline__ WinBins win_resolve(const uint32_t *__restrict__ whis
 #pragma unroll
     for (int i = 0; i < PER; ++i) tot[d] += v[d][i];
     unsigned s = tot[d];  // the wave's inclusive scan by DPP (row shifts, then the two row broadcasts): no LDS crossbar
-#define ICP_SCAN_DPP(x, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, true)
-    s += ICP_SCAN_DPP(s, 0x111, 0xf);
-    s += ICP_SCAN_DPP(s, 0x112, 0xf);
-    s += ICP_SCAN_DPP(s, 0x114, 0xf);
-    s += ICP_SCAN_DPP(s, 0x118, 0xf);
-    s += ICP_SCAN_DPP(s, 0x142, 0xa);
-    s += ICP_SCAN_DPP(s, 0x143, 0xc);
-#undef ICP_SCAN_DPP
+    s = wave_scan_inclusive(s);
     inc[d] = s;
     if (lane == 63) s_wtot[d][wave] = s;
   }
@@ -1107,7 +1128,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_pick(PickArgs A) {
 // and the deciding evaluation of the current one): ONE launch files the candidates of both (2 B workgroups: two per
 // CU, four waves per SIMD instead of two hide each other's latencies), ONE launch of two workgroups finishes both.
 // The deciding evaluation then neither shares the CUs with the search nor needs a stream of its own.
-__global__ __launch_bounds__(kWinThreads) void k_win_hist_sums_bkt2(HistBktArgs A, HistBktArgs B) {
+__global__ __launch_bounds__(kWinThreads, 4) void k_win_hist_sums_bkt2(HistBktArgs A, HistBktArgs B) {
   __shared__ HistBktLds S;
   const unsigned half = gridDim.x >> 1;
   if (blockIdx.x < half) win_hist_sums_bkt_body(A, blockIdx.x, half, S);

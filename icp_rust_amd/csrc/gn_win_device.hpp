@@ -56,6 +56,39 @@ __device__ __forceinline__ unsigned wbin_cold(double r, const WinDim &w) {
   return r >= w.x[5] ? (unsigned)(kWinBins - 1) : j;
 }
 
+// wbin() for the streaming loops that are bound by instruction issue (k_win_hist_sums_bkt: 428 instructions per pair,
+// 62 of them each wbin -- five exec-masked copies of region_bin behind a ladder of compares): the REGION comes from
+// four compares added up, its origin / scale / first bin / last offset from a five-row table in LDS, and region_bin
+// runs once.  Same operations on the same operands as wbin, hence the same bins (tests/test_gpu_gn_win.py compares
+// every evaluation against the oracle's medians, which the bins decide).  `fine`: the bin is one of a fine window's.
+struct WinRegion {
+  double base, scale;
+  unsigned first, last;  // first bin of the region, count - 1
+  unsigned pad[2];
+};
+static_assert(sizeof(WinRegion) == 32, "one ds_read_b128 + one ds_read_b64");
+__device__ __forceinline__ void win_region_table(const WinDim &w, WinRegion *tab, int r) {  // row r of 5
+  const bool coarse = r & 1;
+  WinRegion e;
+  e.base = w.x[r];
+  e.scale = coarse ? w.sc : w.sf;
+  e.first = (unsigned)(r == 0 ? kF0 : r == 1 ? kC0 : r == 2 ? kF1 : r == 3 ? kC1 : kF2);
+  e.last = (unsigned)((coarse ? kWinCoarse : kWinFine) - 1);
+  e.pad[0] = e.pad[1] = 0u;
+  tab[r] = e;
+}
+__device__ __forceinline__ unsigned wbin_tab(double r, const WinDim &w, const WinRegion *tab, bool &below, bool &above,
+                                             bool &fine) {
+  below = !(r >= w.x[0]);  // (NaN residuals are reported through nan_flag)
+  above = r >= w.x[5];
+  const unsigned reg = (unsigned)(r >= w.x[1]) + (unsigned)(r >= w.x[2]) + (unsigned)(r >= w.x[3]) + (unsigned)(r >= w.x[4]);
+  const WinRegion e = tab[reg];
+  const unsigned k = (unsigned)((r - e.base) * e.scale);
+  fine = !(reg & 1u) & !below & !above;
+  const unsigned j = e.first + (k < e.last ? k : e.last);
+  return below ? 0u : (above ? (unsigned)(kWinBins - 1) : j);
+}
+
 // is regular bin j one of the three fine windows' (where every candidate of a window that holds lies)?
 __device__ __forceinline__ bool fine_bin(unsigned j) {
   return (j - (unsigned)kF0 < (unsigned)kWinFine) | (j - (unsigned)kF1 < (unsigned)kWinFine) |
@@ -213,16 +246,7 @@ __device__ __forceinline__ bool resolve_window(const uint32_t *c, unsigned n, co
 __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *total) {
   __shared__ unsigned s_w[kReduceThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the wave's inclusive scan without the LDS pipe: DPP row shifts inside rows of 16, then the two row broadcasts
-  unsigned s = v;
-#define ICP_SCAN_DPP(x, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, true)
-  s += ICP_SCAN_DPP(s, 0x111, 0xf);  // row_shr:1 (zero fill at the row's start)
-  s += ICP_SCAN_DPP(s, 0x112, 0xf);  // row_shr:2
-  s += ICP_SCAN_DPP(s, 0x114, 0xf);  // row_shr:4
-  s += ICP_SCAN_DPP(s, 0x118, 0xf);  // row_shr:8  -> inclusive within each row of 16
-  s += ICP_SCAN_DPP(s, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-  s += ICP_SCAN_DPP(s, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
-#undef ICP_SCAN_DPP
+  const unsigned s = wave_scan_inclusive(v);
   if (lane == 63) s_w[wave] = s;
   __syncthreads();
   unsigned before = 0, all = 0;
