@@ -415,10 +415,15 @@ class _Icp:
             return o
         s = _host(src, self.DIM)
         n = s.shape[0]
-        idx = np.zeros(max(n, 1), dtype=np.uint32)
+        # (the reference returns the transform alone: the last correspondences are copied back only on request --
+        # 113 KB and a stream synchronisation per 28k-point frame otherwise)
+        want_idx = return_info is True
+        idx = np.zeros(max(n, 1), dtype=np.uint32) if want_idx else None
         check(lib().icp_estimate(self._h, _ptr(s), n, C.byref(initial_transform.pose), max_iter,
-                                 C.byref(o.pose), C.c_void_p(idx.ctypes.data),
+                                 C.byref(o.pose), C.c_void_p(idx.ctypes.data) if want_idx else None,
                                  C.c_void_p(inner.ctypes.data)), "icp_estimate")
+        if return_info == "inner":
+            return o, inner[:max_iter]
         if return_info:
             return o, idx[:n], inner[:max_iter]
         return o
