@@ -146,6 +146,7 @@ SIGNATURES = {
     "icp_gn_path_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_gn_loop_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_gn_loop_timeouts": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "icp_fixed_point_skips": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_run_ahead_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_trim_pool": (None, []),
     "icp_append_targets": (C.c_int, [_vp, _vp, _sz, _pp]),

@@ -295,6 +295,13 @@ def gn_loop_timeouts(icp):
     return int(out.value)
 
 
+def fixed_point_skips(icp):
+    """outer iterations not run because the pose had stopped moving (their inner counts are 0, the result the same bits)"""
+    out = C.c_uint64(0)
+    check(lib().icp_fixed_point_skips(icp._h, C.byref(out)), "icp_fixed_point_skips")
+    return int(out.value)
+
+
 def run_ahead_counters(icp):
     """(run-ahead searches whose device-derived pose the host confirmed bit for bit, ... that it did not)"""
     out = (C.c_uint64 * 2)()

@@ -1347,7 +1347,19 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     if (inner_iters) inner_iters[it] = inner;
     prev_inner = inner;
     w.last_inner = inner;
-    T = transform_mul(dT, T);  // src/lib.rs:127, 170
+    const Pose T_next = transform_mul(dT, T);  // src/lib.rs:127, 170
+    // An outer iteration that leaves the pose as it found it, bit for bit, is a fixed point of the loop: every later
+    // iteration repeats it (correspondences and updates are functions of the pose and the two clouds -- whichever
+    // kernels serve them return the same bits).  Only the last one still runs: it reports the correspondences.  A
+    // settled registration stops paying for the iterations the reference spends re-deriving the same zero update, and
+    // a cloud registered against itself (the first frame of examples/scan3d.rs) for twenty rounds of its slowest path.
+    if (inner == 0 && it + 2 < max_iter && memcmp(&T_next, &T, sizeof(Pose)) == 0) {
+      if (inner_iters)
+        for (size_t k = it + 1; k + 1 < max_iter; ++k) inner_iters[k] = 0;
+      w.fixed_point_skips += max_iter - 2 - it;
+      it = max_iter - 2;
+    }
+    T = T_next;
   }
 #ifdef ICP_EXPERIMENTS
   if (exp_env("ICP_STEP_TRACE")) {
@@ -1486,6 +1498,13 @@ extern "C" int icp_run_ahead_counters(icp_handle *h, uint64_t out[2]) {
 extern "C" int icp_gn_loop_timeouts(icp_handle *h, uint64_t *out) {
   if (!h || !out) return ICP_BAD_ARGUMENT;
   *out = h->ws.loop_timeouts;
+  return ICP_OK;
+}
+
+// outer iterations icp_estimate[_device] did not run because the pose had stopped moving (a fixed point repeats)
+extern "C" int icp_fixed_point_skips(icp_handle *h, uint64_t *out) {
+  if (!h || !out) return ICP_BAD_ARGUMENT;
+  *out = h->ws.fixed_point_skips;
   return ICP_OK;
 }
 

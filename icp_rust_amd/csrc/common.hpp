@@ -253,6 +253,7 @@ struct Workspace : GnCtx {
   // bucketed candidates (gn_win.hip): evaluations served that way, how many found their buckets too small, and for how
   // many more window evaluations this handle keeps to the second pass over the points after such a miss
   unsigned long long bkt_evals = 0, bkt_misses = 0;
+  unsigned long long fixed_point_skips = 0;  // outer iterations not run because the pose had stopped moving (icp_estimate_device)
   unsigned bkt_off = 0;
   // one-launch inner loop (gn_loop.hip): control block, the two parity histograms / block-sum sets, the pinned result
   void *d_loop_ctl = nullptr, *h_loop_res = nullptr;

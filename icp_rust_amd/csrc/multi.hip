@@ -587,7 +587,15 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
       }
     }
     if (inner_iters) inner_iters[it] = applied;
-    T = transform_mul(Ti, T);
+    const Pose T_next = transform_mul(Ti, T);
+    // (a fixed point of the loop, as in icp_estimate_device: the iterations after it repeat it -- and here every search
+    // leaves its indices, so not even the last one has to run)
+    if (applied == 0 && memcmp(&T_next, &T, sizeof(Pose)) == 0) {
+      if (inner_iters)
+        for (size_t k = it + 1; k < max_iter; ++k) inner_iters[k] = 0;
+      break;
+    }
+    T = T_next;
   }
   // the last search's indices back to the caller's point order, on the devices: every rank puts its slice into rank 0's
   // fold-order array (a peer write between devices), rank 0 un-permutes, one transfer to the host

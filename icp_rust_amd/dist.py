@@ -31,6 +31,12 @@ INNER_MAX_ITER = 200          # src/lib.rs:61
 DELTA_NORM_THRESHOLD = 1e-6   # src/lib.rs:60
 
 
+def _same_bits(T1, T0):
+    """two poses equal bit for bit (objects with .as_array(): api.Transform, or the CPU stand-ins of the gloo tests)"""
+    a, b = np.ascontiguousarray(T1.as_array(), dtype=np.float64), np.ascontiguousarray(T0.as_array(), dtype=np.float64)
+    return a.tobytes() == b.tobytes()
+
+
 def shard_range(n, rank, world):
     """contiguous range [lo, hi) of rank `rank`: sizes differ by at most one (round-1 sharding; still
     what the brute-force engine's bench uses)."""
@@ -642,8 +648,12 @@ class BlockShardedIcp:
                 if hasattr(rk.stages, "prepare") and self.geom[rk.rank][3]:
                     rk.stages.prepare(src_local[rk.rank], T)
         for _ in range(max_iter):
-            T, k = self.step(src_local, T)
+            T_next, k = self.step(src_local, T)
             inner.append(k)
+            if k == 0 and _same_bits(T_next, T):  # a fixed point of the loop: the iterations after it repeat it
+                inner.extend([0] * (max_iter - len(inner)))  # (every step leaves its indices: the last need not run)
+                break
+            T = T_next
         return T, np.array(inner, dtype=np.uint32)
 
     def last_indices(self):
@@ -737,6 +747,10 @@ class ShardedIcp:
         if max_iter > 0 and hasattr(self.stages, "prepare"):
             self.stages.prepare(src_shard, T)  # once per estimate call, like Icp::estimate itself
         for _ in range(max_iter):
-            T, k = self.step(src_shard, T)
+            T_next, k = self.step(src_shard, T)
             inner.append(k)
+            if k == 0 and _same_bits(T_next, T):  # a fixed point of the loop: the iterations after it repeat it
+                inner.extend([0] * (max_iter - len(inner)))
+                break
+            T = T_next
         return T, np.array(inner, dtype=np.uint32)

@@ -28,6 +28,10 @@ int icp_gn_loop_counters(icp_handle *h, uint64_t out[3]);
  * workgroup arriving at the grid barrier; 3 s between the ranks of a sharded launch).  After one, the handle steps its
  * next 64 inner loops from the host and then tries the launch again. */
 int icp_gn_loop_timeouts(icp_handle *h, uint64_t *out);
+/* outer iterations of icp_estimate[_device] that were not run because the one before them had left the pose as it found
+ * it, bit for bit: every later iteration would repeat it (src/lib.rs:105-130 is a function of the pose and the clouds),
+ * so only the last one -- which reports the correspondences -- still runs.  The inner counts of the skipped ones are 0. */
+int icp_fixed_point_skips(icp_handle *h, uint64_t *out);
 
 /* ... and the run-ahead searches of icp_estimate[_device] (a search enqueued behind the pre-launched first evaluation
  * of the next iteration, its pose derived on the device): out[0] the host derived the same pose bit for bit and took

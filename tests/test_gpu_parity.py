@@ -268,6 +268,41 @@ def test_every_iteration_count_around_the_run_ahead_search_matches_the_oracle(n,
     assert hits > 0, (hits, misses)
 
 
+@pytest.mark.parametrize("case", ["a cloud against itself", "a registration that settles", "a 2-D scan pair in one launch"])
+def test_a_pose_that_has_stopped_moving_ends_the_loop_with_the_bits_of_all_twenty_iterations(case):
+    """An outer iteration that leaves the pose as it found it is a fixed point of src/lib.rs:105-130 / 148-173: the
+    iterations after it repeat it.  icp_estimate[_device] and the single-launch kernel run only the last of them (the one
+    that reports the correspondences); pose, indices and every inner count must be what the oracle gets by running all
+    twenty -- and the counter must show that iterations were in fact left out where the host steps the loop."""
+    if case == "a cloud against itself":  # the first frame of examples/scan3d.rs:104-131: every residual is exactly 0
+        pk = synth.synthetic_scan3d_packets(75)
+        src = dst = synth.remove_invalid_values(pk)
+        dim, max_iter = 3, 20
+    elif case == "a registration that settles":
+        src, dst, _ = synth.converging_pair(100_000, 100_000)
+        dim, max_iter = 3, 20
+    else:
+        src = load_scan2d(os.path.join(GOLDEN, "scans2d", "001.txt"))
+        dst = load_scan2d(os.path.join(GOLDEN, "scans2d", "002.txt"))
+        dim, max_iter = 2, 20
+    icp = (I.Icp3d if dim == 3 else I.Icp2d)(dst)
+    got, idx, inner = icp.estimate(src, I.Transform(), max_iter, return_info=True)
+    rc, want, oidx, oinner = oracle_in_device_order(icp, dim, dst, src, opose(I.Transform()), max_iter, use_kdtree=True)
+    assert rc == O.OK
+    assert np.array_equal(got.as_array(), want.as_array())
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(inner, oinner), (inner, oinner)
+    assert inner[-1] == 0 and inner[-3] == 0, inner  # (the case does reach a fixed point before the end)
+    if dim == 3:
+        assert I.fixed_point_skips(icp) > 0
+    # the same call again, shorter and longer: the fixed point may come before, at or after the last iteration
+    for k in (1, 2, int(np.argmin(inner > 0)) + 1, int(np.argmin(inner > 0)) + 2, max_iter + 5):
+        g2, i2, n2 = icp.estimate(src, I.Transform(), k, return_info=True)
+        rc, w2, oi2, on2 = oracle_in_device_order(icp, dim, dst, src, opose(I.Transform()), k, use_kdtree=True)
+        assert rc == O.OK and np.array_equal(g2.as_array(), w2.as_array()), k
+        assert np.array_equal(i2, oi2) and np.array_equal(n2, on2), (k, n2, on2)
+
+
 def test_icp_is_run_to_run_deterministic():
     src, dst = synth.synthetic_pair(50_000, 40_000)
     icp = I.Icp3d(dst)
