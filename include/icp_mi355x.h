@@ -154,8 +154,11 @@ int icp_set_stream(icp_handle *h, void *hip_stream);
 int icp_use_own_stream(icp_handle *h);
 
 /* Icp2d::estimate (src/lib.rs:105-130) / Icp3d::estimate (src/lib.rs:148-173):
- * exactly `max_iter` outer iterations of transform -> exact NN -> estimate_transform
- * -> compose.  src: n points AoS (host).  Optional outputs (NULL to skip):
+ * the result of exactly `max_iter` outer iterations of transform -> exact NN -> estimate_transform
+ * -> compose.  (An iteration that applies no update and returns the pose it was given, bit for bit, is a fixed point:
+ * the iterations after it would repeat it and are not run, except the last, which reports the correspondences; their
+ * inner counts are 0, as they would be.  icp_fixed_point_skips, icp_mi355x_debug.h, counts them.)
+ * src: n points AoS (host).  Optional outputs (NULL to skip):
  *   last_idx[n]          correspondence indices of the last outer iteration,
  *   inner_iters[max_iter] inner Gauss-Newton updates applied per outer iteration. */
 int icp_estimate(icp_handle *h, const double *src, size_t n, const icp_pose *init,
