@@ -733,8 +733,11 @@ void icp::api::record_statistics(Workspace &w, int kind, bool has_median, const 
 // library's own loops call this (estimate_transform_loop): a handle that serves as a rank of a sharded evaluation goes
 // through the stage calls, where a rank-local prediction (and the `wide` flag a miss leaves behind) would give the
 // ranks different windows for the same histogram sum.
+// (Whether the handle has evaluated anything else yet does not matter: the second evaluation of a frame's first iteration
+// is predicted far better by the previous frame's second evaluation than by this frame's first -- their medians differ by
+// 0.6 sigma on the scan3d frames, a miss even with the widest windows: profiles/r05_frame_trace_fresh.txt.)
 static void adopt_pool_hint(Workspace &w, int kind) {
-  if (Workspace::kind_has_slot(kind) && !w.win_kind[kind].valid && !w.win_valid && w.hint_kind[kind].valid) {
+  if (Workspace::kind_has_slot(kind) && !w.win_kind[kind].valid && w.hint_kind[kind].valid) {
     w.win_kind[kind] = w.hint_kind[kind];
     w.hint_kind[kind].valid = false;
   }

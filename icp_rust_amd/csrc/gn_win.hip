@@ -1480,7 +1480,14 @@ bool window_usable(const icp_handle *h, size_t n, WinParams *P, int kind, bool a
 
 // half-width of the fine windows in sigmas: the prediction may be off by about that much (4 x after a miss)
 double window_half_width(size_t n, bool wide) {
-  static const double hw_sigmas = exp_env("ICP_WIN_HW") ? atof(exp_env("ICP_WIN_HW")) : 0.05;
+  static const double hw_env = exp_env("ICP_WIN_HW") ? atof(exp_env("ICP_WIN_HW")) : 0.;
+  // Clouds of up to 2^17 points (512 per workgroup of the tree): even the widest windows leave a handful of candidates in
+  // a fine bin and a few hundred members for a workgroup to stage, so narrow windows save nothing there -- and they cost
+  // a fresh handle (one per frame in examples/scan3d.rs) two evaluations through the seven-launch pipeline, when the first
+  // evaluations of a kind are predicted from another kind's statistics and miss (0.18 ms of a 1.28-ms frame:
+  // profiles/r05_frame_trace_fresh.txt).
+  if (hw_env <= 0. && n <= ((size_t)1 << 17)) return 0.2;
+  const double hw_sigmas = hw_env > 0. ? hw_env : 0.05;
   double f = hw_sigmas * (wide ? 4. : 1.);
   if (n > 1000000) f *= 1e6 / (double)n;  // candidates per fine bin grow with n
   return f > 0.2 ? 0.2 : f;               // the windows must not overlap (MAD = 0.6745 sigma)

@@ -27,6 +27,23 @@ def run():
     print(f"frame {len(s3)} x {len(d3)}: estimate(20) median {1e3 * ts[len(ts) // 2]:.3f} ms min {1e3 * ts[0]:.3f} ms inner {list(inner)}")
 
 
+def run_fresh():
+    """a fresh handle per frame, warm-started pose: what the scan3d loop does"""
+    import icp_rust_amd as I
+    from icp_rust_amd import synth
+    from icp_rust_amd.harness import remove_invalid_values
+    pk = synth.synthetic_scan3d_packets(75 * 10)
+    src = remove_invalid_values(pk[:75])
+    T = I.Transform.identity()
+    for k in range(9):
+        icp = I.Icp3d(remove_invalid_values(pk[75 * k:75 * (k + 1)]))
+        t0 = time.perf_counter()
+        T = icp.estimate(src, T, 20)
+        dt = time.perf_counter() - t0
+        icp.close()
+    print(f"last frame of a fresh-handle loop: estimate(20) {1e3 * dt:.3f} ms")
+
+
 def show(d):
     f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
@@ -44,4 +61,4 @@ def show(d):
 
 
 if __name__ == "__main__":
-    run() if sys.argv[1] == "run" else show(sys.argv[2])
+    {"run": run, "fresh": run_fresh}[sys.argv[1]]() if sys.argv[1] != "show" else show(sys.argv[2])

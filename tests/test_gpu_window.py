@@ -164,7 +164,11 @@ def test_inner_loops_of_varying_length_on_the_device_leave_the_result_alone():
     T, idx, inner = icp.estimate(src, I.Transform(), 12, return_info=True)
     launches, served, handbacks = delta(l0, I.gn_loop_counters(icp))
     assert max(int(x) for x in inner) >= 5, inner
-    assert launches >= 6 and served >= launches and handbacks <= launches // 2
+    # (one launch per inner loop that did not follow a one-update loop, plus one per evaluation handed back; with the
+    # widest windows for clouds of this size -- round 5 -- nothing is handed back here, and the loops after the pose has
+    # stopped moving are not run at all: the count of loops with several updates is the floor)
+    several = sum(1 for x in inner if int(x) >= 2)
+    assert launches >= max(several, 4) and served >= launches and handbacks <= launches // 2, (launches, served, handbacks, inner)
     rc, oT, oidx, oinner = oracle_in_device_order(icp, 3, dst, src, O.transform_identity(), 12)
     assert rc == O.OK
     assert np.array_equal(idx, oidx)
