@@ -36,6 +36,13 @@ ICP_MI355X_LIB=icp_rust_amd/lib/libicp_ab_loopprof.so python3 profiles/loop_prob
 echo "== head of a call"
 rocprofv3 --kernel-trace --output-format csv -d $O/kh -- python3 profiles/call_head_trace.py run > /dev/null 2>&1
 python3 profiles/call_head_trace.py analyze $O/kh > $O/call_head_trace.txt; rm -rf $O/kh
+echo "== a 28k-point frame: the launches of one estimate(20) in order, on a reused handle and on a fresh one per frame (the scan3d loop); the loop's parts on the host's clock"
+python3 profiles/frame_trace.py run > $O/frame_run.txt 2>&1; python3 profiles/frame_trace.py fresh >> $O/frame_run.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/ft -- python3 profiles/frame_trace.py run > /dev/null 2>&1
+python3 profiles/frame_trace.py show $O/ft > $O/frame_trace.txt; rm -rf $O/ft
+rocprofv3 --kernel-trace --output-format csv -d $O/ft -- python3 profiles/frame_trace.py fresh > /dev/null 2>&1
+python3 profiles/frame_trace.py show $O/ft > $O/frame_trace_fresh.txt; rm -rf $O/ft
+python3 profiles/frame_loop_parts.py 2>&1 | grep -v "^/opt" | cut -c1-120 > $O/frame_loop_parts.txt
 echo "== two independent tenants on the one GPU (tests/test_gpu_tenants.py's helper)"
 D=$(mktemp -d); (python3 tests/helpers/independent_handle.py 200 1 $D 2 > $O/tenant1.txt 2>&1 &) ; python3 tests/helpers/independent_handle.py 200 2 $D 2 > $O/tenant2.txt 2>&1; sleep 2
 cat $O/tenant1.txt $O/tenant2.txt | grep "^tenant" > $O/two_tenants.txt; rm -f $O/tenant1.txt $O/tenant2.txt
