@@ -99,19 +99,20 @@ __device__ __forceinline__ void wave_tree(double (&acc)[N]) {
 
 // Fixed association order (mirrored by the oracle's *_tree variant): a wave folds with
 // v[l] += v[l+off], off = 32..1; thread 0 left-folds the wave sums from wave 0.
-template <int N, bool SC1 = false>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[N], double *__restrict__ out) {
-  __shared__ double sm[16][N];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // step-major: the N shuffles of one step are independent and pipeline through the LDS
-  // crossbar; accumulator-major code runs N dependent 6-step chains one after the other
-  // (measured: 14k cycles for N = 13).  Same association order per accumulator either way.
+// ... in two halves, for kernels that have a workgroup barrier of their own between the pairs and what follows (a
+// histogram to complete): the wave's tree and its sum into LDS go IN FRONT of that barrier -- a wave that is through
+// with its pairs folds while the slower ones finish -- and the fold of the wave sums behind it.  Same operations in
+// the same order as block_reduce_store.
+template <int N>
+__device__ __forceinline__ void block_reduce_waves(double (&acc)[N], double (*sm)[N]) {
   wave_tree<N>(acc);
-  if (lane == 0) {
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) sm[wave][k] = acc[k];
+    for (int k = 0; k < N; ++k) sm[threadIdx.x >> 6][k] = acc[k];
   }
-  __syncthreads();
+}
+template <int N, bool SC1 = false>
+__device__ __forceinline__ void block_reduce_finish(const double (*sm)[N], double *__restrict__ out) {
   if (threadIdx.x < N) {
     const int k = threadIdx.x;
     double s = sm[0][k];
@@ -119,6 +120,16 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double *__r
     if (SC1) __hip_atomic_store(out + k, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else out[k] = s;
   }
+}
+template <int N, bool SC1 = false>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[N], double *__restrict__ out) {
+  __shared__ double sm[16][N];
+  // step-major: the N shuffles of one step are independent and pipeline through the LDS
+  // crossbar; accumulator-major code runs N dependent 6-step chains one after the other
+  // (measured: 14k cycles for N = 13).  Same association order per accumulator either way.
+  block_reduce_waves<N>(acc, sm);
+  __syncthreads();
+  block_reduce_finish<N, SC1>(sm, out);
 }
 
 

@@ -376,6 +376,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
   __shared__ double s_med[2][kWinBlkMed], s_ring[2][kWinBlkRing];
   __shared__ unsigned s_cnt[4], s_base[4];
   __shared__ double s_tot[kNSum + 1], s_acc[kNAcc + 3];
+  __shared__ double s_wv[kReduceThreads / 64][kNSum];  // the waves' sums of phase A (block_reduce_waves / _finish)
   __shared__ WinSel s_ws;
   __shared__ LoopLocal L;
   constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
@@ -464,13 +465,14 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
           if (edge[k]) atomicAdd(&s_bins[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], edge[k]);
       }
       if (saw_nan) atomicOr(&ctl->nan_flag[0], 1u);
+      block_reduce_waves<kNSum>(acc, s_wv);  // (in front of the barrier: gn_device.hpp)
       __syncthreads();
       LOOP_STAMP(1);
+      block_reduce_finish<kNSum, true>(s_wv, partials + (size_t)blockIdx.x * (kNSum + 1));
       for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads) {  // dense flush: contiguous words
         const uint32_t c = s_bins[i];
         if (c) atomicAdd(&whist[i], c);
       }
-      block_reduce_store<kNSum, true>(acc, partials + (size_t)blockIdx.x * (kNSum + 1));
     }
     LOOP_STAMP(2);
     if (!flag_barrier(ctl->flag1, ctl, round + 1u, 0ull, nullptr)) {
@@ -868,6 +870,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
   __shared__ double s_med[2][kWinBlkMed], s_ring[2][kWinBlkRing];
   __shared__ unsigned s_cnt[4];
   __shared__ double s_tot[kNSum + 1], s_acc[kNAcc + 3], s_row[kNSum + 1];
+  __shared__ double s_wv[kReduceThreads / 64][kNSum];  // the waves' sums of phase A (block_reduce_waves / _finish)
   // (the flag words of the second wait and the prefix of their counts overlay the same workspace: they live between
   // phase B's last look at the cumulative counts and the first selection)
   unsigned long long *const s_seen = reinterpret_cast<unsigned long long *>(s_work), *const s_incl = s_seen + kReduceMaxBlocks;
@@ -977,12 +980,13 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
           if (edge[k]) atomicAdd(&s_bins[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], edge[k]);
       }
       if (saw_nan) atomicOr(&s_flags, 2u);
+      block_reduce_waves<kNSum>(acc, s_wv);  // (in front of the barrier: gn_device.hpp)
       __syncthreads();
+      block_reduce_finish<kNSum, false>(s_wv, s_row);
       for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads) {
         const uint32_t c = s_bins[i];
         if (c) atomicAdd(&whist[i], c);
       }
-      block_reduce_store<kNSum, false>(acc, s_row);  // (LDS; stored by lanes of wave 0)
       __syncthreads();
       // the block sum into every rank's inbox, row = global block: the fold of phase C reads them in block order
       for (unsigned j = tid; j < (unsigned)W * (kNSum + 1); j += kReduceThreads) {

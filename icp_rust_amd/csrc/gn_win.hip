@@ -95,6 +95,8 @@ __device__ __forceinline__ void win_hist_body(const double2 *__restrict__ a, con
     if ((threadIdx.x & 63) == 63 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
   }
   if (saw_nan) atomicOr(&scal->nan_flag, 1);
+  __shared__ double s_wsum[kWinThreads / 64][SUMS ? kNSum : 1];
+  if (SUMS) block_reduce_waves<SUMS ? kNSum : 1>(acc, s_wsum);  // (in front of the barrier: gn_device.hpp)
 #ifdef ICP_WIN_DEBUG
   wst[2] = wall_clock64();
 #endif
@@ -114,7 +116,7 @@ __device__ __forceinline__ void win_hist_body(const double2 *__restrict__ a, con
     printf("[W blk %d] zero %lld stream %lld barrier %lld flush %lld (x10ns)\n", blockIdx.x, wst[1] - wst[0],
            wst[2] - wst[1], wst[3] - wst[2], wst[4] - wst[3]);
 #endif
-  if (SUMS) block_reduce_store<SUMS ? kNSum : 1, true>(acc, partials + (size_t)blockIdx.x * (kNSum + 1));
+  if (SUMS) block_reduce_finish<SUMS ? kNSum : 1, true>(s_wsum, partials + (size_t)blockIdx.x * (kNSum + 1));
 }
 
 #ifdef ICP_EXPERIMENTS  // (the histograms alone: first launch of the four-launch forms of rounds 1-3)
@@ -190,6 +192,7 @@ struct HistBktLds {
   double mv[kBktStage];
   unsigned short mk[kBktStage];
   WinRegion tab[2][8];  // (five rows each: wbin_tab)
+  double wsum[kWinThreads / 64][kNSum];  // the waves' sums (block_reduce_store's `sm`)
   unsigned nmem;
 };
 
@@ -319,6 +322,10 @@ __device__ __forceinline__ void win_hist_sums_bkt_body(const HistBktArgs &A, con
     if ((threadIdx.x & 63) == 63 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
   }
   if (saw_nan) atomicOr(&scal->nan_flag, 1);
+  // the wave's part of the block sums (block_reduce_store's: same tree, same order) BEFORE the barrier: a wave that is
+  // through with its pairs folds while the slower ones finish, and the barrier that completes the histograms also
+  // completes the wave sums
+  block_reduce_waves<kNSum>(acc, S.wsum);
 #ifdef ICP_WIN_DEBUG
   bst[1] = wall_clock64();
 #endif
@@ -326,6 +333,7 @@ __device__ __forceinline__ void win_hist_sums_bkt_body(const HistBktArgs &A, con
 #ifdef ICP_WIN_DEBUG
   bst[2] = wall_clock64();
 #endif
+  block_reduce_finish<kNSum, true>(S.wsum, partials + (size_t)blk * (kNSum + 1));
   for (unsigned i = threadIdx.x; i < 2u * kWinBins; i += kWinThreads) {  // dense flush: contiguous words, nobody waits
     const uint32_t c = lh[i];
     if (c) atomicAdd(&whist[i], c);
@@ -362,9 +370,7 @@ __device__ __forceinline__ void win_hist_sums_bkt_body(const HistBktArgs &A, con
     *reinterpret_cast<uint4 *>(dir + f0) = pk;
   }
   if (threadIdx.x == 0) dir[kBktFine] = (unsigned short)(total < 0xffffu ? total : 0xffffu);
-  // (the block sums go out while the directory lands in LDS)
-  block_reduce_store<kNSum, true>(acc, partials + (size_t)blk * (kNSum + 1));
-  __syncthreads();
+  __syncthreads();  // (the directory's offsets are in LDS)
 #ifdef ICP_WIN_DEBUG
   bst[3] = wall_clock64();
 #endif
