@@ -394,6 +394,36 @@ __device__ __forceinline__ void publish_folded(const double *s_tot, GnResult *re
   }
 }
 
+// The same result, stored by the lanes of wave `W` WITHOUT the sequence number: for a finishing launch whose lane 0 is
+// busy deriving the next outer pose meanwhile (gn_win.hip: fill_ahead_pose -- a 3 x 3 solve, sin, cos and two pose
+// products, as long as these stores to host memory take).  The caller drains (done here), meets at a workgroup barrier
+// and releases the sequence number from wave 0 (publish_seq).
+template <int W>
+__device__ __forceinline__ void publish_values(const double *s_tot, GnResult *res, const double (&sig)[2],
+                                               const double (&med)[2], int nan_flag, int overflow) {
+  const int t = (int)threadIdx.x - 64 * W;
+  if (t >= 0 && t < 64) {
+    if (t < kNAcc + 1) res->acc[t] = t < kNAcc ? combine_sum(s_tot, t, sig) : 0.;
+    if (t == kNAcc + 1) {
+      res->sigma[0] = sig[0];
+      res->sigma[1] = sig[1];
+      res->median[0] = med[0];
+      res->median[1] = med[1];
+    }
+    if (t == kNAcc + 2) {
+      res->nan_flag = nan_flag;
+      res->overflow = overflow;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+__device__ __forceinline__ void publish_seq(GnResult *res, unsigned seq) {
+  if (threadIdx.x < 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 __device__ __forceinline__ void publish_result(const double *partials, GnResult *res, unsigned seq,
                                                const double (&sig)[2], const double (&med)[2], int nan_flag,
                                                int overflow, int blocks_override = 0) {

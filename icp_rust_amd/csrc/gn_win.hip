@@ -1110,10 +1110,18 @@ __device__ __forceinline__ void win_pick_body(const PickArgs &A, PickLds &L) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   PSTAMP(6);
-  if (ahead && tid == 0) fill_ahead_pose(s_tot, sig, !missed && !nan_flag, outer, ahead, res);
-  PSTAMP(7);
   // overflow 3: the window may have been right, the FILES were not usable (the host steps back to the second pass)
-  publish_folded(s_tot, res, seq, sig, med, nan_flag, missed ? (fail ? 2 : 3) : 0);
+  const int overflow = missed ? (fail ? 2 : 3) : 0;
+  if (ahead) {  // (uniform) lane 0 derives the next outer pose while wave 1 stores the result; wave 0 releases both
+    if (tid == 0) fill_ahead_pose(s_tot, sig, !missed && !nan_flag, outer, ahead, res);
+    publish_values<1>(s_tot, res, sig, med, nan_flag, overflow);
+    PSTAMP(7);
+    __syncthreads();
+    publish_seq(res, seq);
+  } else {
+    PSTAMP(7);
+    publish_folded(s_tot, res, seq, sig, med, nan_flag, overflow);
+  }
 #ifdef ICP_WIN_DEBUG
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PSTAMP(8);
