@@ -377,6 +377,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
   __shared__ unsigned s_cnt[4], s_base[4];
   __shared__ double s_tot[kNSum + 1], s_acc[kNAcc + 3];
   __shared__ double s_wv[kReduceThreads / 64][kNSum];  // the waves' sums of phase A (block_reduce_waves / _finish)
+  __shared__ WinRegion s_tab[2][8];  // phase A's bins: wbin_tab (five rows per dimension, rewritten for every evaluation's windows)
   __shared__ WinSel s_ws;
   __shared__ LoopLocal L;
   constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
     // ---- A: residuals -> histograms + running sums ----------------------------------------------------------------
     for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads) s_bins[i] = 0;
     if (tid == 0) s_nmem = 0;
+    if (tid < 10u) win_region_table(L.P.d[tid / 5u], s_tab[tid / 5u], (int)(tid % 5u));  // (from the LDS copy: a run-time index into registers would go through scratch)
     __syncthreads();
     {
       double acc[kNSum];
@@ -445,18 +447,18 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop(LoopArgs A, unsigned
         const double v0 = ((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x;
         const double v1 = ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y;
         saw_nan |= (v0 != v0) | (v1 != v1);
-        const unsigned j0 = wbin_cold(v0, P.d[0]), j1 = wbin_cold(v1, P.d[1]);
+        bool lo0, hi0, f0, lo1, hi1, f1;  // (gn_win_device.hpp: four compares added up + a table row + ONE region_bin)
+        const unsigned j0 = wbin_tab(v0, P.d[0], s_tab[0], lo0, hi0, f0), j1 = wbin_tab(v1, P.d[1], s_tab[1], lo1, hi1, f1);
         // (the catch-all bins hold most of a far-off prediction's points: counted by ballot, not by 64 LDS atomics on
         // one word -- and not by shuffles: four dependent six-step reductions were a microsecond per evaluation)
-        const bool lo0 = j0 == 0u, hi0 = j0 == (unsigned)(kWinBins - 1), lo1 = j1 == 0u, hi1 = j1 == (unsigned)(kWinBins - 1);
         edge[0] += (unsigned)__popcll(__ballot(lo0));
         edge[1] += (unsigned)__popcll(__ballot(hi0));
         edge[2] += (unsigned)__popcll(__ballot(lo1));
         edge[3] += (unsigned)__popcll(__ballot(hi1));
         if (!lo0 && !hi0) atomicAdd(&s_bins[j0], 1u);
         if (!lo1 && !hi1) atomicAdd(&s_bins[kWinBins + j1], 1u);
-        if (fine_bin(j0)) stage((k << 10) | (tid << 1));
-        if (fine_bin(j1)) stage((k << 10) | (tid << 1) | 1u);
+        if (f0) stage((k << 10) | (tid << 1));
+        if (f1) stage((k << 10) | (tid << 1) | 1u);
         accumulate_pair<true>(ak, v0, v1, T, acc);  // (this thread's points in index order: the tree's first level)
       }
       if ((tid & 63) == 0) {
@@ -871,6 +873,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
   __shared__ unsigned s_cnt[4];
   __shared__ double s_tot[kNSum + 1], s_acc[kNAcc + 3], s_row[kNSum + 1];
   __shared__ double s_wv[kReduceThreads / 64][kNSum];  // the waves' sums of phase A (block_reduce_waves / _finish)
+  __shared__ WinRegion s_tab[2][8];  // phase A's bins: wbin_tab (five rows per dimension, rewritten for every evaluation's windows)
   // (the flag words of the second wait and the prefix of their counts overlay the same workspace: they live between
   // phase B's last look at the cumulative counts and the first selection)
   unsigned long long *const s_seen = reinterpret_cast<unsigned long long *>(s_work), *const s_incl = s_seen + kReduceMaxBlocks;
@@ -943,6 +946,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
       s_flags = 0u;
       s_nmem = 0u;
     }
+    if (tid < 10u) win_region_table(L.P.d[tid / 5u], s_tab[tid / 5u], (int)(tid % 5u));  // (from the LDS copy: a run-time index into registers would go through scratch)
     __syncthreads();
     {
       double acc[kNSum];
@@ -962,16 +966,16 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
         const double v0 = ((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x;  // residual(), src/lib.rs:34-36
         const double v1 = ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y;
         saw_nan |= (v0 != v0) | (v1 != v1);
-        const unsigned j0 = wbin_cold(v0, P.d[0]), j1 = wbin_cold(v1, P.d[1]);
-        const bool lo0 = j0 == 0u, hi0 = j0 == (unsigned)(kWinBins - 1), lo1 = j1 == 0u, hi1 = j1 == (unsigned)(kWinBins - 1);
+        bool lo0, hi0, f0, lo1, hi1, f1;  // (gn_win_device.hpp: four compares added up + a table row + ONE region_bin)
+        const unsigned j0 = wbin_tab(v0, P.d[0], s_tab[0], lo0, hi0, f0), j1 = wbin_tab(v1, P.d[1], s_tab[1], lo1, hi1, f1);
         edge[0] += (unsigned)__popcll(__ballot(lo0));
         edge[1] += (unsigned)__popcll(__ballot(hi0));
         edge[2] += (unsigned)__popcll(__ballot(lo1));
         edge[3] += (unsigned)__popcll(__ballot(hi1));
         if (!lo0 && !hi0) atomicAdd(&s_bins[j0], 1u);
         if (!lo1 && !hi1) atomicAdd(&s_bins[kWinBins + j1], 1u);
-        if (fine_bin(j0)) stage((k << 10) | (tid << 1));
-        if (fine_bin(j1)) stage((k << 10) | (tid << 1) | 1u);
+        if (f0) stage((k << 10) | (tid << 1));
+        if (f1) stage((k << 10) | (tid << 1) | 1u);
         accumulate_pair<true>(ak, v0, v1, T, acc);
       }
       if ((tid & 63) == 0) {
