@@ -997,13 +997,16 @@ __device__ __forceinline__ void win_pick_body(const PickArgs &A, PickLds &L) {
 #define PSTAMP(k)
 #endif
   if (tid < 4) s_cnt[tid] = 0;
-  WinSel sel;
-  const WinBins R = win_resolve<true, true>(whist, n, P, st, nullptr, 0u, L.g.cum, sel);
-  // (the block sums and the flags travel while the candidates are listed: the histograms went first)
-  double fx[kFoldH];
-  fold256_load(partials, sum_blocks, fx);
+  // (the two flags of the launch in front of this one are asked for FIRST: read after the resolve they were a round trip
+  // of their own -- 3 us between the resolve's last stamp and the lists, r05_pick_phases.txt -- because the lists'
+  // branch needs them at once)
   const int nan_flag = __hip_atomic_load(&scal->nan_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned stage_overflow = __hip_atomic_load(&st->stage_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  WinSel sel;
+  const WinBins R = win_resolve<true, true>(whist, n, P, st, nullptr, 0u, L.g.cum, sel);
+  // (the block sums travel while the candidates are listed: the histograms went first)
+  double fx[kFoldH];
+  fold256_load(partials, sum_blocks, fx);
   PSTAMP(1);
   bool fail = R.fail;
   bool bucket_miss = stage_overflow != 0;
