@@ -213,11 +213,46 @@ __device__ __forceinline__ void accumulate_rho(double r0, double r1, double *err
   *err = *err + rho;
 }
 
+// the nine sums of dimension j with the Huber weight w handed in (accumulate_dim's arithmetic, operation by operation)
+__device__ __forceinline__ void accumulate_dim_w(int j, const double2 &s, double r_j, double w, const Pose &T, double *S) {
+  const double a0 = -s.y, a1 = s.x;  // jacobian(), src/lib.rs:176-184
+  const double J0 = j ? T.r10 : T.r00, J1 = j ? T.r11 : T.r01;
+  const double J2 = J0 * a0 + J1 * a1;
+  const double t0 = w * J0, t1 = w * J1, t2 = w * J2;
+  S[0] = S[0] + t0 * J0;
+  S[1] = S[1] + t0 * J1;
+  S[2] = S[2] + t0 * J2;
+  S[3] = S[3] + t1 * J1;
+  S[4] = S[4] + t1 * J2;
+  S[5] = S[5] + t2 * J2;
+  S[6] = S[6] + t0 * r_j;
+  S[7] = S[7] + t1 * r_j;
+  S[8] = S[8] + t2 * r_j;
+}
+
 template <bool UNIFORM>
 __device__ __forceinline__ void accumulate_pair(const double2 &s, double r0, double r1, const Pose &T, double *acc) {
-  accumulate_dim<UNIFORM>(0, s, r0, T, acc);
-  accumulate_dim<UNIFORM>(1, s, r1, T, acc + 9);
-  accumulate_rho<UNIFORM>(r0, r1, acc + 18);
+  if constexpr (UNIFORM) {
+    // ONE test for the wave instead of three (x, y, the norm): the square roots and divisions of huber::drho / rho run
+    // only where some lane of the wave has a squared residual above k^2 -- the streaming launches are bound by
+    // instruction issue (profiles/r05_p1_instruction_issue.txt).  A lane at or below k^2 gets w = 1 and rho = e either
+    // way, so the sums are the ones accumulate_dim / accumulate_rho give.
+    const double k2 = ICP_HUBER_K * ICP_HUBER_K;
+    const double e0 = r0 * r0, e1 = r1 * r1, e2 = e0 + e1;
+    double w0 = 1., w1 = 1., rho = e2;  // huber::drho, src/huber.rs:17-26; huber::rho, :6-15
+    if (__ballot((e0 > k2) | (e1 > k2) | (e2 > k2))) {
+      w0 = huber_drho(e0);
+      w1 = huber_drho(e1);
+      rho = huber_rho(e2);
+    }
+    accumulate_dim_w(0, s, r0, w0, T, acc);
+    accumulate_dim_w(1, s, r1, w1, T, acc + 9);
+    acc[18] = acc[18] + rho;
+  } else {
+    accumulate_dim<UNIFORM>(0, s, r0, T, acc);
+    accumulate_dim<UNIFORM>(1, s, r1, T, acc + 9);
+    accumulate_rho<UNIFORM>(r0, r1, acc + 18);
+  }
 }
 
 // Entry k of what the host solves with -- jtj[9] (k = 3 p + q), jtr[3] (k = 9 ..), the Huber error (k = 12) -- from
