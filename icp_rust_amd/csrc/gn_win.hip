@@ -228,8 +228,6 @@ __device__ __forceinline__ void win_hist_sums_bkt_body(const HistBktArgs &A, con
   if (threadIdx.x == 0) s_nmem = 0;
   if (threadIdx.x < 10) win_region_table(P.d[threadIdx.x / 5], S.tab[threadIdx.x / 5], (int)(threadIdx.x % 5));
   __syncthreads();
-  unsigned edge[4] = {0u, 0u, 0u, 0u};  // {below, above} x {x, y}: one word each, kept out of the LDS atomics
-  bool saw_nan = false;
   const unsigned G = nblk * kWinThreads;
   const unsigned lane = threadIdx.x & 63u;
   // The loop's condition is the WAVE's (every lane stays active for the scan below).
@@ -282,15 +280,13 @@ __device__ __forceinline__ void win_hist_sums_bkt_body(const HistBktArgs &A, con
       // residual(), src/lib.rs:34-36
       const double v0 = ((T.r00 * s[u].x + T.r01 * s[u].y) + T.tx) - d[u].x;
       const double v1 = ((T.r10 * s[u].x + T.r11 * s[u].y) + T.ty) - d[u].y;
-      saw_nan |= (v0 != v0) | (v1 != v1);
       bool lo0, hi0, f0, lo1, hi1, f1;
       const unsigned j0 = wbin_tab(v0, P.d[0], S.tab[0], lo0, hi0, f0), j1 = wbin_tab(v1, P.d[1], S.tab[1], lo1, hi1, f1);
-      edge[0] += (unsigned)lo0;
-      edge[1] += (unsigned)hi0;
-      edge[2] += (unsigned)lo1;
-      edge[3] += (unsigned)hi1;
-      if (!(lo0 | hi0)) atomicAdd(&lh[j0], 1u);
-      if (!(lo1 | hi1)) atomicAdd(&lh[kWinBins + j1], 1u);
+      // (the catch-all bins 0 and kWinBins - 1 are counted like any other: kept out of the LDS atomics they cost four
+      // selects, four adds and two exec masks per pair of a launch that is bound by instruction issue; a window that holds
+      // sends them a few lanes of a wave, and one that does not is repeated anyway)
+      atomicAdd(&lh[j0], 1u);
+      atomicAdd(&lh[kWinBins + j1], 1u);
       mv[2 * u] = v0;
       mv[2 * u + 1] = v1;
       mj[u] = j0 | (j1 << 16);
@@ -315,13 +311,9 @@ __device__ __forceinline__ void win_hist_sums_bkt_body(const HistBktArgs &A, con
       }
     }
   }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    unsigned v = edge[k];  // the wave's total in its lane 63, by DPP (an inclusive scan's last lane): no LDS crossbar
-    v = wave_scan_inclusive(v);
-    if ((threadIdx.x & 63) == 63 && v) atomicAdd(&lh[(k >> 1) * kWinBins + ((k & 1) ? kWinBins - 1 : 0)], v);
-  }
-  if (saw_nan) atomicOr(&scal->nan_flag, 1);
+  // (a NaN residual makes the Huber sum NaN -- rho(NaN) is NaN on either branch -- and nothing else can: its terms are
+  // >= 0; no test per pair)
+  if (acc[kNSum - 1] != acc[kNSum - 1]) atomicOr(&scal->nan_flag, 1);
   // the wave's part of the block sums (block_reduce_store's: same tree, same order) BEFORE the barrier: a wave that is
   // through with its pairs folds while the slower ones finish, and the barrier that completes the histograms also
   // completes the wave sums
