@@ -879,7 +879,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
   unsigned long long *const s_seen = reinterpret_cast<unsigned long long *>(s_work), *const s_incl = s_seen + kReduceMaxBlocks;
   // (the members of the fine bins, staged by phase A behind the histograms: k_gn_loop has the explanation)
   constexpr unsigned kStageCap = (sizeof(s_work) - 2 * kWinBins * sizeof(uint32_t)) / sizeof(unsigned short);
-  static_assert(kStageCap >= 4096 && kLoopStreamMaxK <= 32, "staged members: 5 + 9 + 1 bits each");
+  static_assert(kStageCap >= 4096 && kLoopStreamMaxK <= 64, "staged members: 6 + 9 + 1 bits each, in an unsigned short");
   unsigned short *const s_mem = reinterpret_cast<unsigned short *>(s_work + 2 * kWinBins * sizeof(uint32_t));
   __shared__ unsigned s_nmem;
   __shared__ unsigned long long s_wsum[4];

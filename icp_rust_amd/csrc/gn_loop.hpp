@@ -5,7 +5,7 @@
 namespace icp {
 
 constexpr int kLoopMaxK = 8;  // pairs per thread of the reduction tree that a launch keeps in LDS (2^20 pairs in all)
-constexpr int kLoopStreamMaxK = 32;  // ... the sharded launch takes up to this many, streamed from memory beyond kLoopMaxK (2^22 pairs)
+constexpr int kLoopStreamMaxK = 64;  // ... the sharded launch takes up to this many, streamed from memory beyond kLoopMaxK (2^23 pairs: eight ranks' 1M each)
 
 // Device-resident control block of the launch; all zero between launches (the last workgroup to leave resets it).
 // One 128-byte line per word that is polled or hit by atomics.

@@ -294,7 +294,7 @@ int icp_shard_eval_abort_device(icp_handle *h);
  *   icp_shard_loop_launch_device: from evaluation it0 with the loop's state (inner pose, previous Huber error, updates
  *     applied: src/lib.rs:62-82); launch_no = 1, 2, ... the same on every rank for the same launch; eval_base = the
  *     evaluations earlier launches of this connection served.  ICP_RETRY_SHARDED: nothing launched (no window
- *     prediction for it0 yet, more than 2^22 pairs in total, fewer tree blocks than ranks) -- every rank answers alike, and the
+ *     prediction for it0 yet, more than 2^23 pairs in total, fewer tree blocks than ranks) -- every rank answers alike, and the
  *     stage calls of section 5 serve that evaluation.
  *   icp_shard_loop_wait: the state after the launch; *evals = the evaluation ROUNDS it ran (an evaluation whose
  *     window missed is repeated once inside the launch with the widest windows and counts twice): what eval_base

@@ -145,11 +145,11 @@ def test_icp_create_multi_with_virtual_ranks_equals_one_handle(world, n, m, dim)
     multi.close()
 
 
-@pytest.mark.parametrize("world,n", [(2, 2_000_000), (4, 4_000_000)])
+@pytest.mark.parametrize("world,n", [(2, 2_000_000), (4, 4_000_000), (8, 8 * 1024 * 1024)])
 def test_the_one_launch_loop_serves_more_than_a_million_pairs_across_ranks(world, n):
     """the sharded inner loop used to stop at 2^20 pairs IN TOTAL (its launch keeps a rank's pairs in
     LDS, eight per thread); clouds beyond that -- the weak-scaling regime, the only one where more GPUs can pay -- fell
-    back to the stage calls.  Now a rank streams what LDS does not hold (k_gn_loop_shard<true>, up to 2^22 pairs): the
+    back to the stage calls.  Now a rank streams what LDS does not hold (k_gn_loop_shard<true>, up to 2^23 pairs = eight ranks' 1M each): the
     result must be ONE handle's, bit for bit (one handle steps such clouds from the host: /root/reference/src/lib.rs:59-84),
     and the loop launches must really have served the evaluations."""
     m = 500_000
