@@ -474,9 +474,18 @@ def main():
                     if transport is None:
                         ok, why = 0, "no transport passed the ping-pong probe"
                     else:
-                        T, _, _ = driver.estimate_full(full, T, max(warmup, 2))  # (also seeds the window predictions)
+                        T, k_loop, _ = driver.estimate_full(full, T, max(warmup, 2))  # (also seeds the window predictions)
                         if driver.counters.get("loop_gave_up", 0):
                             ok, why = 0, "a launch gave up waiting for a peer"
+                        else:
+                            #  ... and the SAME call through the stage calls + collectives: pose and inner counts
+                            # must be the launches', bit for bit -- a transport that delivered stale words which still
+                            # passed the kernels' count cross-checks would show here, before anything is timed
+                            saved, driver._loop = driver._loop, None
+                            T_chk, k_chk, _ = driver.estimate_full(full, I.Transform(), max(warmup, 2))
+                            driver._loop = saved
+                            if T_chk.as_array().tobytes() != T.as_array().tobytes() or not np.array_equal(k_chk, k_loop):
+                                ok, why = 0, "the launches' result differs from the stage calls' on the same call"
                 except Exception as e:  # noqa: BLE001
                     ok, why = 0, repr(e)
                 flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
