@@ -857,13 +857,31 @@ __device__ __forceinline__ unsigned payload_count(unsigned p, int k) {
 // n / W pairs) -- instead of once per launch; everything else, and every bit of the result, is the same.
 template <bool STREAM>
 __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, LoopShardArgs S, LoopRankPtrs R_, unsigned K) {
+  // The per-rank tables of the arguments, copied into LDS with CONSTANT indices: a run-time index into a by-value
+  // argument struct sends the whole of it through scratch memory (848 bytes per lane until round 5), and the exchange
+  // phases index the inboxes by rank in their inner loops.
+  __shared__ LoopInbox *s_inbox[kShardMaxWorld];
+  __shared__ int s_first[kShardMaxWorld + 1];
+  __shared__ const double2 *s_ra[kShardMaxWorld], *s_rb[kShardMaxWorld];
+  __shared__ LoopResult *s_rres[kShardMaxWorld];
+#pragma unroll
+  for (int q = 0; q < kShardMaxWorld; ++q)
+    if ((int)threadIdx.x == q) {
+      s_inbox[q] = S.inbox[q];
+      s_first[q] = S.first_block[q];
+      s_ra[q] = R_.a[q];
+      s_rb[q] = R_.b[q];
+      s_rres[q] = R_.res[q];
+    }
+  if (threadIdx.x == 0) s_first[kShardMaxWorld] = S.first_block[kShardMaxWorld];
+  __syncthreads();
   const int rank = S.rank + (int)blockIdx.y;
-  const unsigned nbl = (unsigned)(S.first_block[rank + 1] - S.first_block[rank]);  // this rank's workgroups
+  const unsigned nbl = (unsigned)(s_first[rank + 1] - s_first[rank]);  // this rank's workgroups
   if (blockIdx.x >= nbl) return;
-  A.a = R_.a[rank];
-  A.b = R_.b[rank];
-  A.res = R_.res[rank];
-  S.b0 = S.first_block[rank];
+  // (locals, not fields of the arguments: writing to a by-value argument makes it a private copy)
+  const double2 *const Aa = s_ra[rank], *const Ab = s_rb[rank];
+  LoopResult *const Ares = s_rres[rank];
+  const int rank_b0 = s_first[rank];
   extern __shared__ double2 s_pts[];
   __shared__ __align__(16) unsigned char s_work[sizeof(SelectLds<2>) > 2 * kWinBins * sizeof(uint32_t) ? sizeof(SelectLds<2>)
                                                                                                          : 2 * kWinBins * sizeof(uint32_t)];
@@ -889,27 +907,30 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
   constexpr int PR = kWinCapRing / kReduceThreads, PM = kWinCapMed / kReduceThreads;
   const unsigned tid = threadIdx.x, n = A.n;
   const int W = S.world;
-  const unsigned gb = (unsigned)S.b0 + blockIdx.x, B = (unsigned)S.blocks_total;
+  const unsigned gb = (unsigned)rank_b0 + blockIdx.x, B = (unsigned)S.blocks_total;
   const unsigned G = B * kReduceThreads, first = gb * kReduceThreads + tid;
   const unsigned row_w = nbl * kReduceThreads, loc0 = blockIdx.x * kReduceThreads + tid;  // local layout (shard.hip)
-  LoopInbox *const me = S.inbox[rank];
-  AbortPeers peers;
-  peers.n = 0;
-  for (int q = 0; q < W; ++q)
-    if (S.inbox[q] != me) peers.w[peers.n++] = &S.inbox[q]->abort[0];
+  LoopInbox *const me = s_inbox[rank];
+  __shared__ AbortPeers s_peers;  // (filled behind a run-time index: LDS, not private memory; read behind the barriers below)
+  if (tid == 0) {
+    int np = 0;
+    for (int q = 0; q < W; ++q)
+      if (s_inbox[q] != me) s_peers.w[np++] = &s_inbox[q]->abort[0];
+    s_peers.n = np;
+  }
   double2 *const s_a = s_pts, *const s_b = s_pts + (size_t)K * kReduceThreads;
   const unsigned mine = first < n ? (n - 1u - first) / G + 1u : 0u;
   if (!STREAM)
     for (unsigned k = 0; k < mine; ++k) {
-      s_a[k * kReduceThreads + tid] = A.a[(size_t)k * row_w + loc0];
-      s_b[k * kReduceThreads + tid] = A.b[(size_t)k * row_w + loc0];
+      s_a[k * kReduceThreads + tid] = Aa[(size_t)k * row_w + loc0];
+      s_b[k * kReduceThreads + tid] = Ab[(size_t)k * row_w + loc0];
     }
   // point k of thread t of this workgroup (LDS, or the rank's arrays in the local layout of shard.hip)
   auto pair_of = [&](unsigned k, unsigned t, double2 &ak, double2 &bk) {
     if (STREAM) {
       const size_t at = (size_t)k * row_w + blockIdx.x * kReduceThreads + t;
-      ak = A.a[at];
-      bk = A.b[at];
+      ak = Aa[at];
+      bk = Ab[at];
     } else {
       ak = s_a[k * kReduceThreads + t];
       bk = s_b[k * kReduceThreads + t];
@@ -995,28 +1016,28 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
       // the block sum into every rank's inbox, row = global block: the fold of phase C reads them in block order
       for (unsigned j = tid; j < (unsigned)W * (kNSum + 1); j += kReduceThreads) {
         const unsigned q = j / (kNSum + 1), k = j % (kNSum + 1);
-        st_sys_f64(&S.inbox[q]->partials[par][gb][k], k < (unsigned)kNSum ? s_row[k] : 0.);
+        st_sys_f64(&s_inbox[q]->partials[par][gb][k], k < (unsigned)kNSum ? s_row[k] : 0.);
       }
     }
     // ---- L1: this rank's workgroups ----------------------------------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&me->flag_block[gb], (unsigned long long)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!poll_words(&me->flag_block[S.b0], nbl, gen, &me->abort[0], nullptr, &peers)) {
+    if (!poll_words(&me->flag_block[rank_b0], nbl, gen, &me->abort[0], nullptr, &s_peers)) {
       aborted = true;
       break;
     }
     // ---- X1: the rank's histogram into every inbox (workgroup q serves rank q) -------------------------------------
     for (int q = (int)blockIdx.x; q < W; q += (int)nbl) {
-      uint32_t *dst = S.inbox[q]->hist_from[rank][par];
+      uint32_t *dst = s_inbox[q]->hist_from[rank][par];
       for (unsigned i = tid; i < 2u * kWinBins; i += kReduceThreads) st_sys_u32(&dst[i], ld_u32(&whist[i]));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0)
-        __hip_atomic_store(&S.inbox[q]->flag_rank[rank], (unsigned long long)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&s_inbox[q]->flag_rank[rank], (unsigned long long)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // ---- W1 ----------------------------------------------------------------------------------------------------------
-    if (!poll_words(me->flag_rank, (unsigned)W, gen, &me->abort[0], nullptr, &peers)) {
+    if (!poll_words(me->flag_rank, (unsigned)W, gen, &me->abort[0], nullptr, &s_peers)) {
       aborted = true;
       break;
     }
@@ -1079,7 +1100,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
                        s_cnt[3] > (unsigned)kWinBlkRing;
       const unsigned c[4] = {ovf ? 0u : s_cnt[0], ovf ? 0u : s_cnt[1], ovf ? 0u : s_cnt[2], ovf ? 0u : s_cnt[3]};
       for (int q = 0; q < W; ++q) {
-        double *dst = S.inbox[q]->cand[gb];
+        double *dst = s_inbox[q]->cand[gb];
         if (tid < 2 * kWinBlkMed) {
           const int d = tid / kWinBlkMed, e = tid % kWinBlkMed;
           if ((unsigned)e < c[d]) st_sys_f64(&dst[d * kWinBlkMed + e], s_med[d][e]);
@@ -1092,12 +1113,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
       __syncthreads();
       if (tid < (unsigned)W) {
         const unsigned pay = cand_payload(c[0], c[1], c[2], c[3], ovf || R.fail, (s_flags & 2u) != 0u);
-        __hip_atomic_store(&S.inbox[tid]->flag_cand[gb], (unsigned long long)gen | ((unsigned long long)pay << 32), __ATOMIC_RELEASE,
+        __hip_atomic_store(&s_inbox[tid]->flag_cand[gb], (unsigned long long)gen | ((unsigned long long)pay << 32), __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     // ---- W2 ----------------------------------------------------------------------------------------------------------
-    if (!poll_words(me->flag_cand, B, gen, &me->abort[0], s_seen, &peers)) {
+    if (!poll_words(me->flag_cand, B, gen, &me->abort[0], s_seen, &s_peers)) {
       aborted = true;
       break;
     }
@@ -1241,15 +1262,15 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
         if (blockIdx.x == 0 && !nan_flag && !fail) {
           const unsigned nth = it - A.it0;  // (which evaluation of the loop this launch has reached)
           const int slot = nth < 2u ? (int)nth : 2;
-          A.res->med[slot][0] = med[0];
-          A.res->med[slot][1] = med[1];
-          A.res->sigma[slot][0] = sig[0];
-          A.res->sigma[slot][1] = sig[1];
+          Ares->med[slot][0] = med[0];
+          Ares->med[slot][1] = med[1];
+          Ares->sigma[slot][0] = sig[0];
+          Ares->sigma[slot][1] = sig[1];
           if (slot < 2) {
-            A.res->med[2][0] = med[0];
-            A.res->med[2][1] = med[1];
-            A.res->sigma[2][0] = sig[0];
-            A.res->sigma[2][1] = sig[1];
+            Ares->med[2][0] = med[0];
+            Ares->med[2][1] = med[1];
+            Ares->sigma[2][0] = sig[0];
+            Ares->sigma[2][1] = sig[1];
           }
         }
       }
@@ -1285,7 +1306,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
     ++evals;
   }
   if (blockIdx.x == 0 && tid < 64) {
-    LoopResult *res = A.res;
+    LoopResult *res = Ares;
     if (tid == 0) {
       res->Ti = L.Ti;
       res->prev_error = L.prev_error;
