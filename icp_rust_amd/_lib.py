@@ -115,6 +115,10 @@ SIGNATURES = {
     "icp_multi_estimate": (C.c_int, [_vp, _vp, _sz, _pp, _sz, _pp, _vp, _vp]),
     "icp_multi_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_multi_loop_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "icp_multi_pipe_iterations": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "icp_pipe_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "icp_shard_pipe_run_device": (C.c_int, [_vp, _vp, _sz, _sz, C.c_int, C.c_int, _pp, C.POINTER(_sz), _sz, _vp, _vp,
+                                            C.POINTER(C.c_int)]),
     "icp_loop_inbox_bytes": (_sz, []),
     "icp_loop_inbox": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
     "icp_loop_inbox_ipc_handle": (C.c_int, [_vp, C.c_char_p]),

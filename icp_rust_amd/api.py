@@ -687,6 +687,12 @@ class IcpMulti:
         check(lib().icp_multi_loop_counters(self._h, out), "icp_multi_loop_counters")
         return tuple(int(x) for x in out)
 
+    def pipe_iterations(self):
+        """outer iterations served by the pipelined sharded evaluation (csrc/pipe.hip) over the life of the object"""
+        out = C.c_uint64(0)
+        check(lib().icp_multi_pipe_iterations(self._h, C.byref(out)), "icp_multi_pipe_iterations")
+        return int(out.value)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             lib().icp_destroy_multi(self._h)

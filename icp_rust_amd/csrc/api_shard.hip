@@ -186,6 +186,8 @@ extern "C" int icp_shard_loop_connect(icp_handle *h, int rank, int world, void *
   w.loop_world = world;
   HIP_TRY(ensure_loop(h));  // (the pinned result block)
   w.loop_seq = 0;           // launch numbers restart with the connection
+  w.pipe_gen = 0;           // ... and so do the generations of the pipelined evaluation's exchanges
+  w.pipe_off = 0;
   memset(w.h_loop_res, 0, sizeof(LoopResult));
   return ICP_OK;
 }

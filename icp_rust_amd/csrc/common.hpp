@@ -273,6 +273,11 @@ struct Workspace : GnCtx {
   void *loop_peers[kShardMaxWorld] = {};
   int loop_rank = -1, loop_world = 0;
   void *loop_plan = nullptr;  // LoopPlan of the launch in flight (api.hip)
+  // the pipelined sharded evaluation (pipe.hip): generations of its exchanges so far (the same on every rank of the
+  // connection), iterations it served / handed back / gave up on, iterations it keeps away after a miss of its files
+  unsigned pipe_gen = 0;
+  unsigned long long pipe_iters = 0, pipe_handbacks = 0, pipe_gave_up = 0;
+  unsigned pipe_off = 0;
 };
 
 // ---- uniform grid over the target cloud (nn_grid.hip) ------------------------------
@@ -493,6 +498,32 @@ bool bkt_fits(size_t n, const WinParams &P);
 hipError_t launch_bkt_pair(icp_handle *h, hipStream_t s, GnCtx &first, const double *a1, const double *b1, const WinParams &P1,
                            bool ahead_on, const Pose &ahead_outer, GnCtx &second, const double *a2, const double *b2,
                            const Pose &T2, const WinParams &P2, size_t n);
+// the pipelined sharded evaluation (gn_win.hip: k_win_pick_shard; pipe.hip drives it)
+struct ShardPickRank {
+  icp_handle *h;
+  int rank, b0, nbl;          // the rank's tree blocks [b0, b0 + nbl)
+  size_t n_local;
+  const double *a[2], *b[2];  // its pairs of the (up to two) evaluations
+};
+struct ShardPickEval {
+  bool alt_ctx;   // which of the handle's two evaluation contexts carries it
+  Pose T;         // inner pose
+  WinParams P;
+  bool ahead_on;  // its finishing workgroup leaves "update x outer" for the run-ahead search
+  Pose outer;
+};
+hipError_t launch_shard_evals(const ShardPickRank *rk, int nranks, int world, int B, size_t n_total, unsigned gen0,
+                              const ShardPickEval *ev, int nevals);
+// ... and the host loop around it (pipe.hip): a rank of the pipelined sharded registration
+struct PipeRank {
+  icp_handle *h;
+  const double *d_src;  // the rank's points (a slice of the fold order; its search snapshot is prepared)
+  size_t n_local;
+  int rank, b0, nbl;    // its tree blocks [b0, b0 + nbl)
+  uint32_t *d_idx;      // where the LAST search of the call leaves its correspondences (local order), or null
+};
+int pipe_run(PipeRank *rk, int nranks, int world, size_t n_total, Pose *T_io, size_t *it_io, size_t max_iter,
+             uint32_t *inner_iters, int *why);
 // n > 4M: the window is found in two passes (gn_win.hip, "refined windows"); the host part of the
 // orchestration (two waits) lives in api.hip:wgn_step
 constexpr size_t kRefineListCap = 1u << 21;  // expected: ~4e5 per dimension

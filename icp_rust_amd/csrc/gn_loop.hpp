@@ -65,6 +65,24 @@ struct LoopArgs {
 // Flag words carry (generation | payload << 32); generations grow over the launches of a handle (launch number x 1024 +
 // evaluation), so nothing has to be reset between launches and a rank that is one launch ahead cannot be mistaken.
 constexpr int kLoopCandPerBlock = 2 * kWinBlkMed + 2 * kWinBlkRing;  // doubles a workgroup may contribute per evaluation
+// ---- the PIPELINED sharded evaluation (round 6: gn_win.hip k_win_pick_shard, pipe.hip) -------------------------------
+// A rank's outer iteration in the steady state of a registration (the inner loop applies one update) is the one-GPU
+// pipeline -- search -> the two evaluations' first launches on the rank's own points -> ONE finishing workgroup per
+// evaluation -- and that finishing workgroup is where the ranks meet: it pushes the rank's window histogram and block
+// sums into every inbox, waits for every rank's, resolves the bins from the summed counts (every rank the same), picks
+// ITS candidates out of its own segments, pushes them, waits for every rank's, and selects / folds / solves like one
+// GPU.  One slot per evaluation in flight; kPipeBufs of them, taken round robin by the evaluation's generation: a
+// rank can be at most one evaluation pair ahead of the slowest (it needs that rank's pushes to finish its own).
+constexpr int kPipeBufs = 4;
+constexpr int kPipeCandPerRank = 2 * kWinCapMed + 2 * kWinCapRing;  // med x | med y | ring x | ring y, full capacity each
+struct PipeSlot {
+  unsigned long long flag_hist[kShardMaxWorld];  // rank s: histogram + block sums of generation g are in; payload: NaN | files unusable << 1
+  unsigned long long flag_cand[kShardMaxWorld];  // rank s: candidates (and their counts) of generation g are in
+  unsigned cand_cnt[kShardMaxWorld][8];          // {med x, med y, ring x, ring y, this rank could not list its candidates}
+  uint32_t hist[kShardMaxWorld][2 * kWinBins];   // every rank's counts, pushed
+  double rows[kReduceMaxBlocks][kNSum + 1];      // block sums by global block
+  double cand[kShardMaxWorld][kPipeCandPerRank];
+};
 struct LoopInbox {
   unsigned long long flag_block[kReduceMaxBlocks];  // own workgroups only: phase A of evaluation g is out (local barrier)
   unsigned long long flag_rank[kShardMaxWorld];     // rank s has pushed its histogram of evaluation g
@@ -76,6 +94,7 @@ struct LoopInbox {
   double partials[2][kReduceMaxBlocks][kNSum + 1];        // block sums by global block, by parity
   double cand[kReduceMaxBlocks][kLoopCandPerBlock];       // med x | med y | ring x | ring y of every workgroup
   unsigned long long probe[kShardMaxWorld];               // transport probe (icp_loop_transport_probe): rank s' last token
+  PipeSlot pipe[kPipeBufs];                               // the pipelined evaluation's exchanges (above)
 };
 
 struct LoopShardArgs {

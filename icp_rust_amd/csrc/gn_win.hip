@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "gn_device.hpp"
 #include "gn_win_device.hpp"
+#include "gn_loop.hpp"
 
 namespace icp {
 
@@ -502,10 +503,12 @@ struct WinBins {
 // side by side) -> the candidate bins.  REQUIRE_FINE: the median bins must lie in the middle fine window and the two
 // arcs of the ring in the outer ones (the callers whose candidates exist only there: lists, buckets).  WANT_SEL: `sel`
 // is filled (what the histogram says about the candidate lists).  Workgroup 0 also leaves everything in `st`.
-template <bool REQUIRE_FINE, bool WANT_SEL>
+// SUM_RANKS (the pipelined sharded evaluation): the counts are the sum of `nsrc` histograms `stride` words apart -- every
+// rank's, pushed into this rank's inbox (system-scope loads).
+template <bool REQUIRE_FINE, bool WANT_SEL, bool SUM_RANKS = false>
 __device__ __forceinline__ WinBins win_resolve(const uint32_t *__restrict__ whist, unsigned n, const WinParams &P,
                                                WinState *st, const unsigned *__restrict__ llen, unsigned lcap,
-                                               uint32_t *cum, WinSel &sel) {
+                                               uint32_t *cum, WinSel &sel, int nsrc = 1, size_t stride = 0) {
   __shared__ unsigned s_selu[2][4];
   __shared__ double s_seld[2][4];
   __shared__ unsigned s_wtot[2][16];
@@ -527,7 +530,20 @@ __device__ __forceinline__ WinBins win_resolve(const uint32_t *__restrict__ whis
   unsigned v[2][PER], inc[2], tot[2];
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
-    if (PER == 2) {
+    if (SUM_RANKS) {
+      static_assert(!SUM_RANKS || PER == 4, "two 64-bit loads per thread, dimension and rank");
+#pragma unroll
+      for (int i = 0; i < PER; ++i) v[d][i] = 0u;
+      for (int q = 0; q < nsrc; ++q) {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(whist + (size_t)q * stride + d * kWinBins) + 2 * tid;
+        const unsigned long long x0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long x1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        v[d][0] += (unsigned)x0;
+        v[d][1] += (unsigned)(x0 >> 32);
+        v[d][PER - 2] += (unsigned)x1;
+        v[d][PER - 1] += (unsigned)(x1 >> 32);
+      }
+    } else if (PER == 2) {
       const uint2 x = reinterpret_cast<const uint2 *>(whist + d * kWinBins)[tid];
       v[d][0] = x.x;
       v[d][1] = x.y;
@@ -1151,6 +1167,343 @@ __global__ __launch_bounds__(kReduceThreads) void k_win_pick2(PickArgs A, PickAr
   else win_pick_body(B, L);
 }
 
+// ---- P across ranks (round 6): the finishing workgroup of an evaluation whose points are SHARDED -----------------
+// Every rank has run the first launch (k_win_hist_sums_bkt / _bkt2) over ITS tree blocks on ITS pairs: its window
+// histogram, its block sums, its filed candidates.  This workgroup -- one per rank and evaluation -- is where the ranks
+// meet (gn_loop.hpp: PipeSlot): push histogram + block sums into every inbox, wait for every rank's, resolve the bins
+// from the SUMMED counts (the same on every rank), list the rank's own candidates of those bins out of its own
+// segments, push them, wait for every rank's, and from there on be k_win_pick: exact selections over ALL candidates,
+// the fold of ALL block sums in block order, the solve, the next outer pose for the run-ahead search.  Every rank
+// therefore releases the bits one GPU would have.  Two exchanges, no host, no collective library.
+// Ranks that share a device (virtual ranks) ride in ONE launch (blockIdx.y = rank): workgroups of one launch are all
+// resident and may wait for each other; separate launches on one hardware queue could not.
+namespace {
+constexpr long long kPipeTimeoutTicks = 300000000;  // wall_clock64 runs at 100 MHz: 3 s (processes sharing a GPU take turns)
+__device__ __forceinline__ void pst_u32(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void pst_f64(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned pld_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double pld_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// wave 0 waits (bounded) until the first `count` (<= 16) flag words carry generation `gen`; *payload_or = the OR of their
+// upper halves.  A wait that runs out raises `abort` in every inbox: the peers are waiting for data this rank will not
+// send, and leave with it.  Uniform over the workgroup.
+__device__ __forceinline__ bool pipe_poll(const unsigned long long *words, int count, unsigned gen, LoopInbox *const *box, int W,
+                                          LoopInbox *me, unsigned *payload_or) {
+  __shared__ int s_pok;
+  __shared__ unsigned s_ppay;
+  if (threadIdx.x < 64) {
+    const int lane = (int)threadIdx.x;
+    unsigned long long seen = 0;
+    int ok = 1;
+    const long long t0 = wall_clock64();
+    for (;;) {
+      bool here = true;
+      if (lane < count) {
+        seen = __hip_atomic_load(&words[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        here = (int)((unsigned)seen - gen) >= 0;
+      }
+      if (__all(here)) break;
+      int stop = 0;
+      if (lane == 0) {
+        if (pld_u32(&me->abort[0]) != 0u) stop = 1;
+        else if (wall_clock64() - t0 > kPipeTimeoutTicks) {
+          for (int q = 0; q < W; ++q) pst_u32(&box[q]->abort[0], 1u);
+          stop = 1;
+        }
+      }
+      if (__builtin_amdgcn_readfirstlane(stop)) {
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    unsigned pay = lane < count ? (unsigned)(seen >> 32) : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) pay |= (unsigned)__shfl_xor((int)pay, off);
+    if (lane == 0) {
+      s_pok = ok;
+      s_ppay = pay;
+    }
+  }
+  __syncthreads();
+  *payload_or = s_ppay;
+  return s_pok != 0;
+}
+}  // namespace
+
+constexpr int kPipeFuse = 8;  // ranks of ONE device a launch can carry (its arguments must stay below 4 KB)
+struct PickRank {  // what differs from rank to rank
+  uint32_t *whist;
+  WinState *st;
+  const double *seg_all;
+  const unsigned short *dir_all;
+  GnScalars *scal;
+  const double *partials;
+  GnResult *res;
+  AheadPose *ahead;
+  int rank, b0, nbl;  // this rank's tree blocks [b0, b0 + nbl): its segments and block sums are rows 0 .. nbl - 1 of its arrays
+  unsigned seq;
+};
+struct PickEval {
+  unsigned n;    // points of ALL ranks: the ranks of the order statistics
+  unsigned gen;  // generation of this evaluation's exchange, the same on every rank
+  int ahead_on, pad;
+  WinParams P;
+  Pose outer;
+  PickRank rk[kPipeFuse];
+};
+struct PickShardLaunch {
+  int world, B, nranks, nevals;
+  LoopInbox *inbox[kShardMaxWorld];  // every rank's inbox as mapped on this device
+  PickEval ev[2];
+};
+static_assert(sizeof(PickShardLaunch) <= 4000, "kernel arguments");
+
+__device__ __forceinline__ void win_pick_shard_body(const unsigned n, const unsigned gen, const bool ahead_on, const WinParams &P,
+                                                    const Pose &outer, const PickRank &K, LoopInbox *const *box, const int W,
+                                                    const int B, PickLds &L) {
+  constexpr int PM = kWinCapMed / kReduceThreads, PR = kWinCapRing / kReduceThreads;
+  constexpr int HW = 2 * kWinBins / kReduceThreads;
+  __shared__ double s_tot[kNSum + 1];
+  __shared__ unsigned s_cnt[4];
+  __shared__ unsigned s_base[kShardMaxWorld + 1][4];
+  __shared__ unsigned s_bad;
+  const unsigned tid = threadIdx.x;
+  const unsigned buf = gen & (unsigned)(kPipeBufs - 1);
+  LoopInbox *const me = box[K.rank];
+  PipeSlot *const mine = &me->pipe[buf];
+  if (tid < 4) s_cnt[tid] = 0;
+  if (tid == 0) s_bad = 0;
+  const int nan_own = __hip_atomic_load(&K.scal->nan_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned ovf_own = __hip_atomic_load(&K.st->stage_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- exchange 1: this rank's counts and block sums into every inbox ------------------------------------------------
+  {
+    unsigned hv[HW];
+#pragma unroll
+    for (int k = 0; k < HW; ++k) hv[k] = __hip_atomic_load(&K.whist[tid + k * kReduceThreads], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q = 0; q < W; ++q) {
+      uint32_t *dst = box[q]->pipe[buf].hist[K.rank];
+#pragma unroll
+      for (int k = 0; k < HW; ++k) pst_u32(&dst[tid + k * kReduceThreads], hv[k]);
+    }
+    const unsigned nrow = (unsigned)K.nbl * (unsigned)(kNSum + 1);
+    for (unsigned j = tid; j < nrow; j += kReduceThreads) {
+      const unsigned row = j / (unsigned)(kNSum + 1), k = j % (unsigned)(kNSum + 1);
+      const double v = k < (unsigned)kNSum ? __hip_atomic_load(&K.partials[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.;
+      for (int q = 0; q < W; ++q) pst_f64(&box[q]->pipe[buf].rows[(unsigned)K.b0 + row][k], v);
+    }
+    // the histograms of this rank's next evaluation start from zero (its counts are on their way)
+#pragma unroll
+    for (int k = 0; k < HW; ++k) __hip_atomic_store(&K.whist[tid + k * kReduceThreads], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && ovf_own) __hip_atomic_store(&K.st->stage_overflow, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((int)tid < W) {
+    const unsigned pay = (nan_own ? 1u : 0u) | (ovf_own ? 2u : 0u);
+    __hip_atomic_store(&box[tid]->pipe[buf].flag_hist[K.rank], (unsigned long long)gen | ((unsigned long long)pay << 32), __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  unsigned pay1 = 0;
+  bool alive = pipe_poll(mine->flag_hist, W, gen, box, W, me, &pay1);
+  const int nan_flag = (pay1 & 1u) ? 1 : 0;
+  bool bucket_miss = (pay1 & 2u) != 0u;
+  WinSel sel = {};
+  WinBins R = {};
+  R.fail = true;
+  double fx[kFoldH];
+#pragma unroll
+  for (int k = 0; k < kFoldH; ++k) fx[k] = 0.;
+  if (alive) {  // (uniform)
+    R = win_resolve<true, true, true>(&mine->hist[0][0], n, P, K.st, nullptr, 0u, L.g.cum, sel, W, (size_t)2 * kWinBins);
+    fold256_load<__HIP_MEMORY_SCOPE_SYSTEM>(&mine->rows[0][0], B, fx);
+  }
+  bool fail = R.fail;
+  double med[2] = {0., 0.}, sig[2] = {0., 0.};
+  {
+    // ---- this rank's candidates of the resolved bins, out of its own segments (win_pick_body has the comments) -------
+    const unsigned w = tid & (unsigned)(kReduceMaxBlocks - 1), d = tid / (unsigned)kReduceMaxBlocks;
+    const bool usable = alive && !fail && !bucket_miss;  // (uniform, and the same on every rank)
+    const unsigned mlo_d = d ? R.mlo[1] : R.mlo[0], mhi_d = d ? R.mhi[1] : R.mhi[0], a0_d = d ? R.a0[1] : R.a0[0];
+    const unsigned b1_d = d ? R.b1[1] : R.b1[0], i0_d = d ? R.i0[1] : R.i0[0], i1_d = d ? R.i1[1] : R.i1[0];
+    const unsigned len_m = usable ? mhi_d - mlo_d + 1u : 0u;
+    const unsigned len_a = usable ? i0_d - a0_d : 0u, len_b = usable ? b1_d - i1_d : 0u;
+    __syncthreads();  // (s_cnt's zeros)
+    if (usable && (int)w < K.nbl) {
+      const unsigned short *dir = K.dir_all + (size_t)w * kBktDir;
+      const unsigned fm = word_to_fine(d, mlo_d), fa = word_to_fine(d, a0_d), fb = word_to_fine(d, i1_d + 1u);
+      const unsigned short q0 = dir[fm], q1 = dir[fm + len_m], q2 = dir[fa], q3 = dir[fa + len_a], q4 = dir[fb],
+                           q5 = dir[fb + len_b];
+      const unsigned m0 = q0, m_end = q1, a_beg = q2, a_end = q3, b_beg = q4, b_end = q5;
+      const unsigned cm = m_end - m0, cr = (a_end - a_beg) + (b_end - b_beg);
+      if (cm) {
+        const unsigned pos = atomicAdd(&s_cnt[d], cm);
+        for (unsigned k = 0; k < cm; ++k)
+          if (pos + k < (unsigned)kWinCapMed) L.g.med[d][pos + k] = (w << 12) | (m0 + k);
+      }
+      if (cr) {
+        unsigned pos = atomicAdd(&s_cnt[2 + d], cr);
+        for (unsigned k = a_beg; k < a_end; ++k, ++pos)
+          if (pos < (unsigned)kWinCapRing) L.g.ring[d][pos] = (w << 12) | k;
+        for (unsigned k = b_beg; k < b_end; ++k, ++pos)
+          if (pos < (unsigned)kWinCapRing) L.g.ring[d][pos] = (w << 12) | k;
+      }
+    }
+    __syncthreads();
+    // ---- exchange 2: their values (and how many) into every inbox -------------------------------------------------------
+    const unsigned own[4] = {s_cnt[0], s_cnt[1], s_cnt[2], s_cnt[3]};
+    const bool own_fail = usable && (own[0] > (unsigned)kWinCapMed || own[1] > (unsigned)kWinCapMed || own[2] > (unsigned)kWinCapRing ||
+                                     own[3] > (unsigned)kWinCapRing);
+    if (usable && !own_fail) {
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) {
+#pragma unroll
+        for (int u = 0; u < PM; ++u) {
+          const unsigned e = tid + u * kReduceThreads;
+          if (e < own[dd]) {
+            const uint32_t x = L.g.med[dd][e];
+            const double v = K.seg_all[(size_t)(x >> 12) * kBktStage + (x & 0xfffu)];
+            for (int q = 0; q < W; ++q) pst_f64(&box[q]->pipe[buf].cand[K.rank][dd * kWinCapMed + e], v);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+          const unsigned e = tid + u * kReduceThreads;
+          if (e < own[2 + dd]) {
+            const uint32_t x = L.g.ring[dd][e];
+            const double v = K.seg_all[(size_t)(x >> 12) * kBktStage + (x & 0xfffu)];
+            for (int q = 0; q < W; ++q) pst_f64(&box[q]->pipe[buf].cand[K.rank][2 * kWinCapMed + dd * kWinCapRing + e], v);
+          }
+        }
+      }
+    }
+    if (tid < 5u) {
+      const unsigned v = tid < 4u ? ((usable && !own_fail) ? own[tid & 3u] : 0u) : (own_fail ? 1u : 0u);
+      for (int q = 0; q < W; ++q) pst_u32(&box[q]->pipe[buf].cand_cnt[K.rank][tid], v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if ((int)tid < W)
+      __hip_atomic_store(&box[tid]->pipe[buf].flag_cand[K.rank], (unsigned long long)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned pay2 = 0;
+    if (alive) alive = pipe_poll(mine->flag_cand, W, gen, box, W, me, &pay2);
+    // ---- all candidates: where the lists of the ranks start in the concatenation (rank order; any order would do) ------
+    if (tid == 0) {
+      unsigned base[4] = {0u, 0u, 0u, 0u}, bad = 0u;
+      if (alive)
+        for (int q = 0; q < W; ++q) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            s_base[q][k] = base[k];
+            base[k] += pld_u32(&mine->cand_cnt[q][k]);
+          }
+          bad |= pld_u32(&mine->cand_cnt[q][4]);
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_base[W][k] = base[k];
+      s_bad = bad;
+    }
+    __syncthreads();
+    // (the gathered counts are cross-checked against the histogram: a mismatch is a miss)
+    if (usable)
+      bucket_miss = s_bad != 0u || s_base[W][0] != sel.med_cnt[0] || s_base[W][1] != sel.med_cnt[1] ||
+                    s_base[W][2] != sel.ring_cnt[0] || s_base[W][3] != sel.ring_cnt[1];
+    const bool take = usable && alive && !bucket_miss;
+    auto fetch = [&](int k, unsigned e) -> double {
+      int q = 0;
+      while (q + 1 < W && s_base[q + 1][k] <= e) ++q;
+      const unsigned off = k < 2 ? (unsigned)k * kWinCapMed : 2u * kWinCapMed + (unsigned)(k - 2) * kWinCapRing;
+      return pld_f64(&mine->cand[q][off + (e - s_base[q][k])]);
+    };
+    double vm[2][PM], vr[2][PR];
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+#pragma unroll
+      for (int u = 0; u < PM; ++u) {
+        const unsigned e = tid + u * kReduceThreads;
+        vm[dd][u] = (take && e < sel.med_cnt[dd]) ? fetch(dd, e) : 0.;
+      }
+#pragma unroll
+      for (int u = 0; u < PR; ++u) {
+        const unsigned e = tid + u * kReduceThreads;
+        vr[dd][u] = (take && e < sel.ring_cnt[dd]) ? fetch(2 + dd, e) : 0.;
+      }
+    }
+    fold256_reduce(fx, B, s_tot);  // (a barrier inside)
+    __syncthreads();               // (the descriptor lists are read: the selections may overlay them)
+    const unsigned klo = (n - 1) / 2, khi = n / 2;
+    if (take) {
+      unsigned long long key[2][2];
+      const double m_lo[2] = {sel.range[0][0], sel.range[1][0]}, m_hi[2] = {sel.range[0][1], sel.range[1][1]};
+      const long long mlo[2] = {(long long)klo - sel.med_base[0], (long long)klo - sel.med_base[1]};
+      const long long mhi[2] = {(long long)khi - sel.med_base[0], (long long)khi - sel.med_base[1]};
+      select_n_lds<2, PM>(vm, sel.med_cnt, m_lo, m_hi, mlo, mhi, key, fail, L.sel);
+      if (!fail) {
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+          med[dd] = middle_of(n, key[dd][0], key[dd][1]);
+#pragma unroll
+          for (int u = 0; u < PR; ++u) vr[dd][u] = fabs(vr[dd][u] - med[dd]);  // src/stats.rs:35
+        }
+        const double r_lo[2] = {sel.range[0][2], sel.range[1][2]}, r_hi[2] = {sel.range[0][3], sel.range[1][3]};
+        const long long dlo[2] = {(long long)klo - sel.inner[0], (long long)klo - sel.inner[1]};
+        const long long dhi[2] = {(long long)khi - sel.inner[0], (long long)khi - sel.inner[1]};
+        select_n_lds<2, PR>(vr, sel.ring_cnt, r_lo, r_hi, dlo, dhi, key, fail, L.sel);
+        if (!fail) {
+          sig[0] = ICP_PPF34 * middle_of(n, key[0][0], key[0][1]);  // src/stats.rs:42-46
+          sig[1] = ICP_PPF34 * middle_of(n, key[1][0], key[1][1]);
+        } else {
+          med[0] = med[1] = 0.;
+        }
+      }
+    }
+  }
+  const bool missed = fail || bucket_miss;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // overflow 5: a wait for a peer ran out (every rank reports it: the abort word went into every inbox); 2: the window
+  // missed; 3: the files were not usable
+  const int overflow = !alive ? 5 : (missed ? (fail ? 2 : 3) : 0);
+  if (ahead_on && K.ahead) {  // (uniform)
+    if (tid == 0) fill_ahead_pose(s_tot, sig, alive && !missed && !nan_flag, outer, K.ahead, K.res);
+    publish_values<1>(s_tot, K.res, sig, med, nan_flag, overflow);
+    __syncthreads();
+    publish_seq(K.res, K.seq);
+  } else {
+    publish_folded(s_tot, K.res, K.seq, sig, med, nan_flag, overflow);
+  }
+}
+
+__global__ __launch_bounds__(kReduceThreads) void k_win_pick_shard(PickShardLaunch A) {
+  __shared__ PickLds L;
+  // (the per-rank and per-evaluation tables of the arguments into LDS with CONSTANT indices: a run-time index into a
+  // by-value argument makes the whole of it a private copy in scratch memory -- gn_loop.hip: k_gn_loop_shard)
+  __shared__ LoopInbox *s_box[kShardMaxWorld];
+  __shared__ PickRank s_rk;
+  __shared__ WinParams s_P;
+  __shared__ Pose s_outer;
+  __shared__ unsigned s_n, s_gen;
+  __shared__ int s_ahead;
+#pragma unroll
+  for (int q = 0; q < kShardMaxWorld; ++q)
+    if ((int)threadIdx.x == q) s_box[q] = A.inbox[q];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    if ((int)blockIdx.x != e || threadIdx.x != 0) continue;
+    s_P = A.ev[e].P;
+    s_outer = A.ev[e].outer;
+    s_n = A.ev[e].n;
+    s_gen = A.ev[e].gen;
+    s_ahead = A.ev[e].ahead_on;
+#pragma unroll
+    for (int j = 0; j < kPipeFuse; ++j)
+      if ((int)blockIdx.y == j) s_rk = A.ev[e].rk[j];
+  }
+  __syncthreads();
+  const PickRank K = s_rk;
+  win_pick_shard_body(s_n, s_gen, s_ahead != 0, s_P, s_outer, K, s_box, A.world, A.B, L);
+}
+
 #ifdef ICP_EXPERIMENTS  // ---- the four-launch forms of rounds 1-3 (W, C, selection, A): `make experiments` only ----
 // The order statistics of one evaluation from its candidate lists, one workgroup per dimension
 // (half the registers of doing both at once): the co-resident variant of the pipeline runs this
@@ -1574,6 +1927,61 @@ hipError_t launch_bkt_pair(icp_handle *h, hipStream_t s, GnCtx &first, const dou
                      bkt_pick_args(first, n, P1, ahead_on, ahead_outer, w.d_ahead),
                      bkt_pick_args(second, n, P2, false, transform_identity()));
   second.bkt_pair_launched = true;
+  return hipGetLastError();
+}
+
+// ---- the pipelined sharded evaluation: host side (pipe.hip drives it) -----------------------------------------------------
+// One or two evaluations (ev[0], ev[1]) on the ranks rk[0 .. nranks) of ONE device: each rank's first launch over its own
+// tree blocks on its own stream, then ONE finishing launch for all of them (k_win_pick_shard: a workgroup per rank and
+// evaluation) on rk[0]'s stream -- ranks that share a device share that stream (icp_multi), a rank with a device of
+// its own is a call of its own.  gen0: generation of ev[0]'s exchange (ev[1]: gen0 + 1), the same on every rank.
+hipError_t launch_shard_evals(const ShardPickRank *rk, int nranks, int world, int B, size_t n_total, unsigned gen0,
+                              const ShardPickEval *ev, int nevals) {
+  if (nranks < 1 || nranks > kPipeFuse || nevals < 1 || nevals > 2 || world < 1 || world > kShardMaxWorld) return hipErrorInvalidValue;
+  PickShardLaunch L = {};
+  L.world = world;
+  L.B = B;
+  L.nranks = nranks;
+  L.nevals = nevals;
+  const Workspace &w0 = rk[0].h->ws;
+  for (int q = 0; q < kShardMaxWorld; ++q) L.inbox[q] = reinterpret_cast<LoopInbox *>(w0.loop_peers[q < world ? q : 0]);
+  for (int j = 0; j < nranks; ++j) {
+    icp_handle *h = rk[j].h;
+    Workspace &w = h->ws;
+    const unsigned nl = (unsigned)rk[j].n_local;
+    GnCtx *ctx[2] = {nullptr, nullptr};
+    HistBktArgs HA[2];
+    for (int e = 0; e < nevals; ++e) {
+      ctx[e] = ev[e].alt_ctx ? &w.alt : static_cast<GnCtx *>(&w);
+      HA[e] = bkt_hist_args(*ctx[e], (const double2 *)rk[j].a[e], (const double2 *)rk[j].b[e], ev[e].T, nl, ev[e].P);
+      PickRank &K = L.ev[e].rk[j];
+      K.whist = ctx[e]->d_whist;
+      K.st = ctx[e]->d_wstate;
+      K.seg_all = ctx[e]->d_bkt;
+      K.dir_all = ctx[e]->d_bkt_dir;
+      K.scal = ctx[e]->d_scal;
+      K.partials = ctx[e]->d_partials;
+      K.res = ctx[e]->h_res;
+      K.ahead = w.d_ahead;
+      K.rank = rk[j].rank;
+      K.b0 = rk[j].b0;
+      K.nbl = rk[j].nbl;
+      K.seq = ++ctx[e]->seq;
+    }
+    w.bkt_evals += (unsigned)nevals;
+    if (nevals == 2)
+      hipLaunchKernelGGL(k_win_hist_sums_bkt2, dim3(2u * (unsigned)rk[j].nbl), dim3(kWinThreads), 0, h->stream, HA[0], HA[1]);
+    else
+      hipLaunchKernelGGL(k_win_hist_sums_bkt, dim3((unsigned)rk[j].nbl), dim3(kWinThreads), 0, h->stream, HA[0]);
+  }
+  for (int e = 0; e < nevals; ++e) {
+    L.ev[e].n = (unsigned)n_total;
+    L.ev[e].gen = gen0 + (unsigned)e;
+    L.ev[e].ahead_on = ev[e].ahead_on ? 1 : 0;
+    L.ev[e].P = ev[e].P;
+    L.ev[e].outer = ev[e].ahead_on ? ev[e].outer : transform_identity();
+  }
+  hipLaunchKernelGGL(k_win_pick_shard, dim3((unsigned)nevals, (unsigned)nranks), dim3(kReduceThreads), 0, rk[0].h->stream, L);
   return hipGetLastError();
 }
 

@@ -72,6 +72,9 @@ struct icp_multi {
   uint64_t sharded = 0, replicated = 0;
   // the inner loop as one launch per rank (gn_loop.hip: k_gn_loop_shard; api.hip: icp_shard_loop_*)
   bool loop_ok = false;
+  bool pipe_ok = false;     // the pipelined evaluation across the ranks (pipe.hip) may serve the steady state
+  unsigned pipe_skip = 0;
+  uint64_t pipe_served = 0;
   unsigned loop_launch = 0, loop_evals = 0;
   uint64_t loop_launches = 0, loop_served = 0, loop_handbacks = 0;
 };
@@ -447,6 +450,8 @@ extern "C" int icp_create_multi(icp_multi **out, int dim, const double *dst, siz
     for (int q = 0; q < n_devices && rc == ICP_OK; ++q) rc = icp_loop_inbox(M->r[q].h, M->one_device ? 0 : 1, &boxes[q]);
     for (int q = 0; q < n_devices && rc == ICP_OK; ++q) rc = icp_shard_loop_connect(M->r[q].h, q, n_devices, boxes);
     M->loop_ok = rc == ICP_OK;
+    // (ranks that share a device ride in one finishing launch: its arguments hold eight of them)
+    M->pipe_ok = M->loop_ok && getenv("ICP_NO_SPECULATION") == nullptr && (!M->one_device || n_devices <= 8);
   }
   if (rc != ICP_OK) {
     icp_destroy_multi(M);
@@ -481,6 +486,13 @@ extern "C" int icp_multi_loop_counters(const icp_multi *M, uint64_t out[3]) {
   out[0] = M->loop_launches;
   out[1] = M->loop_served;
   out[2] = M->loop_handbacks;
+  return ICP_OK;
+}
+
+// outer iterations the pipelined evaluation (pipe.hip) served over the life of `M`
+extern "C" int icp_multi_pipe_iterations(const icp_multi *M, uint64_t *out) {
+  if (!M || !out) return ICP_BAD_ARGUMENT;
+  *out = M->pipe_served;
   return ICP_OK;
 }
 
@@ -559,7 +571,38 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
     if (max_iter > 0) ICP_TRY(icp_prepare_source_device(R.h, R.d_src, n_local[q], init));
     R.h->qsort.presorted = false;
   }
+  uint32_t prev_applied = 0xffffffffu;
   for (size_t it = 0; it < max_iter; ++it) {
+    // Round 6: once an inner loop has applied exactly one update (a settled registration; the benchmark pair from its
+    // second iteration on), the ranks run the one-GPU pipeline -- search -> paired first launches -> finishing workgroups
+    // that meet across the ranks, the next search already behind them (pipe.hip) -- until something else happens, and
+    // this loop takes over again at the start of that iteration.
+    if (M->pipe_ok && M->loop_ok && prev_applied == 1u && M->pipe_skip == 0) {
+      PipeRank pr[kShardMaxWorld];
+      bool all = true;
+      for (int q = 0; q < W; ++q) {
+        int b0, b1, B;
+        size_t nl;
+        shard_geometry(n, q, W, &b0, &b1, &B, &nl);
+        pr[q] = PipeRank{M->r[q].h, M->r[q].d_src, n_local[q], q, b0, b1 - b0, M->r[q].d_idx};
+        all = all && n_local[q] > 0;
+      }
+      if (all) {
+        size_t it2 = it;
+        int why = 1;
+        ICP_TRY(pipe_run(pr, W, W, n, &T, &it2, max_iter, inner_iters, &why));
+        M->pipe_served += it2 - it;
+        if (why == 5) {  // a wait for a peer ran out: the inboxes carry a raised abort word, the stage calls serve from here
+          M->pipe_ok = M->loop_ok = false;
+          if (getenv("ICP_MULTI_DEBUG")) fprintf(stderr, "[multi] the pipelined evaluation gave up waiting: stage calls from now on\n");
+        }
+        if (it2 == it) M->pipe_skip = 2;  // (handed back at once: this loop serves a few iterations before the next try)
+        it = it2;
+        if (it >= max_iter) break;
+      }
+    } else if (M->pipe_skip > 0) {
+      --M->pipe_skip;
+    }
     for (int q = 0; q < W; ++q) {
       auto &R = M->r[q];
       if (n_local[q]) ICP_TRY(icp_correspond_device(R.h, R.d_src, n_local[q], &T, R.d_a, R.d_b, R.d_idx));
@@ -587,6 +630,7 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
       }
     }
     if (inner_iters) inner_iters[it] = applied;
+    prev_applied = applied;
     const Pose T_next = transform_mul(Ti, T);
     // (a fixed point of the loop, as in icp_estimate_device: the iterations after it repeat it -- and here every search
     // leaves its indices, so not even the last one has to run)

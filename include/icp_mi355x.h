@@ -55,7 +55,10 @@ extern "C" {
  * sharded one-launch inner loop that gives up raises the abort word in every rank's inbox, so all ranks report
  * ICP_HIP_ERROR for that launch; the evaluations of icp_estimate[_device] file their candidates in the first pass over
  * the pairs and finish in one workgroup (same bits: the order statistics are exact either way) */
-#define ICP_ABI_VERSION 6
+/* 7: additions only (section 5c: icp_shard_pipe_run_device, the pipelined sharded registration; icp_pipe_counters,
+ * icp_multi_pipe_iterations in icp_mi355x_debug.h).  Behavioural note: icp_multi_estimate and the sharded drivers serve
+ * the steady state of a registration through it (same bits) */
+#define ICP_ABI_VERSION 7
 
 typedef enum icp_status {
   ICP_OK = 0,
@@ -341,6 +344,27 @@ int icp_shard_loop_launch_device(icp_handle *h, const double *d_a_xy_local, cons
                                  double prev_error, int first_kind, int second_kind);
 int icp_shard_loop_wait(icp_handle *h, icp_pose *Ti, double *prev_error, uint32_t *applied, int *it, int *finished,
                         uint32_t *evals);
+
+/* ---- 5c. The PIPELINED sharded registration (round 6; csrc/pipe.hip, csrc/gn_win.hip: k_win_pick_shard) -------------
+ * Replaces, for a rank of a sharded registration, the body of the reference's outer loop (src/lib.rs:113-127 / 156-170)
+ * in the steady state of a registration -- the inner loop (src/lib.rs:59-84) applies exactly one update -- by the one-GPU
+ * pipeline: search -> the two evaluations' first launches over the rank's own points -> their finishing workgroups, which
+ * meet the other ranks' through the connected inboxes (section 5b: two exchanges per evaluation, no host, no collective)
+ * and leave the next pose on the device for the search already enqueued behind them.  Three launches and one host wait
+ * per outer iteration and rank.
+ * icp_shard_pipe_run_device: collective -- every rank of the connection calls it at the same outer iteration *it_io with
+ * the same pose *T_io (replicated state), after at least one outer iteration served by the stage calls or the loop
+ * launches (they seed the window predictions and the snapshot's previous matches).  d_src_local: the rank's points
+ * (icp_shard_take_device out of the fold order, icp_prepare_source_device called on them).  On return *it_io / *T_io
+ * are the iteration and pose the caller continues from; inner_iters[k] = 1 for every iteration k served (nullable);
+ * d_idx_local receives the correspondences if the call's last iteration (max_iter - 1) was served.  *why = 0: served
+ * through max_iter; 1: handed back (a window missed, an inner loop of no or several updates, a NaN: the caller's loop
+ * serves iteration *it_io and may call again); 5: a wait for a peer ran out -- every rank reports it, the inboxes carry a
+ * raised abort word, and the caller serves the rest through the stage calls.  The bits are those of the other two ways
+ * to run a sharded evaluation, and of one GPU.  Clouds of up to 2^20 points in total. */
+int icp_shard_pipe_run_device(icp_handle *h, const double *d_src_local, size_t n_local, size_t n_total, int rank, int world,
+                              icp_pose *T_io, size_t *it_io, size_t max_iter, uint32_t *inner_iters, uint32_t *d_idx_local,
+                              int *why);
 
 /* (STATUS: with every rank on ONE device -- "virtual ranks" -- this path runs in the test-suite; between DISTINCT
  * devices it has never run on hardware (no multi-GPU box was available to the build): experimental there.  Mixed lists

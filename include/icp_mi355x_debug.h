@@ -67,6 +67,12 @@ int icp_multi_counters(const icp_multi *M, uint64_t out[2]);
  * calls from then on, silently: the results are the same bits either way. */
 int icp_multi_loop_counters(const icp_multi *M, uint64_t out[3]);
 
+/* ... and of the pipelined sharded registration (section 5c): outer iterations it served over the life of `M`; per
+ * handle: out[0] iterations served, out[1] hand-backs, out[2] waits for a peer that ran out, out[3] run-ahead searches
+ * whose pose the host confirmed. */
+int icp_multi_pipe_iterations(const icp_multi *M, uint64_t *out);
+int icp_pipe_counters(icp_handle *h, uint64_t out[4]);
+
 /* Live kernel timing for the benchmark: with enable = k > 0, HIP events bracket every
  * k-th launch of the nearest-neighbour search kernel on the handle's stream (an event pair
  * costs a few us of stream time, so the benchmark samples instead of timing every launch);
