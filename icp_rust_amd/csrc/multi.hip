@@ -477,7 +477,8 @@ extern "C" size_t icp_multi_target_count(const icp_multi *M) { return M ? M->m :
 
 extern "C" int icp_multi_counters(const icp_multi *M, uint64_t out[2]) {
   if (!M || !out) return ICP_BAD_ARGUMENT;
-  out[0] = M->sharded + M->loop_served;  // evaluations that ran sharded: stepped from the host, or inside a loop launch
+  // evaluations that ran sharded: stepped from the host, inside a loop launch, or pipelined (two per outer iteration)
+  out[0] = M->sharded + M->loop_served + 2 * M->pipe_served;
   out[1] = M->replicated;
   return ICP_OK;
 }

@@ -107,6 +107,20 @@ class TorchComm:
         if self.world > 1:
             dist.barrier(group=self.group)
 
+    def all_ok(self, ok, like=None):
+        """True iff `ok` on EVERY rank (one small all_reduce(MIN)): how the ranks agree on the outcome of an operation
+        that went through the mapped inboxes, whose bounded waits can end differently on different ranks"""
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return bool(ok)
+        # (RCCL reduces device tensors; gloo -- the CPU tests, ranks sharing one GPU -- host tensors)
+        dev = (like.device if like is not None else "cuda") if dist.get_backend(self.group) == "nccl" else "cpu"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
+
 
 class LocalComm:
     """All ranks live in this process (virtual ranks): the exchanges are plain copies."""
@@ -120,6 +134,9 @@ class LocalComm:
 
     def barrier(self):
         pass
+
+    def all_ok(self, ok, like=None):
+        return bool(ok)
 
     def sum_(self, bufs):
         total = bufs[0].clone()
@@ -297,6 +314,24 @@ class HipStages:
                                        C.byref(ev))
         return rc, Ti, pe.value, ap.value, it.value, bool(fin.value), ev.value
 
+    def pipe_run(self, src_local, n_total, rank, world, T, it, max_iter, inner, idx_out):
+        """icp_shard_pipe_run_device (include/icp_mi355x.h section 5c): this rank's iterations of the pipelined sharded
+        registration from outer iteration `it` on.  inner: uint32 numpy array of max_iter entries (filled for the
+        iterations served); idx_out: int32 device tensor for the last search's correspondences.  Returns (T, it, why)."""
+        To = Transform()
+        To.pose = type(T.pose).from_buffer_copy(T.pose)
+        itc, why = C.c_size_t(int(it)), C.c_int(1)
+        _lib.check(lib().icp_shard_pipe_run_device(self.icp._h, C.c_void_p(src_local.data_ptr()), src_local.shape[0], n_total, rank,
+                                                   world, C.byref(To.pose), C.byref(itc), max_iter,
+                                                   C.c_void_p(inner.ctypes.data), C.c_void_p(idx_out.data_ptr()), C.byref(why)),
+                   "icp_shard_pipe_run_device")
+        return To, int(itc.value), int(why.value)
+
+    def pipe_counters(self):
+        out = (C.c_uint64 * 4)()
+        _lib.check(lib().icp_pipe_counters(self.icp._h, out), "icp_pipe_counters")
+        return tuple(int(x) for x in out)
+
     def eval_finish(self, exch_all):
         delta = np.zeros(3)
         err = C.c_double(0.0)
@@ -314,6 +349,11 @@ class HipStages:
 
 
 # ------------------------------------------------------------------------ block-sharded driver ----
+class _GaveUp(Exception):
+    """some rank's wait for a peer ran out inside a launch that exchanges through the mapped inboxes (agreed on by all
+    ranks: BlockShardedIcp.estimate starts the call again through the stage calls + collectives)"""
+
+
 class _Rank:
     def __init__(self, rank, stages):
         self.rank, self.stages = rank, stages
@@ -369,7 +409,10 @@ class BlockShardedIcp:
         if len({h for h, _ in ids}) > 1:
             return None  # (more than one node: no memory to share)
         same_device = len({d for _, d in ids}) == 1
-        order = [transport] if transport != "auto" else (["device_ipc"] if same_device else ["fine_ipc", "host_shm"])
+        # (auto: the remaining transports stay as fallbacks -- ranks that see one GPU each through HIP_VISIBLE_DEVICES may
+        # all report "device 0" while sitting on different devices, where device_ipc fails its probe: ADVICE r5)
+        order = [transport] if transport != "auto" else (["device_ipc", "fine_ipc", "host_shm"] if same_device
+                                                         else ["fine_ipc", "host_shm"])
         for name in order:
             kind = self.TRANSPORTS[name]
             ok, err, opened, ptrs = 1, "", [], []
@@ -444,7 +487,13 @@ class BlockShardedIcp:
             _lib.check(rc, "icp_shard_loop_launch_device")
         L["launch"] = launch_no
         outs = [rk.stages.loop_wait() for rk in self.ranks]
-        if any(o[0] == _lib.HIP_ERROR for o in outs):
+        gave_up = any(o[0] == _lib.HIP_ERROR for o in outs)
+        if not isinstance(self.comm, LocalComm) and self.world > 1:
+            #  the bounded waits of a launch can end differently on different ranks -- one finishes its last wait
+            # while a peer's runs out -- so the hosts AGREE on the outcome before anybody uses it: one small all_reduce
+            if not self.comm.all_ok(not gave_up, like=self.ranks[0].bufs["a"]):
+                raise _GaveUp()
+        if gave_up:
             # A launch gave up waiting for a peer.  The rank whose wait ran out raised the abort word in EVERY inbox, so
             # every rank's launch ended the same way and every host is here (no collective needed to agree).  Nothing
             # of the launch is used; the prediction histories may have diverged inside it and are dropped; the stage
@@ -640,21 +689,68 @@ class BlockShardedIcp:
                 it += 1
         return self._mul(Ti, T), applied
 
+    def _pipe_usable(self):
+        """the pipelined evaluation (csrc/pipe.hip) serves ONE local rank per process (ranks of one process on one stream
+        would wait for kernels that are not enqueued yet: icp_create_multi fuses their launches instead) over connected
+        inboxes, clouds of up to 2^20 points; ICP_DIST_NO_PIPE=1 switches it off"""
+        import os
+
+        return (getattr(self, "_loop", None) is not None and len(self.ranks) == 1 and self.n <= (1 << 20) and
+                hasattr(self.ranks[0].stages, "pipe_run") and os.environ.get("ICP_DIST_NO_PIPE") != "1" and
+                all(g[3] > 0 for g in self.geom.values()))
+
     def estimate(self, src_local, initial_transform, max_iter):
+        try:
+            return self._estimate(src_local, initial_transform, max_iter)
+        except _GaveUp:
+            # Agreed on by every rank (comm.all_ok): a launch that exchanges through the inboxes gave up somewhere.  Nothing
+            # of this call is kept -- the ranks may have got one iteration apart -- the inbox paths are off for the rest of
+            # the connection, the prediction histories are dropped, and the call starts again through the stage calls +
+            # collectives, which every rank enters at the same point (same bits either way).
+            for rk in self.ranks:
+                if hasattr(rk.stages, "reset_predictions"):
+                    rk.stages.reset_predictions()
+            self._loop = None
+            self.counters["loop_gave_up"] = self.counters.get("loop_gave_up", 0) + 1
+            return self._estimate(src_local, initial_transform, max_iter)
+
+    def _estimate(self, src_local, initial_transform, max_iter):
         T = initial_transform
-        inner = []
+        inner = np.zeros(max_iter, dtype=np.uint32)
         if max_iter > 0:
             for rk in self.ranks:
                 if hasattr(rk.stages, "prepare") and self.geom[rk.rank][3]:
                     rk.stages.prepare(src_local[rk.rank], T)
-        for _ in range(max_iter):
+        it, prev_k, skip = 0, None, 0
+        while it < max_iter:
+            # Round 6: once an inner loop has applied exactly one update, the rank runs the one-GPU pipeline with finishing
+            # workgroups that meet its peers' (HipStages.pipe_run) until something else happens; this loop then serves
+            # that iteration and may come back.
+            if prev_k == 1 and skip == 0 and self._pipe_usable():
+                rk = self.ranks[0]
+                bf = self._buffers(rk, src_local[rk.rank])
+                nl = self.geom[rk.rank][3]
+                T2, it2, why = rk.stages.pipe_run(src_local[rk.rank], self.n, rk.rank, self.world, T, it, max_iter, inner,
+                                                  bf["idx"][:nl])
+                if not self.comm.all_ok(why != 5, like=bf["a"]):
+                    raise _GaveUp()
+                self.counters["pipe_iterations"] = self.counters.get("pipe_iterations", 0) + (it2 - it)
+                self.counters["sharded"] += 2 * (it2 - it)
+                if it2 == it:
+                    skip = 2  # (handed back at once: a few iterations through this loop before the next try)
+                T, it = T2, it2
+                if it >= max_iter:
+                    break
+            elif skip > 0:
+                skip -= 1
             T_next, k = self.step(src_local, T)
-            inner.append(k)
+            inner[it] = k
+            prev_k = k
+            it += 1
             if k == 0 and _same_bits(T_next, T):  # a fixed point of the loop: the iterations after it repeat it
-                inner.extend([0] * (max_iter - len(inner)))  # (every step leaves its indices: the last need not run)
-                break
+                break  # (every step leaves its indices: the last need not run; the remaining inner counts are 0)
             T = T_next
-        return T, np.array(inner, dtype=np.uint32)
+        return T, inner
 
     def last_indices(self):
         """{rank: correspondence indices of its local points in the last outer iteration}"""

@@ -43,7 +43,10 @@ def main():
     if c.get("loop_gave_up", 0):  # (the two processes were not scheduled side by side: the stage calls served -- same bits)
         print(f"rank {rank}: icp_shard_loop_wait: HIP error (a launch gave up waiting)", flush=True)
     else:
-        assert c["loop_launches"] >= iters and c["loop_served"] >= iters, c
+        # every outer iteration through the inboxes: a one-launch inner loop, or the pipelined evaluation (round 6)
+        assert c["loop_launches"] + c.get("pipe_iterations", 0) >= iters and c["loop_served"] + 2 * c.get("pipe_iterations", 0) >= iters, c
+        if kind != "converging":
+            assert c.get("pipe_iterations", 0) >= 2 * (iters - 4), c  # (both calls: all but their first iterations)
     ok = 1
     if rank == 0:
         one = I.Icp3d(d_dst)
