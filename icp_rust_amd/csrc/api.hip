@@ -113,7 +113,7 @@ hipError_t alloc_ctx(GnCtx &c, hipStream_t s) {
   if ((e = hipMalloc(&c.d_sel, 2 * kSelProblems * sizeof(SelState))) != hipSuccess) return e;
   if ((e = hipMalloc(&c.d_scal, sizeof(GnScalars))) != hipSuccess) return e;
   // (+ one row: the folded totals k_win_finish's first workgroups leave for its last one)
-  if ((e = hipMalloc(&c.d_partials, (size_t)(kReduceMaxBlocks + 1) * (kNSum + 1) * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc(&c.d_partials, (size_t)(kTreeMaxBlocks + 1) * (kNSum + 1) * sizeof(double))) != hipSuccess) return e;
   const size_t whist_bytes = ((size_t)2 * kWinBins + kShardStatusWords) * sizeof(uint32_t);  // (+ the sharded status words)
   if ((e = hipMalloc(&c.d_whist, whist_bytes)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(c.d_whist, 0, whist_bytes, s)) != hipSuccess) return e;

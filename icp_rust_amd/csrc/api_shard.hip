@@ -450,7 +450,7 @@ static int shard_eval_hist_impl(icp_handle *h, const double *d_a, const double *
   }
   S.attempt_refined = refined != 0;
   S.refined_ready = false;
-  if (!S.d_ordered) HIP_TRY(hipMalloc(&S.d_ordered, (size_t)kReduceMaxBlocks * (kNSum + 1) * sizeof(double)));
+  if (!S.d_ordered) HIP_TRY(hipMalloc(&S.d_ordered, (size_t)kTreeMaxBlocks * (kNSum + 1) * sizeof(double)));
   if (!w.h_whist) HIP_TRY(hipHostMalloc(&w.h_whist, (size_t)2 * kWinBins * sizeof(uint32_t), hipHostMallocDefault));
   if (w.gn_dirty) {
     HIP_TRY(launch_sel_init(h, S.n_local));

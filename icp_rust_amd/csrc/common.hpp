@@ -34,7 +34,13 @@ struct Range {
 };
 
 constexpr int kReduceThreads = 512;   // threads per block of the GN reduction tree
-constexpr int kReduceMaxBlocks = 256;
+constexpr int kReduceMaxBlocks = 256;  // blocks of the tree up to 2^20 points (one per CU), and of ONE rank's share beyond
+// Round 6: beyond 2^20 points the tree GROWS with the cloud -- a block per 4 096 points (eight per thread, as at 2^20),
+// up to kTreeMaxBlocks -- instead of keeping 256 blocks whose threads fold more and more points: a rank of an N-GPU
+// registration of N x 1M points then owns 256 blocks and evaluates on all its CUs, with the launches one GPU runs on 1M
+// points.  The second stage folds the block sums as before: thread t of one 512-thread block takes
+// rows t, t + 512, ...  Bits of clouds beyond 2^20 points changed once with this.
+constexpr int kTreeMaxBlocks = 4096;
 constexpr int kShardMaxWorld = 16;  // ranks of one sharded evaluation (a node has 8 GPUs)
 constexpr int kNAcc = 13;             // what a weighted evaluation hands the host: jtj[9], jtr[3], huber error
 // Round 3: the device folds the weighted normal equations PER DIMENSION j, WITHOUT the factor g_j = 1 / sigma_j, and
@@ -73,6 +79,10 @@ inline void reduce_geometry(size_t n, int *blocks, int *threads) {
   size_t b = (n + kReduceThreads - 1) / kReduceThreads;
   if (b < 1) b = 1;
   if (b > (size_t)kReduceMaxBlocks) b = kReduceMaxBlocks;
+  if (n > ((size_t)kReduceMaxBlocks * kReduceThreads * 8)) {  // beyond 2^20 points: a block per 4 096
+    b = (n + (size_t)kReduceThreads * 8 - 1) / ((size_t)kReduceThreads * 8);
+    if (b > (size_t)kTreeMaxBlocks) b = kTreeMaxBlocks;
+  }
   *blocks = (int)b;
   *threads = kReduceThreads;
 }
@@ -173,7 +183,7 @@ struct GnCtx {
   SelCtl *d_ctl = nullptr;
   SelState *d_sel = nullptr;    // 2 x kSelProblems (gn_pull.hip ping-pongs between the halves)
   GnScalars *d_scal = nullptr;
-  double *d_partials = nullptr; // kReduceMaxBlocks x (kNSum+1)
+  double *d_partials = nullptr; // kTreeMaxBlocks x (kNSum+1)
   GnResult *h_res = nullptr;    // pinned coherent host memory, written by the last workgroup
   unsigned seq = 0;             // sequence number of the last fast evaluation launched
   bool gn_dirty = true;         // selection scratch is not in its all-zero rest state: k_sel_init first
@@ -409,7 +419,7 @@ struct icp_handle {
     size_t n_local = 0, n_total = 0;
     const double *d_a = nullptr;
     icp::Pose T;
-    double *d_ordered = nullptr;  // kReduceMaxBlocks x (kNSum + 1): the block sums of all ranks in block order
+    double *d_ordered = nullptr;  // kTreeMaxBlocks x (kNSum + 1): the block sums of all ranks in block order
     bool active = false;
     icp::WinParams P2;            // the window refined from a missed attempt's global counts
     bool refined_ready = false, attempt_refined = false;
@@ -495,6 +505,7 @@ hipError_t launch_weighted_gn_win(icp_handle *h, const double *d_a, const double
 // filed candidates (gn_win.hip, round 5): can the workgroups stage the members of these windows; two evaluations in
 // two launches on one stream
 bool bkt_fits(size_t n, const WinParams &P);
+bool bkt_fits_rank(size_t n_total, const WinParams &P);
 hipError_t launch_bkt_pair(icp_handle *h, hipStream_t s, GnCtx &first, const double *a1, const double *b1, const WinParams &P1,
                            bool ahead_on, const Pose &ahead_outer, GnCtx &second, const double *a2, const double *b2,
                            const Pose &T2, const WinParams &P2, size_t n);

@@ -305,6 +305,7 @@ __device__ __forceinline__ void accumulate_points(const double2 *__restrict__ a,
 // Executed by the last workgroup: fold the block sums (block order, same tree) into s_tot[kNSum + 1] (LDS; valid
 // after the next barrier).  The sums do not depend on the order statistics, so a kernel that still has to select
 // those folds first -- the loads of the block sums then share a round trip with the loads of its candidates.
+template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT>
 __device__ __forceinline__ void fold_block_sums(const double *partials, int blocks, double *s_tot) {
   double tot[kNSum + 1];
 #pragma unroll
@@ -313,7 +314,7 @@ __device__ __forceinline__ void fold_block_sums(const double *partials, int bloc
     double v[kNSum];
 #pragma unroll
     for (int k = 0; k < kNSum; ++k)
-      v[k] = __hip_atomic_load(&partials[(size_t)i * (kNSum + 1) + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v[k] = __hip_atomic_load(&partials[(size_t)i * (kNSum + 1) + k], __ATOMIC_RELAXED, SCOPE);
 #pragma unroll
     for (int k = 0; k < kNSum; ++k) tot[k] = tot[k] + v[k];
   }

@@ -852,10 +852,9 @@ __device__ __forceinline__ unsigned payload_count(unsigned p, int k) {
 // gridDim.y > 1: several ranks in ONE launch (ranks that share a device -- "virtual ranks": the launches of ranks wait
 // for each other, and more streams than hardware queues would queue one behind the other); blockIdx.y picks the rank,
 // R has each rank's pairs and result block.
-// STREAM (round 5): more pairs per thread than LDS holds (K > kLoopMaxK: more than 2^20 pairs in total) are read from
-// the rank's arrays again in every phase that needs them -- they sit in L2 / the Infinity Cache (a rank of W holds
-// n / W pairs) -- instead of once per launch; everything else, and every bit of the result, is the same.
-template <bool STREAM>
+// (Round 5 streamed more than eight pairs per thread from the rank's arrays to reach 2^23 pairs with 256 blocks; since
+// round 6 the tree grows beyond 2^20 points -- more blocks, never more than eight pairs per thread -- and such clouds
+// are served by the pipelined evaluation, pipe.hip, and the stage calls: this launch keeps to 2^20 pairs in total.)
 __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, LoopShardArgs S, LoopRankPtrs R_, unsigned K) {
   // The per-rank tables of the arguments, copied into LDS with CONSTANT indices: a run-time index into a by-value
   // argument struct sends the whole of it through scratch memory (848 bytes per lane until round 5), and the exchange
@@ -897,7 +896,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
   unsigned long long *const s_seen = reinterpret_cast<unsigned long long *>(s_work), *const s_incl = s_seen + kReduceMaxBlocks;
   // (the members of the fine bins, staged by phase A behind the histograms: k_gn_loop has the explanation)
   constexpr unsigned kStageCap = (sizeof(s_work) - 2 * kWinBins * sizeof(uint32_t)) / sizeof(unsigned short);
-  static_assert(kStageCap >= 4096 && kLoopStreamMaxK <= 64, "staged members: 6 + 9 + 1 bits each, in an unsigned short");
+  static_assert(kStageCap >= 4096 && kLoopMaxK <= 8, "staged members: 3 + 9 + 1 bits each");
   unsigned short *const s_mem = reinterpret_cast<unsigned short *>(s_work + 2 * kWinBins * sizeof(uint32_t));
   __shared__ unsigned s_nmem;
   __shared__ unsigned long long s_wsum[4];
@@ -920,21 +919,14 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
   }
   double2 *const s_a = s_pts, *const s_b = s_pts + (size_t)K * kReduceThreads;
   const unsigned mine = first < n ? (n - 1u - first) / G + 1u : 0u;
-  if (!STREAM)
-    for (unsigned k = 0; k < mine; ++k) {
-      s_a[k * kReduceThreads + tid] = Aa[(size_t)k * row_w + loc0];
-      s_b[k * kReduceThreads + tid] = Ab[(size_t)k * row_w + loc0];
-    }
-  // point k of thread t of this workgroup (LDS, or the rank's arrays in the local layout of shard.hip)
+  for (unsigned k = 0; k < mine; ++k) {  // (the rank's arrays in the local layout of shard.hip)
+    s_a[k * kReduceThreads + tid] = Aa[(size_t)k * row_w + loc0];
+    s_b[k * kReduceThreads + tid] = Ab[(size_t)k * row_w + loc0];
+  }
+  // point k of thread t of this workgroup
   auto pair_of = [&](unsigned k, unsigned t, double2 &ak, double2 &bk) {
-    if (STREAM) {
-      const size_t at = (size_t)k * row_w + blockIdx.x * kReduceThreads + t;
-      ak = Aa[at];
-      bk = Ab[at];
-    } else {
-      ak = s_a[k * kReduceThreads + t];
-      bk = s_b[k * kReduceThreads + t];
-    }
+    ak = s_a[k * kReduceThreads + t];
+    bk = s_b[k * kReduceThreads + t];
   };
   if (tid < sizeof(WinParams) / sizeof(double))
     reinterpret_cast<double *>(&L.P)[tid] = reinterpret_cast<const double *>(&A.PA)[tid];
@@ -983,7 +975,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_gn_loop_shard(LoopArgs A, Lo
       if (mine) pair_of(0, tid, nak, nbk);
       for (unsigned k = 0; k < mine; ++k) {
         const double2 ak = nak, bk = nbk;
-        if (k + 1 < mine) pair_of(k + 1, tid, nak, nbk);  // (STREAM: the next pair travels while this one is worked on)
+        if (k + 1 < mine) pair_of(k + 1, tid, nak, nbk);
         const double v0 = ((T.r00 * ak.x + T.r01 * ak.y) + T.tx) - bk.x;  // residual(), src/lib.rs:34-36
         const double v1 = ((T.r10 * ak.x + T.r11 * ak.y) + T.ty) - bk.y;
         saw_nan |= (v0 != v0) | (v1 != v1);
@@ -1388,7 +1380,7 @@ bool gn_loop_shard_applies(size_t n_total, int world) {
   // (ranks that share a device need all `blocks` slots on it; a rank with a device of its own needs fewer: the check is
   // the conservative one)
   return !off && world >= 1 && world <= kShardMaxWorld && blocks >= world && n_total >= (size_t)(1u << 12) &&
-         n_total <= (size_t)kLoopStreamMaxK * (size_t)blocks * (size_t)threads && blocks <= loop_slots();
+         n_total <= (size_t)kLoopMaxK * (size_t)blocks * (size_t)threads && blocks <= loop_slots();
 }
 
 hipError_t launch_gn_loop_shard(icp_handle *h, const LoopArgs &args, const LoopShardArgs &sh, const LoopRankPtrs &ptrs, int ranks) {
@@ -1398,7 +1390,7 @@ hipError_t launch_gn_loop_shard(icp_handle *h, const LoopArgs &args, const LoopS
   const unsigned K = (unsigned)((args.n + G - 1) / G);
   static int lds_granted = 0;
   if (lds_granted == 0) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gn_loop_shard<false>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gn_loop_shard),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              kLoopMaxK * kReduceThreads * 2 * (int)sizeof(double2));
     lds_granted = e == hipSuccess ? 1 : -1;
@@ -1406,14 +1398,10 @@ hipError_t launch_gn_loop_shard(icp_handle *h, const LoopArgs &args, const LoopS
   }
   int nb = 0;  // the widest of the ranks this launch carries
   for (int q = sh.rank; q < sh.rank + ranks; ++q) nb = std::max(nb, sh.first_block[q + 1] - sh.first_block[q]);
-  if (lds_granted < 0 || K > (unsigned)kLoopStreamMaxK || nb < 1 || ranks < 1 || sh.rank + ranks > sh.world || sh.blocks_total != blocks)
+  if (lds_granted < 0 || K > (unsigned)kLoopMaxK || nb < 1 || ranks < 1 || sh.rank + ranks > sh.world || sh.blocks_total != blocks)
     return hipErrorInvalidValue;
-  if (K > (unsigned)kLoopMaxK) {  // more pairs per thread than LDS holds: streamed from the rank's arrays
-    hipLaunchKernelGGL(k_gn_loop_shard<true>, dim3(nb, ranks), dim3(threads), 0, h->stream, args, sh, ptrs, K);
-    return hipGetLastError();
-  }
   const size_t lds = (size_t)K * kReduceThreads * 2 * sizeof(double2);
-  hipLaunchKernelGGL(k_gn_loop_shard<false>, dim3(nb, ranks), dim3(threads), lds, h->stream, args, sh, ptrs, K);
+  hipLaunchKernelGGL(k_gn_loop_shard, dim3(nb, ranks), dim3(threads), lds, h->stream, args, sh, ptrs, K);
   return hipGetLastError();
 }
 

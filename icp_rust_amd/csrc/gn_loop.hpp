@@ -5,7 +5,6 @@
 namespace icp {
 
 constexpr int kLoopMaxK = 8;  // pairs per thread of the reduction tree that a launch keeps in LDS (2^20 pairs in all)
-constexpr int kLoopStreamMaxK = 64;  // ... the sharded launch takes up to this many, streamed from memory beyond kLoopMaxK (2^23 pairs: eight ranks' 1M each)
 
 // Device-resident control block of the launch; all zero between launches (the last workgroup to leave resets it).
 // One 128-byte line per word that is polled or hit by atomics.
@@ -80,7 +79,7 @@ struct PipeSlot {
   unsigned long long flag_cand[kShardMaxWorld];  // rank s: candidates (and their counts) of generation g are in
   unsigned cand_cnt[kShardMaxWorld][8];          // {med x, med y, ring x, ring y, this rank could not list its candidates}
   uint32_t hist[kShardMaxWorld][2 * kWinBins];   // every rank's counts, pushed
-  double rows[kReduceMaxBlocks][kNSum + 1];      // block sums by global block
+  double rows[kTreeMaxBlocks][kNSum + 1];        // block sums by global block
   double cand[kShardMaxWorld][kPipeCandPerRank];
 };
 struct LoopInbox {

@@ -835,8 +835,8 @@ __global__ __launch_bounds__(kWinThreads) void k_win_finish(const double *__rest
   // The block sums of the launch in front of this one are complete: the first twenty workgroups fold one SUM each
   // (fold_one_load now, fold_one_reduce behind their candidate pass: gn_device.hpp) and leave the totals in the row
   // behind the block sums; the last workgroup loads twenty doubles instead of folding 256 x 20 in its serial tail.
-  double *const totals = const_cast<double *>(partials) + (size_t)kReduceMaxBlocks * (kNSum + 1);
-  const bool fold_early = gridDim.x >= (unsigned)(kNSum + 1);
+  double *const totals = const_cast<double *>(partials) + (size_t)kTreeMaxBlocks * (kNSum + 1);
+  const bool fold_early = gridDim.x >= (unsigned)(kNSum + 1) && sum_blocks <= kReduceMaxBlocks;  // (beyond 2^20 pairs: the general fold)
   const double fold_x = (fold_early && blockIdx.x < (unsigned)(kNSum + 1)) ? fold_one_load(partials, sum_blocks, (int)blockIdx.x) : 0.;
   bool fail = win_compact_body<LISTS, true>(rx, ry, n, n, P, whist, st, wmed, wring, llen, lcap, sel);
   if (fold_early && blockIdx.x < (unsigned)(kNSum + 1)) {
@@ -879,8 +879,10 @@ __global__ __launch_bounds__(kWinThreads) void k_win_finish(const double *__rest
       got[k] = __hip_atomic_load(&st->list_cnt[k][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (fold_early) {  // (the totals the first workgroups left: stored before their tickets)
       if (tid < kNSum + 1) s_tot[tid] = __hip_atomic_load(&totals[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
+    } else if (sum_blocks <= kReduceMaxBlocks) {
       fold_block_sums_256(partials, sum_blocks, s_tot);  // (they do not depend on the statistics selected below)
+    } else {
+      fold_block_sums(partials, sum_blocks, s_tot);
     }
     // the histograms of the next evaluation start from zero (every workgroup has read them); write-through, and
     // drained before the barriers in front of the release below: the host may hand the next evaluation to the
@@ -1316,7 +1318,7 @@ __device__ __forceinline__ void win_pick_shard_body(const unsigned n, const unsi
   for (int k = 0; k < kFoldH; ++k) fx[k] = 0.;
   if (alive) {  // (uniform)
     R = win_resolve<true, true, true>(&mine->hist[0][0], n, P, K.st, nullptr, 0u, L.g.cum, sel, W, (size_t)2 * kWinBins);
-    fold256_load<__HIP_MEMORY_SCOPE_SYSTEM>(&mine->rows[0][0], B, fx);
+    if (B <= kReduceMaxBlocks) fold256_load<__HIP_MEMORY_SCOPE_SYSTEM>(&mine->rows[0][0], B, fx);
   }
   bool fail = R.fail;
   double med[2] = {0., 0.}, sig[2] = {0., 0.};
@@ -1429,7 +1431,8 @@ __device__ __forceinline__ void win_pick_shard_body(const unsigned n, const unsi
         vr[dd][u] = (take && e < sel.ring_cnt[dd]) ? fetch(2 + dd, e) : 0.;
       }
     }
-    fold256_reduce(fx, B, s_tot);  // (a barrier inside)
+    if (B <= kReduceMaxBlocks) fold256_reduce(fx, B, s_tot);  // (a barrier inside)
+    else fold_block_sums<__HIP_MEMORY_SCOPE_SYSTEM>(&mine->rows[0][0], B, s_tot);  // (beyond 2^20 points: thread t folds rows t, t + 512, ...)
     __syncthreads();               // (the descriptor lists are read: the selections may overlay them)
     const unsigned klo = (n - 1) / 2, khi = n / 2;
     if (take) {
@@ -1706,10 +1709,10 @@ __global__ __launch_bounds__(kReduceThreads) void k_shard_finish(ShardPtrs srcs,
     s_fail = fail;
   }
   // the block sums into block order (rank r owns blocks [B r / world, B (r + 1) / world)), the flags of every rank
-  const int rows = (kReduceMaxBlocks + world - 1) / world + 1;
+  const int rows = (kTreeMaxBlocks + world - 1) / world + 1;
   const size_t part_off = sizeof(ShardCandHeader) + (size_t)(2 * kWinCapMed + 2 * kWinCapRing) * sizeof(double);
   for (int b = tid; b < blocks_total; b += kReduceThreads) {
-    // the rank whose range holds b (32-bit arithmetic: blocks_total <= 256, world <= 16)
+    // the rank whose range holds b (32-bit arithmetic: blocks_total <= 4096, world <= 16)
     unsigned r = ((unsigned)(b + 1) * (unsigned)world - 1u) / (unsigned)blocks_total;
     while ((unsigned)blocks_total * r / (unsigned)world > (unsigned)b) --r;
     while ((unsigned)blocks_total * (r + 1u) / (unsigned)world <= (unsigned)b) ++r;
@@ -1866,7 +1869,11 @@ static unsigned tree_blocks(size_t n) {
 // Can a workgroup stage its fine-window members?  Their expected number under a bell is 1.04 (x[1] - x[0]) / sigma of
 // its points per dimension; a factor two to spare.  (Wider windows -- after a miss -- and handles whose files were not
 // usable recently take the second pass over the points: Workspace::bkt_off.)
-bool bkt_fits(size_t n, const WinParams &P) {
+// (bkt_fits: one handle, which has segments for kReduceMaxBlocks workgroups -- the whole tree up to 2^20 pairs;
+// bkt_fits_rank: a rank of a sharded registration, which files its own share -- at most that many blocks -- of a tree
+// that may be larger)
+bool bkt_fits(size_t n, const WinParams &P) { return tree_blocks(n) <= (unsigned)kReduceMaxBlocks && bkt_fits_rank(n, P); }
+bool bkt_fits_rank(size_t n, const WinParams &P) {
   double frac = 0.;
   for (int d = 0; d < 2; ++d) {
     const WinDim &D = P.d[d];
@@ -1919,6 +1926,7 @@ hipError_t launch_bkt_pair(icp_handle *h, hipStream_t s, GnCtx &first, const dou
                            const Pose &T2, const WinParams &P2, size_t n_) {
   Workspace &w = h->ws;
   const unsigned n = (unsigned)n_, blocks = tree_blocks(n_);
+  if (blocks > (unsigned)kReduceMaxBlocks) return hipErrorInvalidValue;  // (a context has segments for that many workgroups)
   w.bkt_evals += 2;
   hipLaunchKernelGGL(k_win_hist_sums_bkt2, dim3(2 * blocks), dim3(kWinThreads), 0, s,
                      bkt_hist_args(first, (const double2 *)a1, (const double2 *)b1, transform_identity(), n, P1),
@@ -1937,7 +1945,12 @@ hipError_t launch_bkt_pair(icp_handle *h, hipStream_t s, GnCtx &first, const dou
 // its own is a call of its own.  gen0: generation of ev[0]'s exchange (ev[1]: gen0 + 1), the same on every rank.
 hipError_t launch_shard_evals(const ShardPickRank *rk, int nranks, int world, int B, size_t n_total, unsigned gen0,
                               const ShardPickEval *ev, int nevals) {
-  if (nranks < 1 || nranks > kPipeFuse || nevals < 1 || nevals > 2 || world < 1 || world > kShardMaxWorld) return hipErrorInvalidValue;
+  if (nranks < 1 || nranks > kPipeFuse || nevals < 1 || nevals > 2 || world < 1 || world > kShardMaxWorld || B < 1 || B > kTreeMaxBlocks)
+    return hipErrorInvalidValue;
+  for (int j = 0; j < nranks; ++j)  // (a rank's segments, block sums and inbox rows)
+    if (rk[j].nbl < 1 || rk[j].nbl > kReduceMaxBlocks || rk[j].b0 < 0 || rk[j].b0 + rk[j].nbl > B || rk[j].rank < 0 || rk[j].rank >= world ||
+        !rk[j].h->ws.d_loop_inbox)
+      return hipErrorInvalidValue;
   PickShardLaunch L = {};
   L.world = world;
   L.B = B;

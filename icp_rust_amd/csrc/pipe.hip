@@ -49,7 +49,7 @@ bool pipe_window(const icp_handle *h, size_t n_total, int kind, PipeWin *out) {
     out->med[d] = w.win_kind[kind].med[d];
     out->sigma[d] = w.win_kind[kind].sigma[d];
   }
-  return bkt_fits(n_total, out->P);
+  return bkt_fits_rank(n_total, out->P);
 }
 
 // what an evaluation leaves in the prediction history (api.hip: wgn_step does the same for one handle)
@@ -78,9 +78,10 @@ int pipe_run(PipeRank *rk, int nranks, int world, size_t n_total, Pose *T_io, si
     *why = 0;
     return ICP_OK;
   }
-  if (nranks < 1 || world < 1 || world > kShardMaxWorld || n_total < ((size_t)1 << 12) || n_total > ((size_t)1 << 20)) return ICP_OK;
+  if (nranks < 1 || world < 1 || world > kShardMaxWorld || n_total < ((size_t)1 << 12)) return ICP_OK;
   int B, threads;
   reduce_geometry(n_total, &B, &threads);
+  if ((size_t)B * (size_t)threads * 8 < n_total) return ICP_OK;  // (beyond 2^24 points a thread folds more than eight)
   for (int j = 0; j < nranks; ++j) {
     icp_handle *h = rk[j].h;
     Workspace &w = h->ws;

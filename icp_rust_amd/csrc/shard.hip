@@ -98,7 +98,7 @@ hipError_t launch_shard_copy(icp_handle *h, const void *src, void *dst, size_t n
 //   then shard_part_rows(world) rows of (kNSum + 1) doubles: the rank's block sums first (unused rows zero), the
 //   last row = {nan flag}
 size_t shard_cand_bytes() { return sizeof(ShardCandHeader) + (size_t)(2 * kWinCapMed + 2 * kWinCapRing) * sizeof(double); }
-int shard_part_rows(int world) { return (kReduceMaxBlocks + world - 1) / world + 1; }
+int shard_part_rows(int world) { return (kTreeMaxBlocks + world - 1) / world + 1; }
 size_t shard_part_bytes(int world) { return (size_t)shard_part_rows(world) * (kNSum + 1) * sizeof(double); }
 size_t shard_exchange_bytes(int world) { return shard_cand_bytes() + shard_part_bytes(world); }
 

@@ -692,12 +692,12 @@ class BlockShardedIcp:
     def _pipe_usable(self):
         """the pipelined evaluation (csrc/pipe.hip) serves ONE local rank per process (ranks of one process on one stream
         would wait for kernels that are not enqueued yet: icp_create_multi fuses their launches instead) over connected
-        inboxes, clouds of up to 2^20 points; ICP_DIST_NO_PIPE=1 switches it off"""
+        inboxes, every rank with at most 256 tree blocks (N ranks: N x 2^20 points); ICP_DIST_NO_PIPE=1 switches it off"""
         import os
 
-        return (getattr(self, "_loop", None) is not None and len(self.ranks) == 1 and self.n <= (1 << 20) and
+        return (getattr(self, "_loop", None) is not None and len(self.ranks) == 1 and
                 hasattr(self.ranks[0].stages, "pipe_run") and os.environ.get("ICP_DIST_NO_PIPE") != "1" and
-                all(g[3] > 0 for g in self.geom.values()))
+                all(g[3] > 0 and g[1] - g[0] <= 256 for g in self.geom.values()))
 
     def estimate(self, src_local, initial_transform, max_iter):
         try:

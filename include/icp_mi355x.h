@@ -361,7 +361,7 @@ int icp_shard_loop_wait(icp_handle *h, icp_pose *Ti, double *prev_error, uint32_
  * through max_iter; 1: handed back (a window missed, an inner loop of no or several updates, a NaN: the caller's loop
  * serves iteration *it_io and may call again); 5: a wait for a peer ran out -- every rank reports it, the inboxes carry a
  * raised abort word, and the caller serves the rest through the stage calls.  The bits are those of the other two ways
- * to run a sharded evaluation, and of one GPU.  Clouds of up to 2^20 points in total. */
+ * to run a sharded evaluation, and of one GPU.  A rank may own up to 256 tree blocks (world x 2^20 points in total). */
 int icp_shard_pipe_run_device(icp_handle *h, const double *d_src_local, size_t n_local, size_t n_total, int rank, int world,
                               icp_pose *T_io, size_t *it_io, size_t max_iter, uint32_t *inner_iters, uint32_t *d_idx_local,
                               int *why);

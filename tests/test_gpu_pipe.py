@@ -55,6 +55,22 @@ def test_pipelined_ranks_against_the_oracle_and_at_the_full_size():
     one.close()
 
 
+@pytest.mark.parametrize("world,n", [(2, 2 * 1024 * 1024), (8, 8 * 1000 * 1000)])
+def test_weak_scaling_sizes_go_through_the_pipeline(world, n):
+    """world x 1M source points against a 1M target (BASELINE configs[3] scaled weakly): the tree has world x 256 blocks,
+    every rank files and finishes its own 256 -- pose, indices, inner counts of ONE handle on the whole cloud"""
+    src, dst = synth.synthetic_pair(n, 1_000_000)
+    one = I.Icp3d(dst)
+    T1, idx1, inner1 = one.estimate(src, I.Transform(), 8, return_info=True)
+    one.close()
+    multi = I.IcpMulti(dst, [0] * world)
+    T, idx, inner = multi.estimate(src, I.Transform(), 8, return_info=True)
+    assert np.array_equal(inner, inner1), (inner, inner1)
+    assert np.array_equal(T.as_array(), T1.as_array()) and np.array_equal(idx, idx1)
+    print("pipelined iterations:", multi.pipe_iterations(), "sharded / replicated:", multi.counters())
+    multi.close()
+
+
 def test_a_converging_pair_hands_back_and_comes_back():
     """inner loops of many updates, then of none: the pipeline must stay out of the way (same bits), whatever it serves"""
     src, dst, _ = synth.converging_pair(200_000, 200_000)
