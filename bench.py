@@ -664,9 +664,11 @@ def main():
                 "n_src": n, "n_dst": m, "nn": res["engine"], "outer_iterations_per_estimate_call": MAX_ITER,
                 "parallelism": ("one GPU" if world == 1 else
                                 f"source cloud sharded x{world} by reduction-tree block (every rank searches and evaluates "
-                                "its blocks' points; every inner loop is ONE launch per rank whose workgroups exchange window "
-                                "histograms, candidates and block sums through hipIpc-mapped inboxes over xGMI; RCCL serves "
-                                "only the evaluations a launch hands back), target replicated; bit-identical to one GPU"
+                                "its blocks' points with the one-GPU pipeline -- search, paired first launches, finishing "
+                                "workgroups -- and the ranks meet inside the finishing workgroups: window histograms, block sums "
+                                "and candidates through mapped inboxes over xGMI, two exchanges per evaluation, the next search "
+                                "already enqueued behind them; RCCL serves the rendezvous, one agreement flag per call and "
+                                "whatever the pipeline hands back), target replicated; bit-identical to one GPU"
                                 if res["engine"] == "grid" else
                                 f"NN over contiguous source shards x{world} (index all-gather), target replicated, inner "
                                 "loop replicated"),
@@ -685,11 +687,20 @@ def main():
             out["sharded_evaluations"] = dict(res["counters"], inner_loops=loop_state["mode"], transport=loop_state.get("transport"),
                                               rccl_world=dist.get_world_size() if dist.is_initialized() else 1,
                                               backend=dist.get_backend() if dist.is_initialized() else None)
+            out["n_gpus_note"] = ("strong scaling of ONE 1M-point registration (BASELINE configs[3]): the step is a chain of dependent "
+                                  "launches of ~25-50 us each, so more GPUs shorten only the search and the first launches; "
+                                  "`weak_scaling` (N x 1M source points) is where N GPUs pay, `brute_force` is configs[3] as worded")
+        rccl_world = dist.get_world_size() if dist.is_initialized() else 1
+        backend = dist.get_backend() if dist.is_initialized() else None
         if brute is not None:
             out["brute_force"] = {
+                "workload": "BASELINE configs[2] / [3] as worded: brute-force NN (LDS-tiled sweep) + Huber, 1M x 1M; N ranks: the "
+                            "search over contiguous source shards (99.8 % of the step), one index all-gather per iteration, "
+                            "the inner loop replicated",
                 "value": brute["steps"] / brute["elapsed"], "unit": "iterations/s", "steps": brute["steps"],
                 "ms_per_step": 1e3 * brute["elapsed"] / brute["steps"], "roofline": nn_roofline(brute, hi - lo),
-                "scaling": "strong", "n_gpus": world,
+                "scaling": "strong", "n_gpus": world, "transport": "RCCL all_gather (torch.distributed)" if world > 1 else None,
+                "rccl_world": rccl_world, "backend": backend,
             }
         if weak is not None:
             wv = weak["steps"] / weak["elapsed"]
@@ -699,7 +710,11 @@ def main():
                 "value": wv, "unit": "iterations/s", "steps": weak["steps"], "ms_per_step": 1e3 / wv,
                 "source_points_per_second": wv * weak["n_run"],
                 "inner_iterations_per_step": weak["inner"], "sharded_evaluations": weak["counters"],
-                "note": "compare source_points_per_second with n_src x value of the 1-GPU line",
+                "transport": loop_state.get("transport"), "inner_loops": loop_state["mode"], "rccl_world": rccl_world, "backend": backend,
+                "tree_blocks": block_shard(weak["n_run"], rank, world)[2],
+                "note": "compare source_points_per_second with n_src x value of the 1-GPU line: every rank searches and evaluates "
+                        f"its own {n} points with the launches one GPU runs on {n} (the reduction tree grows with the cloud: a rank "
+                        "owns 256 of its blocks), and the ranks meet in the finishing workgroups of the evaluations",
             }
         if world == 1 and args.rotating_calls > 0:
             out["rotating_inputs"] = rotating(args.rotating_calls, n, m, nn_mode, d_dst)

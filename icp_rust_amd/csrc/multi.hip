@@ -75,6 +75,7 @@ struct icp_multi {
   bool pipe_ok = false;     // the pipelined evaluation across the ranks (pipe.hip) may serve the steady state
   unsigned pipe_skip = 0;
   uint64_t pipe_served = 0;
+  uint32_t first_applied = 0xffffffffu;  // updates the first inner loop of the previous call applied
   unsigned loop_launch = 0, loop_evals = 0;
   uint64_t loop_launches = 0, loop_served = 0, loop_handbacks = 0;
 };
@@ -260,7 +261,8 @@ int evaluate(icp_multi *M, size_t n_total, const Pose &T, int kind, double delta
 // no host wait inside the loop; the ranks exchange histograms, candidates and block sums through their inboxes from
 // inside the launches.  *served = false: nothing was launched (every rank said so: no window prediction yet, or the
 // pair set does not fit) -- evaluate() steps evaluation *k.
-int multi_loop(icp_multi *M, size_t n_total, Pose *Ti, double *prev_error, uint32_t *applied, int *k, bool *finished, bool *served) {
+int multi_loop(icp_multi *M, size_t n_total, Pose *Ti, double *prev_error, uint32_t *applied, int *k, bool *finished, bool *served,
+               int first_kind, int second_kind) {
   const int W = M->world;
   *served = *finished = false;
   const unsigned launch_no = M->loop_launch + 1;
@@ -275,13 +277,15 @@ int multi_loop(icp_multi *M, size_t n_total, Pose *Ti, double *prev_error, uint3
       as[q] = M->r[q].d_a;
       bs[q] = M->r[q].d_b;
     }
-    const int rc = icp_shard_loop_launch_fused(hs, W, as, bs, n_total, launch_no, M->loop_evals, *k, *applied, Ti, *prev_error, 0, 1);
+    const int rc = icp_shard_loop_launch_fused(hs, W, as, bs, n_total, launch_no, M->loop_evals, *k, *applied, Ti, *prev_error, first_kind,
+                                               second_kind);
     if (rc == ICP_OK) launched = W;
     else if (rc != ICP_RETRY_SHARDED) return rc;
   } else {
     for (int q = 0; q < W; ++q) {
       auto &R = M->r[q];
-      const int rc = icp_shard_loop_launch_device(R.h, R.d_a, R.d_b, n_total, launch_no, M->loop_evals, *k, *applied, Ti, *prev_error, 0, 1);
+      const int rc = icp_shard_loop_launch_device(R.h, R.d_a, R.d_b, n_total, launch_no, M->loop_evals, *k, *applied, Ti, *prev_error,
+                                                  first_kind, second_kind);
       if (rc == ICP_OK) ++launched;
       else if (rc != ICP_RETRY_SHARDED) return rc;
     }
@@ -572,7 +576,10 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
     if (max_iter > 0) ICP_TRY(icp_prepare_source_device(R.h, R.d_src, n_local[q], init));
     R.h->qsort.presorted = false;
   }
-  uint32_t prev_applied = 0xffffffffu;
+  // (the bet needs "the inner loop applied exactly one update last time": a call's first iteration goes by what the previous
+  // call's first iteration did -- the next frame, or the same cloud again, usually starts like the last one; its two
+  // evaluations are predicted from the previous call's first two, kinds 3 and 4 of common.hpp: Workspace::win_kind)
+  uint32_t prev_applied = M->first_applied;
   for (size_t it = 0; it < max_iter; ++it) {
     // Round 6: once an inner loop has applied exactly one update (a settled registration; the benchmark pair from its
     // second iteration on), the ranks run the one-GPU pipeline -- search -> paired first launches -> finishing workgroups
@@ -593,6 +600,7 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
         int why = 1;
         ICP_TRY(pipe_run(pr, W, W, n, &T, &it2, max_iter, inner_iters, &why));
         M->pipe_served += it2 - it;
+        if (it == 0 && it2 > 0) M->first_applied = 1u;
         if (why == 5) {  // a wait for a peer ran out: the inboxes carry a raised abort word, the stage calls serve from here
           M->pipe_ok = M->loop_ok = false;
           if (getenv("ICP_MULTI_DEBUG")) fprintf(stderr, "[multi] the pipelined evaluation gave up waiting: stage calls from now on\n");
@@ -614,13 +622,14 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
     if (n >= 2) {
       double prev_error = DBL_MAX;
       for (int k = 0; k < ICP_INNER_MAX_ITER; ++k) {
+        const int kind_a = it == 0 ? 3 : 0, kind_b = it == 0 ? 4 : 1;  // (the first / second evaluation of this inner loop)
         if (M->loop_ok) {
           bool finished = false, served = false;
-          ICP_TRY(multi_loop(M, n, &Ti, &prev_error, &applied, &k, &finished, &served));
+          ICP_TRY(multi_loop(M, n, &Ti, &prev_error, &applied, &k, &finished, &served, kind_a, kind_b));
           if (finished || k >= ICP_INNER_MAX_ITER) break;
         }
         double delta[3], err = 0.;
-        const int rc = evaluate(M, n, Ti, k < 2 ? k : 2, delta, &err);
+        const int rc = evaluate(M, n, Ti, k == 0 ? kind_a : (k == 1 ? kind_b : 2), delta, &err);
         if (rc == ICP_NONE) break;
         if (rc != ICP_OK) return rc;
         if ((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2] < ICP_DELTA_NORM_THRESHOLD) break;
@@ -632,6 +641,7 @@ extern "C" int icp_multi_estimate(icp_multi *M, const double *src, size_t n, con
     }
     if (inner_iters) inner_iters[it] = applied;
     prev_applied = applied;
+    if (it == 0) M->first_applied = applied;
     const Pose T_next = transform_mul(Ti, T);
     // (a fixed point of the loop, as in icp_estimate_device: the iterations after it repeat it -- and here every search
     // leaves its indices, so not even the last one has to run)

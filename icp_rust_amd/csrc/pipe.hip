@@ -89,7 +89,7 @@ int pipe_run(PipeRank *rk, int nranks, int world, size_t n_total, Pose *T_io, si
         rk[j].n_local == 0 || resolved_nn_mode(h) != ICP_NN_GRID)
       return ICP_OK;
     const QuerySort &Q = h->qsort;
-    if (!(Q.valid && Q.src == rk[j].d_src && Q.n == rk[j].n_local && Q.have_prev)) return ICP_OK;  // (the run-ahead search needs them)
+    if (!(Q.valid && Q.src == rk[j].d_src && Q.n == rk[j].n_local)) return ICP_OK;  // (the snapshot the searches below work in)
   }
   {
     Workspace &w0 = rk[0].h->ws;
@@ -98,12 +98,16 @@ int pipe_run(PipeRank *rk, int nranks, int world, size_t n_total, Pose *T_io, si
       return ICP_OK;
     }
   }
+  // the kinds of an iteration's two evaluations (common.hpp: Workspace::win_kind): a call's first iteration is predicted
+  // from the previous call's first iteration (3, 4), every other from the iteration before it (0, 1)
+  auto kind1 = [](size_t i) { return i == 0 ? 3 : 0; };
+  auto kind2 = [](size_t i) { return i == 0 ? 4 : 1; };
   PipeWin W1, W2;
-  if (!pipe_window(rk[0].h, n_total, 0, &W1) || !pipe_window(rk[0].h, n_total, 1, &W2)) return ICP_OK;
+  if (!pipe_window(rk[0].h, n_total, kind1(it), &W1) || !pipe_window(rk[0].h, n_total, kind2(it), &W2)) return ICP_OK;
   for (int j = 1; j < nranks; ++j) {  // ranks of one process: their histories are the same history
     PipeWin a, b;
-    if (!pipe_window(rk[j].h, n_total, 0, &a) || !pipe_window(rk[j].h, n_total, 1, &b) || memcmp(&a.P, &W1.P, sizeof(WinParams)) != 0 ||
-        memcmp(&b.P, &W2.P, sizeof(WinParams)) != 0)
+    if (!pipe_window(rk[j].h, n_total, kind1(it), &a) || !pipe_window(rk[j].h, n_total, kind2(it), &b) ||
+        memcmp(&a.P, &W1.P, sizeof(WinParams)) != 0 || memcmp(&b.P, &W2.P, sizeof(WinParams)) != 0)
       return ICP_OK;
   }
   for (int j = 0; j < nranks; ++j) {
@@ -244,10 +248,10 @@ int pipe_run(PipeRank *rk, int nranks, int world, size_t n_total, Pose *T_io, si
       return leave(1);  // (the caller's own evaluation reports the NaN)
     }
     if (r1.overflow) {
-      book_miss(0, r1.overflow);
+      book_miss(kind1(it), r1.overflow);
       return leave(1);
     }
-    for (int j = 0; j < nranks; ++j) pipe_record(rk[j].h->ws, 0, W1, r1);
+    for (int j = 0; j < nranks; ++j) pipe_record(rk[j].h->ws, kind1(it), W1, r1);
     double delta1[3];
     if (!solve_update(r1.acc, r1.acc + 9, delta1)) return leave(1);           // src/lib.rs:67-69
     if (norm2(delta1) < ICP_DELTA_NORM_THRESHOLD) return leave(1);            // :71-73 (no update: not the steady state)
@@ -255,7 +259,7 @@ int pipe_run(PipeRank *rk, int nranks, int world, size_t n_total, Pose *T_io, si
     const Pose T1 = transform_mul(transform_new(delta1), transform_identity());  // :81
     const Pose spec = transform_mul(T1, T);                                       // :127, 170 -- if the deciding evaluation ends the loop
     const bool last = it + 1 == max_iter;
-    if (!pipe_window(rk[0].h, n_total, 1, &W2)) return leave(1);
+    if (!pipe_window(rk[0].h, n_total, kind2(it), &W2)) return leave(1);
     const int nxt = (cur + 1) % 3, nxt2 = (cur + 2) % 3;
     for (int j = 0; j < nranks; ++j) ++rk[j].h->ws.win_tried;
     if (last) {
@@ -266,7 +270,7 @@ int pipe_run(PipeRank *rk, int nranks, int world, size_t n_total, Pose *T_io, si
       const int bufs[1] = {cur};
       ICP_TRY_RC(launch_evals(&e2, 1, bufs));
     } else {
-      if (!pipe_window(rk[0].h, n_total, 0, &W1)) return leave(1);
+      if (!pipe_window(rk[0].h, n_total, kind1(it + 1), &W1)) return leave(1);
       // the search for `spec`: in flight already if the device derived the same pose
       const bool have_search = ahead_issued && r1.next_valid != 0 && memcmp(&r1.next_pose, &spec, sizeof(Pose)) == 0;
       for (int j = 0; j < nranks && ahead_issued; ++j) ++(have_search ? rk[j].h->ws.ahead_hits : rk[j].h->ws.ahead_misses);
@@ -297,10 +301,10 @@ int pipe_run(PipeRank *rk, int nranks, int world, size_t n_total, Pose *T_io, si
       return leave(1);
     }
     if (r2.overflow) {
-      book_miss(1, r2.overflow);
+      book_miss(kind2(it), r2.overflow);
       return leave(1);
     }
-    for (int j = 0; j < nranks; ++j) pipe_record(rk[j].h->ws, 1, W2, r2);
+    for (int j = 0; j < nranks; ++j) pipe_record(rk[j].h->ws, kind2(it), W2, r2);
     double delta2[3];
     const bool stop = !solve_update(r2.acc, r2.acc + 9, delta2) || norm2(delta2) < ICP_DELTA_NORM_THRESHOLD || r2.acc[12] > err1;
     if (!stop) {  // the inner loop goes on: the bet is off, the caller's loop serves this iteration from its start

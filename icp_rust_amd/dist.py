@@ -471,7 +471,7 @@ class BlockShardedIcp:
             self._loop_opened = []
             self.comm.barrier()
 
-    def _loop_run(self, Ti, prev_error, applied, it):
+    def _loop_run(self, Ti, prev_error, applied, it, first_kind=0, second_kind=1):
         """the inner loop from evaluation `it` on as one launch per local rank; None: nothing was launched, or the
         launch gave up (the loop's state is then the one it was started with, and the stage calls serve from here on)"""
         L = self._loop
@@ -480,7 +480,7 @@ class BlockShardedIcp:
         for rk in self.ranks:
             nl = self.geom[rk.rank][3]
             rcs.append(rk.stages.loop_launch(rk.bufs["a"][:nl], rk.bufs["b"][:nl], self.n, launch_no, L["evals"], it, applied, Ti,
-                                             prev_error))
+                                             prev_error, first_kind, second_kind))
         if all(rc == _lib.RETRY_SHARDED for rc in rcs):
             return None
         for rc in rcs:
@@ -664,18 +664,21 @@ class BlockShardedIcp:
         # estimate_transform, src/lib.rs:59-84
         Ti = Transform()
         applied = 0
+        # the kinds of this inner loop's first two evaluations (csrc/common.hpp: Workspace::win_kind): a call's first outer
+        # iteration is predicted from the previous call's first iteration (3, 4), every other from the one before it (0, 1)
+        ka, kb = (3, 4) if getattr(self, "_outer_it", 1) == 0 else (0, 1)
         if self.n >= 2:
             prev_error = float(np.finfo(np.float64).max)
             it = 0
             while it < INNER_MAX_ITER:
                 if getattr(self, "_loop", None) is not None:
-                    o = self._loop_run(Ti, prev_error, applied, it)
+                    o = self._loop_run(Ti, prev_error, applied, it, ka, kb)
                     if o is not None:
                         rc, Ti, prev_error, applied, it, finished, _ = o
                         _lib.check(rc, "icp_shard_loop_wait")
                         if finished or it >= INNER_MAX_ITER:
                             break
-                rc, delta, err = self._evaluate(Ti, min(it, 2))
+                rc, delta, err = self._evaluate(Ti, ka if it == 0 else (kb if it == 1 else 2))
                 if rc == _lib.NONE:
                     break
                 _lib.check(rc, "sharded evaluation")
@@ -721,7 +724,9 @@ class BlockShardedIcp:
             for rk in self.ranks:
                 if hasattr(rk.stages, "prepare") and self.geom[rk.rank][3]:
                     rk.stages.prepare(src_local[rk.rank], T)
-        it, prev_k, skip = 0, None, 0
+        # (the bet needs "the inner loop applied exactly one update last time": a call's first iteration goes by what the
+        # previous call's first iteration did -- the next frame, or the same cloud again, usually starts like the last one)
+        it, prev_k, skip = 0, getattr(self, "_first_k", None), 0
         while it < max_iter:
             # Round 6: once an inner loop has applied exactly one update, the rank runs the one-GPU pipeline with finishing
             # workgroups that meet its peers' (HipStages.pipe_run) until something else happens; this loop then serves
@@ -738,12 +743,17 @@ class BlockShardedIcp:
                 self.counters["sharded"] += 2 * (it2 - it)
                 if it2 == it:
                     skip = 2  # (handed back at once: a few iterations through this loop before the next try)
+                elif it == 0:
+                    self._first_k = 1
                 T, it = T2, it2
                 if it >= max_iter:
                     break
             elif skip > 0:
                 skip -= 1
+            self._outer_it = it
             T_next, k = self.step(src_local, T)
+            if it == 0:
+                self._first_k = k
             inner[it] = k
             prev_k = k
             it += 1
