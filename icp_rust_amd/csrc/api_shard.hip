@@ -368,6 +368,17 @@ static int shard_copy(icp_handle *h, const void *src, void *dst, size_t n_total,
   HIP_TRY(launch_shard_copy(h, src, dst, n_total, rank, world, (unsigned)(elem_bytes / 4), take));
   return ICP_OK;
 }
+// icp_prepare_source_device for a rank's slice of the fold order (icp_shard_take_device): its points are runs of the
+// cell-sorted cloud already, so the search snapshot keeps their order -- no second sort, pairs and indices stored as
+// they lie (what icp_multi_estimate does for its ranks)
+extern "C" int icp_shard_prepare_source_device(icp_handle *h, const double *d_src_local, size_t n_local, const icp_pose *T) {
+  if (!h) return ICP_BAD_ARGUMENT;
+  h->qsort.presorted = true;
+  const int rc = icp_prepare_source_device(h, d_src_local, n_local, T);
+  h->qsort.presorted = false;
+  return rc;
+}
+
 extern "C" int icp_shard_take_device(icp_handle *h, const void *d_full, void *d_local, size_t n_total, int rank, int world,
                                      size_t elem_bytes) {
   return shard_copy(h, d_full, d_local, n_total, rank, world, elem_bytes, true);

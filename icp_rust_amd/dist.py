@@ -178,8 +178,14 @@ class HipStages:
         return self.torch.empty(n, dtype=self.torch.int32, device=like.device)
 
     # -- round-1 stage calls (replicated inner loop) --
-    def prepare(self, src_shard, T):
-        self.icp.prepare_source_device(src_shard, T)
+    def prepare(self, src_shard, T, presorted=False):
+        """the search snapshot of a call; presorted: the shard is a slice of the fold order (take_source after sort_source),
+        whose order the snapshot keeps"""
+        if presorted:
+            _lib.check(lib().icp_shard_prepare_source_device(self.icp._h, C.c_void_p(src_shard.data_ptr()), src_shard.shape[0],
+                                                             C.byref(T.pose)), "icp_shard_prepare_source_device")
+        else:
+            self.icp.prepare_source_device(src_shard, T)
 
     def correspond(self, src_shard, T, a_out, b_out, idx_out=None):
         self.icp.correspond_device(src_shard, T, a_out, b_out, idx_out)
@@ -550,7 +556,11 @@ class BlockShardedIcp:
         Returns (T, inner, {rank: permutation of the fold order or None})."""
         srt, perms = self.sort_source(src_full_by_rank, initial_transform)
         local = self.take_source(srt)
-        T, inner = self.estimate(local, initial_transform, max_iter)
+        self._presorted = all(p is not None for p in perms.values())  # (the ranks' slices are runs of the sorted cloud)
+        try:
+            T, inner = self.estimate(local, initial_transform, max_iter)
+        finally:
+            self._presorted = False
         return T, inner, perms
 
     def _buffers(self, rk, like):
@@ -723,7 +733,10 @@ class BlockShardedIcp:
         if max_iter > 0:
             for rk in self.ranks:
                 if hasattr(rk.stages, "prepare") and self.geom[rk.rank][3]:
-                    rk.stages.prepare(src_local[rk.rank], T)
+                    if getattr(self, "_presorted", False) and isinstance(rk.stages, HipStages):
+                        rk.stages.prepare(src_local[rk.rank], T, presorted=True)
+                    else:
+                        rk.stages.prepare(src_local[rk.rank], T)
         # (the bet needs "the inner loop applied exactly one update last time": a call's first iteration goes by what the
         # previous call's first iteration did -- the next frame, or the same cloud again, usually starts like the last one)
         it, prev_k, skip = 0, getattr(self, "_first_k", None), 0

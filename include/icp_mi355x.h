@@ -269,6 +269,9 @@ size_t icp_shard_partials_bytes(int world);  /* ... then the block sums */
 size_t icp_shard_exchange_bytes(int world);  /* = the two together */
 int icp_shard_take_device(icp_handle *h, const void *d_full, void *d_local, size_t n_total, int rank, int world,
                           size_t elem_bytes);
+/* icp_prepare_source_device for a rank's points as icp_shard_take_device compacts them out of the fold order: runs of
+ * the cell-sorted cloud, whose order the search snapshot keeps (no second sort) */
+int icp_shard_prepare_source_device(icp_handle *h, const double *d_src_local, size_t n_local, const icp_pose *T);
 int icp_shard_put_device(icp_handle *h, const void *d_local, void *d_full, size_t n_total, int rank, int world,
                          size_t elem_bytes);
 int icp_shard_eval_hist_device(icp_handle *h, const double *d_a_xy_local, const double *d_b_xy_local, size_t n_total,
@@ -353,9 +356,10 @@ int icp_shard_loop_wait(icp_handle *h, icp_pose *Ti, double *prev_error, uint32_
  * and leave the next pose on the device for the search already enqueued behind them.  Three launches and one host wait
  * per outer iteration and rank.
  * icp_shard_pipe_run_device: collective -- every rank of the connection calls it at the same outer iteration *it_io with
- * the same pose *T_io (replicated state), after at least one outer iteration served by the stage calls or the loop
- * launches (they seed the window predictions and the snapshot's previous matches).  d_src_local: the rank's points
- * (icp_shard_take_device out of the fold order, icp_prepare_source_device called on them).  On return *it_io / *T_io
+ * the same pose *T_io (replicated state); it serves nothing until the stage calls or the loop launches have seeded the
+ * window predictions of both kinds of evaluation (one outer iteration; a later call on the same handle starts from the
+ * previous call's).  d_src_local: the rank's points (icp_shard_take_device out of the fold order,
+ * icp_shard_prepare_source_device called on them).  On return *it_io / *T_io
  * are the iteration and pose the caller continues from; inner_iters[k] = 1 for every iteration k served (nullable);
  * d_idx_local receives the correspondences if the call's last iteration (max_iter - 1) was served.  *why = 0: served
  * through max_iter; 1: handed back (a window missed, an inner loop of no or several updates, a NaN: the caller's loop
