@@ -73,6 +73,11 @@ int icp_multi_loop_counters(const icp_multi *M, uint64_t out[3]);
 int icp_multi_pipe_iterations(const icp_multi *M, uint64_t *out);
 int icp_pipe_counters(icp_handle *h, uint64_t out[4]);
 
+/* The per-call sort of the source points by target-grid cell (csrc/qsort.hip: hand-written LSD radix sort, digits of up to
+ * eleven bits) alone, on host arrays: keys_out = the keys ascending, perm_out = their original indices, equal keys in
+ * ascending index -- the order icp_last_fold_order documents.  bits: the keys' significant bits (1 .. 32). */
+int icp_debug_sort_cells(const uint32_t *keys, size_t n, unsigned bits, uint32_t *keys_out, uint32_t *perm_out);
+
 /* Live kernel timing for the benchmark: with enable = k > 0, HIP events bracket every
  * k-th launch of the nearest-neighbour search kernel on the handle's stream (an event pair
  * costs a few us of stream time, so the benchmark samples instead of timing every launch);
