@@ -60,6 +60,7 @@ SIGNATURES = {
     "icp_status_string": (C.c_char_p, [C.c_int]),
     "icp_abi_version": (C.c_int, []),
     "icp_device_count": (C.c_int, []),
+    "icp_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p]),
     "icp_transform_new": (None, [_dp, _pp]),
     "icp_transform_from_rt": (None, [_dp, _dp, _pp]),
     "icp_transform_identity": (None, [_pp]),

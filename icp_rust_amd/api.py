@@ -409,7 +409,7 @@ class _Icp:
 
             self._dev(src, "src")
             n = src.shape[0]
-            want_idx = return_info is True
+            want_idx = bool(return_info) and return_info != "inner"
             idx = torch.empty(max(n, 1), dtype=torch.int32, device=src.device) if want_idx else None
             check(lib().icp_estimate_device(self._h, C.c_void_p(src.data_ptr()), n,
                                             C.byref(initial_transform.pose), max_iter, C.byref(o.pose),
@@ -424,7 +424,7 @@ class _Icp:
         n = s.shape[0]
         # (the reference returns the transform alone: the last correspondences are copied back only on request --
         # 113 KB and a stream synchronisation per 28k-point frame otherwise)
-        want_idx = return_info is True
+        want_idx = bool(return_info) and return_info != "inner"
         idx = np.zeros(max(n, 1), dtype=np.uint32) if want_idx else None
         check(lib().icp_estimate(self._h, _ptr(s), n, C.byref(initial_transform.pose), max_iter,
                                  C.byref(o.pose), C.c_void_p(idx.ctypes.data) if want_idx else None,

@@ -223,6 +223,17 @@ extern "C" const char *icp_status_string(int s) {
 
 extern "C" int icp_abi_version(void) { return ICP_ABI_VERSION; }
 
+// what tells two devices of one node apart, whatever ordinal a process sees them under (HIP_VISIBLE_DEVICES)
+extern "C" int icp_device_pci_bus_id(int device, char out[64]) {
+  if (!out) return ICP_BAD_ARGUMENT;
+  out[0] = 0;
+  if (hipDeviceGetPCIBusId(out, 64, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return ICP_NO_DEVICE;
+  }
+  return ICP_OK;
+}
+
 extern "C" int icp_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -186,7 +186,8 @@ extern "C" int icp_shard_loop_connect(icp_handle *h, int rank, int world, void *
   w.loop_world = world;
   HIP_TRY(ensure_loop(h));  // (the pinned result block)
   w.loop_seq = 0;           // launch numbers restart with the connection
-  w.pipe_gen = 0;           // ... and so do the generations of the pipelined evaluation's exchanges
+  w.loop_probe_gen = 0;     // ... the tokens of the transport probe (every rank connects, then probes: the same tokens)
+  w.pipe_gen = 0;           // ... and the generations of the pipelined evaluation's exchanges
   w.pipe_off = 0;
   memset(w.h_loop_res, 0, sizeof(LoopResult));
   return ICP_OK;
@@ -247,7 +248,9 @@ static int shard_loop_launch_common(icp_handle *const *hs, int nh, const double 
   for (int q = 0; q < nh; ++q) {
     Workspace &w = hs[q]->ws;
     if (!d_a[q] || !d_b[q] || w.loop_world != world || (nh > 1 && w.loop_rank != q) || !w.d_loop_inbox) return ICP_BAD_ARGUMENT;
-    if (w.loop_off) return ICP_RETRY_SHARDED;
+    // (w.loop_off -- "this handle's own one-launch loops were not resident lately" -- is rank-local state and must not
+    // decide here: every rank has to give the same answer, ADVICE r5.  A sharded launch that gives up is reported by
+    // every rank, and the drivers drop the loop for the connection.)
   }
   HIP_TRY(hipSetDevice(h0->device));
   LoopRankPtrs ptrs = {};
@@ -331,7 +334,7 @@ extern "C" int icp_shard_loop_wait(icp_handle *h, icp_pose *Ti, double *prev_err
   HIP_TRY(wait_seq(h, &res->seq, w.loop_seq));
   if (evals) *evals = res->rounds;  // (what the connection's eval_base advances by)
   if (res->status == 5) {
-    loop_timed_out(w);
+    ++w.loop_timeouts;  // (observability; the single-handle loop's back-off, Workspace::loop_off, is not touched)
     return ICP_HIP_ERROR;
   }
   bool fin = false;

@@ -321,6 +321,31 @@ __device__ __forceinline__ void fold_block_sums(const double *partials, int bloc
   block_reduce_store<kNSum + 1>(tot, s_tot);  // (stored by lanes of wave 0)
 }
 
+// The same fold, bit for bit, one sum at a time: two registers instead of forty, twenty rounds of two barriers -- for
+// kernels that must stay inside a register budget (tests/test_registers.py) and only meet more than 256 block sums on
+// clouds beyond 2^20 points.  Every thread of a 512-thread workgroup calls it; s_tot is valid after it returns.
+template <int SCOPE = __HIP_MEMORY_SCOPE_AGENT>
+__device__ __forceinline__ void fold_block_sums_lean(const double *partials, int blocks, double *s_tot) {
+  __shared__ double sm[kReduceThreads / 64];
+  const int t = threadIdx.x;
+  for (int q = 0; q < kNSum; ++q) {
+    double v[1] = {0.};
+    for (int i = t; i < blocks; i += kReduceThreads)
+      v[0] = v[0] + __hip_atomic_load(&partials[(size_t)i * (kNSum + 1) + q], __ATOMIC_RELAXED, SCOPE);
+    wave_tree<1>(v);
+    if ((t & 63) == 0) sm[t >> 6] = v[0];
+    __syncthreads();
+    if (t == 0) {
+      double s = sm[0];
+      for (int w = 1; w < kReduceThreads / 64; ++w) s = s + sm[w];
+      s_tot[q] = s;
+    }
+    __syncthreads();
+  }
+  if (t == 0) s_tot[kNSum] = 0.;
+  __syncthreads();
+}
+
 // The same fold (bit for bit) for at most 256 block sums -- what reduce_geometry yields -- in half the registers:
 // thread t takes sums [10 h, 10 h + 10) of row t % 256, h = t / 256, so waves 0-3 and 4-7 each see the rows in the
 // lanes fold_block_sums has them in; the wave sums are left-folded per half, plus the one `+ 0.` that stands for

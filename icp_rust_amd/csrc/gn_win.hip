@@ -882,7 +882,7 @@ __global__ __launch_bounds__(kWinThreads) void k_win_finish(const double *__rest
     } else if (sum_blocks <= kReduceMaxBlocks) {
       fold_block_sums_256(partials, sum_blocks, s_tot);  // (they do not depend on the statistics selected below)
     } else {
-      fold_block_sums(partials, sum_blocks, s_tot);
+      fold_block_sums_lean(partials, sum_blocks, s_tot);  // (beyond 2^20 pairs; inside this kernel's register budget)
     }
     // the histograms of the next evaluation start from zero (every workgroup has read them); write-through, and
     // drained before the barriers in front of the release below: the host may hand the next evaluation to the
@@ -1432,7 +1432,7 @@ __device__ __forceinline__ void win_pick_shard_body(const unsigned n, const unsi
       }
     }
     if (B <= kReduceMaxBlocks) fold256_reduce(fx, B, s_tot);  // (a barrier inside)
-    else fold_block_sums<__HIP_MEMORY_SCOPE_SYSTEM>(&mine->rows[0][0], B, s_tot);  // (beyond 2^20 points: thread t folds rows t, t + 512, ...)
+    else fold_block_sums_lean<__HIP_MEMORY_SCOPE_SYSTEM>(&mine->rows[0][0], B, s_tot);  // (beyond 2^20 points: thread t folds rows t, t + 512, ...)
     __syncthreads();               // (the descriptor lists are read: the selections may overlay them)
     const unsigned klo = (n - 1) / 2, khi = n / 2;
     if (take) {

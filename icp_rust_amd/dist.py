@@ -300,6 +300,9 @@ class HipStages:
     def device_id(self):
         """what tells two devices of one node apart (ranks that share a device share its L2)"""
         dev = self.torch.cuda.current_device()
+        buf = C.create_string_buffer(64)
+        if lib().icp_device_pci_bus_id(int(dev), buf) == _lib.OK and buf.value:
+            return buf.value.decode(), dev  # (the same for every process that sees this GPU, whatever its ordinal there)
         props = self.torch.cuda.get_device_properties(dev)
         return str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or dev), dev
 

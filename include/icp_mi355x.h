@@ -97,6 +97,9 @@ const char *icp_status_string(int status);
 int icp_abi_version(void);
 /* number of usable HIP devices (0 on a CPU-only host; never initialises a context) */
 int icp_device_count(void);
+/* the PCI bus id of a device ("0000:c1:00.0"): what tells two devices of one node apart whatever ordinal a process sees
+ * them under (the sharded drivers pick the transport of their inboxes by it) */
+int icp_device_pci_bus_id(int device, char out[64]);
 
 /* ================================================================================
  * 1. Host-side pose algebra: Transform / se2 / so2 (tiny, runs on the host exactly as
