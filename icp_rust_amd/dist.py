@@ -483,9 +483,22 @@ class BlockShardedIcp:
     def _loop_run(self, Ti, prev_error, applied, it, first_kind=0, second_kind=1):
         """the inner loop from evaluation `it` on as one launch per local rank; None: nothing was launched, or the
         launch gave up (the loop's state is then the one it was started with, and the stage calls serve from here on)"""
+        import os
+
         L = self._loop
         launch_no = L["launch"] + 1
         rcs = []
+        # TEST HOOK (tests/test_gpu_ipc.py): ICP_DIST_TEST_WITHHOLD="<rank>:<launch>" -- that rank does not launch that
+        # inner loop, i.e. withholds every flag its peers wait for: their launches run into their bounded waits (3 s), raise
+        # abort in every inbox and report it; this rank reports the same; every rank agrees (comm.all_ok below) and the
+        # call starts again through the stage calls + collectives.  Never set outside the test.
+        hook = os.environ.get("ICP_DIST_TEST_WITHHOLD")
+        if hook and not isinstance(self.comm, LocalComm) and self.world > 1:
+            r_h, l_h = (int(x) for x in hook.split(":"))
+            if launch_no == l_h:
+                if self.ranks[0].rank == r_h:
+                    if not self.comm.all_ok(False, like=self.ranks[0].bufs["a"]):
+                        raise _GaveUp()
         for rk in self.ranks:
             nl = self.geom[rk.rank][3]
             rcs.append(rk.stages.loop_launch(rk.bufs["a"][:nl], rk.bufs["b"][:nl], self.n, launch_no, L["evals"], it, applied, Ti,

@@ -19,12 +19,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(world, *args):
+def run_ranks(world, *args, extra_env=None):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, HELPER, *[str(a) for a in args]], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -66,3 +66,17 @@ def test_processes_sharing_a_gpu_exchange_through_mapped_inboxes(world, n, m, ki
             return
         assert all(rc in (0, 4) for rc in rcs) and "gave up" in text, text
     pytest.skip("two processes were not scheduled side by side on this GPU in three attempts (bounded waits gave up)")
+
+
+def test_a_rank_that_withholds_its_flags_sends_every_rank_to_the_stage_calls():
+    """VERDICT r5 item 7b / ADVICE r5: the give-up path on the GPU, with the real kernels.  Rank 1 does not launch its third
+    inner loop (a test hook of the driver: it withholds every flag rank 0 waits for); rank 0's launch runs into its bounded
+    wait, raises abort and reports it; the ranks AGREE on the outcome (one all_reduce) before either uses anything of
+    that launch, drop the inbox paths and their prediction histories, and start the call again through the stage calls +
+    collectives -- the pose and the inner counts must still be one handle's, bit for bit, on both calls of the helper."""
+    rcs, outs = run_ranks(2, 200_000, 200_000, 6, "converging", "auto",
+                          extra_env={"ICP_DIST_TEST_WITHHOLD": "1:3", "ICP_DIST_NO_PIPE": "1"})
+    text = "\n".join(outs)
+    assert all(rc == 0 for rc in rcs), text
+    assert "pose equals one handle's: True" in outs[0], outs[0]
+    assert text.count("forced give-up") == 2, text
