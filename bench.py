@@ -208,10 +208,11 @@ def nn_large(npts, warm_searches=6):
     nn_bytes = 52.0 * npts
     gbs = nn_bytes / per / 1e9 if per > 0 else 0.0
     traffic, tf_src = None, None
-    tf_path = os.path.join(ROOT, "profiles", "r05_traffic_pmc_nn_large.json")
-    if os.path.exists(tf_path) and npts == 16 * 1024 * 1024:
-        traffic = json.load(open(tf_path))["k_nn_grid"]["warm_kernel_bytes_per_launch"]  # (the line times warm searches)
-        tf_src = "profiles/r05_traffic_pmc_nn_large.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/nn_large_only.py)"
+    tf_name = next((f for f in ("r06_traffic_pmc_nn_large.json", "r05_traffic_pmc_nn_large.json")
+                    if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+    if tf_name and npts == 16 * 1024 * 1024:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", tf_name)))["k_nn_grid"]["warm_kernel_bytes_per_launch"]  # (the line times warm searches)
+        tf_src = f"profiles/{tf_name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/nn_large_only.py)"
     return {"points": npts, "kernel": "k_nn_grid_warm_coop", "warm_searches": launches, "first_search_ms": ms1 / max(k1, 1),
             "ms_per_search": 1e3 * per, "algorithmic_bytes_per_launch": nn_bytes, "achieved_GBs": gbs, "peak_GBs": HBM_PEAK_GBS,
             "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tf_src,
@@ -247,30 +248,24 @@ def converging(calls, n, m, nn_mode):
     skipped = I.fixed_point_skips(icp) - skipped0
     steps = calls * MAX_ITER
     steps_run = steps - skipped
-    # ... and what the same call costs with ALL twenty iterations run: the library only leaves out
-    # iterations when two or more remain behind a fixed point, so estimate(f + 2) -- f = the fixed point's iteration --
-    # runs every one of its iterations, the last of them a repeat; twenty of them = that + (18 - f) more repeats
+    # ... and what the same call costs with ALL twenty iterations run: the handle's fixed-point exit
+    # switched off (icp_set_fixed_point_exit, include/icp_mi355x_debug.h) -- same pose, indices and inner counts
     all_run = None
-    if skipped > 0 and skipped % calls == 0:
-        f = MAX_ITER - 2 - skipped // calls
-
-        def timed(k):
-            icp.estimate(d_src, I.Transform(), k)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(calls):
-                icp.estimate(d_src, I.Transform(), k)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t1) / calls
-
+    if skipped > 0 and I.lib().icp_set_fixed_point_exit(icp._h, 0) == 0:
+        Ta, inner_a = icp.estimate(d_src, I.Transform(), MAX_ITER, return_info="inner")
+        torch.cuda.synchronize()
         s0 = I.fixed_point_skips(icp)
-        t_a, t_b = timed(f + 1), timed(f + 2)
-        if I.fixed_point_skips(icp) == s0:  # (nothing was left out of those calls)
-            t_all = t_b + (MAX_ITER - f - 2) * (t_b - t_a)
-            all_run = {"fixed_point_at_iteration": int(f), "ms_per_call": 1e3 * t_all, "ms_per_step": 1e3 * t_all / MAX_ITER,
-                       "ms_per_repeated_iteration": 1e3 * (t_b - t_a),
-                       "how": "estimate(f + 2) runs all its iterations (the library leaves iterations out only when two or more "
-                              "remain behind the fixed point f); twenty = that + (18 - f) x [estimate(f + 2) - estimate(f + 1)]"}
+        t1 = time.perf_counter()
+        for _ in range(calls):
+            icp.estimate(d_src, I.Transform(), MAX_ITER)
+        torch.cuda.synchronize()
+        t_all = (time.perf_counter() - t1) / calls
+        same = bool(np.array_equal(Ta.as_array(), T.as_array()) and np.array_equal(inner_a, inner))
+        all_run = {"ms_per_call": 1e3 * t_all, "ms_per_step": 1e3 * t_all / MAX_ITER, "iterations_left_out": int(I.fixed_point_skips(icp) - s0),
+                   "same_pose_and_inner_counts_as_the_default": same,
+                   "how": "the handle's fixed-point exit switched off (icp_set_fixed_point_exit): every one of the twenty outer "
+                          "iterations runs, also those that repeat the fixed point"}
+        I.lib().icp_set_fixed_point_exit(icp._h, 1)
     icp.close()
     evals = [int(k) + 1 for k in inner]
     evals_run = (sum(evals) * calls - skipped) / max(steps_run, 1)  # (a skipped iteration would have been one evaluation)
@@ -646,7 +641,7 @@ def main():
         # separate passes and committed under profiles/ (a PMC pass cannot run inside this process); only
         # valid for the full-size single-GPU workload it was measured on
         traffic, tf_name = None, None
-        for tf_name in ("r05_traffic_pmc.json", "r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_traffic_pmc.json"):
+        for tf_name in ("r06_traffic_pmc.json", "r05_traffic_pmc.json", "r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_traffic_pmc.json"):
             tf_path = os.path.join(ROOT, "profiles", tf_name)
             if os.path.exists(tf_path):
                 break

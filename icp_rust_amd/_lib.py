@@ -120,6 +120,7 @@ SIGNATURES = {
     "icp_multi_pipe_iterations": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_pipe_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_debug_sort_cells": (C.c_int, [_vp, _sz, C.c_uint, _vp, _vp]),
+    "icp_set_fixed_point_exit": (C.c_int, [_vp, C.c_int]),
     "icp_shard_pipe_run_device": (C.c_int, [_vp, _vp, _sz, _sz, C.c_int, C.c_int, _pp, C.POINTER(_sz), _sz, _vp, _vp,
                                             C.POINTER(C.c_int)]),
     "icp_loop_inbox_bytes": (_sz, []),

@@ -464,6 +464,7 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->owns_dst = false;
     h->nn_mode = ICP_NN_AUTO;
     h->single_launch = true;
+    h->fixed_point_exit = true;
     h->stream = h->own_stream;
     h->profile = 0;
     h->prof_seen = 0;
@@ -548,6 +549,13 @@ static hipError_t launch_nn(icp_handle *h, const double *d_src, size_t n, const 
 extern "C" int icp_set_single_launch(icp_handle *h, int enable) {
   if (!h) return ICP_BAD_ARGUMENT;
   h->single_launch = enable != 0;
+  return ICP_OK;
+}
+// Observability (include/icp_mi355x_debug.h): enable = 0 makes icp_estimate[_device] run every one of its max_iter outer
+// iterations, also those behind a fixed point (same outputs either way: what the benchmark's `all_twenty_run` line times)
+extern "C" int icp_set_fixed_point_exit(icp_handle *h, int enable) {
+  if (!h) return ICP_BAD_ARGUMENT;
+  h->fixed_point_exit = enable != 0;
   return ICP_OK;
 }
 extern "C" int icp_single_launch_counters(icp_handle *h, uint64_t out[3]) {
@@ -1367,7 +1375,7 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
     // kernels serve them return the same bits).  Only the last one still runs: it reports the correspondences.  A
     // settled registration stops paying for the iterations the reference spends re-deriving the same zero update, and
     // a cloud registered against itself (the first frame of examples/scan3d.rs) for twenty rounds of its slowest path.
-    if (inner == 0 && it + 2 < max_iter && memcmp(&T_next, &T, sizeof(Pose)) == 0) {
+    if (h->fixed_point_exit && inner == 0 && it + 2 < max_iter && memcmp(&T_next, &T, sizeof(Pose)) == 0) {
       if (inner_iters)
         for (size_t k = it + 1; k + 1 < max_iter; ++k) inner_iters[k] = 0;
       w.fixed_point_skips += max_iter - 2 - it;

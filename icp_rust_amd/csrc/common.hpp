@@ -398,6 +398,7 @@ struct icp_handle {
   int device = 0;
   int nn_mode = ICP_NN_AUTO;
   bool single_launch = true;  // small clouds: the whole estimate in one launch (icp_set_single_launch)
+  bool fixed_point_exit = true;  // icp_estimate_device leaves out the iterations behind a fixed point (icp_set_fixed_point_exit)
   bool owns_dst = false;
   const double *d_dst = nullptr; // AoS m x dim (the owned copy below, or borrowed)
   double *d_dst_own = nullptr;   // buffer for a host-supplied target cloud

@@ -73,6 +73,12 @@ int icp_multi_loop_counters(const icp_multi *M, uint64_t out[3]);
 int icp_multi_pipe_iterations(const icp_multi *M, uint64_t *out);
 int icp_pipe_counters(icp_handle *h, uint64_t out[4]);
 
+/* enable = 0: icp_estimate[_device] on this handle runs every one of its max_iter outer iterations, also those behind a
+ * fixed point of the loop (the default leaves them out: they repeat the fixed point -- same pose, indices and inner
+ * counts either way).  What bench.py's `converging_pair.all_twenty_run` times.  Large clouds only (the one-launch
+ * registration of clouds of up to 1 024 points has its own exit). */
+int icp_set_fixed_point_exit(icp_handle *h, int enable);
+
 /* The per-call sort of the source points by target-grid cell (csrc/qsort.hip: hand-written LSD radix sort, digits of up to
  * eleven bits) alone, on host arrays: keys_out = the keys ascending, perm_out = their original indices, equal keys in
  * ascending index -- the order icp_last_fold_order documents.  bits: the keys' significant bits (1 .. 32). */

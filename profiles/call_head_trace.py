@@ -18,7 +18,7 @@ else:
     for f in glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True):
         rows += list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("icp::", "")[:46]
+    name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("icp::", "")[:46]
     seeded = [i for i, r in enumerate(rows) if "k_nn_grid_seeded" in r["Kernel_Name"]]
     i0 = seeded[-1]
     # back up to the first kernel of that call: the query-cell kernel

@@ -26,7 +26,7 @@ def read(dirname, counter):
             per_dispatch[key] += float(r["Counter_Value"])  # summed over XCDs / instances
             names[key] = r["Kernel_Name"]
         for key, v in per_dispatch.items():
-            k = re.sub(r"\(.*", "", names[key]).replace("void ", "")
+            k = re.sub(r"\(.*", "", names[key].replace("(anonymous namespace)::", "")).replace("void ", "")
             acc[k][0] += v
             acc[k][1] += 1
     return acc
