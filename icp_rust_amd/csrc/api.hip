@@ -394,7 +394,6 @@ void free_handle(icp_handle *h) {  // really release everything
   (void)hipFree(h->grid.t_cell_new);
   (void)hipFree(h->grid.d_flag);
   (void)hipFree(h->qsort.d_cell_of);
-  (void)hipFree(h->qsort.d_cell);
   (void)hipFree(h->qsort.d_tmp);
   (void)hipFree(h->qsort.d_list);
   (void)hipFree(h->qsort.d_cert_lists);
@@ -1403,11 +1402,17 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
 extern "C" int icp_last_fold_order(icp_handle *h, size_t n, uint32_t *perm, uint32_t *cell) {
   if (!h || n >= 0xffffffffull) return ICP_BAD_ARGUMENT;
   if (n == 0) return ICP_OK;
-  if (h->qsort.fold_n == n && h->qsort.d_perm && h->qsort.d_cell) {
+  if (h->qsort.fold_n == n && h->qsort.d_perm && h->qsort.d_cell_of) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (perm) HIP_TRY(hipMemcpy(perm, h->qsort.d_perm, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (cell) HIP_TRY(hipMemcpy(cell, h->qsort.d_cell, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // (the sort leaves the permutation alone: the sorted keys are the keys gathered through it)
+    std::vector<uint32_t> p(n), c(cell ? n : 0);
+    HIP_TRY(hipMemcpy(p.data(), h->qsort.d_perm, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (cell) {
+      HIP_TRY(hipMemcpy(c.data(), h->qsort.d_cell_of, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      for (size_t k = 0; k < n; ++k) cell[k] = p[k] < n ? c[p[k]] : 0u;
+    }
+    if (perm) memcpy(perm, p.data(), n * sizeof(uint32_t));
     return ICP_OK;
   }
   for (size_t i = 0; i < n; ++i) {

@@ -364,7 +364,6 @@ struct QuerySort {
   const double *src = nullptr;  // the device buffer this snapshot was taken from
   size_t n = 0, cap = 0;
   uint32_t *d_cell_of = nullptr;  // cell of every source point, original order (sort keys in)
-  uint32_t *d_cell = nullptr;     // the same, sorted (sort keys out)
   uint32_t *d_perm = nullptr;     // slot -> original index
   void *d_tmp = nullptr;          // the radix sort's temporary storage
   size_t cap_tmp = 0;
@@ -386,9 +385,9 @@ struct QuerySort {
   unsigned long long cert_searches = 0;
 };
 
-// stable LSD radix sort of (cell, index) pairs by cell (qsort.hip); values in = 0 .. n-1
-hipError_t stable_sort_cells(const uint32_t *keys_in, uint32_t *keys_out, uint32_t *perm_out, unsigned n, unsigned bits,
-                             void *&tmp, size_t &cap_tmp, hipStream_t s);
+// stable LSD radix sort of the indices 0 .. n-1 by cell (qsort.hip): perm_out[k] = index of the k-th point in (cell, index) order
+hipError_t stable_sort_cells(const uint32_t *keys_in, uint32_t *perm_out, unsigned n, unsigned bits, void *&tmp, size_t &cap_tmp,
+                             hipStream_t s);
 
 }  // namespace icp
 

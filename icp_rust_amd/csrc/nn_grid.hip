@@ -2014,7 +2014,7 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   Grid &G = h->grid;
   QuerySort &Q = h->qsort;
   Q.valid = false;
-  Q.fold_n = 0;  // d_perm / d_cell are about to be rewritten: icp_estimate_device declares a fold order AFTER this call
+  Q.fold_n = 0;  // d_perm / d_cell_of are about to be rewritten: icp_estimate_device declares a fold order AFTER this call
   if (!G.built || n_ == 0) return hipSuccess;
   const unsigned n = (unsigned)n_;
   hipError_t e;
@@ -2022,7 +2022,6 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   if (n_ > Q.cap) {
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     (void)hipFree(Q.d_cell_of);
-    (void)hipFree(Q.d_cell);
     (void)hipFree(Q.d_perm);
     (void)hipFree(Q.d_sorted);
     (void)hipFree(Q.d_prev);
@@ -2034,12 +2033,11 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     Q.d_list = nullptr;
     Q.d_cert_lists = nullptr;
     Q.d_cert_ctr = nullptr;
-    Q.d_cell_of = Q.d_cell = Q.d_perm = nullptr;
+    Q.d_cell_of = Q.d_perm = nullptr;
     Q.d_sorted = nullptr;
     Q.cap = 0;
     Q.fold_n = 0;
     if ((e = hipMalloc(&Q.d_cell_of, n_ * 4)) != hipSuccess) return e;
-    if ((e = hipMalloc(&Q.d_cell, n_ * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_perm, n_ * 4)) != hipSuccess) return e;
     // three doubles per point whatever this handle's dimension: the buffers outlive it in the handle
     // pool, and a 2-D owner followed by a 3-D one of the same size must not find them short
@@ -2102,7 +2100,7 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   hipLaunchKernelGGL(k_query_cell, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, h->dim, T, G.p, blk, Q.d_cell_of, xshift);
   unsigned bits = 1;
   while (bits < 32 && (1ull << bits) < keys) ++bits;
-  if ((e = stable_sort_cells(Q.d_cell_of, Q.d_cell, Q.d_perm, n, bits, Q.d_tmp, Q.cap_tmp, s)) != hipSuccess) return e;
+  if ((e = stable_sort_cells(Q.d_cell_of, Q.d_perm, n, bits, Q.d_tmp, Q.cap_tmp, s)) != hipSuccess) return e;
   {
     const size_t pairs = ((size_t)n * h->dim + 1) / 2;
     hipLaunchKernelGGL(k_query_gather, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, d_src, n, h->dim,

@@ -9,6 +9,8 @@
 //   tile      16 384 consecutive items = one workgroup of 16 waves, 1 024 consecutive items per wave
 //   hist      every wave counts the digits of its items (LDS, 16-bit counters packed in pairs); the tile's counts go
 //             to cnt[tile][bin] (a row per tile: coalesced for the writer and for every reader below)
+//   items     between two passes (key, index) pairs travel together: one 8-byte store per item; the last pass stores the
+//             indices alone (the sorted keys are cell_of[perm[k]]: nothing on the path reads them)
 //   scatter   the position of an item = (items of lower bins, all tiles) + (items of its bin in earlier tiles)
 //                                     + (items of its bin in earlier waves of its tile) + (rank among its wave's items of
 //             that bin, in item order).  The first two come straight out of cnt: a workgroup adds up the rows of the
@@ -29,7 +31,10 @@ namespace icp {
 namespace {
 
 constexpr int kRsThreads = 1024, kRsWaves = kRsThreads / 64;
-constexpr int kRsPerWave = 1024, kRsSteps = kRsPerWave / 64;
+#ifndef ICP_RS_PER_WAVE
+#define ICP_RS_PER_WAVE 1024
+#endif
+constexpr int kRsPerWave = ICP_RS_PER_WAVE, kRsSteps = kRsPerWave / 64;
 constexpr unsigned kRsTile = (unsigned)kRsWaves * kRsPerWave;
 constexpr int kRsMaxBits = 11, kRsMaxBins = 1 << kRsMaxBits;
 constexpr unsigned kRsDirectTiles = 128;  // up to here a scatter workgroup adds up the tiles' rows itself
@@ -45,14 +50,23 @@ struct RsLds {
 
 // the waves' digit counts of tile `tile` (every wave its 1 024 items); the lane's sixteen keys stay in registers (all
 // loads in flight at once: a wave per SIMD has nothing else to hide their latency behind)
-__device__ __forceinline__ void rs_count(const uint32_t *__restrict__ keys, unsigned n, unsigned tile, unsigned shift, unsigned dmask,
-                                         RsLds &S, uint32_t (&kreg)[kRsSteps]) {
+// PACKED: the items are (key, index) pairs, as the pass in front left them; else keys alone, the index = the position
+template <bool PACKED>
+__device__ __forceinline__ void rs_count(const void *__restrict__ items, unsigned n, unsigned tile, unsigned shift, unsigned dmask,
+                                         RsLds &S, uint32_t (&kreg)[kRsSteps], uint32_t (&vreg)[kRsSteps]) {
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned base = tile * kRsTile + wave * kRsPerWave + lane;
 #pragma unroll
   for (int st = 0; st < kRsSteps; ++st) {
     const unsigned e = base + 64u * st;
-    kreg[st] = e < n ? keys[e] : 0u;
+    if (PACKED) {
+      const uint2 kv = e < n ? reinterpret_cast<const uint2 *>(items)[e] : make_uint2(0u, 0u);
+      kreg[st] = kv.x;
+      vreg[st] = kv.y;
+    } else {
+      kreg[st] = e < n ? reinterpret_cast<const uint32_t *>(items)[e] : 0u;
+      vreg[st] = e;
+    }
   }
   for (unsigned i = tid; i < (unsigned)kRsWaves * (kRsMaxBins / 2); i += kRsThreads) (&S.cw[0][0])[i] = 0u;
   __syncthreads();
@@ -67,13 +81,14 @@ __device__ __forceinline__ void rs_count(const uint32_t *__restrict__ keys, unsi
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kRsThreads) void k_rs_hist(const uint32_t *__restrict__ keys, unsigned n, unsigned shift, unsigned bits,
+template <bool PACKED>
+__global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void *__restrict__ items, unsigned n, unsigned shift, unsigned bits,
                                                         uint32_t *__restrict__ cnt, unsigned T) {
   extern __shared__ unsigned char rs_raw[];
   RsLds &S = *reinterpret_cast<RsLds *>(rs_raw);
   const unsigned bins = 1u << bits;
-  uint32_t kreg[kRsSteps];
-  rs_count(keys, n, blockIdx.x, shift, bins - 1u, S, kreg);
+  uint32_t kreg[kRsSteps], vreg[kRsSteps];
+  rs_count<PACKED>(items, n, blockIdx.x, shift, bins - 1u, S, kreg, vreg);
   const unsigned j = threadIdx.x;  // bins 2 j, 2 j + 1
   if (2u * j < bins) {
     unsigned lo = 0, hi = 0;
@@ -118,25 +133,18 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_chunks(const uint32_t *__rest
 }
 
 // CHUNKED: more than kRsDirectTiles tiles -- ctot holds the rows of cnt added up per chunk of kRsChunk tiles
-template <bool CHUNKED>
-__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                           unsigned n, unsigned shift, unsigned bits, const uint32_t *__restrict__ cnt,
-                                                           const uint32_t *__restrict__ ctot, unsigned T,
-                                                           uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+// IN_PACKED / OUT_PACKED: (key, index) pairs between the passes -- one 8-byte store per item instead of two of four;
+// the LAST pass stores the indices alone (the sorted keys are cell_of[perm[k]]: nobody on the path reads them)
+template <bool CHUNKED, bool IN_PACKED, bool OUT_PACKED>
+__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const void *__restrict__ items, unsigned n, unsigned shift, unsigned bits,
+                                                           const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ ctot,
+                                                           unsigned T, void *__restrict__ out) {
   extern __shared__ unsigned char rs_raw[];
   RsLds &S = *reinterpret_cast<RsLds *>(rs_raw);
   const unsigned bins = 1u << bits, dmask = bins - 1u, tile = blockIdx.x;
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   uint32_t kreg[kRsSteps], vreg[kRsSteps];
-  {
-    const unsigned base0 = tile * kRsTile + wave * kRsPerWave + lane;
-#pragma unroll
-    for (int st = 0; st < kRsSteps; ++st) {
-      const unsigned e = base0 + 64u * st;
-      vreg[st] = (vals && e < n) ? vals[e] : e;
-    }
-  }
-  rs_count(keys, n, tile, shift, dmask, S, kreg);
+  rs_count<IN_PACKED>(items, n, tile, shift, dmask, S, kreg, vreg);
   {
     // the tile's bins 2 j, 2 j + 1: counts per wave -> exclusive prefix over the waves; where the tile's items of these bins
     // start in the output
@@ -203,8 +211,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
     const uint32_t word = S.cw[wave][d >> 1];
     const unsigned pos = S.gbase[d] + ((word >> (16u * (d & 1u))) & 0xffffu) + (unsigned)__popcll(below);
     if (valid) {
-      keys_out[pos] = key;
-      vals_out[pos] = val;
+      if (OUT_PACKED) reinterpret_cast<uint2 *>(out)[pos] = make_uint2(key, val);
+      else reinterpret_cast<uint32_t *>(out)[pos] = val;
       if (below == 0ull) atomicAdd(&S.cw[wave][d >> 1], (unsigned)__popcll(same) << (16u * (d & 1u)));  // (one lane per digit)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next step reads the counters this one advanced: same wave, in order)
@@ -213,10 +221,23 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
 
 }  // namespace
 
-// stable LSD radix sort of (key, index) pairs by key; values in = 0 .. n-1.  `bits`: the keys' significant bits.
-// tmp: grow-only scratch of the handle (a second pair of arrays, the counts, the scan's block totals).
-hipError_t stable_sort_cells(const uint32_t *keys_in, uint32_t *keys_out, uint32_t *perm_out, unsigned n, unsigned bits,
-                             void *&tmp, size_t &cap_tmp, hipStream_t s) {
+// stable LSD radix sort of the indices 0 .. n-1 by key: perm_out[k] = the index of the k-th item in ascending (key, index)
+// order.  `bits`: the keys' significant bits.  tmp: grow-only scratch of the handle (two arrays of pairs, the counts).
+namespace {
+template <bool CH, bool IP, bool OP>
+void rs_launch_scatter(unsigned T, hipStream_t s, const void *in, unsigned n, unsigned shift, unsigned d, const uint32_t *cnt,
+                       const uint32_t *ctot, void *out) {
+  hipLaunchKernelGGL((k_rs_scatter<CH, IP, OP>), dim3(T), dim3(kRsThreads), sizeof(RsLds), s, in, n, shift, d, cnt, ctot, T, out);
+}
+template <bool CH, bool IP, bool OP>
+bool rs_grant() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rs_scatter<CH, IP, OP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)sizeof(RsLds)) == hipSuccess;
+}
+}  // namespace
+
+hipError_t stable_sort_cells(const uint32_t *keys_in, uint32_t *perm_out, unsigned n, unsigned bits, void *&tmp, size_t &cap_tmp,
+                             hipStream_t s) {
   if (n == 0) return hipSuccess;
   if (bits < 1) bits = 1;
   if (bits > 32) bits = 32;
@@ -225,7 +246,7 @@ hipError_t stable_sort_cells(const uint32_t *keys_in, uint32_t *keys_out, uint32
   if (T > kRsMaxTiles) return hipErrorInvalidValue;  // (134M items: a third level of row sums would be next)
   const size_t cnt_words = (size_t)kRsMaxBins * T;
   const unsigned nc = (T + kRsChunk - 1) / kRsChunk;
-  const size_t need = ((size_t)2 * n + cnt_words + (size_t)kRsMaxBins * nc + 64) * sizeof(uint32_t);
+  const size_t need = ((size_t)4 * n + cnt_words + (size_t)kRsMaxBins * nc + 64) * sizeof(uint32_t);
   hipError_t e;
   if (need > cap_tmp || !tmp) {
     if (tmp) {
@@ -243,32 +264,40 @@ hipError_t stable_sort_cells(const uint32_t *keys_in, uint32_t *keys_out, uint32
   (void)hipGetDevice(&dev);
   signed char &granted = lds_granted[(unsigned)dev % 64u];
   if (granted == 0) {
-    bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rs_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RsLds)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rs_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RsLds)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rs_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RsLds)) == hipSuccess;
+    bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rs_hist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RsLds)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rs_hist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RsLds)) == hipSuccess;
+    ok = ok && rs_grant<false, false, false>() && rs_grant<false, false, true>() && rs_grant<false, true, false>() && rs_grant<false, true, true>();
+    ok = ok && rs_grant<true, false, false>() && rs_grant<true, false, true>() && rs_grant<true, true, false>() && rs_grant<true, true, true>();
     granted = ok ? 1 : -1;
     if (!ok) (void)hipGetLastError();
   }
   if (granted < 0) return hipErrorInvalidValue;
-  uint32_t *tmp_k = reinterpret_cast<uint32_t *>(tmp), *tmp_v = tmp_k + n, *cnt = tmp_v + n, *ctot = cnt + cnt_words;
-  // the passes ping-pong between the output arrays and the scratch pair so that the LAST pass writes the output
-  const uint32_t *kin = keys_in, *vin = nullptr;
+  uint2 *pairs_a = reinterpret_cast<uint2 *>(tmp), *pairs_b = pairs_a + n;
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(pairs_b + n), *ctot = cnt + cnt_words;
+  // pass p reads what pass p - 1 wrote (pairs, alternating between the two scratch arrays); the first reads the keys,
+  // the last writes the indices
+  const void *in = keys_in;
   unsigned shift = 0;
   for (unsigned p = 0; p < passes; ++p) {
     const unsigned left = bits - shift, d = (left + (passes - p) - 1) / (passes - p);  // the remaining bits, evenly
-    const bool to_out = ((passes - 1 - p) % 2u) == 0u;
-    uint32_t *kout = to_out ? keys_out : tmp_k, *vout = to_out ? perm_out : tmp_v;
-    hipLaunchKernelGGL(k_rs_hist, dim3(T), dim3(kRsThreads), sizeof(RsLds), s, kin, n, shift, d, cnt, T);
-    if (T > kRsDirectTiles) {
-      hipLaunchKernelGGL(k_rs_chunks, dim3(nc), dim3(kRsThreads), 0, s, (const uint32_t *)cnt, T, d, ctot);
-      hipLaunchKernelGGL(k_rs_scatter<true>, dim3(T), dim3(kRsThreads), sizeof(RsLds), s, kin, vin, n, shift, d, (const uint32_t *)cnt,
-                         (const uint32_t *)ctot, T, kout, vout);
+    const bool first = p == 0, last = p + 1 == passes, chunked = T > kRsDirectTiles;
+    void *out = last ? static_cast<void *>(perm_out) : static_cast<void *>((p & 1u) ? pairs_b : pairs_a);
+    if (first) hipLaunchKernelGGL(k_rs_hist<false>, dim3(T), dim3(kRsThreads), sizeof(RsLds), s, in, n, shift, d, cnt, T);
+    else hipLaunchKernelGGL(k_rs_hist<true>, dim3(T), dim3(kRsThreads), sizeof(RsLds), s, in, n, shift, d, cnt, T);
+    if (chunked) hipLaunchKernelGGL(k_rs_chunks, dim3(nc), dim3(kRsThreads), 0, s, (const uint32_t *)cnt, T, d, ctot);
+    const uint32_t *cc = cnt, *ct = chunked ? ctot : nullptr;
+    if (chunked) {
+      if (first && last) rs_launch_scatter<true, false, false>(T, s, in, n, shift, d, cc, ct, out);
+      else if (first) rs_launch_scatter<true, false, true>(T, s, in, n, shift, d, cc, ct, out);
+      else if (last) rs_launch_scatter<true, true, false>(T, s, in, n, shift, d, cc, ct, out);
+      else rs_launch_scatter<true, true, true>(T, s, in, n, shift, d, cc, ct, out);
     } else {
-      hipLaunchKernelGGL(k_rs_scatter<false>, dim3(T), dim3(kRsThreads), sizeof(RsLds), s, kin, vin, n, shift, d, (const uint32_t *)cnt,
-                         (const uint32_t *)nullptr, T, kout, vout);
+      if (first && last) rs_launch_scatter<false, false, false>(T, s, in, n, shift, d, cc, ct, out);
+      else if (first) rs_launch_scatter<false, false, true>(T, s, in, n, shift, d, cc, ct, out);
+      else if (last) rs_launch_scatter<false, true, false>(T, s, in, n, shift, d, cc, ct, out);
+      else rs_launch_scatter<false, true, true>(T, s, in, n, shift, d, cc, ct, out);
     }
-    kin = kout;
-    vin = vout;
+    in = out;
     shift += d;
   }
   return hipGetLastError();
@@ -281,19 +310,18 @@ hipError_t stable_sort_cells(const uint32_t *keys_in, uint32_t *keys_out, uint32
 extern "C" int icp_debug_sort_cells(const uint32_t *keys, size_t n, unsigned bits, uint32_t *keys_out, uint32_t *perm_out) {
   if ((n > 0 && (!keys || !keys_out || !perm_out)) || n >= 0xffff0000ull) return 4;  // ICP_BAD_ARGUMENT
   if (n == 0) return 0;
-  uint32_t *d_in = nullptr, *d_k = nullptr, *d_p = nullptr;
+  uint32_t *d_in = nullptr, *d_p = nullptr;
   void *tmp = nullptr;
   size_t cap = 0;
   hipError_t e = hipMalloc(&d_in, n * 4);
-  if (e == hipSuccess) e = hipMalloc(&d_k, n * 4);
   if (e == hipSuccess) e = hipMalloc(&d_p, n * 4);
   if (e == hipSuccess) e = hipMemcpy(d_in, keys, n * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = icp::stable_sort_cells(d_in, d_k, d_p, (unsigned)n, bits, tmp, cap, nullptr);
+  if (e == hipSuccess) e = icp::stable_sort_cells(d_in, d_p, (unsigned)n, bits, tmp, cap, nullptr);
   if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (e == hipSuccess) e = hipMemcpy(keys_out, d_k, n * 4, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(perm_out, d_p, n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess)
+    for (size_t k = 0; k < n; ++k) keys_out[k] = perm_out[k] < n ? keys[perm_out[k]] : 0xffffffffu;  // (the sort leaves the indices)
   (void)hipFree(d_in);
-  (void)hipFree(d_k);
   (void)hipFree(d_p);
   (void)hipFree(tmp);
   return e == hipSuccess ? 0 : 6;  // ICP_OK / ICP_HIP_ERROR
