@@ -98,6 +98,7 @@ SIGNATURES = {
     "icp_materialize_pairs_device": (C.c_int, [_vp, _vp, _sz, _pp, _vp, _vp, _vp]),
     "icp_prepare_source_device": (C.c_int, [_vp, _vp, _sz, _pp]),
     "icp_shard_prepare_source_device": (C.c_int, [_vp, _vp, _sz, _pp]),
+    "icp_shard_sort_take_device": (C.c_int, [_vp, _vp, _sz, _pp, C.c_int, C.c_int, _vp, _vp]),
     "icp_estimate_transform_device": (C.c_int, [_vp, _vp, _vp, _sz, _pp, _vp]),
     "icp_nn_search_device": (C.c_int, [_vp, _vp, _sz, _vp]),
     "icp_weighted_gn_step_device": (C.c_int, [_vp, _vp, _vp, _sz, _pp, C.c_int, _dp, _dp]),

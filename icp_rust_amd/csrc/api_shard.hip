@@ -20,6 +20,11 @@
 using namespace icp;
 using namespace icp::api;
 
+namespace icp {
+__global__ void k_iota_u32(uint32_t *p, unsigned n);  // (api.hip)
+long grid_coop_max();
+}
+
 // ---- ... and over the ranks of a sharded registration (include/icp_mi355x.h section 5b) ---------------------------------
 extern "C" size_t icp_loop_inbox_bytes(void) { return sizeof(LoopInbox); }
 
@@ -380,6 +385,45 @@ extern "C" int icp_shard_prepare_source_device(icp_handle *h, const double *d_sr
   const int rc = icp_prepare_source_device(h, d_src_local, n_local, T);
   h->qsort.presorted = false;
   return rc;
+}
+
+// A rank's points of a sharded registration in ONE call: the fold order of the whole cloud under pose T (the sort of
+// icp_sort_source_device: every rank computes the same permutation from the same inputs) and this rank's points gathered
+// through it -- no sorted copy of the whole cloud (at N x 1M points that copy and its gather were a third of a call's head).
+// d_perm (nullable, n_total words): the permutation, for whoever wants to put results back into the caller's order.
+// Where one handle keeps the caller's order (sweep engine, up to 65 536 points) the permutation is the identity.
+extern "C" int icp_shard_sort_take_device(icp_handle *h, const double *d_src_full, size_t n_total, const icp_pose *T, int rank, int world,
+                                          double *d_local, uint32_t *d_perm) {
+  if (!h || !T || world < 1 || world > kShardMaxWorld || rank < 0 || rank >= world || n_total >= 0xffffffffull ||
+      (n_total > 0 && !d_src_full))
+    return ICP_BAD_ARGUMENT;
+  if (n_total == 0) return ICP_OK;
+  {
+    int b0, b1, blocks;
+    size_t n_local;
+    shard_geometry(n_total, rank, world, &b0, &b1, &blocks, &n_local);
+    if (n_local > 0 && !d_local) return ICP_BAD_ARGUMENT;  // (more ranks than tree blocks: a rank without points has no buffer)
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const unsigned words = (unsigned)(h->dim * 2);
+  bool sorted = false;
+  if ((long)n_total > grid_coop_max() && resolved_nn_mode(h) == ICP_NN_GRID) {  // (exactly where icp_estimate_device folds in snapshot order)
+    h->qsort.sort_only = true;
+    const int prc = icp_prepare_source_device(h, d_src_full, n_total, T);
+    sorted = prc == ICP_OK && !h->qsort.sort_only && h->qsort.src == d_src_full && h->qsort.n == n_total && !h->qsort.valid;
+    h->qsort.sort_only = false;
+    if (prc != ICP_OK) return prc;
+  }
+  if (sorted) {
+    HIP_TRY(launch_shard_take_perm(h, d_src_full, h->qsort.d_perm, d_local, n_total, rank, world, words));
+    if (d_perm) HIP_TRY(hipMemcpyAsync(d_perm, h->qsort.d_perm, n_total * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    HIP_TRY(launch_shard_copy(h, d_src_full, d_local, n_total, rank, world, words, true));
+    if (d_perm) hipLaunchKernelGGL(icp::k_iota_u32, dim3(((unsigned)n_total + 255) / 256), dim3(256), 0, h->stream, d_perm, (unsigned)n_total);
+  }
+  h->qsort.valid = false;
+  h->qsort.have_prev = false;
+  return ICP_OK;
 }
 
 extern "C" int icp_shard_take_device(icp_handle *h, const void *d_full, void *d_local, size_t n_total, int rank, int world,

@@ -36,11 +36,11 @@ struct Range {
 constexpr int kReduceThreads = 512;   // threads per block of the GN reduction tree
 constexpr int kReduceMaxBlocks = 256;  // blocks of the tree up to 2^20 points (one per CU), and of ONE rank's share beyond
 // Round 6: beyond 2^20 points the tree GROWS with the cloud -- a block per 4 096 points (eight per thread, as at 2^20),
-// up to kTreeMaxBlocks -- instead of keeping 256 blocks whose threads fold more and more points: a rank of an N-GPU
+// up to kTreeMaxBlocks (2^23 points: eight ranks' 1M each; larger clouds fold more per thread again) -- instead of keeping 256 blocks whose threads fold more and more points: a rank of an N-GPU
 // registration of N x 1M points then owns 256 blocks and evaluates on all its CUs, with the launches one GPU runs on 1M
 // points.  The second stage folds the block sums as before: thread t of one 512-thread block takes
 // rows t, t + 512, ...  Bits of clouds beyond 2^20 points changed once with this.
-constexpr int kTreeMaxBlocks = 4096;
+constexpr int kTreeMaxBlocks = 2048;
 constexpr int kShardMaxWorld = 16;  // ranks of one sharded evaluation (a node has 8 GPUs)
 constexpr int kNAcc = 13;             // what a weighted evaluation hands the host: jtj[9], jtr[3], huber error
 // Round 3: the device folds the weighted normal equations PER DIMENSION j, WITHOUT the factor g_j = 1 / sigma_j, and
@@ -360,6 +360,7 @@ struct QuerySort {
   bool slot_order = false;
   bool identity = false;       // the snapshot keeps the caller's order (no sort: clouds of up to ICP_NN_COOP_MAX_N points)
   bool presorted = false;      // one-shot hint: the next snapshot's cloud is already in cell order (a rank's slice of a sorted cloud)
+  bool sort_only = false;      // one-shot: the next prepare_queries only sorts (d_perm; no sorted copy, no snapshot): icp_shard_sort_take_device
   size_t fold_n = 0;           // > 0: d_perm / d_cell hold the fold order of the last estimate call on fold_n points
   const double *src = nullptr;  // the device buffer this snapshot was taken from
   size_t n = 0, cap = 0;
@@ -551,6 +552,8 @@ hipError_t launch_win_second_pass(icp_handle *h, const double *d_a, size_t n, co
 void shard_geometry(size_t n_total, int rank, int world, int *b0, int *b1, int *blocks, size_t *n_local);
 hipError_t launch_shard_copy(icp_handle *h, const void *src, void *dst, size_t n_total, int rank, int world,
                              unsigned words, bool take);
+hipError_t launch_shard_take_perm(icp_handle *h, const void *src, const uint32_t *perm, void *dst, size_t n_total, int rank, int world,
+                                  unsigned words);
 size_t shard_cand_bytes();
 int shard_part_rows(int world);
 size_t shard_part_bytes(int world);

@@ -2101,6 +2101,12 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
   unsigned bits = 1;
   while (bits < 32 && (1ull << bits) < keys) ++bits;
   if ((e = stable_sort_cells(Q.d_cell_of, Q.d_perm, n, bits, Q.d_tmp, Q.cap_tmp, s)) != hipSuccess) return e;
+  if (Q.sort_only) {  // (a rank of a sharded registration wants the fold order of the WHOLE cloud, and only its own points out of it)
+    Q.sort_only = false;
+    Q.src = d_src;
+    Q.n = n_;
+    return hipGetLastError();  // (Q.valid stays false: no snapshot)
+  }
   {
     const size_t pairs = ((size_t)n * h->dim + 1) / 2;
     hipLaunchKernelGGL(k_query_gather, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, d_src, n, h->dim,

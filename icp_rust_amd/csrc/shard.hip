@@ -76,6 +76,25 @@ __global__ void k_shard_put(const uint32_t *__restrict__ local, uint32_t *__rest
   for (unsigned k = 0; k < words; ++k) full[i * words + k] = local[l * words + k];
 }
 
+// ... straight out of the UNSORTED cloud through the fold order's permutation: local[l] = src[perm[global index of l]]
+__global__ void k_shard_take_perm(const uint32_t *__restrict__ full, const uint32_t *__restrict__ perm, uint32_t *__restrict__ local,
+                                  size_t n_local, unsigned b0, unsigned b1, unsigned B, unsigned words) {
+  const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_local) return;
+  const size_t i = perm[shard_global_index(l, b0, b1, B)];
+  for (unsigned k = 0; k < words; ++k) local[l * words + k] = full[i * words + k];
+}
+hipError_t launch_shard_take_perm(icp_handle *h, const void *src, const uint32_t *perm, void *dst, size_t n_total, int rank, int world,
+                                  unsigned words) {
+  int b0, b1, B;
+  size_t n_local;
+  shard_geometry(n_total, rank, world, &b0, &b1, &B, &n_local);
+  if (n_local == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_shard_take_perm, dim3((unsigned)((n_local + 255) / 256)), dim3(256), 0, h->stream, (const uint32_t *)src, perm,
+                     (uint32_t *)dst, n_local, (unsigned)b0, (unsigned)b1, (unsigned)B, words);
+  return hipGetLastError();
+}
+
 hipError_t launch_shard_copy(icp_handle *h, const void *src, void *dst, size_t n_total, int rank, int world,
                              unsigned words, bool take) {
   int b0, b1, B;

@@ -199,6 +199,15 @@ class HipStages:
     def estimate_transform(self, a_full, b_full):
         return self.icp.estimate_transform_device(a_full, b_full)
 
+    def sort_take(self, src_full, T, n_total, rank, world, n_local):
+        """(this rank's points in fold order, permutation of the whole cloud): icp_shard_sort_take_device -- the sort of
+        sort_source without the sorted copy of the whole cloud"""
+        loc = self.torch.empty((max(n_local, 1), src_full.shape[1]), dtype=self.torch.float64, device=src_full.device)[:n_local]
+        perm = self.torch.empty(max(n_total, 1), dtype=self.torch.int32, device=src_full.device)
+        _lib.check(lib().icp_shard_sort_take_device(self.icp._h, C.c_void_p(src_full.data_ptr()), n_total, C.byref(T.pose), rank, world,
+                                                    C.c_void_p(loc.data_ptr()), C.c_void_p(perm.data_ptr())), "icp_shard_sort_take_device")
+        return loc, perm[:n_total]
+
     def sort_source(self, src_full, T):
         """(sorted cloud, permutation): the fold order of a one-GPU estimate call that starts at T
         (icp_sort_source_device); every rank computes the same one from the same inputs"""
@@ -570,8 +579,16 @@ class BlockShardedIcp:
     def estimate_full(self, src_full_by_rank, initial_transform, max_iter):
         """Icp::estimate from the full source cloud, as one GPU runs it: fold order, shard, iterate.
         Returns (T, inner, {rank: permutation of the fold order or None})."""
-        srt, perms = self.sort_source(src_full_by_rank, initial_transform)
-        local = self.take_source(srt)
+        if all(hasattr(rk.stages, "sort_take") for rk in self.ranks):
+            # (the fold order of the whole cloud and the rank's points gathered through it: no sorted copy of the whole cloud)
+            local, perms = {}, {}
+            for rk in self.ranks:
+                full = src_full_by_rank[rk.rank] if isinstance(src_full_by_rank, dict) else src_full_by_rank
+                local[rk.rank], perms[rk.rank] = rk.stages.sort_take(full, initial_transform, self.n, rk.rank, self.world,
+                                                                      self.geom[rk.rank][3])
+        else:
+            srt, perms = self.sort_source(src_full_by_rank, initial_transform)
+            local = self.take_source(srt)
         self._presorted = all(p is not None for p in perms.values())  # (the ranks' slices are runs of the sorted cloud)
         try:
             T, inner = self.estimate(local, initial_transform, max_iter)

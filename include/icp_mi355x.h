@@ -272,6 +272,10 @@ size_t icp_shard_partials_bytes(int world);  /* ... then the block sums */
 size_t icp_shard_exchange_bytes(int world);  /* = the two together */
 int icp_shard_take_device(icp_handle *h, const void *d_full, void *d_local, size_t n_total, int rank, int world,
                           size_t elem_bytes);
+/* icp_sort_source_device + icp_shard_take_device in one: the fold order of the WHOLE cloud under pose T and this rank's
+ * points gathered through it, without a sorted copy of the whole cloud.  d_perm: nullable (n_total words). */
+int icp_shard_sort_take_device(icp_handle *h, const double *d_src_full, size_t n_total, const icp_pose *T, int rank, int world,
+                               double *d_local, uint32_t *d_perm);
 /* icp_prepare_source_device for a rank's points as icp_shard_take_device compacts them out of the fold order: runs of
  * the cell-sorted cloud, whose order the search snapshot keeps (no second sort) */
 int icp_shard_prepare_source_device(icp_handle *h, const double *d_src_local, size_t n_local, const icp_pose *T);

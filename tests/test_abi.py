@@ -95,10 +95,10 @@ def test_reduce_geometry():
     assert b1 == 1 and t % 64 == 0
     assert I.reduce_geometry(t + 1) == (2, t)
     # up to 2^20 points: a block per `t` points, at most 256 (one per CU); beyond: a block per 8 t points (the tree grows
-    # with the cloud -- a rank of N x 1M points owns 256 blocks), at most 4 096
+    # with the cloud -- a rank of N x 1M points owns 256 blocks), at most 2 048 (eight ranks' 1M each)
     assert I.reduce_geometry(10**6)[0] == min((10**6 + t - 1) // t, 256) and I.reduce_geometry(1 << 20)[0] == 256
     assert I.reduce_geometry((1 << 20) + 1)[0] == 257 and I.reduce_geometry(8 << 20)[0] == 2048
-    assert I.reduce_geometry(10**9)[0] == 4096
+    assert I.reduce_geometry(10**9)[0] == 2048
 
 
 @pytest.mark.skipif(I.lib().icp_device_count() > 0, reason="a GPU is present")
