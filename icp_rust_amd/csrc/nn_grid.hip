@@ -1867,11 +1867,15 @@ __device__ __forceinline__ PrevMatch seed_match(const unsigned k, const double *
       qf[d] = (float)(q[d] - g.lo[d]);
       c[d] = (int)fminf(fmaxf(__builtin_floorf(qf[d] * (float)g.inv_h[d]), 0.f), (float)(g.n[d] - 1));
     }
-    const int hx = g.fx > 1 ? g.fx / 2 : 1;
+    // (round 6, profiles/r06_cold_search_ab.txt: a quarter of a cubic cell either way and eight records in flight --
+    // 113.4 -> 103.4 us for the first search of a 1M-point call; half a cell / four records was round 4's)
+    constexpr int kSeedDiv = 4;
+    constexpr uint32_t kSeedBatch = 8;
+    const int hx = g.fx > kSeedDiv ? g.fx / kSeedDiv : 1;
     float best = __builtin_huge_valf();
     uint32_t bi = 0xffffffffu, any = 0xffffffffu;  // any: a finite target whose screened distance overflowed f32
     // blocks of cells growing around the query's own until one holds a record (the first: its own row,
-    // half a cubic cell either way along x)
+    // a quarter of a cubic cell either way along x)
     for (int r = 0;; ++r) {
       const int wx = r * g.fx + hx;
       const int x0 = max(c[0] - wx, 0), x1 = min(c[0] + wx, g.n[0] - 1);
@@ -1881,14 +1885,14 @@ __device__ __forceinline__ PrevMatch seed_match(const unsigned k, const double *
         for (int iy = y0; iy <= y1; ++iy) {
           const uint32_t rb = ((uint32_t)iz * g.n[1] + iy) * g.n[0];
           const uint32_t s0 = start[rb + x0], e0 = start[rb + x1 + 1];
-          // four records in flight (a run is a handful of records; one by one each load waited out the one before:
+          // several records in flight (a run is a handful of records; one by one each load waited out the one before:
           // 113 us per 1M queries); a slot past the run repeats its last record, which changes nothing
-          for (uint32_t j0 = s0; j0 < e0; j0 += 4) {
-            uint4 wv[4];
+          for (uint32_t j0 = s0; j0 < e0; j0 += kSeedBatch) {
+            uint4 wv[kSeedBatch];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) wv[u] = reinterpret_cast<const uint4 *>(pts)[min(j0 + u, e0 - 1)];
+            for (uint32_t u = 0; u < kSeedBatch; ++u) wv[u] = reinterpret_cast<const uint4 *>(pts)[min(j0 + u, e0 - 1)];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kSeedBatch; ++u) {
               const uint4 w = wv[u];
               const float fx = qf[0] - __uint_as_float(w.x), fy = qf[1] - __uint_as_float(w.y);
               const float fz = DIM == 3 ? qf[2] - __uint_as_float(w.z) : 0.f;
