@@ -19,7 +19,7 @@ else:
         rows += list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("icp::", "")[:46]
-    seeded = [i for i, r in enumerate(rows) if "k_nn_grid_seeded" in r["Kernel_Name"]]
+    seeded = [i for i, r in enumerate(rows) if "k_nn_grid_seeded" in r["Kernel_Name"] or "k_nn_grid_seed<" in r["Kernel_Name"]]
     i0 = seeded[-1]
     # back up to the first kernel of that call: the query-cell kernel
     while i0 > 0 and "k_nn_grid_warm_coop" not in rows[i0 - 1]["Kernel_Name"] and "k_unpermute" not in rows[i0 - 1]["Kernel_Name"] and "k_win" not in rows[i0 - 1]["Kernel_Name"]:
