@@ -144,7 +144,6 @@ SIGNATURES = {
     "icp_profile_enable": (C.c_int, [_vp, C.c_int]),
     "icp_profile_read": (C.c_int, [_vp, _dp, C.POINTER(C.c_uint64)]),
     "icp_reduce_geometry": (None, [_sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "icp_nn_tile_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_nn_cert_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "icp_multi_append_targets": (C.c_int, [_vp, _vp, _sz, _pp]),
     "icp_multi_target_count": (_sz, [_vp]),

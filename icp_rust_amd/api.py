@@ -309,13 +309,6 @@ def run_ahead_counters(icp):
     return tuple(int(x) for x in out)
 
 
-def nn_tile_counters(icp):
-    """(waves launched, waves handed to the per-lane gather walk) of the handle's last LDS-tile search"""
-    out = (C.c_uint64 * 2)()
-    check(lib().icp_nn_tile_counters(icp._h, out), "icp_nn_tile_counters")
-    return int(out[0]), int(out[1])
-
-
 def nn_cert_counters(icp):
     """(searches that checked certificates so far, queries whose certificate failed in the last of them)"""
     out = (C.c_uint64 * 2)()

@@ -395,7 +395,6 @@ void free_handle(icp_handle *h) {  // really release everything
   (void)hipFree(h->grid.d_flag);
   (void)hipFree(h->qsort.d_cell_of);
   (void)hipFree(h->qsort.d_tmp);
-  (void)hipFree(h->qsort.d_list);
   (void)hipFree(h->qsort.d_cert_lists);
   (void)hipFree(h->qsort.d_cert_ctr);
   (void)hipFree(h->qsort.d_perm);
@@ -475,7 +474,6 @@ extern "C" void icp_destroy(icp_handle *h) {
     h->qsort.fold_n = 0;
     h->qsort.last_cert_ctr = nullptr;  // (observability of the previous owner's searches)
     h->qsort.cert_searches = 0;
-    h->qsort.last_waves = 0;
     h->qsort.have_certs = false;
     h->shard.active = false;
     h->shard.refined_ready = h->shard.attempt_refined = false;
@@ -1419,21 +1417,6 @@ extern "C" int icp_last_fold_order(icp_handle *h, size_t n, uint32_t *perm, uint
     if (perm) perm[i] = (uint32_t)i;
     if (cell) cell[i] = 0;
   }
-  return ICP_OK;
-}
-
-// Observability: the last LDS-tile search of `h` (nn_tile.hip) -- out[0] = waves it launched, out[1] = waves it
-// handed to the per-lane gather walk (unions beyond the LDS budget).  Zeros if no such search ran.
-extern "C" int icp_nn_tile_counters(icp_handle *h, uint64_t out[2]) {
-  if (!h || !out) return ICP_BAD_ARGUMENT;
-  out[0] = out[1] = 0;
-  if (!h->qsort.d_list || h->qsort.last_waves == 0) return ICP_OK;
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  std::vector<uint32_t> flags(h->qsort.last_waves);
-  HIP_TRY(hipMemcpy(flags.data(), h->qsort.d_list, flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  out[0] = h->qsort.last_waves;
-  for (uint32_t f : flags) out[1] += f != 0;
   return ICP_OK;
 }
 

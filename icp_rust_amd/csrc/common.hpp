@@ -368,9 +368,6 @@ struct QuerySort {
   uint32_t *d_perm = nullptr;     // slot -> original index
   void *d_tmp = nullptr;          // the radix sort's temporary storage
   size_t cap_tmp = 0;
-  // nn_tile.hip: a flag per wave of 64 queries -- set when the LDS-tile search hands the wave to the gather walk
-  uint32_t *d_list = nullptr;
-  unsigned last_waves = 0;
   bool have_prev = false;      // d_prev holds the matches of an earlier search of this snapshot
   PrevMatch *d_prev = nullptr; // per sorted slot: the last match (idx = ~0u: none)
   double *d_sorted = nullptr;
@@ -476,8 +473,6 @@ hipError_t build_grid(icp_handle *h);
 hipError_t append_grid(icp_handle *h, size_t m_old, size_t k, bool *done);
 hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n, const Pose &T);
 long grid_coop_max();
-hipError_t launch_nn_tile(icp_handle *h, const double *q_src, const uint32_t *q_perm, unsigned n, const Pose &T,
-                          uint32_t *d_idx, double2 *d_a, double2 *d_b);
 hipError_t launch_unpermute_idx(icp_handle *h, const uint32_t *d_slot_idx, size_t n, uint32_t *d_out);
 hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n, const Pose *T, double *d_a,
                           double *d_b, uint32_t *d_idx);

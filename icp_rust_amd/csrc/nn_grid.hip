@@ -1799,36 +1799,6 @@ __global__ __launch_bounds__(kGridThreads) ICP_WARM_ATTR void k_nn_walk_lists(
   warm_query<DIM, true>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev, cd);
 }
 
-#ifdef ICP_EXPERIMENTS  // (serves nn_tile.hip)
-// The same search for the waves the tile kernel (nn_tile.hip) handed back (a flag per wave): one workgroup
-// per wave of queries, the unflagged ones leave at once.
-template <int DIM>
-__global__ __launch_bounds__(kGridThreads) void k_nn_grid_warm_flagged(const double *__restrict__ src,
-                                                                       const uint32_t *__restrict__ perm, unsigned n, Pose T,
-                                                                       GridParams g, const uint32_t *__restrict__ start,
-                                                                       const GridPoint *__restrict__ pts,
-                                                                       const double *__restrict__ dst,
-                                                                       uint32_t *__restrict__ idx, double2 *__restrict__ a,
-                                                                       double2 *__restrict__ b, PrevMatch *prev,
-                                                                       const uint32_t *__restrict__ flags) {
-  if (flags[blockIdx.x] == 0u) return;
-  const unsigned k = blockIdx.x * kGridThreads + threadIdx.x;
-  if (k < n) warm_query<DIM>(k, src, perm, T, g, start, pts, dst, idx, a, b, prev);
-}
-
-hipError_t launch_nn_warm_flagged(icp_handle *h, const double *q_src, const uint32_t *q_perm, unsigned n, const Pose &T,
-                                  uint32_t *d_idx, double2 *d_a, double2 *d_b, const uint32_t *flags) {
-  const Grid &G = h->grid;
-  const unsigned blocks = (n + kGridThreads - 1) / kGridThreads;
-  if (h->dim == 3)
-    hipLaunchKernelGGL(k_nn_grid_warm_flagged<3>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
-                       G.d_start, G.d_pts, h->d_dst, d_idx, d_a, d_b, h->qsort.d_prev, flags);
-  else
-    hipLaunchKernelGGL(k_nn_grid_warm_flagged<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, q_perm, n, T, G.p,
-                       G.d_start, G.d_pts, h->d_dst, d_idx, d_a, d_b, h->qsort.d_prev, flags);
-  return hipGetLastError();
-}
-
 // ---------------------------------------------------------------- seeds ----------
 // The FIRST search of a snapshot has no previous matches.  The general kernel above then starts every
 // query with an infinite radius and sweeps its whole 3 x 3 x 3 block before it can prune anything
@@ -1837,7 +1807,6 @@ hipError_t launch_nn_warm_flagged(icp_handle *h, const double *q_src, const uint
 // around it that holds any record -- as if it were its previous match, and the warm kernel does the
 // search proper from that radius.  Nothing here needs to be exact or even good: the warm kernel's
 // result does not depend on where it starts (a poor seed only costs it time).
-#endif  // ICP_EXPERIMENTS
 
 template <int DIM>
 __device__ __forceinline__ PrevMatch seed_match(const unsigned k, const double *__restrict__ src, const Pose &T,
@@ -1962,7 +1931,8 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid_seeded(const double *_
 // `blk`: sort key = the cell index with the ROWS grouped in blocks of 2^blk x 2^blk (y, z) and the rows of a block
 // interleaved -- ((block row, x cell), row in block) -- instead of row after row: 64 consecutive queries then
 // come from a stretch of a 2^blk x 2^blk bundle of rows, a fraction as long as the stretch of ONE row that holds
-// 64 queries, and the union of their search boxes (nn_tile.hip) is that much more compact.  Any key is exact;
+// 64 queries, and the union of their search boxes is that much more compact (an experiment knob since the LDS-tile
+// search of round 3 left the tree: HISTORY.md).  Any key is exact;
 // this one only shapes the waves.
 __global__ void k_query_cell(const double *__restrict__ src, unsigned n, int dim, Pose T, GridParams g, int blk,
                              uint32_t *__restrict__ cell_of, int xshift) {
@@ -2029,12 +1999,10 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     (void)hipFree(Q.d_perm);
     (void)hipFree(Q.d_sorted);
     (void)hipFree(Q.d_prev);
-    (void)hipFree(Q.d_list);
     (void)hipFree(Q.d_cert_lists);
     (void)hipFree(Q.d_cert_ctr);
     Q.last_cert_ctr = nullptr;  // (pointed into the buffer just freed)
     Q.d_prev = nullptr;
-    Q.d_list = nullptr;
     Q.d_cert_lists = nullptr;
     Q.d_cert_ctr = nullptr;
     Q.d_cell_of = Q.d_perm = nullptr;
@@ -2047,7 +2015,6 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     // pool, and a 2-D owner followed by a 3-D one of the same size must not find them short
     if ((e = hipMalloc(&Q.d_sorted, n_ * 3 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_prev, n_ * sizeof(PrevMatch))) != hipSuccess) return e;
-    if ((e = hipMalloc(&Q.d_list, (n_ / 64 + 1) * sizeof(uint32_t))) != hipSuccess) return e;
     // work lists of the certified search: every list can take all the queries of its workgroups
     if ((e = hipMalloc(&Q.d_cert_lists, (n_ + (size_t)(kCertLists + 1) * kCertThreads) * sizeof(uint32_t))) != hipSuccess) return e;
     if ((e = hipMalloc(&Q.d_cert_ctr, (size_t)2 * kCertLists * kCertCtrStride * sizeof(unsigned))) != hipSuccess) return e;
@@ -2056,7 +2023,7 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     Q.cap = n_;
   }
   // Clouds that get four lanes per query (frames of a few tens of thousands of points) keep the caller's order: the
-  // snapshot exists for the per-slot previous matches, and the sort (a cell pass, eight rocprim launches, a gather:
+  // snapshot exists for the per-slot previous matches, and the sort (a cell pass, the sort's launches, a gather:
   // 50 us of a 1.26 ms registration of a 28k-point frame) buys such a search nothing measurable -- the targets it
   // walks fit the L2 whatever order the queries come in.  ICP_QSORT_SMALL=1 sorts them all the same.
   static const bool sort_small = exp_env("ICP_QSORT_SMALL") != nullptr;
@@ -2074,10 +2041,8 @@ hipError_t prepare_queries(icp_handle *h, const double *d_src, size_t n_, const 
     return hipSuccess;
   }
   // ICP_QSORT_BLOCK: log2 of the row bundle's side (0: row after row); the key must fit 32 bits
-  // (row after row serves the gather walk best: 84.1 / 86.3 / 90.4 / 94.3 us per search for 0 / 1 / 2 / 3; the
-  // LDS-tile search wants 1: 5 100 -> 700 of 15 625 waves beyond its LDS budget)
-  static const bool tile_on = exp_env("ICP_NN_TILE") != nullptr && atoi(exp_env("ICP_NN_TILE")) != 0;
-  static const int blk_env = exp_env("ICP_QSORT_BLOCK") ? atoi(exp_env("ICP_QSORT_BLOCK")) : (tile_on ? 1 : 0);
+  // (row after row serves the gather walk best: 84.1 / 86.3 / 90.4 / 94.3 us per search for 0 / 1 / 2 / 3)
+  static const int blk_env = exp_env("ICP_QSORT_BLOCK") ? atoi(exp_env("ICP_QSORT_BLOCK")) : 0;
   int blk = blk_env < 0 ? 0 : (blk_env > 3 ? 3 : blk_env);
   unsigned long long keys;
   for (;; --blk) {
@@ -2237,21 +2202,6 @@ hipError_t launch_nn_grid(icp_handle *h, const double *d_src, size_t n_, const P
       hipLaunchKernelGGL(k_nn_grid_seed<2>, dim3(blocks), dim3(kGridThreads), 0, h->stream, q_src, n, T, G.p, G.d_start,
                          G.d_pts, h->d_dst, Q.d_prev);
   };
-#ifdef ICP_EXPERIMENTS
-  // ICP_NN_TILE=1: the LDS-tile search of nn_tile.hip (round 3; same indices).  Built, parity-green at 1M x 1M and
-  // measured slower than the gather walk on the benchmark pair (109 + 42 us against 84 us: DESIGN.md section 5),
-  // so it is opt-in
-  static const bool use_tile = exp_env("ICP_NN_TILE") != nullptr && atoi(exp_env("ICP_NN_TILE")) != 0;
-  if ((q_prev || seeded) && !coop && xform && G.p.f32_ok && !old_warm && use_tile) {
-    if (seeded) launch_seeds();
-    hipError_t we = launch_nn_tile(h, q_src, q_perm, n, T, d_idx, (double2 *)d_a, (double2 *)d_b);
-    if (ev0 && ev1) {
-      (void)hipEventRecord(ev1, h->stream);
-      h->prof_events.emplace_back(ev0, ev1);
-    }
-    return we;
-  }
-#endif
   if ((q_prev || seeded) && !coop && xform && G.p.f32_ok && !old_warm) {
     // certificates (k_nn_cert above): ICP_NN_NO_CERT=1 searches every query every time, as rounds 1-2 did
     static const bool no_cert = exp_env("ICP_NN_NO_CERT") != nullptr;

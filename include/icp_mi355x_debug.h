@@ -38,10 +38,6 @@ int icp_fixed_point_skips(icp_handle *h, uint64_t *out);
  * the pairs, out[1] it did not (the search was repeated for the host's pose). */
 int icp_run_ahead_counters(icp_handle *h, uint64_t out[2]);
 
-/* Observability: the last LDS-tile search of `h` (the warm grid search beyond 65 536 source points): out[0] = waves
- * launched, out[1] = waves handed to the per-lane gather walk because their unions exceeded the LDS budget. */
-int icp_nn_tile_counters(icp_handle *h, uint64_t out[2]);
-
 /* Observability: certified matches (the searches of an estimate call after the first, beyond 65 536 source points:
  * a query whose previous match is provably still its nearest neighbour -- it has moved less than the margin the
  * last walk left it -- is not searched again).  out[0] = searches that checked certificates
