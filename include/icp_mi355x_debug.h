@@ -35,7 +35,8 @@ int icp_fixed_point_skips(icp_handle *h, uint64_t *out);
 
 /* ... and the run-ahead searches of icp_estimate[_device] (a search enqueued behind the pre-launched first evaluation
  * of the next iteration, its pose derived on the device): out[0] the host derived the same pose bit for bit and took
- * the pairs, out[1] it did not (the search was repeated for the host's pose). */
+ * the pairs, out[1] it derived another (the search was repeated for the host's pose).  A run-ahead search behind an
+ * evaluation that missed its window finds no pose on the device, does not run and is counted in neither. */
 int icp_run_ahead_counters(icp_handle *h, uint64_t out[2]);
 
 /* Observability: certified matches (the searches of an estimate call after the first, beyond 65 536 source points:
