@@ -1350,33 +1350,6 @@ extern "C" int icp_estimate_device(icp_handle *h, const double *d_src, size_t n,
       return e;
     };
     auto hook = [&](const Pose &T1) -> hipError_t { return speculate ? launch_spec(T1) : hipSuccess; };
-    // Round 6: the FIRST iteration of a call joins the pipeline too -- its first evaluation goes out right behind the call's
-    // first search, with the run-ahead search of iteration 1 behind it: the host's wait for that evaluation no longer
-    // stands between the two (12 us per call at 1M points, 11 at 28k: profiles/r06_call_head_trace.txt)
-    static const bool no_pre0 = exp_env("ICP_NO_PRE_EVAL0") != nullptr;
-    if (it == 0 && speculate && !first_pre_launched && two_streams && !no_pre && !no_pre0 && can_ahead) {
-      WinParams P;
-      hipError_t e = hipSuccess;
-      if (w.gn_dirty) {
-        e = launch_sel_init(h, n);
-        w.gn_dirty = false;
-      }
-      adopt_pool_hint(w, 3);  // (estimate_transform_loop would, in front of this evaluation)
-      if (e == hipSuccess && window_usable(h, n, &P, 3)) {
-        ++w.win_tried;
-        ++w.pre_evals;
-        w.ahead_on = true;
-        w.ahead_outer = T;
-        e = launch_weighted_gn_win(h, A[cur], B[cur], n, transform_identity(), P);
-        w.ahead_on = false;
-        if (e == hipSuccess) {
-          first_pre_launched = true;
-          uint32_t *idx_out1 = (it + 2 == max_iter && d_last_idx) ? idx_target : nullptr;
-          e = launch_nn_grid_ahead(h, d_src, n, w.d_ahead, A[(cur + 1) % 3], B[(cur + 1) % 3], idx_out1, &ahead_issued);
-        }
-      }
-      if (e != hipSuccess) return map_hip(e);
-    }
     Pose dT;
     uint32_t inner = 0;
     // two streams: the search is enqueued first; the evaluation's workgroups arrive on the
