@@ -278,10 +278,11 @@ def converging(calls, n, m, nn_mode):
             # as ms_per_step -- is kept under its own name, and `all_twenty_run` is the call with nothing left out
             "value": steps_run / dt, "unit": "iterations/s (iterations run)", "ms_per_step": 1e3 * dt / max(steps_run, 1),
             "steps": steps_run, "ms_per_call": 1e3 * dt / calls, "ms_per_requested_iteration": 1e3 * dt / steps,
-            "all_twenty_run": all_run,
+            "all_twenty_run": all_run, "ms_per_step_all_run": all_run["ms_per_step"] if all_run else 1e3 * dt / steps,
             "fixed_point": {"iterations_requested": steps, "iterations_run": steps_run, "ms_per_iteration_run": 1e3 * dt / max(steps_run, 1),
                             "gn_evaluations_per_iteration_run": evals_run,
-                            "note": "ms_per_step divides the call by the 20 iterations it asks for, as in earlier rounds; the "
+                            "note": "value and ms_per_step count the iterations that were RUN (ms_per_requested_iteration divides "
+                                    "the call by the 20 it asks for, as earlier rounds' ms_per_step did); the "
                                     "iterations after the pose has stopped moving (inner count 0, pose bit-equal) repeat the "
                                     "one before them and are not run, except the last -- same pose, indices and inner counts "
                                     "as running all of them (icp_fixed_point_skips, include/icp_mi355x_debug.h)"},
