@@ -727,6 +727,9 @@ def main():
                                   "`weak_scaling` (N x 1M source points) is where N GPUs pay, `brute_force` is configs[3] as worded")
         rccl_world = dist.get_world_size() if dist.is_initialized() else 1
         backend = dist.get_backend() if dist.is_initialized() else None
+        #  every multi-GPU line says how its ranks talked: the headline line too
+        out["transport"] = (loop_state.get("transport") or loop_state["mode"]) if (world > 1 and res.get("counters")) else None
+        out["rccl_world"], out["backend"] = rccl_world, backend
         if brute is not None:
             out["brute_force"] = {
                 "workload": "BASELINE configs[2] / [3] as worded: brute-force NN (LDS-tiled sweep) + Huber, 1M x 1M; N ranks: the "
@@ -734,7 +737,7 @@ def main():
                             "the inner loop replicated",
                 "value": brute["steps"] / brute["elapsed"], "unit": "iterations/s", "steps": brute["steps"],
                 "ms_per_step": 1e3 * brute["elapsed"] / brute["steps"], "roofline": nn_roofline(brute, hi - lo),
-                "scaling": "strong", "n_gpus": world, "transport": "RCCL all_gather (torch.distributed)" if world > 1 else None,
+                "scaling": "strong", "n_gpus": world, "transport": (f"{'RCCL' if backend == 'nccl' else backend} all_gather (torch.distributed)") if world > 1 else None,
                 "rccl_world": rccl_world, "backend": backend,
             }
         if weak is not None:

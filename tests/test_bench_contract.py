@@ -51,3 +51,33 @@ def test_bench_line_carries_the_contract_fields_and_is_consistent():
         assert key in nl, key
     b = d["brute_force"]["roofline"]
     assert b["bound"] == "fp32_valu" and 0.0 < b["frac"] < 1.0
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_lines_say_how_the_ranks_talked():
+    """ `bench.py --gpus 2` as the driver launches it, both ranks on the one GPU of the box
+    (ICP_BENCH_SHARE_GPU=1: gloo for the rendezvous, the mapped inboxes for the iterations -- a rehearsal of the launch,
+    not a measurement): the headline line, `brute_force` and `weak_scaling` each carry n_gpus, transport and rccl_world,
+    and the sharded registration is the one-GPU registration bit for bit (`parity` is rank 0's check against the oracle)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ICP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n-src", "200000", "--n-dst",
+                          "150000", "--steps", "10", "--warmup", "2", "--brute-steps", "1", "--weak-steps", "5", "--cpu-iters", "0",
+                          "--gn-points", "0", "--nn-points", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["rccl_world"] == 2 and d["backend"] == "gloo"
+    assert d["transport"]  # the inboxes' transport, or the stage calls if the two processes never ran side by side
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    for leg, scaling in (("brute_force", "strong"), ("weak_scaling", "weak")):
+        assert d[leg]["n_gpus"] == 2 and d[leg]["rccl_world"] == 2 and d[leg]["transport"] and d[leg]["scaling"] == scaling, leg
+    if "parity" in d:
+        assert d["parity"]["pose_bits_equal"] is True and d["parity"]["inner_iterations_equal"] is True
