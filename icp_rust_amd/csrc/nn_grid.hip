@@ -136,7 +136,7 @@ __global__ void k_grid_scatter(const double *__restrict__ dst, unsigned m, int d
                                uint32_t *__restrict__ cursor, GridParams g, GridPoint *__restrict__ pts) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) {
-    // sentinels behind the last record: the warm search reads records in aligned quads (64-byte lines)
+    // sentinels behind the last record: the warm searches read records in quads (four records past a run's last at most)
     if (i < m + kGridPad) pts[i] = GridPoint{__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf(), 0u};
     return;
   }
@@ -882,10 +882,12 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid(const double *__restri
 //   * every bound is conservative by construction: radii are rounded up, distances to cell slabs
 //     down, by margins `mgf` / `em` that dominate the f32 rounding of the quantities involved
 //     (derivations at the definitions); a bound can therefore only cause extra visits;
-//   * the records of a row are read in ALIGNED QUADS (one 64-byte line): a run [s, e) becomes the
-//     quads [s / 4, (e + 3) / 4), so the flattening arithmetic is paid per quad, not per record.  The
-//     extra records a quad drags in are real targets of the neighbouring cells (or the +inf sentinels
-//     behind the last record): screening them can add candidates, never remove one.
+//   * the records of a row are read in QUADS of four (64 bytes): a run [s, e) becomes the quads that
+//     start at s, s + 4, ... (round 6; rounds 2-5 aligned them to four records: up to three extra
+//     records on EITHER side of the run, a quarter more quads for the usual runs of three to six), so
+//     the flattening arithmetic is paid per quad, not per record.  The extra records the last quad
+//     drags in are real targets of the cells behind the run (or the +inf sentinels behind the last
+//     record): screening them can add candidates, never remove one.
 // Lanes whose geometry does not fit f32 (|q - lo| or the radius beyond 1e18) walk the whole grid
 // unpruned: correct, and never seen outside adversarial tests.
 #ifdef ICP_WARM_WAVES
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(kGridThreads) void k_nn_grid(const double *__restri
 #define ICP_WARM_ATTR
 #endif
 #ifndef ICP_WARM_QUADS
-#define ICP_WARM_QUADS 2  // aligned quads (of four records) in flight per lane
+#define ICP_WARM_QUADS 2  // quads (of four records) in flight per lane
 #endif
 // CERT: the walk also leaves a CERTIFICATE in the slot's record (PrevMatch::pad, see k_nn_cert below): a lower
 // bound on the distance from this query to every target other than its match, from what the walk saw anyway --
@@ -1104,14 +1106,14 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
     const uint32_t s1 = start[ra1], e1 = start[rz1];
     const uint32_t s2 = start[ra2], e2 = start[rz2];
     const uint32_t s3 = start[ra3], e3 = start[rz3];
-    // runs -> aligned quads; an empty run has no quads
-    const uint32_t q0 = s0 >> 2, n0 = e0 > s0 ? ((e0 + 3) >> 2) - q0 : 0u;
-    const uint32_t q1 = s1 >> 2, n1 = (nr > 1 && e1 > s1) ? ((e1 + 3) >> 2) - q1 : 0u;
-    const uint32_t q2 = s2 >> 2, n2 = (nr > 2 && e2 > s2) ? ((e2 + 3) >> 2) - q2 : 0u;
-    const uint32_t q3 = s3 >> 2, n3 = (nr > 3 && e3 > s3) ? ((e3 + 3) >> 2) - q3 : 0u;
+    // runs -> quads that start at the run's first record (round 6: see warm_wave); an empty run has no quads
+    const uint32_t n0 = e0 > s0 ? (e0 - s0 + 3) >> 2 : 0u;
+    const uint32_t n1 = (nr > 1 && e1 > s1) ? (e1 - s1 + 3) >> 2 : 0u;
+    const uint32_t n2 = (nr > 2 && e2 > s2) ? (e2 - s2 + 3) >> 2 : 0u;
+    const uint32_t n3 = (nr > 3 && e3 > s3) ? (e3 - s3 + 3) >> 2 : 0u;
     const uint32_t o1 = n0, o2 = o1 + n1, o3 = o2 + n2, Q = o3 + n3;
-    // quad j of the flattened sequence lives at quad index j + dk of the record array
-    const uint32_t d0 = q0, d1 = q1 - o1, d2 = q2 - o2, d3 = q3 - o3;
+    // quad j of the flattened sequence starts at record 4 j + dk of the record array (modulo 2^32)
+    const uint32_t d0 = s0, d1 = s1 - 4u * o1, d2 = s2 - 4u * o2, d3 = s3 - 4u * o3;
     constexpr uint32_t kQ = ICP_WARM_QUADS, kR = 4 * kQ;
     for (uint32_t base = 0; base < Q; base += kQ) {
       GridPoint t[kR];
@@ -1123,7 +1125,7 @@ __device__ __forceinline__ void warm_query(const unsigned k, const double *__res
         if (j >= o1) dq = d1;
         if (j >= o2) dq = d2;
         if (j >= o3) dq = d3;
-        line[h2] = reinterpret_cast<const uint4 *>(pts) + (size_t)(j + dq) * 4;
+        line[h2] = reinterpret_cast<const uint4 *>(pts) + (size_t)(uint32_t)(4u * j + dq);
       }
 #pragma unroll
       for (uint32_t u = 0; u < kR; ++u) {  // all loads in flight before the first use
@@ -1261,7 +1263,7 @@ constexpr int kCoopCandCap = 256;           // >= 4 records x 64 lanes: one quad
 constexpr int kCoopFlushAt = ICP_COOP_FLUSH_AT;  // pending exact tests that are worth a gather between two rounds of rows
 struct CoopLds {
   uint32_t pref[64];            // quads of the owners before this one
-  uint32_t rows_d[64][kCoopRows];  // quad j of owner's flattened rows lives at record quad j + d_r ...
+  uint32_t rows_d[64][kCoopRows];  // quad j of owner's flattened rows starts at record 4 j + d_r ...
   uint32_t rows_o[64][kCoopRows];  // ... r = the number of o_1.. that j has reached (o_0 unused)
   float4 oq[64];                // the owner's grid-relative query and screening threshold
   uint32_t obi[64];             // the owner's current match
@@ -1524,10 +1526,14 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
     }
     uint32_t rd[kCoopRows], ro[kCoopRows], Q = 0;
 #pragma unroll
-    for (int r = 0; r < kCoopRows; ++r) {  // runs -> aligned quads; an empty run has no quads
-      const uint32_t qr = sb[r] >> 2, nq = ((nr > r) & (se[r] > sb[r])) ? ((se[r] + 3) >> 2) - qr : 0u;  // (no short circuit: every bound is loaded up front)
+    for (int r = 0; r < kCoopRows; ++r) {  // runs -> quads; an empty run has no quads
+      // (round 6) quads START at the run's first record: only the last quad of a run reads past it (up to three records of
+      // the cells behind, or the sentinels), where quads aligned to four records read up to three on either side -- a
+      // quarter fewer quads for runs of three to six records (46.3 -> 43.1 us per warm search at 1M:
+      // profiles/r06_search_unaligned_quads_ab.txt)
+      const uint32_t nq = ((nr > r) & (se[r] > sb[r])) ? ((se[r] - sb[r] + 3) >> 2) : 0u;  // (no short circuit: every bound is loaded up front)
       ro[r] = Q;
-      rd[r] = qr - Q;
+      rd[r] = sb[r] - 4u * Q;  // (first record of flat quad j: 4 j + this, modulo 2^32)
       Q += nq;
     }
     COOP_STAMP(2);
@@ -1572,7 +1578,7 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
 #pragma unroll
         for (int r = 1; r < kCoopRows; ++r)
           if (j >= S.rows_o[L][r]) dq = S.rows_d[L][r];
-        const uint4 *line = reinterpret_cast<const uint4 *>(pts) + (size_t)(j + dq) * 4;
+        const uint4 *line = reinterpret_cast<const uint4 *>(pts) + (size_t)(uint32_t)(4u * j + dq);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const uint4 wv = line[u];
