@@ -13,6 +13,7 @@
 // bound can only cause extra visits, never a missed candidate; candidates are compared
 // by (d^2, original index), so the visiting order cannot change the winner.
 #include "common.hpp"
+#include <type_traits>
 
 namespace icp {
 
@@ -1558,13 +1559,18 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
     __syncthreads();
     COOP_STAMP(3);
     // ---- worker: quads lane, lane + 64, ... of the list ----
-    for (uint32_t w0 = 0; w0 < total; w0 += 64u * kCoopItems) {
+    // batches of kCoopItems quads per lane while more than 64 quads are left, ONE quad per lane for a rest of up to 64
+    // (round 6: half of the batches are such rests, and an item without quads costs what a full one does -- 43.1 -> 41.3 us
+    // per warm search; skipping the empty item by a branch INSIDE the batch was slower, the items' lookups no longer
+    // interleave: profiles/r06_search_unaligned_quads_ab.txt)
+    auto batch = [&](auto ni_, const uint32_t w0) {
+      constexpr int NI = decltype(ni_)::value;
       COOP_COUNT(9, 1);
-      GridPoint t[4 * kCoopItems];
-      unsigned own[kCoopItems];
-      bool has[kCoopItems];
+      GridPoint t[4 * NI];
+      unsigned own[NI];
+      bool has[NI];
 #pragma unroll
-      for (int it = 0; it < kCoopItems; ++it) {
+      for (int it = 0; it < NI; ++it) {
         const uint32_t w = w0 + 64u * it + lane;
         has[it] = w < total;
         const uint32_t wc = has[it] ? w : total - 1;
@@ -1590,7 +1596,7 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int it = 0; it < kCoopItems; ++it) {
+      for (int it = 0; it < NI; ++it) {
         const float4 oq = S.oq[own[it]];
         const uint32_t obi = S.obi[own[it]];
         bool pass[4];
@@ -1617,6 +1623,11 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
           cnt += (unsigned)__popcll(bal[u]);
         }
       }
+    };
+    {
+      uint32_t w0 = 0;
+      for (; w0 + 64u < total; w0 += 64u * kCoopItems) batch(std::integral_constant<int, kCoopItems>{}, w0);
+      if (w0 < total) batch(std::integral_constant<int, 1>{}, w0);
     }
     __syncthreads();  // the list and the row tables are rewritten by the next round
     COOP_STAMP(4);
