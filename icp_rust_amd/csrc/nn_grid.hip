@@ -1280,6 +1280,7 @@ struct CoopLds {
 // [4] worker rounds  [5] flushes  [6] outputs  [7] waves  [8] rounds of rows  [9] worker rounds  [10] flushes  [11] candidates
 __device__ unsigned long long g_coop_prof[64][12];
 __device__ long long g_coop_span[16384][2];  // start / end tick of every wave (workgroup) of the last launch
+__device__ unsigned long long g_coop_rows[32];  // owners by the number of box rows their walk took (31: more); profiles/coop_rows_hist.py
 #define COOP_STAMP(i)                                                  \
   do {                                                                 \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
@@ -1488,6 +1489,9 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
         if (vy[jy] && vz[jz] && !(sy[jy] + sz[jz] > bf)) mask |= 1u << (jz * 4 + jy);
   };
   if (alive) make_mask();
+#ifdef ICP_COOP_PROFILE
+  unsigned rows_total = 0;
+#endif
   for (;;) {
     // ---- owner: the next rows of its box ----
     int nr = 0;
@@ -1516,6 +1520,9 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
       ++nr;
     }
     if (__ballot(nr > 0) == 0ull) break;
+#ifdef ICP_COOP_PROFILE
+    rows_total += (unsigned)nr;
+#endif
     COOP_STAMP(1);
     COOP_COUNT(8, 1);
     uint32_t sb[kCoopRows], se[kCoopRows];
@@ -1643,6 +1650,7 @@ __device__ __forceinline__ void warm_wave(const unsigned k, const unsigned n, co
   auto coop_report = [&]() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     cprof[6] += (unsigned long long)(wall_clock64() - ct_last);
+    if (in_range) atomicAdd(&g_coop_rows[rows_total < 31u ? rows_total : 31u], 1ull);
     if (lane == 0) {
       for (int j = 0; j < 12; ++j) atomicAdd(&g_coop_prof[blockIdx.x & 63][j], cprof[j]);
       if (blockIdx.x < 16384u) {
@@ -2381,6 +2389,14 @@ extern "C" int icp_debug_nn_hist(unsigned long long out[64], int reset) {
 
 #endif
 #ifdef ICP_COOP_PROFILE
+extern "C" int icp_debug_coop_rows(unsigned long long out[32], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_rows), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_coop_rows), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
 extern "C" int icp_debug_coop_spans(long long *out, int n) {  // n <= 16384 (start, end) pairs by workgroup
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_span), (size_t)n * 2 * sizeof(long long)) == hipSuccess ? 0 : 1;
 }
